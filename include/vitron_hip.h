@@ -1,0 +1,246 @@
+/* vitron_hip.h -- C ABI of libvitron_hip.so: the MI355X (gfx950) implementation of Vitron's multimodal
+ * forward pass (LanguageBind ViT image/video tower -> region_extractor -> mm_projector -> Vicuna/LLaMA decoder).
+ *
+ * The reference (SkyworkAI/Vitron) has no FFI on this path: the boundary is the Python surface of
+ * vitron.model. This ABI sits directly below that surface; vitron_amd/ binds it with
+ * ctypes and keeps the reference's Python signatures. Each entry point names the reference code it replaces.
+ *
+ * Conventions
+ *   - plain C, no torch types; every tensor is a raw DEVICE pointer owned by the caller (PyTorch's caching
+ *     allocator in practice) and valid for the duration of the call. The library never allocates or frees
+ *     tensor memory: scratch comes in as (workspace, workspace_bytes); query the size with *_workspace_bytes.
+ *   - bf16 tensors are uint16_t* (raw bits), row-major. Linear weights keep torch's [out][in] layout.
+ *   - every function is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream),
+ *     re-entrant, and returns 0 on success or a negative vt_status; vt_last_error() gives the message of the
+ *     calling thread's last failure. Nothing throws, nothing synchronises the device.
+ *   - "host struct" arguments (vt_vit_model, vt_llama_model, ...) are read on the host during the call; the
+ *     pointers inside them are device pointers.
+ */
+#ifndef VITRON_HIP_H
+#define VITRON_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { VT_STATUS_OK = 0, VT_STATUS_ARG = -1, VT_STATUS_HIP = -2, VT_STATUS_WORKSPACE = -3 } vt_status;
+
+/* GEMM epilogues: C = epi(A.W^T + bias) */
+enum {
+  VT_EPI_BF16 = 0,        /* bf16 out                                                                     */
+  VT_EPI_BF16_GELU = 1,   /* bf16 out, exact-erf GELU   (CLIPMLP 'gelu', mm_projector nn.GELU)               */
+  VT_EPI_BF16_QGELU = 2,  /* bf16 out, x*sigmoid(1.702x) (CLIPMLP 'quick_gelu')                              */
+  VT_EPI_BF16_RELU = 3,   /* bf16 out, ReLU             (region_extractor MLP / LocationEncoder)            */
+  VT_EPI_F32_RESID = 4,   /* fp32 C += A.W^T + bias      (residual stream accumulate)                        */
+  VT_EPI_F32 = 5,         /* fp32 out                    (logits)                                            */
+  VT_EPI_SWIGLU_BF16 = 6  /* W rows = [gate16|up16|gate16|up16...]; bf16 out [M][N/2] = silu(gate)*up          */
+};
+/* tile configurations of the MFMA GEMM (VT_GEMM_CFG_AUTO lets the library choose) */
+enum {
+  VT_GEMM_CFG_AUTO = 0,
+  VT_GEMM_CFG_SKINNY = 1,   /* M <= 16 weight-streaming kernel */
+  VT_GEMM_CFG_128x128 = 2,
+  VT_GEMM_CFG_256x128 = 3,
+  VT_GEMM_CFG_256x256 = 4,
+  VT_GEMM_CFG_64x128 = 5,
+  VT_GEMM_CFG_256x256_P8 = 6 /* 256x256 tile, 8-phase pipelined main loop */
+};
+enum { VT_DTYPE_BF16 = 0, VT_DTYPE_F32 = 1 };
+enum { VT_ACT_GELU = 0, VT_ACT_QUICK_GELU = 1 };
+
+#define VT_PAGE_TOKENS 64 /* tokens per KV-cache page == keys per attention tile */
+
+int vt_version(void);
+/* copies the calling thread's last error message (NUL terminated) into buf; returns its length */
+int vt_last_error(char* buf, size_t buf_len);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Primitive operators (exported for unit parity tests and for composing other models)
+ * ---------------------------------------------------------------------------------------------------------- */
+
+/* nn.Linear: C = epi(A[M,K] . W[N,K]^T + bias[N]).  bias may be NULL. C is bf16 or fp32 per `epi`.
+ * `scratch` (fp32, >= M*N floats) is only needed for VT_EPI_SWIGLU_BF16 with M <= 16.
+ * Replaces every torch.nn.Linear on the path (transformers-4.31 CLIPAttention/CLIPMLP/LlamaAttention/LlamaMLP,
+ * reference call sites modeling_video.py:69,71,81; llava_llama.py:49,91-102; multimodal_projector/builder.py:33-51). */
+int vt_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, void* C, int ldc, const float* bias, int M,
+                 int N, int K, int epi, int cfg, void* scratch, void* stream);
+
+/* y_bf16[rows][D] = LayerNorm(x_f32) * gamma + beta. If temb != NULL first x[row] += temb[(row / tokens_per_frame) % T]
+ * (written back): the video tower's temporal_embedding add (reference modeling_video.py:110-114) fused with
+ * temporal_layer_norm1 (:117). */
+int vt_layernorm(float* x, const float* temb, int T, int tokens_per_frame, const float* gamma, const float* beta,
+                 uint16_t* y, int rows, int D, float eps, void* stream);
+
+/* y_bf16[r] = w * x[idx ? idx[r] : r] * rsqrt(mean(x^2) + eps) : transformers-4.31 LlamaRMSNorm. */
+int vt_rmsnorm(const float* x, const int* idx, const float* w, uint16_t* y, int rows, int D, float eps, void* stream);
+
+/* Attention over 64-key tiles. seq_desc: device int32 [nseq][4] = {q_row0, q_len, kv_len, table_off};
+ * tile_table: device int32, tile_table[table_off + t] = index of the sequence's t-th K / V^T tile.
+ * K tile = [64 keys][HD], V^T tile = [HD][64 keys]; tile i of head h starts at (i*heads + h)*64*HD elements.
+ * q_len > 1 anywhere -> MFMA flash kernel (causal: query i sees keys <= kv_len - q_len + i); all q_len == 1 is
+ * routed to the single-query kernel by vt_llama_forward. Replaces CLIPAttention (non-causal, modeling_video.py:136-146)
+ * and LlamaAttention's softmax(QK^T/sqrt(d) + mask)V (reference restatement: llama_flash_attn_monkey_patch.py:30-66). */
+int vt_flash_attn(const uint16_t* Q, int ldq, const uint16_t* k_tiles, const uint16_t* vt_tiles, const int* tile_table,
+                  const int* seq_desc, int nseq, int max_q_len, uint16_t* O, int ldo, int heads, int head_dim,
+                  int causal, float scale, void* stream);
+int vt_attn_decode(const uint16_t* Q, int ldq, const uint16_t* k_tiles, const uint16_t* vt_tiles, const int* tile_table,
+                   const int* seq_desc, int nseq, uint16_t* O, int ldo, int heads, int head_dim, float scale,
+                   void* stream);
+/* fused-QKV rows -> K tiles / V^T tiles for the NEW tokens of each sequence; when rope_cos != NULL applies the
+ * half-split rotary embedding (tables [rope_len][HD/2] fp32, row = positions[row]) to k and, in place, to q.
+ * Replaces apply_rotary_pos_emb + the torch.cat KV-cache append of transformers-4.31 LlamaAttention. */
+int vt_kv_tiles(uint16_t* qkv, int ldqkv, int q_col0, int k_col0, int v_col0, uint16_t* k_tiles, uint16_t* vt_tiles,
+                const int* tile_table, const int* seq_desc, int nseq, int max_new_tiles, int heads, int head_dim,
+                const float* rope_cos, const float* rope_sin, const int* positions, void* stream);
+/* temporal attention of the video tower: qkv bf16 [B*T*N][3*heads*64] (row (b*T+t)*N+n, q pre-scaled) ->
+ * out bf16 [B*T*N][heads*64]; attends over the T frames at each (b, n). Reference modeling_video.py:105-127. */
+int vt_attn_temporal(const uint16_t* qkv, uint16_t* out, int B, int T, int N, int heads, void* stream);
+
+/* CLIPVisionEmbeddings patch gather: pixels ([F][3][H][W] or, video_layout=1, [B][3][T][H][W]; bf16 or fp32) ->
+ * patches bf16 [B*T*(H/P)*(W/P)][k_pad], K order (c,py,px), zero padded. */
+int vt_im2col(const void* pixels, int pix_dtype, uint16_t* patches, int B, int T, int H, int W, int P, int k_pad,
+              int video_layout, void* stream);
+
+/* embed_tokens gather + visual / region splice (reference llava_arch.py:306-398, 479-558).
+ * plan: device int32 [rows][2] = {kind, index}; kind 0 = token id, 1 = row of vis, 2 = row of reg, 3 = zero row. */
+int vt_embed_splice(const uint16_t* tok_table, const uint16_t* vis, const uint16_t* reg, const int* plan, int rows,
+                    int H, uint16_t* out, void* stream);
+
+/* greedy next token: first index of the row maximum (GenerationMixin greedy search). */
+int vt_argmax(const float* logits, int rows, int V, int ldl, int* out_ids, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * mm_projector: Linear(Din,Dh) -> GELU(erf) -> Linear(Dh,Dout)   ('mlp2x_gelu';  w2 == NULL -> 'linear')
+ * reference vitron/model/multimodal_projector/builder.py:33-51, called at llava_arch.py:175,186
+ * ---------------------------------------------------------------------------------------------------------- */
+size_t vt_projector_workspace_bytes(int M, int Dh);
+int vt_projector_forward(const uint16_t* x, int M, int Din, const uint16_t* w1, const float* b1, int Dh,
+                         const uint16_t* w2, const float* b2, int Dout, uint16_t* out, void* workspace,
+                         size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * region_extractor (reference vitron/model/region_extractor/layer.py:58-130), one box per image.
+ *   feats   bf16 [B][G*G][D]      patch features of the image tower (pre-projector)
+ *   slices  int32 [B][4]          {row_start,row_stop,col_start,col_stop} = Python slice(int(x1),int(x2)) /
+ *                                  slice(int(y1),int(y2)) resolved against image_size on the host (x -> rows, :83)
+ *   coords  bf16 [B][8]           raw box {x1,y1,x2,y2,0,0,0,0} (LocationEncoder input, :126)
+ *   mlp_w[3]/mlp_b[3]             region_linear (D->H->H->H, ReLU between); loc_w[0] is [H/2][8] (zero padded
+ *                                  from [H/2][4]), loc_w[1] is [H][H/2]
+ *   out     bf16 [B][H]; cell_mask int32 [B][G*G] and cell_count int32 [B] are optional outputs (may be NULL)
+ *   B <= 16 per call.
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct vt_region_weights {
+  int in_dim, out_dim;
+  const uint16_t* mlp_w[3];
+  const float* mlp_b[3];
+  const uint16_t* loc_w[2];
+  const float* loc_b[2];
+} vt_region_weights;
+size_t vt_region_workspace_bytes(int B, int in_dim, int out_dim);
+int vt_region_forward(const vt_region_weights* w, const uint16_t* feats, const int* slices, const uint16_t* coords,
+                      int B, int G, int image_size, uint16_t* out, int* cell_mask, int* cell_count, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * LanguageBind ViT tower (CLIP ViT + optional per-layer temporal attention)
+ * reference CLIPVisionTransformer.forward / CLIPEncoderLayer.forward
+ *   vitron/model/multimodal_encoder/languagebind/video/modeling_video.py:65-158,596-675 (image twin: image/modeling_image.py)
+ * and the tower wrappers' feature_select (languagebind/__init__.py:96-121,182-204): the library runs `num_layers`
+ * encoder layers (= n_hidden + 1 + select_layer, 23 of 24 for select_layer = -2) and returns the patch tokens
+ * (CLS dropped) of that hidden state.
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct vt_vit_layer {
+  /* temporal block -- all NULL unless add_time_attn */
+  const float *t_ln_g, *t_ln_b;
+  const float* t_embed;   /* [num_frames][D]; NULL when num_frames == 1 (reference skips the add, :110) */
+  const uint16_t* t_wqkv; /* [3D][D], q rows pre-scaled by head_dim^-0.5 */
+  const float* t_bqkv;    /* [3D], q part pre-scaled */
+  const uint16_t* t_wo;
+  const float* t_bo;
+  /* spatial block */
+  const float *ln1_g, *ln1_b;
+  const uint16_t* wqkv;
+  const float* bqkv;
+  const uint16_t* wo;
+  const float* bo;
+  const float *ln2_g, *ln2_b;
+  const uint16_t* w1; /* fc1 [I][D] */
+  const float* b1;
+  const uint16_t* w2; /* fc2 [D][I] */
+  const float* b2;
+} vt_vit_layer;
+
+typedef struct vt_vit_model {
+  int image_size, patch, hidden, heads, intermediate;
+  int num_layers;    /* encoder layers to run */
+  int num_frames;    /* T of the temporal attention (config.num_frames) */
+  int add_time_attn; /* 1 = video tower */
+  int act;           /* VT_ACT_* */
+  float ln_eps;
+  int k_pad;               /* padded K of the patch GEMM (multiple of 64, >= 3*patch*patch) */
+  const uint16_t* w_patch; /* [D][k_pad] */
+  const float* cls;        /* [D] */
+  const float* pos;        /* [G*G+1][D] */
+  const float *pre_ln_g, *pre_ln_b;
+  const vt_vit_layer* layers; /* host array [num_layers] */
+} vt_vit_model;
+
+size_t vt_vit_workspace_bytes(const vt_vit_model* m, int B, int T);
+/* pixels: image tower [B][3][H][W] (T = 1, video_layout = 0); video tower [B][3][T][H][W] (video_layout = 1).
+ * out_feats  bf16 [B*T*G*G][D]  patch tokens of the selected hidden state (required)
+ * out_hidden fp32 [B*T*(G*G+1)][D] the full selected hidden state incl. CLS (optional, NULL to skip) */
+int vt_vit_forward(const vt_vit_model* m, const void* pixels, int pix_dtype, int B, int T, int video_layout,
+                   uint16_t* out_feats, float* out_hidden, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * LLaMA decoder (Vicuna-7B shape class): prefill and decode through one entry point, paged KV cache.
+ * reference LlavaLlamaForCausalLM.forward -> transformers-4.31 LlamaForCausalLM.forward
+ *   vitron/model/language_model/llava_llama.py:57-102 ; decode-step plumbing llava_arch.py:196-205
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct vt_llama_layer {
+  const float* rms1;     /* input_layernorm.weight [H] */
+  const uint16_t* wqkv;  /* [3H][H] rows = q | k | v */
+  const uint16_t* wo;    /* [H][H] */
+  const float* rms2;     /* post_attention_layernorm.weight */
+  const uint16_t* wgu;   /* [2I][H], rows interleaved in blocks of 16: gate | up | gate | up ... */
+  const uint16_t* wdown; /* [H][I] */
+} vt_llama_layer;
+
+typedef struct vt_llama_model {
+  int hidden, heads, head_dim, intermediate, num_layers, vocab;
+  float rms_eps;
+  const float* final_norm;    /* [H] */
+  const uint16_t* lm_head;    /* [V][H] */
+  const float* rope_cos;      /* [rope_len][head_dim/2] */
+  const float* rope_sin;
+  int rope_len;
+  const vt_llama_layer* layers; /* host array [num_layers] */
+} vt_llama_model;
+
+/* KV pool: k  [num_layers][num_pages][heads][64][head_dim]   (K rows, rotary applied)
+ *          vt [num_layers][num_pages][heads][head_dim][64]   (V transposed inside the page) */
+typedef struct vt_kv_cache {
+  uint16_t* k;
+  uint16_t* vt;
+  int num_pages;
+} vt_kv_cache;
+
+size_t vt_llama_workspace_bytes(const vt_llama_model* m, int rows, int n_logit_rows);
+/* x_embeds    bf16 [rows][H]   packed input embeddings of all sequences (no padding rows)
+ * positions   int32 [rows]     rotary position of every row
+ * seq_desc    int32 [nseq][4]  {q_row0, q_len, kv_len, table_off} ; kv_len = past + q_len
+ * tile_table  int32            page ids, tile_table[table_off + t] = page of positions [64t, 64t+64)
+ * logit_rows  int32 [n_logit_rows] rows whose logits are wanted (generate: the last row of every sequence)
+ * logits      fp32 [n_logit_rows][V]
+ * The new tokens' K/V are appended to the cache pages; attention is causal over past + new tokens. */
+int vt_llama_forward(const vt_llama_model* m, const vt_kv_cache* kv, const uint16_t* x_embeds, int rows,
+                     const int* positions, const int* seq_desc, int nseq, int max_q_len, int max_new_tiles,
+                     const int* tile_table, const int* logit_rows, int n_logit_rows, float* logits,
+                     float* out_hidden, void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VITRON_HIP_H */

@@ -1,0 +1,469 @@
+"""CPU oracle for the Vitron multimodal forward pass -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module, and only as the
+checker (or as the timed CPU baseline). The product path (vitron_amd/) never imports it and has no CPU fallback.
+
+What it is: a plain-PyTorch fp32 restatement of the reference's algorithm for the hot path, one function per
+SURVEY.md 8(a) row, each citing the reference file:line it follows. The arithmetic of the CLIP / LLaMA blocks
+lives in the third-party dependency transformers==4.31.0 (pinned at /root/reference/pyproject.toml:17,
+requirements.txt:63; not vendored), so those parts restate its published algorithm and
+are anchored on the reference's call sites.
+
+Pinning: the reference ships no tests or golden vectors for this path, so the oracle is pinned
+against outputs of the reference's OWN modules run in the build container under an import shim
+(oracle/ref_shim.py): tests/golden/make_golden.py generated tests/golden/*.npz from
+  - vitron/model/multimodal_encoder/languagebind/video/modeling_video.py  CLIPVisionTransformer
+  - vitron/model/region_extractor/layer.py                               RegionExtractor
+  - vitron/model/multimodal_projector/builder.py                         build_vision_projector
+  - vitron/model/llava_arch.py + language_model/llava_llama.py           prepare_inputs_labels_for_multimodal, forward
+  - vitron/mm_utils.py                                                   tokenizer_image_token, preprocess_region ...
+and tests/test_oracle_golden.py checks this file against them (fp32, rel-L2 <= 1e-5; integer outputs exact).
+
+Two numeric modes:
+  emulate_bf16=False  pure fp32 on the given (bf16-representable) inputs and weights.
+  emulate_bf16=True   same maths, but values are rounded to bf16 at exactly the points where the HIP path
+                      stores bf16 (GEMM operands: norm outputs, fused-QKV, attention outputs, activations);
+                      accumulation, softmax, norms and the residual stream stay fp32 like the kernels.
+State dicts use the reference's parameter names.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+IGNORE_INDEX = -100        # reference vitron/constants.py:7
+IMAGE_TOKEN_INDEX = -200   # reference vitron/constants.py:9
+OBJS_TOKEN_INDEX = -300    # reference vitron/constants.py:24
+
+SD = Dict[str, torch.Tensor]
+
+
+def bf16_round(x: torch.Tensor) -> torch.Tensor:
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def _r(x: torch.Tensor, emulate: bool) -> torch.Tensor:
+    return bf16_round(x) if emulate else x
+
+
+def _lin(x, w, b=None):
+    return F.linear(x, w.float(), None if b is None else b.float())
+
+
+# =====================================================================================================================
+# ViT tower (image: add_time_attn=False, T=1; video: add_time_attn=True, T=num_frames)
+# =====================================================================================================================
+def quick_gelu(x):  # transformers ACT2FN['quick_gelu']
+    return x * torch.sigmoid(1.702 * x)
+
+
+def clip_attention(x, sd: SD, prefix: str, heads: int, emulate: bool):
+    """transformers-4.31 CLIPAttention.forward: q = q_proj(x)*hd^-0.5, bmm, softmax,
+    bmm, out_proj -- no masks on the vision path (reference modeling_video.py:652-657 passes None)."""
+    B, N, D = x.shape
+    hd = D // heads
+    q = _r(_lin(x, sd[prefix + "q_proj.weight"], sd[prefix + "q_proj.bias"]), emulate) * (hd ** -0.5)
+    k = _r(_lin(x, sd[prefix + "k_proj.weight"], sd[prefix + "k_proj.bias"]), emulate)
+    v = _r(_lin(x, sd[prefix + "v_proj.weight"], sd[prefix + "v_proj.bias"]), emulate)
+    q = q.view(B, N, heads, hd).transpose(1, 2)
+    k = k.view(B, N, heads, hd).transpose(1, 2)
+    v = v.view(B, N, heads, hd).transpose(1, 2)
+    s = q @ k.transpose(-1, -2)
+    if emulate:  # kernel: P (relative to the row max) is rounded to bf16 for the PV MFMA, row sum stays fp32
+        p = torch.exp(s - s.amax(-1, keepdim=True))
+        o = (bf16_round(p) @ v) / p.sum(-1, keepdim=True)
+    else:
+        o = torch.softmax(s, dim=-1) @ v
+    o = o.transpose(1, 2).reshape(B, N, D)
+    return _r(o, emulate)  # out_proj is applied by the caller (its output goes straight into the fp32 residual)
+
+
+def vit_forward(sd: SD, cfg: dict, pixels: torch.Tensor, num_layers: Optional[int] = None, emulate_bf16: bool = False):
+    """CLIPVisionTransformer.forward + CLIPEncoderLayer.forward of the reference:
+      vitron/model/multimodal_encoder/languagebind/video/modeling_video.py:610-675 and :65-158
+    pixels: [B,3,H,W] (image) or [B,3,T,H,W] (video). Returns the hidden state after `num_layers` encoder
+    layers as [B*T, N, D] fp32 (hidden_states[num_layers] in HF numbering; select_layer=-2 <=> L-1 layers)."""
+    D, heads, P = cfg["hidden_size"], cfg["num_attention_heads"], cfg["patch_size"]
+    L = cfg["num_hidden_layers"] if num_layers is None else num_layers
+    eps = cfg.get("layer_norm_eps", 1e-5)
+    act = cfg.get("hidden_act", "quick_gelu")
+    time_attn = bool(cfg.get("add_time_attn", False))
+    if pixels.dim() == 5:  # 'b c t h w -> (b t) c h w'   modeling_video.py:637-640
+        B, _, T, _, _ = pixels.shape
+        pixels = pixels.permute(0, 2, 1, 3, 4).reshape(B * T, 3, pixels.shape[3], pixels.shape[4])
+    else:
+        B, T = pixels.shape[0], 1
+    pixels = pixels.float()
+    # CLIPVisionEmbeddings: conv(k=s=P, no bias) -> flatten(2).transpose(1,2) -> cat CLS -> + position   (Appendix A)
+    pe = F.conv2d(pixels, sd["embeddings.patch_embedding.weight"].float(), stride=P)
+    pe = pe.flatten(2).transpose(1, 2)
+    cls = sd["embeddings.class_embedding"].float().expand(pe.shape[0], 1, -1)
+    x = torch.cat([cls, pe], dim=1) + sd["embeddings.position_embedding.weight"].float()[: pe.shape[1] + 1]
+    # PatchDropout is the identity at eval (modeling_video.py:31-32); pre_layrnorm :650
+    x = F.layer_norm(x, (D,), sd["pre_layrnorm.weight"].float(), sd["pre_layrnorm.bias"].float(), eps)
+    N = x.shape[1]
+    for l in range(L):
+        p = f"encoder.layers.{l}."
+        if time_attn:
+            t = cfg["num_frames"]
+            assert t == T, "video tower built for num_frames frames"
+            if t != 1:  # modeling_video.py:110-114 (the add changes the residual stream itself)
+                x = (x.view(B, T, N, D) + sd[p + "temporal_embedding"].float()[:, :t, None, :]).view(B * T, N, D)
+            res = x  # :117
+            h = x.view(B, T, N, D).transpose(1, 2).reshape(B * N, T, D)  # '(b t) n d -> (b n) t d'
+            h = _r(F.layer_norm(h, (D,), sd[p + "temporal_layer_norm1.weight"].float(),
+                                sd[p + "temporal_layer_norm1.bias"].float(), eps), emulate_bf16)
+            h = clip_attention(h, sd, p + "temporal_attn.", heads, emulate_bf16)
+            h = _lin(h, sd[p + "temporal_attn.out_proj.weight"], sd[p + "temporal_attn.out_proj.bias"])
+            x = res + h.view(B, N, T, D).transpose(1, 2).reshape(B * T, N, D)  # :127
+        res = x  # spatial attention :136-146
+        h = _r(F.layer_norm(x, (D,), sd[p + "layer_norm1.weight"].float(), sd[p + "layer_norm1.bias"].float(), eps), emulate_bf16)
+        h = clip_attention(h, sd, p + "self_attn.", heads, emulate_bf16)
+        x = res + _lin(h, sd[p + "self_attn.out_proj.weight"], sd[p + "self_attn.out_proj.bias"])
+        res = x  # MLP :148-151 (CLIPMLP: fc2(act(fc1(x))))
+        h = _r(F.layer_norm(x, (D,), sd[p + "layer_norm2.weight"].float(), sd[p + "layer_norm2.bias"].float(), eps), emulate_bf16)
+        h = _lin(h, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"])
+        h = F.gelu(h) if act == "gelu" else quick_gelu(h)
+        h = _r(h, emulate_bf16)
+        x = res + _lin(h, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
+    return x
+
+
+def tower_features(sd: SD, cfg: dict, pixels: torch.Tensor, select_layer: int = -2, emulate_bf16: bool = False):
+    """LanguageBind{Image,Video}Tower.forward + feature_select (reference languagebind/__init__.py:96-121,182-204):
+    hidden_states[select_layer], CLS dropped. Image -> [B, G*G, D]; video -> [B, T, G*G, D]."""
+    nl = cfg["num_hidden_layers"]
+    layers = select_layer if select_layer >= 0 else nl + 1 + select_layer  # index into the (L+1)-long hidden_states list
+    h = vit_forward(sd, cfg, pixels, layers, emulate_bf16)
+    h = _r(h[:, 1:], emulate_bf16)
+    if pixels.dim() == 5:
+        B, T = pixels.shape[0], pixels.shape[2]
+        return h.view(B, T, h.shape[1], h.shape[2])
+    return h
+
+
+# =====================================================================================================================
+# mm_projector  (reference vitron/model/multimodal_projector/builder.py:33-51 -- 'mlp2x_gelu')
+# =====================================================================================================================
+def projector_forward(sd: SD, x: torch.Tensor, emulate_bf16: bool = False):
+    if "2.weight" not in sd:  # 'linear'
+        return _r(_lin(x.float(), sd["weight"], sd["bias"]), emulate_bf16)
+    h = _r(F.gelu(_lin(x.float(), sd["0.weight"], sd["0.bias"])), emulate_bf16)
+    return _r(_lin(h, sd["2.weight"], sd["2.bias"]), emulate_bf16)
+
+
+# =====================================================================================================================
+# region_extractor  (reference vitron/model/region_extractor/layer.py)
+# =====================================================================================================================
+def region_mask(regions: Sequence[Sequence[float]], image_size: int) -> torch.Tensor:
+    """transform_bbox_2_mask, layer.py:77-85: mask[int(x1):int(x2), int(y1):int(y2)] = 1 -- x indexes rows."""
+    masks = []
+    for bbox in regions:
+        m = torch.zeros((image_size, image_size), dtype=torch.float32)
+        x1, y1, x2, y2 = bbox
+        m[int(x1):int(x2), int(y1):int(y2)] = 1
+        masks.append(m)
+    return torch.stack(masks, 0)
+
+
+def region_forward(sd: SD, feats: torch.Tensor, regions: Sequence[Sequence[float]], image_size: int = 224,
+                   emulate_bf16: bool = False, coords: Optional[torch.Tensor] = None):
+    """RegionExtractor.forward, layer.py:87-130. feats [B, G*G, C]. Returns (region_feats [B,1,H], cell_mask
+    [B,G*G] int, cell_count [B] int). `coords` overrides the LocationEncoder input (e.g. bf16-rounded coords)."""
+    b, n, c = feats.shape
+    g = int(math.sqrt(n))
+    feats = feats.float()
+    mask = region_mask(regions, image_size).unsqueeze(1)                                  # :112-114
+    fm = feats.reshape(b, g, g, c).permute(0, 3, 1, 2)                                    # :116
+    # MaskPooling.forward :27-43
+    if fm.shape[-2:] != mask.shape[-2:]:
+        mask = F.interpolate(mask, size=fm.shape[-2:], mode="bilinear", align_corners=False)
+    mask = (mask > 0).to(mask.dtype)
+    denorm = mask.sum(dim=(-1, -2), keepdim=True) + 1e-8
+    pooled = torch.einsum("bchw,bqhw->bqc", fm, mask / denorm)                            # :38-42
+    x = _r(pooled.reshape(-1, c), emulate_bf16)                                           # :122
+    # MLP (3 layers, ReLU between) :17-20
+    x = _r(F.relu(_lin(x, sd["region_linear.layers.0.weight"], sd["region_linear.layers.0.bias"])), emulate_bf16)
+    x = _r(F.relu(_lin(x, sd["region_linear.layers.1.weight"], sd["region_linear.layers.1.bias"])), emulate_bf16)
+    x = _lin(x, sd["region_linear.layers.2.weight"], sd["region_linear.layers.2.bias"])
+    # LocationEncoder on the raw box coordinates :46-56,126
+    loc_in = torch.tensor(regions, dtype=torch.float32) if coords is None else coords.float()
+    l = _r(F.relu(_lin(loc_in, sd["loc_encoder.loc_encoder.0.weight"], sd["loc_encoder.loc_encoder.0.bias"])), emulate_bf16)
+    l = _lin(l, sd["loc_encoder.loc_encoder.2.weight"], sd["loc_encoder.loc_encoder.2.bias"])
+    out = _r(x + l, emulate_bf16).unsqueeze(1)                                            # :129-130
+    cell_mask = mask.reshape(b, -1).to(torch.int32)
+    return out, cell_mask, cell_mask.sum(-1).to(torch.int32)
+
+
+# =====================================================================================================================
+# prompt -> ids helpers  (reference vitron/mm_utils.py)
+# =====================================================================================================================
+def tokenizer_image_token(prompt, tokenizer, image_token_index=IMAGE_TOKEN_INDEX, is_first=True):
+    """mm_utils.py:80-99."""
+    prompt_chunks = [tokenizer(chunk).input_ids for chunk in prompt.split("<image>")]
+
+    def insert_separator(X, sep):
+        return [ele for sublist in zip(X, [sep] * len(X)) for ele in sublist][:-1]
+
+    input_ids = []
+    offset = 0
+    if len(prompt_chunks) > 0 and len(prompt_chunks[0]) > 0 and prompt_chunks[0][0] == tokenizer.bos_token_id and is_first:
+        offset = 1
+        input_ids.append(prompt_chunks[0][0])
+    for x in insert_separator(prompt_chunks, [image_token_index] * (offset + 1)):
+        input_ids.extend(x[offset:])
+    return input_ids
+
+
+def tokenizer_image_region_token(prompt, tokenizer, region_token_index=OBJS_TOKEN_INDEX):
+    """mm_utils.py:102-117."""
+    input_ids = []
+    chunks = prompt.split("<objs>")
+    for idx, ck in enumerate(chunks):
+        input_ids.extend(tokenizer_image_token(ck, tokenizer, is_first=(idx == 0)))
+        if idx < len(chunks) - 1:
+            input_ids.extend([region_token_index])
+    return input_ids
+
+
+def preprocess_region(region, image_size, target_size):
+    """mm_utils.py:121-135."""
+    x1, y1, x2, y2 = region
+    sx = target_size[0] / image_size[0]
+    sy = target_size[1] / image_size[1]
+    return [x1 * sx, y1 * sy, x2 * sx, y2 * sy]
+
+
+# =====================================================================================================================
+# multimodal glue  (reference vitron/model/llava_arch.py:189-573)
+# =====================================================================================================================
+def splice_embeddings(input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor], embed_tokens: torch.Tensor,
+                      image_features: List[torch.Tensor], region_features: Optional[List[torch.Tensor]],
+                      max_length: Optional[int] = None, padding_side: str = "right"):
+    """prepare_inputs_labels_for_multimodal after the encoders ran: the list surgery of llava_arch.py:306-398
+    (region branch; the plain branch :479-558 is the same loop without the -300 case).
+    image_features: flat list, one [P,H] block per image / per video FRAME (llava_arch.py:259-270);
+    region_features: parallel list ([1,H] per image, dummies for frames) or None.
+    Returns (inputs_embeds [B,S,H], attention_mask [B,S] bool, position_ids [B,S] long)."""
+    B, Lmax = input_ids.shape
+    if attention_mask is None:
+        attention_mask = torch.ones_like(input_ids, dtype=torch.bool)
+    else:
+        attention_mask = attention_mask.bool()
+    ids_list = [ids[m] for ids, m in zip(input_ids, attention_mask)]  # :302
+    new_embeds = []
+    cur_image_idx = 0
+    for cur in ids_list:
+        num_images = int((cur == IMAGE_TOKEN_INDEX).sum())
+        if num_images == 0:  # :310-324 (consumes one feature slot, appends an empty slice)
+            new_embeds.append(torch.cat([embed_tokens[cur], image_features[cur_image_idx][0:0]], dim=0))
+            cur_image_idx += 1
+            continue
+        specials = sorted(torch.where(cur == IMAGE_TOKEN_INDEX)[0].tolist() +
+                          (torch.where(cur == OBJS_TOKEN_INDEX)[0].tolist() if region_features is not None else []))
+        bounds = [-1] + specials + [cur.shape[0]]
+        parts = []
+        for i in range(len(bounds) - 1):
+            seg = cur[bounds[i] + 1: bounds[i + 1]]
+            parts.append(embed_tokens[seg])
+            if i < len(specials):
+                tok = int(cur[specials[i]])
+                if tok == IMAGE_TOKEN_INDEX:
+                    parts.append(image_features[cur_image_idx])
+                    cur_image_idx += 1
+                else:  # -300 binds to the most recently consumed image  :350-351
+                    parts.append(region_features[cur_image_idx - 1])
+        new_embeds.append(torch.cat(parts, dim=0))
+    if max_length is not None:  # :363-366
+        new_embeds = [x[:max_length] for x in new_embeds]
+    max_len = max(x.shape[0] for x in new_embeds)
+    H = embed_tokens.shape[1]
+    out = torch.zeros((B, max_len, H), dtype=new_embeds[0].dtype)
+    mask = torch.zeros((B, max_len), dtype=torch.bool)
+    pos = torch.zeros((B, max_len), dtype=torch.long)
+    for i, e in enumerate(new_embeds):  # :375-396
+        n = e.shape[0]
+        if n == 0:
+            continue
+        if padding_side == "left":
+            out[i, -n:] = e
+            mask[i, -n:] = True
+            pos[i, -n:] = torch.arange(n)
+        else:
+            out[i, :n] = e
+            mask[i, :n] = True
+            pos[i, :n] = torch.arange(n)
+    return out, mask, pos
+
+
+# =====================================================================================================================
+# LLaMA decoder  (transformers-4.31 LlamaForCausalLM; driven by reference llava_llama.py:57-102)
+# =====================================================================================================================
+def rope_tables(head_dim: int, max_pos: int, theta: float = 10000.0):
+    """LlamaRotaryEmbedding (Appendix A): inv_freq = 1/theta^(arange(0,hd,2)/hd); freqs = outer(t, inv_freq);
+    returns cos, sin [max_pos, hd/2] fp32 (the second half of the HF table repeats the first)."""
+    inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2).float() / head_dim))
+    t = torch.arange(max_pos, dtype=torch.float32)
+    freqs = torch.outer(t, inv_freq)
+    return freqs.cos(), freqs.sin()
+
+
+def _rope(x, cos, sin):
+    """apply_rotary_pos_emb with rotate_half = cat(-x2, x1) (half-split). x [.., S, hd]; cos/sin [S, hd/2]."""
+    h = x.shape[-1] // 2
+    x1, x2 = x[..., :h], x[..., h:]
+    return torch.cat([x1 * cos - x2 * sin, x2 * cos + x1 * sin], dim=-1)
+
+
+def rmsnorm(x, w, eps):
+    """LlamaRMSNorm: variance in fp32, x * rsqrt(var + eps), then * weight."""
+    var = x.float().pow(2).mean(-1, keepdim=True)
+    return w.float() * (x.float() * torch.rsqrt(var + eps))
+
+
+def llama_forward(sd: SD, cfg: dict, inputs_embeds: torch.Tensor, position_ids: Optional[torch.Tensor] = None,
+                  attention_mask: Optional[torch.Tensor] = None, past: Optional[list] = None,
+                  emulate_bf16: bool = False, num_layers: Optional[int] = None, return_hidden: bool = False):
+    """LlamaModel + lm_head. inputs_embeds [B,S,H]; attention_mask [B, past+S] (1 = attend) or None;
+    past = list of (k,v) per layer, each [B,heads,Sp,hd]. Returns (logits [B,S,V] fp32, new_past[, hidden])."""
+    B, S, H = inputs_embeds.shape
+    heads = cfg["num_attention_heads"]
+    hd = H // heads
+    L = cfg["num_hidden_layers"] if num_layers is None else num_layers
+    eps = cfg.get("rms_norm_eps", 1e-5)
+    Sp = 0 if past is None else past[0][0].shape[2]
+    if position_ids is None:
+        position_ids = torch.arange(Sp, Sp + S).unsqueeze(0).expand(B, S)
+    cos_t, sin_t = rope_tables(hd, int(position_ids.max()) + 1, cfg.get("rope_theta", 10000.0))
+    cos = cos_t[position_ids].unsqueeze(1)  # [B,1,S,hd/2]
+    sin = sin_t[position_ids].unsqueeze(1)
+    # _prepare_decoder_attention_mask: causal + padding, additive finfo.min
+    kv_len = Sp + S
+    neg = torch.finfo(torch.float32).min
+    causal = torch.full((S, kv_len), neg)
+    causal = torch.triu(causal, diagonal=Sp + 1)
+    mask = causal[None, None]
+    if attention_mask is not None:
+        pad = (1.0 - attention_mask[:, None, None, :].float()) * neg
+        mask = torch.clamp(mask + pad, min=neg)
+    x = inputs_embeds.float()
+    new_past = []
+    for l in range(L):
+        p = f"model.layers.{l}."
+        h = _r(rmsnorm(x, sd[p + "input_layernorm.weight"], eps), emulate_bf16)
+        q = _r(_lin(h, sd[p + "self_attn.q_proj.weight"]), emulate_bf16).view(B, S, heads, hd).transpose(1, 2)
+        k = _r(_lin(h, sd[p + "self_attn.k_proj.weight"]), emulate_bf16).view(B, S, heads, hd).transpose(1, 2)
+        v = _r(_lin(h, sd[p + "self_attn.v_proj.weight"]), emulate_bf16).view(B, S, heads, hd).transpose(1, 2)
+        q = _r(_rope(q, cos, sin), emulate_bf16)
+        k = _r(_rope(k, cos, sin), emulate_bf16)
+        if past is not None:
+            k = torch.cat([past[l][0], k], dim=2)
+            v = torch.cat([past[l][1], v], dim=2)
+        new_past.append((k, v))
+        s = q @ k.transpose(-1, -2) / math.sqrt(hd) + mask
+        if emulate_bf16:
+            pr = torch.exp(s - s.amax(-1, keepdim=True))
+            o = (bf16_round(pr) @ v) / pr.sum(-1, keepdim=True)
+        else:
+            o = torch.softmax(s, dim=-1, dtype=torch.float32) @ v
+        o = _r(o.transpose(1, 2).reshape(B, S, H), emulate_bf16)
+        x = x + _lin(o, sd[p + "self_attn.o_proj.weight"])
+        h = _r(rmsnorm(x, sd[p + "post_attention_layernorm.weight"], eps), emulate_bf16)
+        g = _lin(h, sd[p + "mlp.gate_proj.weight"])
+        u = _lin(h, sd[p + "mlp.up_proj.weight"])
+        a = _r(F.silu(g) * u, emulate_bf16)
+        x = x + _lin(a, sd[p + "mlp.down_proj.weight"])
+    hidden = x
+    xn = _r(rmsnorm(x, sd["model.norm.weight"], eps), emulate_bf16)
+    logits = _lin(xn, sd["lm_head.weight"]).float()
+    if return_hidden:
+        return logits, new_past, hidden
+    return logits, new_past
+
+
+def greedy_generate(sd: SD, cfg: dict, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor,
+                    position_ids: torch.Tensor, max_new_tokens: int, emulate_bf16: bool = False,
+                    eos_token_id: Optional[int] = None):
+    """Greedy GenerationMixin loop with Vitron's decode-step fix-up (reference llava_arch.py:196-205): on every
+    step the mask is extended to past_len+1 and position_ids = sum(mask) - 1. Returns [B, <=max_new_tokens] ids."""
+    B = inputs_embeds.shape[0]
+    embed = sd["model.embed_tokens.weight"].float()
+    logits, past = llama_forward(sd, cfg, inputs_embeds, position_ids, attention_mask, None, emulate_bf16)
+    last = attention_mask.long().sum(1) - 1  # right padding: last valid position
+    nxt = logits[torch.arange(B), last].argmax(-1)
+    out = [nxt]
+    mask = attention_mask.clone()
+    finished = torch.zeros(B, dtype=torch.bool)
+    for _ in range(max_new_tokens - 1):
+        if eos_token_id is not None:
+            finished |= nxt == eos_token_id
+            if bool(finished.all()):
+                break
+        target = past[0][0].shape[2] + 1
+        mask = torch.cat([mask, torch.ones((B, target - mask.shape[1]), dtype=mask.dtype)], dim=1)
+        pos = mask.long().sum(1, keepdim=True) - 1
+        logits, past = llama_forward(sd, cfg, embed[nxt].unsqueeze(1), pos, mask, past, emulate_bf16)
+        nxt = logits[:, -1].argmax(-1)
+        out.append(nxt)
+    return torch.stack(out, dim=1)
+
+
+# =====================================================================================================================
+# whole multimodal prefill, as the reference's LlavaLlamaForCausalLM.forward runs it (llava_llama.py:57-102)
+# =====================================================================================================================
+def multimodal_prepare(weights: dict, cfgs: dict, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor],
+                       images: Sequence[torch.Tensor], regions: Optional[Sequence[Sequence[float]]],
+                       max_length: Optional[int] = None, padding_side: str = "right", emulate_bf16: bool = False,
+                       region_image_size: int = 224):
+    """prepare_inputs_labels_for_multimodal, llava_arch.py:189-573, encoders included.
+    weights: {'image_tower','video_tower','projector','region','llama'} state dicts; cfgs: {'image','video','llama'}.
+    `images` is the reference's mixed list: 3-D tensors are images, 4-D tensors (C,T,H,W) are videos (:234-237)."""
+    use_regions = regions is not None and len(regions) > 0          # :233
+    image_idx = [i for i, im in enumerate(images) if im.dim() == 3]
+    video_idx = [i for i, im in enumerate(images) if im.dim() == 4]
+    feats: List = [None] * len(images)
+    regs: List = [None] * len(images)
+    if image_idx:
+        batch = torch.stack([images[i] for i in image_idx])
+        f = tower_features(weights["image_tower"], cfgs["image"], batch, -2, emulate_bf16)      # encode_images :168-181
+        if use_regions:
+            rb = [regions[i] for i in image_idx]                                                # :241
+            coords = bf16_round(torch.tensor(rb, dtype=torch.float32)) if emulate_bf16 else None
+            r, _, _ = region_forward(weights["region"], f, rb, region_image_size, emulate_bf16, coords)
+        pf = projector_forward(weights["projector"], f, emulate_bf16)
+        for j, i in enumerate(image_idx):
+            feats[i] = pf[j]
+            regs[i] = r[j] if use_regions else None
+    if video_idx:
+        batch = torch.stack([images[i] for i in video_idx])
+        f = tower_features(weights["video_tower"], cfgs["video"], batch, -2, emulate_bf16)      # encode_videos :183-187
+        pf = projector_forward(weights["projector"], f, emulate_bf16)
+        for j, i in enumerate(video_idx):
+            feats[i] = [pf[j][t] for t in range(pf.shape[1])]                                   # :255-258
+            regs[i] = [None] * pf.shape[1]
+    flat_f, flat_r = [], []
+    for f, r in zip(feats, regs):
+        if isinstance(f, list):
+            flat_f += f
+            flat_r += r
+        else:
+            flat_f.append(f)
+            flat_r.append(r)
+    embed = weights["llama"]["model.embed_tokens.weight"].float()
+    return splice_embeddings(input_ids, attention_mask, embed, flat_f, flat_r if use_regions else None,
+                             max_length, padding_side)
+
+
+def multimodal_forward(weights: dict, cfgs: dict, input_ids, attention_mask, images, regions, max_length=None,
+                       padding_side="right", emulate_bf16=False):
+    """Returns (logits [B,S,V], inputs_embeds, mask, position_ids) of the prefill pass."""
+    embeds, mask, pos = multimodal_prepare(weights, cfgs, input_ids, attention_mask, images, regions, max_length,
+                                           padding_side, emulate_bf16)
+    # the reference hands attention_mask/position_ids back as None when the caller passed None (:400-411)
+    am = mask if attention_mask is not None else None
+    logits, _ = llama_forward(weights["llama"], cfgs["llama"], embeds, pos if attention_mask is not None else None,
+                              am, None, emulate_bf16)
+    return logits, embeds, mask, pos

@@ -1,0 +1,89 @@
+"""Shared definitions of the golden cases: tiny configs, seeds and seeded inputs.
+
+Imported by tests/golden/make_golden.py (which runs the REFERENCE on them) and by the tests (which run the
+oracle and the HIP path on the very same inputs). Head dims are the real ones (64 for the ViT, 128 for the LLM)
+because the kernels are specialised for them; widths, depths and sequence lengths are shrunk.
+"""
+from __future__ import annotations
+
+import torch
+
+SEED_VIT, SEED_PIX, SEED_REGION, SEED_FEATS, SEED_PROJ, SEED_LLM, SEED_IDS = 1234, 4321, 77, 78, 79, 80, 81
+
+VIT_VIDEO = dict(hidden_size=128, intermediate_size=256, num_hidden_layers=3, num_attention_heads=2, patch_size=14,
+                 image_size=56, hidden_act="gelu", layer_norm_eps=1e-5, add_time_attn=True, num_frames=4)
+VIT_IMAGE = dict(VIT_VIDEO, add_time_attn=False, num_frames=1)
+MM_HIDDEN = 128
+LLM = dict(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2, vocab_size=512,
+           rms_norm_eps=1e-5, rope_theta=10000.0, max_position_embeddings=512)
+
+# init scales: larger than the 0.02 of the benchmark so attention / biases / norm affine actually matter
+VIT_INIT = dict(w_std=0.05, b_std=0.05, ln_jitter=0.1, attn_std=0.15)
+MLP_INIT = dict(w_std=0.05, b_std=0.05)
+LLM_INIT = dict(w_std=0.05, ln_jitter=0.1, attn_std=0.12)
+
+# boxes in the 224-pixel space of RegionExtractor; the last one selects no cell (empty mask)
+BOXES = [[0, 0, 224, 224], [0, 58.94736842105263, 117.89473684210526, 117.89473684210526], [100, 20, 180, 200],
+         [7, 7, 8, 8], [0, 0, 6, 6]]
+REGION_CASES = {"g16": (128, 256, 16), "g4": (128, 256, 4)}
+
+PROMPTS = ["ab<image>cd", "<image><image>\nq", "a<image>\n<objs> b", "x<objs>y<objs>", "plain text", ""]
+REGION_RESCALE = [([0, 100, 300, 200], [570, 380], [224, 224]), ([12.5, 3, 99, 640], [640, 480], [336, 336])]
+
+
+def bf16r(x: torch.Tensor) -> torch.Tensor:
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def pixels(shape, seed):
+    g = torch.Generator().manual_seed(seed)
+    return bf16r(torch.randn(shape, generator=g))
+
+
+def features(shape, seed):
+    g = torch.Generator().manual_seed(seed)
+    return bf16r(torch.randn(shape, generator=g))
+
+
+def _ids(n, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(3, LLM["vocab_size"], (n,), generator=g).tolist()
+
+
+def glue_cases():
+    """input_ids (with -200/-300 sentinels), images list, regions list -> what the reference's
+    prepare_inputs_labels_for_multimodal + forward are run on."""
+    img = lambda s: pixels((3, 56, 56), SEED_PIX + s)  # noqa: E731
+    vid = lambda s: pixels((3, VIT_VIDEO["num_frames"], 56, 56), SEED_PIX + 100 + s)  # noqa: E731
+    T = VIT_VIDEO["num_frames"]
+    c = {}
+    # image + region prompt (app.py:525-534 layout: <image>\n<objs> ...); stray BOS after -300 (Appendix B quirk)
+    ids = [1] + _ids(2, SEED_IDS) + [-200] + _ids(3, SEED_IDS + 1) + [-300, 1] + _ids(4, SEED_IDS + 2)
+    c["image_region"] = dict(input_ids=torch.tensor([ids]), attention_mask=None, images=[img(0)], regions=[BOXES[1]])
+    # one clip: T consecutive -200 (app.py:520), no regions
+    ids = [1] + [-200] * T + _ids(5, SEED_IDS + 3)
+    c["video"] = dict(input_ids=torch.tensor([ids]), attention_mask=None, images=[vid(0)], regions=None)
+    # batch of two with different lengths -> right padding; sample 1 has an image but no <objs>
+    a = [1] + _ids(1, SEED_IDS + 4) + [-200, -300] + _ids(6, SEED_IDS + 5)
+    b = [1, -200] + _ids(2, SEED_IDS + 6)
+    L = max(len(a), len(b))
+    ids = torch.tensor([a + [0] * (L - len(a)), b + [0] * (L - len(b))])
+    am = torch.tensor([[1] * len(a) + [0] * (L - len(a)), [1] * len(b) + [0] * (L - len(b))])
+    c["batch_pad"] = dict(input_ids=ids, attention_mask=am, images=[img(1), img(2)], regions=[BOXES[2], BOXES[0]])
+    # text-only turn that still passes a (zeros) image and the default region (app.py:492,554-557)
+    ids = [1] + _ids(9, SEED_IDS + 7)
+    c["text_only"] = dict(input_ids=torch.tensor([ids]), attention_mask=None, images=[torch.zeros(3, 56, 56)],
+                          regions=[[0, 0, 224, 224]])
+    # video + image in one sample (videos come first in `images`, app.py:559), truncated by tokenizer_model_max_length
+    ids = [1] + [-200] * T + _ids(2, SEED_IDS + 8) + [-200, -300] + _ids(3, SEED_IDS + 9)
+    c["video_image_trunc"] = dict(input_ids=torch.tensor([ids]), attention_mask=None, images=[vid(1), img(3)],
+                                  regions=[BOXES[0], BOXES[3]], max_length=70)
+    # same, left padding side, in a batch with a short text+image sample
+    a = [1] + _ids(2, SEED_IDS + 10) + [-200] + _ids(2, SEED_IDS + 11)
+    b = [1] + _ids(1, SEED_IDS + 12) + [-200, -300]
+    L = max(len(a), len(b))
+    ids = torch.tensor([a + [0] * (L - len(a)), b + [0] * (L - len(b))])
+    am = torch.tensor([[1] * len(a) + [0] * (L - len(a)), [1] * len(b) + [0] * (L - len(b))])
+    c["batch_left"] = dict(input_ids=ids, attention_mask=am, images=[img(4), img(5)], regions=[BOXES[1], BOXES[2]],
+                           padding_side="left")
+    return c

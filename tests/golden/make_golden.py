@@ -1,0 +1,182 @@
+"""Generate tests/golden/*.npz from the REFERENCE's own modules (run in the build container only).
+
+    python tests/golden/make_golden.py            # needs /root/reference (read-only) and oracle/ref_shim.py
+
+The reference ships no golden vectors for this path, so these fixtures are what pins the oracle:
+each file holds the OUTPUTS the reference's code produced for seeded synthetic weights/inputs. The weights are
+not stored: they are regenerated from the seed by vitron_amd.synth (a checksum of the regenerated state dict is
+stored and verified by the tests). All tensors fp32, CPU, eager attention.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import ref_shim  # noqa: E402
+from vitron_amd import synth  # noqa: E402
+from tests.golden import cases  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def f32(sd):
+    return {k: v.float() for k, v in sd.items()}
+
+
+def build_ref_vit(ns, cfg, sd):
+    # video tower: video/modeling_video.py; image tower: image/modeling_image.py (no 'b t n c' view of hidden states)
+    if cfg["add_time_attn"]:
+        cv, mv = ns.configuration_video, ns.modeling_video
+    else:
+        cv, mv = ns.configuration_image, ns.modeling_image
+    c = cv.CLIPVisionConfig(hidden_size=cfg["hidden_size"], intermediate_size=cfg["intermediate_size"],
+                            num_hidden_layers=cfg["num_hidden_layers"], num_attention_heads=cfg["num_attention_heads"],
+                            image_size=cfg["image_size"], patch_size=cfg["patch_size"], hidden_act=cfg["hidden_act"],
+                            layer_norm_eps=cfg["layer_norm_eps"], add_time_attn=cfg["add_time_attn"],
+                            num_frames=cfg["num_frames"])
+    m = mv.CLIPVisionTransformer(c).eval()
+    missing, unexpected = m.load_state_dict(f32(sd), strict=False)
+    assert not unexpected, unexpected
+    assert all("position_ids" in k for k in missing), missing
+    return m
+
+
+def gen_vit(ns):
+    out = {}
+    for name, cfg, shape in (("video", cases.VIT_VIDEO, (2, 3, cases.VIT_VIDEO["num_frames"], 56, 56)),
+                             ("image", cases.VIT_IMAGE, (3, 3, 56, 56))):
+        sd = synth.vit_state(cfg, synth.make_generator(cases.SEED_VIT), **cases.VIT_INIT)
+        m = build_ref_vit(ns, cfg, sd)
+        x = cases.pixels(shape, cases.SEED_PIX)
+        with torch.no_grad():
+            o = m(x, output_hidden_states=True)
+        hs = o.hidden_states
+        out[f"{name}_checksum"] = np.float64(synth.checksum(sd))
+        for i, h in enumerate(hs):
+            out[f"{name}_hidden_{i}"] = h.reshape(-1, h.shape[-2], h.shape[-1]).numpy()
+    np.savez_compressed(os.path.join(OUT, "vit.npz"), **out)
+    print("vit.npz", {k: getattr(v, "shape", v) for k, v in out.items()})
+
+
+def gen_region_projector(ns):
+    out = {}
+    # region extractor at the reference-native geometry (224 canvas, 16x16 grid) and on a 4x4 grid
+    for tag, (cin, cout, G) in cases.REGION_CASES.items():
+        sd = synth.region_state(cin, cout, synth.make_generator(cases.SEED_REGION), **cases.MLP_INIT)
+        m = ns.region_layer.RegionExtractor(cin, cout).eval()
+        m.load_state_dict(f32(sd))
+        feats = cases.features((len(cases.BOXES), G * G, cin), cases.SEED_FEATS)
+        with torch.no_grad():
+            r = m(feats, cases.BOXES)
+            # the integer side: bbox -> canvas -> bilinear -> >0  (layer.py:27-35,77-85)
+            canvas = m.transform_bbox_2_mask(cases.BOXES, m.image_size, feats.device, feats.dtype).unsqueeze(1)
+            grid = torch.nn.functional.interpolate(canvas, size=(G, G), mode="bilinear", align_corners=False)
+        out[f"region_{tag}_checksum"] = np.float64(synth.checksum(sd))
+        out[f"region_{tag}_out"] = r.numpy()
+        out[f"region_{tag}_cells"] = (grid > 0).reshape(len(cases.BOXES), -1).numpy().astype(np.int32)
+    sd = synth.projector_state(cases.MM_HIDDEN, cases.LLM["hidden_size"], synth.make_generator(cases.SEED_PROJ), **cases.MLP_INIT)
+    cfg = types.SimpleNamespace(mm_projector_type="mlp2x_gelu", mm_hidden_size=cases.MM_HIDDEN, hidden_size=cases.LLM["hidden_size"])
+    pm = ns.projector_builder.build_vision_projector(cfg).eval()
+    pm.load_state_dict(f32(sd))
+    x = cases.features((37, cases.MM_HIDDEN), cases.SEED_FEATS + 1)
+    with torch.no_grad():
+        out["projector_out"] = pm(x).numpy()
+    out["projector_checksum"] = np.float64(synth.checksum(sd))
+    np.savez_compressed(os.path.join(OUT, "region_projector.npz"), **out)
+    print("region_projector.npz", {k: getattr(v, "shape", v) for k, v in out.items()})
+
+
+class _StubTok:  # the stub tokenizer of SURVEY.md Appendix B: ids = [BOS] + [100 + ord(c)]
+    bos_token_id = 1
+
+    def __call__(self, text):
+        return types.SimpleNamespace(input_ids=[1] + [100 + ord(c) for c in text])
+
+
+def gen_mm_utils(ns):
+    mu = ns.mm_utils
+    tok = _StubTok()
+    out = {}
+    for i, p in enumerate(cases.PROMPTS):
+        out[f"image_token_{i}"] = np.array(mu.tokenizer_image_token(p, tok), dtype=np.int64)
+        out[f"region_token_{i}"] = np.array(mu.tokenizer_image_region_token(p, tok), dtype=np.int64)
+    for i, (r, isz, tsz) in enumerate(cases.REGION_RESCALE):
+        out[f"preprocess_region_{i}"] = np.array(mu.preprocess_region(r, isz, tsz), dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "mm_utils.npz"), **out)
+    print("mm_utils.npz", {k: v.tolist() for k, v in out.items()})
+
+
+def build_ref_llava(ns):
+    """The reference's LlavaLlamaForCausalLM with tiny towers attached."""
+    ll, lb = ns.llava_llama, sys.modules["vitron.model.multimodal_encoder.languagebind"]
+    L = cases.LLM
+    cfg = ll.LlavaConfig(hidden_size=L["hidden_size"], intermediate_size=L["intermediate_size"],
+                         num_hidden_layers=L["num_hidden_layers"], num_attention_heads=L["num_attention_heads"],
+                         num_key_value_heads=L["num_attention_heads"], vocab_size=L["vocab_size"],
+                         rms_norm_eps=L["rms_norm_eps"], max_position_embeddings=L["max_position_embeddings"],
+                         rope_theta=L["rope_theta"], tie_word_embeddings=False)
+    cfg._attn_implementation = "eager"
+    cfg.pretraining_tp = 1
+    import io
+    import contextlib
+    with contextlib.redirect_stdout(io.StringIO()):  # the reference prints the whole config in __init__
+        model = ll.LlavaLlamaForCausalLM(cfg).eval()
+    lsd = synth.llama_state(L, synth.make_generator(cases.SEED_LLM), **cases.LLM_INIT)
+    missing, unexpected = model.load_state_dict(f32(lsd), strict=False)
+    assert not unexpected and all("rotary" in k or "inv_freq" in k for k in missing), (missing, unexpected)
+
+    def tower(cls, attr, vit_cfg):
+        sd = synth.vit_state(vit_cfg, synth.make_generator(cases.SEED_VIT), **cases.VIT_INIT)
+        t = cls.__new__(cls)
+        nn.Module.__init__(t)
+        t.is_loaded = True
+        t.select_layer = -2
+        t.select_feature = "patch"
+        setattr(t, attr, build_ref_vit(ns, vit_cfg, sd))
+        return t
+
+    model.model.image_tower = tower(lb.LanguageBindImageTower, "image_tower", cases.VIT_IMAGE)
+    model.model.video_tower = tower(lb.LanguageBindVideoTower, "video_tower", cases.VIT_VIDEO)
+    pcfg = types.SimpleNamespace(mm_projector_type="mlp2x_gelu", mm_hidden_size=cases.MM_HIDDEN, hidden_size=L["hidden_size"])
+    model.model.mm_projector = ns.projector_builder.build_vision_projector(pcfg).eval()
+    model.model.mm_projector.load_state_dict(f32(synth.projector_state(cases.MM_HIDDEN, L["hidden_size"], synth.make_generator(cases.SEED_PROJ), **cases.MLP_INIT)))
+    # the reference builds RegionExtractor(mm_hidden, hidden) with its default 224 canvas (region_extractor/builder.py:5)
+    model.model.region_extractor = ns.region_layer.RegionExtractor(cases.MM_HIDDEN, L["hidden_size"]).eval()
+    model.model.region_extractor.load_state_dict(f32(synth.region_state(cases.MM_HIDDEN, L["hidden_size"], synth.make_generator(cases.SEED_REGION), **cases.MLP_INIT)))
+    return model
+
+
+def gen_glue(ns):
+    import io
+    import contextlib
+    model = build_ref_llava(ns)
+    out = {}
+    for name, case in cases.glue_cases().items():
+        model.config.tokenizer_model_max_length = case.get("max_length")
+        model.config.tokenizer_padding_side = case.get("padding_side", "right")
+        ids, am = case["input_ids"], case["attention_mask"]
+        with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+            (_, pos, mask, _, embeds, _) = model.prepare_inputs_labels_for_multimodal(
+                ids, None, am, None, None, case["images"], case["regions"])
+            logits = model(input_ids=ids, attention_mask=am, images=case["images"], regions=case["regions"]).logits
+        out[f"{name}_embeds"] = embeds.numpy()
+        out[f"{name}_logits"] = logits.float().numpy()
+        out[f"{name}_mask"] = (mask if mask is not None else torch.ones(embeds.shape[:2])).numpy().astype(np.int32)
+    np.savez_compressed(os.path.join(OUT, "glue_llm.npz"), **out)
+    print("glue_llm.npz", {k: v.shape for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    ns = ref_shim.install()
+    gen_mm_utils(ns)
+    gen_vit(ns)
+    gen_region_projector(ns)
+    gen_glue(ns)

@@ -1,0 +1,111 @@
+"""Pin the CPU oracle (oracle/vitron_oracle.py) against golden vectors produced by the REFERENCE's own modules
+(tests/golden/make_golden.py, run in the build container against /root/reference). CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vitron_oracle as O
+from tests.golden import cases
+from vitron_amd import synth
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def f32(sd):
+    return {k: v.float() for k, v in sd.items()}
+
+
+class StubTok:
+    bos_token_id = 1
+
+    def __call__(self, text):
+        class R:
+            pass
+        r = R()
+        r.input_ids = [1] + [100 + ord(c) for c in text]
+        return r
+
+
+def test_mm_utils_known_answers():
+    g = np.load(os.path.join(G, "mm_utils.npz"))
+    tok = StubTok()
+    for i, p in enumerate(cases.PROMPTS):
+        assert O.tokenizer_image_token(p, tok) == g[f"image_token_{i}"].tolist()
+        assert O.tokenizer_image_region_token(p, tok) == g[f"region_token_{i}"].tolist()
+    for i, (r, isz, tsz) in enumerate(cases.REGION_RESCALE):
+        assert O.preprocess_region(r, isz, tsz) == g[f"preprocess_region_{i}"].tolist()
+    # the known answers quoted in SURVEY.md Appendix B
+    assert O.tokenizer_image_token("ab<image>cd", tok) == [1, 197, 198, -200, 199, 200]
+    assert O.tokenizer_image_region_token("a<image>\n<objs> b", tok) == [1, 197, -200, 110, -300, 1, 132, 198]
+
+
+@pytest.mark.parametrize("name,cfg,shape", [("video", cases.VIT_VIDEO, (2, 3, 4, 56, 56)), ("image", cases.VIT_IMAGE, (3, 3, 56, 56))])
+def test_vit_hidden_states(name, cfg, shape):
+    g = np.load(os.path.join(G, "vit.npz"))
+    sd = synth.vit_state(cfg, synth.make_generator(cases.SEED_VIT), **cases.VIT_INIT)
+    assert synth.checksum(sd) == pytest.approx(float(g[f"{name}_checksum"]), rel=1e-12)
+    x = cases.pixels(shape, cases.SEED_PIX)
+    for nl in range(cfg["num_hidden_layers"] + 1):
+        h = O.vit_forward(f32(sd), cfg, x, num_layers=nl)
+        assert rel(h, g[f"{name}_hidden_{nl}"]) <= 1e-5, nl
+    # feature_select: hidden_states[-2] without CLS
+    f = O.tower_features(f32(sd), cfg, x, -2)
+    ref = torch.as_tensor(g[f"{name}_hidden_{cfg['num_hidden_layers'] - 1}"])[:, 1:]
+    assert rel(f.reshape(ref.shape), ref) <= 1e-5
+
+
+@pytest.mark.parametrize("tag", list(cases.REGION_CASES))
+def test_region_extractor(tag):
+    g = np.load(os.path.join(G, "region_projector.npz"))
+    cin, cout, grid = cases.REGION_CASES[tag]
+    sd = synth.region_state(cin, cout, synth.make_generator(cases.SEED_REGION), **cases.MLP_INIT)
+    assert synth.checksum(sd) == pytest.approx(float(g[f"region_{tag}_checksum"]), rel=1e-12)
+    feats = cases.features((len(cases.BOXES), grid * grid, cin), cases.SEED_FEATS)
+    out, cells, count = O.region_forward(f32(sd), feats, cases.BOXES)
+    assert np.array_equal(cells.numpy(), g[f"region_{tag}_cells"])          # integer side: bit exact
+    assert rel(out, g[f"region_{tag}_out"]) <= 1e-5
+    if tag == "g16":  # SURVEY.md 8(c) known answer: box 1 -> rows 0-7 x cols 4-7 of the 16x16 grid
+        m = cells[1].reshape(16, 16)
+        assert int(count[1]) == 32 and bool(m[0:8, 4:8].all()) and int(count[3]) == 1 and int(count[4]) == 0
+
+
+def test_projector():
+    g = np.load(os.path.join(G, "region_projector.npz"))
+    sd = synth.projector_state(cases.MM_HIDDEN, cases.LLM["hidden_size"], synth.make_generator(cases.SEED_PROJ), **cases.MLP_INIT)
+    x = cases.features((37, cases.MM_HIDDEN), cases.SEED_FEATS + 1)
+    assert rel(O.projector_forward(f32(sd), x), g["projector_out"]) <= 1e-5
+
+
+def oracle_weights():
+    w = {
+        "image_tower": f32(synth.vit_state(cases.VIT_IMAGE, synth.make_generator(cases.SEED_VIT), **cases.VIT_INIT)),
+        "video_tower": f32(synth.vit_state(cases.VIT_VIDEO, synth.make_generator(cases.SEED_VIT), **cases.VIT_INIT)),
+        "projector": f32(synth.projector_state(cases.MM_HIDDEN, cases.LLM["hidden_size"], synth.make_generator(cases.SEED_PROJ), **cases.MLP_INIT)),
+        "region": f32(synth.region_state(cases.MM_HIDDEN, cases.LLM["hidden_size"], synth.make_generator(cases.SEED_REGION), **cases.MLP_INIT)),
+        "llama": f32(synth.llama_state(cases.LLM, synth.make_generator(cases.SEED_LLM), **cases.LLM_INIT)),
+    }
+    cfgs = {"image": cases.VIT_IMAGE, "video": cases.VIT_VIDEO, "llama": cases.LLM}
+    return w, cfgs
+
+
+@pytest.mark.parametrize("name", list(cases.glue_cases()))
+def test_glue_and_prefill_logits(name):
+    g = np.load(os.path.join(G, "glue_llm.npz"))
+    case = cases.glue_cases()[name]
+    w, cfgs = oracle_weights()
+    logits, embeds, mask, pos = O.multimodal_forward(w, cfgs, case["input_ids"], case["attention_mask"], case["images"],
+                                                      case["regions"], case.get("max_length"), case.get("padding_side", "right"))
+    ref_e, ref_l, ref_m = g[f"{name}_embeds"], g[f"{name}_logits"], g[f"{name}_mask"]
+    assert tuple(embeds.shape) == ref_e.shape                     # spliced layout: exact
+    assert np.array_equal(mask.numpy().astype(np.int32), ref_m)
+    assert rel(embeds, ref_e) <= 1e-5
+    valid = torch.as_tensor(ref_m).bool()
+    assert rel(logits[valid], torch.as_tensor(ref_l)[valid]) <= 1e-4
+    assert torch.equal(logits[valid].argmax(-1), torch.as_tensor(ref_l)[valid].argmax(-1))

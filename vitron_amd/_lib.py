@@ -1,0 +1,136 @@
+"""ctypes binding of libvitron_hip.so (C ABI: include/vitron_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or fails to load, every operator of
+vitron_amd raises. `load()` builds it with hipcc when the sources are newer than the binary (or the binary is
+absent) and the toolchain is available.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+PKG_DIR = Path(__file__).resolve().parent
+LIB_PATH = PKG_DIR / "libvitron_hip.so"
+
+# ---- enums (mirror include/vitron_hip.h) ---------------------------------------------------------------------
+EPI_BF16, EPI_BF16_GELU, EPI_BF16_QGELU, EPI_BF16_RELU, EPI_F32_RESID, EPI_F32, EPI_SWIGLU_BF16 = range(7)
+CFG_AUTO, CFG_SKINNY, CFG_128x128, CFG_256x128, CFG_256x256, CFG_64x128, CFG_256x256_P8 = range(7)
+DTYPE_BF16, DTYPE_F32 = 0, 1
+ACT_GELU, ACT_QUICK_GELU = 0, 1
+PAGE_TOKENS = 64
+
+u16p = C.c_void_p  # all device pointers travel as void*
+vp = C.c_void_p
+
+
+class VtRegionWeights(C.Structure):
+    _fields_ = [("in_dim", C.c_int), ("out_dim", C.c_int), ("mlp_w", vp * 3), ("mlp_b", vp * 3),
+                ("loc_w", vp * 2), ("loc_b", vp * 2)]
+
+
+class VtVitLayer(C.Structure):
+    _fields_ = [(n, vp) for n in (
+        "t_ln_g", "t_ln_b", "t_embed", "t_wqkv", "t_bqkv", "t_wo", "t_bo",
+        "ln1_g", "ln1_b", "wqkv", "bqkv", "wo", "bo", "ln2_g", "ln2_b", "w1", "b1", "w2", "b2")]
+
+
+class VtVitModel(C.Structure):
+    _fields_ = [("image_size", C.c_int), ("patch", C.c_int), ("hidden", C.c_int), ("heads", C.c_int),
+                ("intermediate", C.c_int), ("num_layers", C.c_int), ("num_frames", C.c_int),
+                ("add_time_attn", C.c_int), ("act", C.c_int), ("ln_eps", C.c_float), ("k_pad", C.c_int),
+                ("w_patch", vp), ("cls", vp), ("pos", vp), ("pre_ln_g", vp), ("pre_ln_b", vp),
+                ("layers", C.POINTER(VtVitLayer))]
+
+
+class VtLlamaLayer(C.Structure):
+    _fields_ = [(n, vp) for n in ("rms1", "wqkv", "wo", "rms2", "wgu", "wdown")]
+
+
+class VtLlamaModel(C.Structure):
+    _fields_ = [("hidden", C.c_int), ("heads", C.c_int), ("head_dim", C.c_int), ("intermediate", C.c_int),
+                ("num_layers", C.c_int), ("vocab", C.c_int), ("rms_eps", C.c_float), ("final_norm", vp),
+                ("lm_head", vp), ("rope_cos", vp), ("rope_sin", vp), ("rope_len", C.c_int),
+                ("layers", C.POINTER(VtLlamaLayer))]
+
+
+class VtKvCache(C.Structure):
+    _fields_ = [("k", vp), ("vt", vp), ("num_pages", C.c_int)]
+
+
+_i, _f, _sz = C.c_int, C.c_float, C.c_size_t
+# name -> (restype, argtypes); this table is also what tests check against the header
+SIGNATURES = {
+    "vt_version": (_i, []),
+    "vt_last_error": (_i, [C.c_char_p, _sz]),
+    "vt_gemm_bf16": (_i, [vp, _i, vp, _i, vp, _i, vp, _i, _i, _i, _i, _i, vp, vp]),
+    "vt_layernorm": (_i, [vp, vp, _i, _i, vp, vp, vp, _i, _i, _f, vp]),
+    "vt_rmsnorm": (_i, [vp, vp, vp, vp, _i, _i, _f, vp]),
+    "vt_flash_attn": (_i, [vp, _i, vp, vp, vp, vp, _i, _i, vp, _i, _i, _i, _i, _f, vp]),
+    "vt_attn_decode": (_i, [vp, _i, vp, vp, vp, vp, _i, vp, _i, _i, _i, _f, vp]),
+    "vt_kv_tiles": (_i, [vp, _i, _i, _i, _i, vp, vp, vp, vp, _i, _i, _i, _i, vp, vp, vp, vp]),
+    "vt_attn_temporal": (_i, [vp, vp, _i, _i, _i, _i, vp]),
+    "vt_im2col": (_i, [vp, _i, vp, _i, _i, _i, _i, _i, _i, _i, vp]),
+    "vt_embed_splice": (_i, [vp, vp, vp, vp, _i, _i, vp, vp]),
+    "vt_argmax": (_i, [vp, _i, _i, _i, vp, vp]),
+    "vt_projector_workspace_bytes": (_sz, [_i, _i]),
+    "vt_projector_forward": (_i, [vp, _i, _i, vp, vp, _i, vp, vp, _i, vp, vp, _sz, vp]),
+    "vt_region_workspace_bytes": (_sz, [_i, _i, _i]),
+    "vt_region_forward": (_i, [C.POINTER(VtRegionWeights), vp, vp, vp, _i, _i, _i, vp, vp, vp, vp, _sz, vp]),
+    "vt_vit_workspace_bytes": (_sz, [C.POINTER(VtVitModel), _i, _i]),
+    "vt_vit_forward": (_i, [C.POINTER(VtVitModel), vp, _i, _i, _i, _i, vp, vp, vp, _sz, vp]),
+    "vt_llama_workspace_bytes": (_sz, [C.POINTER(VtLlamaModel), _i, _i]),
+    "vt_llama_forward": (_i, [C.POINTER(VtLlamaModel), C.POINTER(VtKvCache), vp, _i, vp, vp, _i, _i, _i, vp, vp,
+                              _i, vp, vp, vp, _sz, vp]),
+}
+
+_lib = None
+
+
+class VitronHipError(RuntimeError):
+    pass
+
+
+def _needs_build() -> bool:
+    if not LIB_PATH.exists():
+        return True
+    srcs = list((PKG_DIR / "csrc").glob("*.hip")) + list((PKG_DIR / "csrc").glob("*.h")) + \
+        list((PKG_DIR.parent / "include").glob("*.h"))
+    if not srcs:
+        return False
+    return max(p.stat().st_mtime for p in srcs) > LIB_PATH.stat().st_mtime
+
+
+def load(build_if_needed: bool = True):
+    """Load (building first when stale and hipcc is present) libvitron_hip.so. Raises if unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if build_if_needed and _needs_build() and os.environ.get("VITRON_AMD_NO_BUILD") != "1":
+        from . import build as _build
+        try:
+            _build.build()
+        except Exception as e:  # stale binary is still usable; a missing one is fatal below
+            if not LIB_PATH.exists():
+                raise VitronHipError(f"libvitron_hip.so is missing and could not be built: {e}") from e
+    if not LIB_PATH.exists():
+        raise VitronHipError(f"{LIB_PATH} not found: run `python -m vitron_amd.build` (needs hipcc). "
+                             "vitron_amd has no CPU or PyTorch fallback for its operators.")
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here == header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    buf = C.create_string_buffer(512)
+    load().vt_last_error(buf, 512)
+    return buf.value.decode("utf-8", "replace")
+
+
+def check(status: int, what: str = "") -> None:
+    if status != 0:
+        raise VitronHipError(f"{what or 'libvitron_hip'} failed (status {status}): {last_error()}")

@@ -1,0 +1,79 @@
+"""Build libvitron_hip.so (gfx950) in-tree with hipcc.
+
+The shared library is the product: every compute call of vitron_amd goes through it (ctypes), and there is
+no fallback when it is missing. hipcc cross-compiles for gfx950 without a GPU, so the build runs anywhere the
+ROCm toolchain is installed. Objects are cached under vitron_amd/csrc/build/ keyed on source mtimes.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+PKG_DIR = Path(__file__).resolve().parent
+CSRC = PKG_DIR / "csrc"
+INCLUDE = PKG_DIR.parent / "include"
+LIB_PATH = PKG_DIR / "libvitron_hip.so"
+SOURCES = ["vt_api.hip", "vt_gemm.hip", "vt_norm.hip", "vt_attn.hip", "vt_vit.hip", "vt_region.hip", "vt_llama.hip"]
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
+         "-Wno-unused-but-set-variable", "-Wno-unused-variable"]
+
+
+def _hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: vitron_amd needs the ROCm toolchain to build libvitron_hip.so")
+    return exe
+
+
+def _deps_mtime() -> float:
+    hdrs = list(CSRC.glob("*.h")) + list(INCLUDE.glob("*.h"))
+    return max(p.stat().st_mtime for p in hdrs)
+
+
+def _compile_one(src: Path, obj: Path, verbose: bool) -> None:
+    cmd = [_hipcc(), *FLAGS, "-c", str(src), "-o", str(obj)]
+    if verbose:
+        print("[vitron_amd.build]", " ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src.name}:\n{r.stdout}\n{r.stderr}")
+    if verbose and r.stderr.strip():
+        print(r.stderr, file=sys.stderr)
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    """Compile every HIP source for gfx950 and link libvitron_hip.so. Returns the library path."""
+    bdir = CSRC / "build"
+    bdir.mkdir(exist_ok=True)
+    hdr_m = _deps_mtime()
+    todo = []
+    objs = []
+    for name in SOURCES:
+        src = CSRC / name
+        if not src.exists():
+            raise RuntimeError(f"missing source {src}")
+        obj = bdir / (src.stem + ".o")
+        objs.append(obj)
+        if force or not obj.exists() or obj.stat().st_mtime < max(src.stat().st_mtime, hdr_m):
+            todo.append((src, obj))
+    if todo:
+        with ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 4)) as ex:
+            list(ex.map(lambda so: _compile_one(so[0], so[1], verbose), todo))
+    if todo or not LIB_PATH.exists() or any(o.stat().st_mtime > LIB_PATH.stat().st_mtime for o in objs):
+        cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *map(str, objs), "-o", str(LIB_PATH)]
+        if verbose:
+            print("[vitron_amd.build]", " ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    p = build(force="--force" in sys.argv, verbose=True)
+    print(p)

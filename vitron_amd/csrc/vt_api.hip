@@ -1,0 +1,333 @@
+// vt_api.hip -- the extern "C" surface of libvitron_hip.so (include/vitron_hip.h) and the host-side
+// orchestration of the composite operators (ViT tower, projector, region extractor, LLaMA decoder).
+// The orchestration is plain stream-ordered kernel launches: no allocation, no synchronisation, no
+// hidden state -- so a whole tower / decoder pass is ONE ctypes call from Python.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "vt_common.h"
+#include "vt_kernels.h"
+
+// ---- error plumbing --------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void vt_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+namespace {
+struct Carver {  // bump allocator over the caller's workspace
+  char* base;
+  size_t cap, off;
+  Carver(void* p, size_t n) : base((char*)p), cap(n), off(0) {}
+  void* take(size_t bytes) {
+    off = align_up(off, 256);
+    void* r = base ? base + off : nullptr;
+    off += bytes;
+    return r;
+  }
+  bool ok() const { return off <= cap; }
+};
+inline hipStream_t S(void* s) { return (hipStream_t)s; }
+}  // namespace
+
+extern "C" {
+
+int vt_version(void) { return 100; }
+
+int vt_last_error(char* buf, size_t buf_len) {
+  const size_t n = strlen(g_err);
+  if (buf && buf_len) {
+    const size_t c = n < buf_len - 1 ? n : buf_len - 1;
+    memcpy(buf, g_err, c);
+    buf[c] = 0;
+  }
+  return (int)n;
+}
+
+// ---- primitives -----------------------------------------------------------------------------------------------------
+int vt_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, void* C, int ldc, const float* bias, int M,
+                 int N, int K, int epi, int cfg, void* scratch, void* stream) {
+  return vt_gemm_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, epi, cfg, scratch, S(stream));
+}
+
+int vt_layernorm(float* x, const float* temb, int T, int tokens_per_frame, const float* gamma, const float* beta,
+                 uint16_t* y, int rows, int D, float eps, void* stream) {
+  return vt_layernorm_launch(x, temb, T, tokens_per_frame, gamma, beta, y, rows, D, eps, S(stream));
+}
+
+int vt_rmsnorm(const float* x, const int* idx, const float* w, uint16_t* y, int rows, int D, float eps, void* stream) {
+  return vt_rmsnorm_launch(x, idx, w, y, rows, D, eps, S(stream));
+}
+
+int vt_flash_attn(const uint16_t* Q, int ldq, const uint16_t* k_tiles, const uint16_t* vt_tiles, const int* tile_table,
+                  const int* seq_desc, int nseq, int max_q_len, uint16_t* O, int ldo, int heads, int head_dim,
+                  int causal, float scale, void* stream) {
+  return vt_flash_attn_launch(Q, ldq, k_tiles, vt_tiles, tile_table, (const VtAttnSeq*)seq_desc, nseq, max_q_len, O,
+                              ldo, heads, head_dim, causal, scale, S(stream));
+}
+
+int vt_attn_decode(const uint16_t* Q, int ldq, const uint16_t* k_tiles, const uint16_t* vt_tiles, const int* tile_table,
+                   const int* seq_desc, int nseq, uint16_t* O, int ldo, int heads, int head_dim, float scale,
+                   void* stream) {
+  return vt_attn_decode_launch(Q, ldq, k_tiles, vt_tiles, tile_table, (const VtAttnSeq*)seq_desc, nseq, O, ldo, heads,
+                               head_dim, scale, S(stream));
+}
+
+int vt_kv_tiles(uint16_t* qkv, int ldqkv, int q_col0, int k_col0, int v_col0, uint16_t* k_tiles, uint16_t* vt_tiles,
+                const int* tile_table, const int* seq_desc, int nseq, int max_new_tiles, int heads, int head_dim,
+                const float* rope_cos, const float* rope_sin, const int* positions, void* stream) {
+  return vt_kv_tiles_launch(qkv, ldqkv, q_col0, k_col0, v_col0, k_tiles, vt_tiles, tile_table,
+                            (const VtAttnSeq*)seq_desc, nseq, max_new_tiles, heads, head_dim, rope_cos, rope_sin,
+                            positions, S(stream));
+}
+
+int vt_attn_temporal(const uint16_t* qkv, uint16_t* out, int B, int T, int N, int heads, void* stream) {
+  return vt_attn_temporal_launch(qkv, out, B, T, N, heads, S(stream));
+}
+
+int vt_im2col(const void* pixels, int pix_dtype, uint16_t* patches, int B, int T, int H, int W, int P, int k_pad,
+              int video_layout, void* stream) {
+  return vt_im2col_launch(pixels, pix_dtype, patches, B, T, H, W, P, k_pad, video_layout, S(stream));
+}
+
+int vt_embed_splice(const uint16_t* tok_table, const uint16_t* vis, const uint16_t* reg, const int* plan, int rows,
+                    int H, uint16_t* out, void* stream) {
+  return vt_embed_splice_launch(tok_table, vis, reg, plan, rows, H, out, S(stream));
+}
+
+int vt_argmax(const float* logits, int rows, int V, int ldl, int* out_ids, void* stream) {
+  return vt_argmax_launch(logits, rows, V, ldl, out_ids, S(stream));
+}
+
+// ---- mm_projector ---------------------------------------------------------------------------------------------------
+size_t vt_projector_workspace_bytes(int M, int Dh) { return align_up((size_t)M * Dh * 2, 256) + 256; }
+
+int vt_projector_forward(const uint16_t* x, int M, int Din, const uint16_t* w1, const float* b1, int Dh,
+                         const uint16_t* w2, const float* b2, int Dout, uint16_t* out, void* workspace,
+                         size_t workspace_bytes, void* stream) {
+  VT_REQUIRE(x && w1 && out && M > 0, "vt_projector_forward: null pointer / empty input");
+  hipStream_t s = S(stream);
+  if (!w2) {  // 'linear' projector
+    return vt_gemm_launch(x, Din, w1, Din, out, Dh, b1, M, Dh, Din, VT_EPI_BF16, VT_GEMM_CFG_AUTO, nullptr, s);
+  }
+  Carver ws(workspace, workspace_bytes);
+  bf16_t* h = (bf16_t*)ws.take((size_t)M * Dh * 2);
+  if (!workspace || !ws.ok()) {
+    vt_set_error("vt_projector_forward: workspace too small (%zu < %zu)", workspace_bytes, ws.off);
+    return VT_ERR_WORKSPACE;
+  }
+  VT_TRY(vt_gemm_launch(x, Din, w1, Din, h, Dh, b1, M, Dh, Din, VT_EPI_BF16_GELU, VT_GEMM_CFG_AUTO, nullptr, s));
+  VT_TRY(vt_gemm_launch(h, Dh, w2, Dh, out, Dout, b2, M, Dout, Dh, VT_EPI_BF16, VT_GEMM_CFG_AUTO, nullptr, s));
+  return VT_OK;
+}
+
+// ---- region_extractor ------------------------------------------------------------------------------------------------
+size_t vt_region_workspace_bytes(int B, int in_dim, int out_dim) {
+  size_t n = 0;
+  n += align_up((size_t)B * in_dim * 2, 256);       // pooled
+  n += 2 * align_up((size_t)B * out_dim * 2, 256);  // h1, h2
+  n += align_up((size_t)B * (out_dim / 2) * 2, 256);  // loc hidden
+  n += align_up((size_t)B * out_dim * 4, 256);      // fp32 sum
+  return n + 1024;
+}
+
+int vt_region_forward(const vt_region_weights* w, const uint16_t* feats, const int* slices, const uint16_t* coords,
+                      int B, int G, int image_size, uint16_t* out, int* cell_mask, int* cell_count, void* workspace,
+                      size_t workspace_bytes, void* stream) {
+  VT_REQUIRE(w && feats && slices && coords && out, "vt_region_forward: null pointer");
+  VT_REQUIRE(B > 0 && B <= 16, "vt_region_forward: B=%d (1..16 boxes per call)", B);
+  hipStream_t s = S(stream);
+  const int D = w->in_dim, H = w->out_dim;
+  Carver ws(workspace, workspace_bytes);
+  bf16_t* pooled = (bf16_t*)ws.take((size_t)B * D * 2);
+  bf16_t* h1 = (bf16_t*)ws.take((size_t)B * H * 2);
+  bf16_t* h2 = (bf16_t*)ws.take((size_t)B * H * 2);
+  bf16_t* l1 = (bf16_t*)ws.take((size_t)B * (H / 2) * 2);
+  float* acc = (float*)ws.take((size_t)B * H * 4);
+  if (!workspace || !ws.ok()) {
+    vt_set_error("vt_region_forward: workspace too small (%zu < %zu)", workspace_bytes, ws.off);
+    return VT_ERR_WORKSPACE;
+  }
+  VT_TRY(vt_region_pool_launch(feats, slices, B, G, image_size, D, pooled, cell_mask, cell_count, s));
+  const int SK = VT_GEMM_CFG_SKINNY;
+  VT_TRY(vt_gemm_launch(pooled, D, w->mlp_w[0], D, h1, H, w->mlp_b[0], B, H, D, VT_EPI_BF16_RELU, SK, nullptr, s));
+  VT_TRY(vt_gemm_launch(h1, H, w->mlp_w[1], H, h2, H, w->mlp_b[1], B, H, H, VT_EPI_BF16_RELU, SK, nullptr, s));
+  VT_TRY(vt_gemm_launch(h2, H, w->mlp_w[2], H, acc, H, w->mlp_b[2], B, H, H, VT_EPI_F32, SK, nullptr, s));
+  VT_TRY(vt_gemm_launch(coords, 8, w->loc_w[0], 8, l1, H / 2, w->loc_b[0], B, H / 2, 8, VT_EPI_BF16_RELU, SK, nullptr, s));
+  VT_TRY(vt_gemm_launch(l1, H / 2, w->loc_w[1], H / 2, acc, H, w->loc_b[1], B, H, H / 2, VT_EPI_F32_RESID, SK, nullptr, s));
+  VT_TRY(vt_gather_f32_to_bf16_launch(acc, nullptr, out, B, H, s));
+  return VT_OK;
+}
+
+// ---- ViT tower ---------------------------------------------------------------------------------------------------------
+namespace {
+struct VitWs {
+  float* x;
+  float* patch_out;
+  bf16_t *y, *qkv, *att, *h, *patches, *kt, *vt;
+  int *seq_desc, *tile_table;
+  size_t total;
+};
+VitWs vit_carve(const vt_vit_model* m, int B, int T, void* p, size_t n) {
+  const int G = m->image_size / m->patch, G2 = G * G, N = G2 + 1, F = B * T, R = F * N;
+  const int D = m->hidden, I = m->intermediate;
+  const int ntiles = cdiv(N, 64);
+  Carver ws(p, n);
+  VitWs w;
+  w.x = (float*)ws.take((size_t)R * D * 4);
+  w.patch_out = (float*)ws.take((size_t)F * G2 * D * 4);
+  w.y = (bf16_t*)ws.take((size_t)R * D * 2);
+  w.qkv = (bf16_t*)ws.take((size_t)R * 3 * D * 2);
+  w.att = (bf16_t*)ws.take((size_t)R * D * 2);
+  w.h = (bf16_t*)ws.take((size_t)R * I * 2);
+  w.patches = (bf16_t*)ws.take((size_t)F * G2 * m->k_pad * 2);
+  w.kt = (bf16_t*)ws.take((size_t)F * ntiles * 64 * D * 2);
+  w.vt = (bf16_t*)ws.take((size_t)F * ntiles * 64 * D * 2);
+  w.seq_desc = (int*)ws.take((size_t)F * 4 * 4);
+  w.tile_table = (int*)ws.take((size_t)F * ntiles * 4);
+  w.total = ws.off + 256;
+  return w;
+}
+}  // namespace
+
+size_t vt_vit_workspace_bytes(const vt_vit_model* m, int B, int T) {
+  if (!m) return 0;
+  return vit_carve(m, B, T, nullptr, 0).total;
+}
+
+int vt_vit_forward(const vt_vit_model* m, const void* pixels, int pix_dtype, int B, int T, int video_layout,
+                   uint16_t* out_feats, float* out_hidden, void* workspace, size_t workspace_bytes, void* stream) {
+  VT_REQUIRE(m && pixels && out_feats && workspace, "vt_vit_forward: null pointer");
+  VT_REQUIRE(B > 0 && T > 0, "vt_vit_forward: empty batch");
+  VT_REQUIRE(m->hidden == m->heads * 64, "vt_vit_forward: head_dim must be 64 (hidden=%d heads=%d)", m->hidden, m->heads);
+  VT_REQUIRE(m->image_size % m->patch == 0, "vt_vit_forward: image_size %% patch != 0");
+  VT_REQUIRE(m->k_pad % 64 == 0 && m->k_pad >= 3 * m->patch * m->patch, "vt_vit_forward: bad k_pad %d", m->k_pad);
+  VT_REQUIRE(m->hidden % 64 == 0 && m->intermediate % 64 == 0, "vt_vit_forward: hidden/intermediate must be multiples of 64");
+  if (m->add_time_attn) VT_REQUIRE(T == m->num_frames && T <= 8, "vt_vit_forward: video tower built for %d frames, got T=%d", m->num_frames, T);
+  hipStream_t s = S(stream);
+  VitWs w = vit_carve(m, B, T, workspace, workspace_bytes);
+  if (w.total > workspace_bytes) {
+    vt_set_error("vt_vit_forward: workspace too small (%zu < %zu)", workspace_bytes, w.total);
+    return VT_ERR_WORKSPACE;
+  }
+  const int G = m->image_size / m->patch, G2 = G * G, N = G2 + 1, F = B * T, R = F * N;
+  const int D = m->hidden, I = m->intermediate, heads = m->heads;
+  const int AUTO = VT_GEMM_CFG_AUTO;
+  const int act_epi = (m->act == VT_ACT_QUICK_GELU) ? VT_EPI_BF16_QGELU : VT_EPI_BF16_GELU;
+
+  // embeddings: patch GEMM (fp32 out) -> + CLS / position -> pre-LayerNorm -> fp32 residual stream x
+  VT_TRY(vt_im2col_launch(pixels, pix_dtype, w.patches, B, T, m->image_size, m->image_size, m->patch, m->k_pad, video_layout, s));
+  VT_TRY(vt_gemm_launch(w.patches, m->k_pad, m->w_patch, m->k_pad, w.patch_out, D, nullptr, F * G2, D, m->k_pad, VT_EPI_F32, AUTO, nullptr, s));
+  VT_TRY(vt_vit_embed_launch(w.patch_out, m->cls, m->pos, m->pre_ln_g, m->pre_ln_b, w.x, F, G2, D, m->ln_eps, s));
+  VT_TRY(vt_vit_attn_meta_launch(w.seq_desc, w.tile_table, F, N, s));
+
+  for (int l = 0; l < m->num_layers; ++l) {
+    const vt_vit_layer& L = m->layers[l];
+    if (m->add_time_attn) {
+      // x += temporal_embedding[t]; y = temporal_layer_norm1(x); temporal attention over T; x += out_proj
+      VT_TRY(vt_layernorm_launch(w.x, (T != 1) ? L.t_embed : nullptr, T, N, L.t_ln_g, L.t_ln_b, w.y, R, D, m->ln_eps, s));
+      VT_TRY(vt_gemm_launch(w.y, D, L.t_wqkv, D, w.qkv, 3 * D, L.t_bqkv, R, 3 * D, D, VT_EPI_BF16, AUTO, nullptr, s));
+      VT_TRY(vt_attn_temporal_launch(w.qkv, w.att, B, T, N, heads, s));
+      VT_TRY(vt_gemm_launch(w.att, D, L.t_wo, D, w.x, D, L.t_bo, R, D, D, VT_EPI_F32_RESID, AUTO, nullptr, s));
+    }
+    // spatial attention
+    VT_TRY(vt_layernorm_launch(w.x, nullptr, 0, 0, L.ln1_g, L.ln1_b, w.y, R, D, m->ln_eps, s));
+    VT_TRY(vt_gemm_launch(w.y, D, L.wqkv, D, w.qkv, 3 * D, L.bqkv, R, 3 * D, D, VT_EPI_BF16, AUTO, nullptr, s));
+    VT_TRY(vt_kv_tiles_launch(w.qkv, 3 * D, 0, D, 2 * D, w.kt, w.vt, w.tile_table, (const VtAttnSeq*)w.seq_desc, F,
+                              cdiv(N, 64), heads, 64, nullptr, nullptr, nullptr, s));
+    VT_TRY(vt_flash_attn_launch(w.qkv, 3 * D, w.kt, w.vt, w.tile_table, (const VtAttnSeq*)w.seq_desc, F, N, w.att, D,
+                                heads, 64, 0, 1.0f, s));
+    VT_TRY(vt_gemm_launch(w.att, D, L.wo, D, w.x, D, L.bo, R, D, D, VT_EPI_F32_RESID, AUTO, nullptr, s));
+    // MLP
+    VT_TRY(vt_layernorm_launch(w.x, nullptr, 0, 0, L.ln2_g, L.ln2_b, w.y, R, D, m->ln_eps, s));
+    VT_TRY(vt_gemm_launch(w.y, D, L.w1, D, w.h, I, L.b1, R, I, D, act_epi, AUTO, nullptr, s));
+    VT_TRY(vt_gemm_launch(w.h, I, L.w2, I, w.x, D, L.b2, R, D, I, VT_EPI_F32_RESID, AUTO, nullptr, s));
+  }
+  VT_TRY(vt_drop_cls_launch(w.x, out_feats, F, G2, D, s));
+  if (out_hidden) VT_HIP(hipMemcpyAsync(out_hidden, w.x, (size_t)R * D * 4, hipMemcpyDeviceToDevice, s));
+  return VT_OK;
+}
+
+// ---- LLaMA decoder --------------------------------------------------------------------------------------------------------
+namespace {
+struct LlamaWs {
+  float* x;
+  bf16_t *y, *qkv, *att, *h, *yn;
+  float* scratch;
+  size_t total;
+};
+LlamaWs llama_carve(const vt_llama_model* m, int rows, int n_logit, void* p, size_t n) {
+  Carver ws(p, n);
+  LlamaWs w;
+  const int H = m->hidden, I = m->intermediate;
+  w.x = (float*)ws.take((size_t)rows * H * 4);
+  w.y = (bf16_t*)ws.take((size_t)rows * H * 2);
+  w.qkv = (bf16_t*)ws.take((size_t)rows * 3 * H * 2);
+  w.att = (bf16_t*)ws.take((size_t)rows * H * 2);
+  w.h = (bf16_t*)ws.take((size_t)rows * I * 2);
+  w.yn = (bf16_t*)ws.take((size_t)(n_logit > 0 ? n_logit : 1) * H * 2);
+  w.scratch = (float*)ws.take((size_t)16 * 2 * I * 4);
+  w.total = ws.off + 256;
+  return w;
+}
+}  // namespace
+
+size_t vt_llama_workspace_bytes(const vt_llama_model* m, int rows, int n_logit_rows) {
+  if (!m) return 0;
+  return llama_carve(m, rows, n_logit_rows, nullptr, 0).total;
+}
+
+int vt_llama_forward(const vt_llama_model* m, const vt_kv_cache* kv, const uint16_t* x_embeds, int rows,
+                     const int* positions, const int* seq_desc, int nseq, int max_q_len, int max_new_tiles,
+                     const int* tile_table, const int* logit_rows, int n_logit_rows, float* logits,
+                     float* out_hidden, void* workspace, size_t workspace_bytes, void* stream) {
+  VT_REQUIRE(m && kv && x_embeds && positions && seq_desc && tile_table && workspace, "vt_llama_forward: null pointer");
+  VT_REQUIRE(rows > 0 && nseq > 0 && max_q_len > 0 && max_new_tiles > 0, "vt_llama_forward: empty batch");
+  VT_REQUIRE(m->head_dim == 128 || m->head_dim == 64, "vt_llama_forward: head_dim %d unsupported", m->head_dim);
+  VT_REQUIRE(m->hidden == m->heads * m->head_dim, "vt_llama_forward: hidden != heads*head_dim");
+  VT_REQUIRE(m->hidden % 64 == 0 && m->intermediate % 64 == 0, "vt_llama_forward: hidden/intermediate must be multiples of 64");
+  VT_REQUIRE(m->rope_cos && m->rope_sin, "vt_llama_forward: rope tables missing");
+  if (n_logit_rows > 0) VT_REQUIRE(logits && logit_rows, "vt_llama_forward: logits requested but pointer missing");
+  hipStream_t s = S(stream);
+  LlamaWs w = llama_carve(m, rows, n_logit_rows, workspace, workspace_bytes);
+  if (w.total > workspace_bytes) {
+    vt_set_error("vt_llama_forward: workspace too small (%zu < %zu)", workspace_bytes, w.total);
+    return VT_ERR_WORKSPACE;
+  }
+  const int H = m->hidden, I = m->intermediate, heads = m->heads, HD = m->head_dim;
+  const int AUTO = VT_GEMM_CFG_AUTO;
+  const float scale = 1.0f / sqrtf((float)HD);
+  const size_t layer_stride = (size_t)kv->num_pages * heads * 64 * HD;
+
+  VT_TRY(vt_bf16_to_f32_launch(x_embeds, w.x, (size_t)rows * H, s));
+  for (int l = 0; l < m->num_layers; ++l) {
+    const vt_llama_layer& L = m->layers[l];
+    bf16_t* kt = kv->k + l * layer_stride;
+    bf16_t* vt = kv->vt + l * layer_stride;
+    VT_TRY(vt_rmsnorm_launch(w.x, nullptr, L.rms1, w.y, rows, H, m->rms_eps, s));
+    VT_TRY(vt_gemm_launch(w.y, H, L.wqkv, H, w.qkv, 3 * H, nullptr, rows, 3 * H, H, VT_EPI_BF16, AUTO, nullptr, s));
+    VT_TRY(vt_kv_tiles_launch(w.qkv, 3 * H, 0, H, 2 * H, kt, vt, tile_table, (const VtAttnSeq*)seq_desc, nseq,
+                              max_new_tiles, heads, HD, m->rope_cos, m->rope_sin, positions, s));
+    if (max_q_len == 1)
+      VT_TRY(vt_attn_decode_launch(w.qkv, 3 * H, kt, vt, tile_table, (const VtAttnSeq*)seq_desc, nseq, w.att, H, heads, HD, scale, s));
+    else
+      VT_TRY(vt_flash_attn_launch(w.qkv, 3 * H, kt, vt, tile_table, (const VtAttnSeq*)seq_desc, nseq, max_q_len, w.att, H,
+                                  heads, HD, 1, scale, s));
+    VT_TRY(vt_gemm_launch(w.att, H, L.wo, H, w.x, H, nullptr, rows, H, H, VT_EPI_F32_RESID, AUTO, nullptr, s));
+    VT_TRY(vt_rmsnorm_launch(w.x, nullptr, L.rms2, w.y, rows, H, m->rms_eps, s));
+    VT_TRY(vt_gemm_launch(w.y, H, L.wgu, H, w.h, I, nullptr, rows, 2 * I, H, VT_EPI_SWIGLU_BF16, AUTO, w.scratch, s));
+    VT_TRY(vt_gemm_launch(w.h, I, L.wdown, I, w.x, H, nullptr, rows, H, I, VT_EPI_F32_RESID, AUTO, nullptr, s));
+  }
+  if (out_hidden) VT_HIP(hipMemcpyAsync(out_hidden, w.x, (size_t)rows * H * 4, hipMemcpyDeviceToDevice, s));
+  if (n_logit_rows > 0) {
+    VT_TRY(vt_rmsnorm_launch(w.x, logit_rows, m->final_norm, w.yn, n_logit_rows, H, m->rms_eps, s));
+    VT_TRY(vt_gemm_launch(w.yn, H, m->lm_head, H, logits, m->vocab, nullptr, n_logit_rows, m->vocab, H, VT_EPI_F32, AUTO, nullptr, s));
+  }
+  return VT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,589 @@
+// vt_attn.hip -- attention kernels for gfx950.
+//
+//  * flash_attn_kernel<HD, CAUSAL>: tiled online-softmax attention on v_mfma_f32_32x32x16_bf16.
+//      - ViT spatial attention (HD=64, no mask): CLIPAttention as called by the reference at
+//        vitron/model/multimodal_encoder/languagebind/video/modeling_video.py:136-146
+//      - LLaMA causal prefill (HD=128): LlamaAttention (transformers 4.31; restated in-repo at
+//        reference vitron/train/llama_flash_attn_monkey_patch.py:30-66)
+//    "All-swapped" formulation: S^T = K.Q^T and O^T = V^T.P^T, so a lane owns ONE query row
+//    (lane&31) for the scores, the running max/sum and the output accumulator alike: the softmax
+//    and the rescale are lane-local, P never leaves registers, and the only cross-lane traffic is
+//    one lane<->lane+32 exchange per tile for the row max. K rows are fed to the MFMA through the
+//    permutation pi(i) = 16*((i>>2)&1) + (i&3) + 4*(i>>3) so that each lane's 16 score registers are
+//    16 consecutive keys -- which makes the P fragment of the second MFMA a plain bf16 pack, with V
+//    stored transposed ([HD][64 keys] tiles) so its fragments are single ds_read_b128.
+//    K / V^T live in 64-key tiles (= KV-cache pages) addressed through a tile table; tiles are staged
+//    by LDS-DMA (global_load_lds_dwordx4) into a 2-stage LDS ring with XOR-swizzled chunks.
+//  * kv_tiles_kernel<HD, ROPE>: fused-QKV rows -> (rotary embedding on q,k) -> K tiles / V^T tiles.
+//  * attn_decode_kernel<HD>: single-query attention over the paged tiles (HBM-bound).
+//  * attn_temporal_kernel: the video tower's attention over T frames at one token position
+//    (reference modeling_video.py:105-127) -- T<=8, one wavefront per (position, head).
+#include "vt_common.h"
+#include "vt_kernels.h"
+
+namespace {
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst_wave_uniform) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_dst_wave_uniform, 16, 0, 0);
+}
+
+// chunk swizzles (16-B chunk index inside an LDS row) -- see file header
+template <int HD>
+__device__ __forceinline__ int k_swz(int key) {
+  return (HD == 128) ? (key & 15) : ((key >> 1) & 7);
+}
+__device__ __forceinline__ int v_swz(int d) { return (d >> 1) & 7; }
+
+template <int HD, bool CAUSAL>
+__global__ __launch_bounds__(256) void flash_attn_kernel(const bf16_t* __restrict__ Q, int ldq,
+                                                         const bf16_t* __restrict__ Kt,
+                                                         const bf16_t* __restrict__ Vt,
+                                                         const int* __restrict__ tile_table,
+                                                         const VtAttnSeq* __restrict__ seqs, bf16_t* __restrict__ O,
+                                                         int ldo, int heads, float scale_log2e) {
+  constexpr int KS = HD / 16;          // k-steps of the QK^T MFMA
+  constexpr int DB = HD / 32;          // 32-wide d blocks of the output
+  constexpr int KROW = HD * 2;         // bytes per K row
+  constexpr int KCH = HD / 8;          // 16-B chunks per K row
+  constexpr int TILE_BYTES = 64 * HD * 2;  // K tile == V^T tile == 64*HD bf16
+  constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+  constexpr int PIECES = TILE_BYTES / 1024;  // 1-KiB DMA pieces per tile
+  constexpr int PPW = PIECES / 4;            // per wave
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const VtAttnSeq sq = seqs[blockIdx.z];
+  const int nqb = (sq.q_len + 127) >> 7;
+  const int qb = nqb - 1 - (int)blockIdx.x;  // heavy (late) blocks first
+  if (qb < 0) return;
+  const int head = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ql = lane & 31, hh = lane >> 5;
+  const int past = sq.kv_len - sq.q_len;
+  const int q0 = qb * 128;
+  const int qrow = q0 + wave * 32 + ql;             // row inside the sequence (may be >= q_len)
+  const int qrow_c = min(qrow, sq.q_len - 1);
+
+  // number of 64-key tiles this block needs
+  int ntiles = (sq.kv_len + 63) >> 6;
+  if (CAUSAL) {
+    const int last_key = past + min(q0 + 127, sq.q_len - 1);
+    ntiles = min(ntiles, (last_key >> 6) + 1);
+  }
+
+  // ---- Q fragments (B operand): lane (q, h) holds d = ks*16 + h*8 .. +7 ---------------------------
+  bf16x8 qf[KS];
+  {
+    const bf16_t* qp = Q + (size_t)(sq.q_row0 + qrow_c) * ldq + head * HD + hh * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
+  }
+
+  // ---- DMA source offsets (elements inside a tile), swizzle applied on the source side -------------
+  // K tile piece p covers LDS bytes [p*1024, +1024): rows of KROW bytes.
+  int k_src_off[PPW], v_src_off[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int byte = (wave * PPW + i) * 1024 + lane * 16;
+    {
+      const int row = byte / KROW, c = (byte % KROW) >> 4;
+      k_src_off[i] = row * HD + ((c ^ k_swz<HD>(row)) << 3);
+    }
+    {
+      const int row = byte >> 7, c = (byte & 127) >> 4;  // V^T rows are 64 keys = 128 B
+      v_src_off[i] = row * 64 + ((c ^ v_swz(row)) << 3);
+    }
+  }
+  const size_t head_off = (size_t)head * 64 * HD;
+  const size_t tile_stride = (size_t)heads * 64 * HD;
+  const int* table = tile_table + sq.table_off;
+
+  auto stage = [&](int buf, int t) {
+    const size_t toff = (size_t)table[t] * tile_stride + head_off;
+    char* base = smem + buf * STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) glds16(Kt + toff + k_src_off[i], base + (wave * PPW + i) * 1024);
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) glds16(Vt + toff + v_src_off[i], base + TILE_BYTES + (wave * PPW + i) * 1024);
+  };
+
+  // ---- fragment read offsets ---------------------------------------------------------------------------
+  // K: MFMA row i = lane&31 reads key pi(i) of the 32-key sub tile, chunk ks*2 + h
+  const int pi = 16 * ((ql >> 2) & 1) + (ql & 3) + 4 * (ql >> 3);
+  int k_row_off[2];
+#pragma unroll
+  for (int sub = 0; sub < 2; ++sub) k_row_off[sub] = (sub * 32 + pi) * KROW;
+  const int k_sw0 = k_swz<HD>(pi);  // same for sub 0/1 (32 is a multiple of both swizzle periods)
+  // V^T: MFMA row i = lane&31 reads d = db*32 + i, chunk sub*4 + 2h + j
+  const int v_sw = v_swz(ql);       // (db*32 + ql) has the same swizzle as ql
+
+  f32x16 oacc[DB];
+#pragma unroll
+  for (int db = 0; db < DB; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[db][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  stage(0, 0);
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < ntiles) stage(cur ^ 1, t + 1);
+    const char* kb = smem + cur * STAGE_BYTES;
+    const char* vb = kb + TILE_BYTES;
+
+    // ---- S^T = K . Q^T ---------------------------------------------------------------------------------
+    f32x16 sacc[2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[sub][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int chunk = (ks * 2 + hh) ^ k_sw0;
+        const bf16x8 kf = *(const bf16x8*)(kb + k_row_off[sub] + (chunk << 4));
+        sacc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[sub], 0, 0, 0);
+      }
+    }
+    // lane (q,h): sacc[sub][r] = S[q][t*64 + sub*32 + 16h + r]
+
+    // ---- mask (only tiles that touch the diagonal or the end of the keys) ----------------------------------
+    const int key0 = t * 64;
+    const bool need_mask = (key0 + 64 > sq.kv_len) || (CAUSAL && (key0 + 63 > past + q0 + wave * 32));
+    if (need_mask) {
+      const int lim = CAUSAL ? min(sq.kv_len - 1, past + qrow) : (sq.kv_len - 1);  // last visible key
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = key0 + sub * 32 + 16 * hh + r;
+          if (key > lim) sacc[sub][r] = -INFINITY;
+        }
+    }
+
+    // ---- online softmax (log2 domain) ------------------------------------------------------------------------
+    float mx = sacc[0][0];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[sub][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx * scale_log2e);
+    const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = exp2f(m_run - m_safe);  // m_run = -inf -> 0
+    m_run = m_new;
+    float psum = 0.f;
+    bf16x8 pf[2][2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      float p[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        p[r] = exp2f(sacc[sub][r] * scale_log2e - m_safe);
+        psum += p[r];
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        u32x4 w;
+        w.x = pack_bf16x2(p[8 * j + 0], p[8 * j + 1]);
+        w.y = pack_bf16x2(p[8 * j + 2], p[8 * j + 3]);
+        w.z = pack_bf16x2(p[8 * j + 4], p[8 * j + 5]);
+        w.w = pack_bf16x2(p[8 * j + 6], p[8 * j + 7]);
+        pf[sub][j] = __builtin_bit_cast(bf16x8, w);
+      }
+    }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+
+    // ---- O^T += V^T . P^T --------------------------------------------------------------------------------------
+#pragma unroll
+    for (int db = 0; db < DB; ++db) {
+      const int vrow = (db * 32 + ql) * 128;
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int chunk = (sub * 4 + 2 * hh + j) ^ v_sw;
+          const bf16x8 vf = *(const bf16x8*)(vb + vrow + (chunk << 4));
+          oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[sub][j], oacc[db], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue ------------------------------------------------------------------------------------------------
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = (l_tot > 0.f) ? 1.f / l_tot : 0.f;
+  if (qrow < sq.q_len) {
+    bf16_t* op = O + (size_t)(sq.q_row0 + qrow) * ldo + head * HD + 4 * hh;
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x2 o;
+        o.x = pack_bf16x2(oacc[db][4 * g + 0] * inv, oacc[db][4 * g + 1] * inv);
+        o.y = pack_bf16x2(oacc[db][4 * g + 2] * inv, oacc[db][4 * g + 3] * inv);
+        *(u32x2*)(op + db * 32 + 8 * g) = o;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// kv_tiles_kernel: one block per (64-position tile, head, sequence). Handles the NEW tokens of the sequence
+// (positions past .. kv_len-1) that fall into the tile:
+//   K tile [64][HD]: row = position & 63   (rotary applied when ROPE)
+//   V^T tile [HD][64]: column = position & 63
+//   q rows rotated in place when ROPE.
+// A tile whose first position is new is written completely (padding rows/cols zero-filled) so the flash
+// kernel never sees non-finite padding.
+// ------------------------------------------------------------------------------------------------------------------
+template <int HD, bool ROPE>
+__global__ __launch_bounds__(256) void kv_tiles_kernel(bf16_t* __restrict__ qkv, int ldqkv, int q_col0, int k_col0,
+                                                       int v_col0, bf16_t* __restrict__ Kt, bf16_t* __restrict__ Vt,
+                                                       const int* __restrict__ tile_table,
+                                                       const VtAttnSeq* __restrict__ seqs, int heads,
+                                                       const float* __restrict__ rope_cos,
+                                                       const float* __restrict__ rope_sin,
+                                                       const int* __restrict__ positions) {
+  constexpr int CH = HD / 8;  // 16-B chunks per row
+  __shared__ __attribute__((aligned(16))) bf16_t vs[64][HD + 8];  // V rows of this tile (padded)
+  const VtAttnSeq sq = seqs[blockIdx.z];
+  const int past = sq.kv_len - sq.q_len;
+  const int t = (past >> 6) + blockIdx.x;  // absolute tile index
+  if (t * 64 >= sq.kv_len) return;
+  const int head = blockIdx.y;
+  const int p_lo = max(past, t * 64), p_hi = min(sq.kv_len, t * 64 + 64);  // new positions [p_lo, p_hi)
+  const bool fresh = (t * 64 >= past);  // tile starts with a new position -> full write
+  const size_t toff = ((size_t)tile_table[sq.table_off + t] * heads + head) * 64 * HD;
+  bf16_t* kt = Kt + toff;
+  bf16_t* vt = Vt + toff;
+
+  // ---- K rows (+ rope) and Q rope: thread -> (row, chunk pair) ------------------------------------------------
+  for (int it = threadIdx.x; it < 64 * (CH / 2); it += 256) {
+    const int r = it / (CH / 2), c = it % (CH / 2);  // row in tile, chunk in first half of the head dim
+    const int pos = t * 64 + r;
+    if (pos >= p_lo && pos < p_hi) {
+      const int row = sq.q_row0 + (pos - past);
+      bf16_t* kp = qkv + (size_t)row * ldqkv + k_col0 + head * HD;
+      u32x4 lo = *(const u32x4*)(kp + c * 8);
+      u32x4 hi = *(const u32x4*)(kp + HD / 2 + c * 8);
+      if (ROPE) {
+        const int rp = positions[row];
+        const float* cs = rope_cos + (size_t)rp * (HD / 2) + c * 8;
+        const float* sn = rope_sin + (size_t)rp * (HD / 2) + c * 8;
+        bf16_t* qp = qkv + (size_t)row * ldqkv + q_col0 + head * HD;
+        u32x4 qlo = *(const u32x4*)(qp + c * 8);
+        u32x4 qhi = *(const u32x4*)(qp + HD / 2 + c * 8);
+        u32x4 klo_o, khi_o, qlo_o, qhi_o;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const float c0 = cs[2 * w], c1 = cs[2 * w + 1], s0 = sn[2 * w], s1 = sn[2 * w + 1];
+          {
+            const float a0 = bf16lo_to_f32(lo[w]), a1 = bf16hi_to_f32(lo[w]);
+            const float b0 = bf16lo_to_f32(hi[w]), b1 = bf16hi_to_f32(hi[w]);
+            klo_o[w] = pack_bf16x2(a0 * c0 - b0 * s0, a1 * c1 - b1 * s1);
+            khi_o[w] = pack_bf16x2(b0 * c0 + a0 * s0, b1 * c1 + a1 * s1);
+          }
+          {
+            const float a0 = bf16lo_to_f32(qlo[w]), a1 = bf16hi_to_f32(qlo[w]);
+            const float b0 = bf16lo_to_f32(qhi[w]), b1 = bf16hi_to_f32(qhi[w]);
+            qlo_o[w] = pack_bf16x2(a0 * c0 - b0 * s0, a1 * c1 - b1 * s1);
+            qhi_o[w] = pack_bf16x2(b0 * c0 + a0 * s0, b1 * c1 + a1 * s1);
+          }
+        }
+        lo = klo_o;
+        hi = khi_o;
+        *(u32x4*)(qp + c * 8) = qlo_o;
+        *(u32x4*)(qp + HD / 2 + c * 8) = qhi_o;
+      }
+      *(u32x4*)(kt + r * HD + c * 8) = lo;
+      *(u32x4*)(kt + r * HD + HD / 2 + c * 8) = hi;
+    } else if (fresh && pos >= p_hi) {
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      *(u32x4*)(kt + r * HD + c * 8) = z;
+      *(u32x4*)(kt + r * HD + HD / 2 + c * 8) = z;
+    }
+  }
+
+  // ---- V rows -> LDS -> V^T ----------------------------------------------------------------------------------------
+  for (int it = threadIdx.x; it < 64 * CH; it += 256) {
+    const int r = it / CH, c = it % CH;
+    const int pos = t * 64 + r;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (pos >= p_lo && pos < p_hi) {
+      const int row = sq.q_row0 + (pos - past);
+      v = *(const u32x4*)(qkv + (size_t)row * ldqkv + v_col0 + head * HD + c * 8);
+    }
+    *(u32x4*)(&vs[r][c * 8]) = v;
+  }
+  __syncthreads();
+  // thread -> (d, 8-key chunk)
+  for (int it = threadIdx.x; it < HD * 8; it += 256) {
+    const int d = it >> 3, kc = it & 7;
+    const int pos0 = t * 64 + kc * 8;
+    // fresh tile: every chunk is ours (new keys then zero padding). Otherwise only chunks with new keys,
+    // and a chunk that also holds old keys / old padding is written element-wise.
+    const bool full = fresh || (pos0 >= p_lo && pos0 + 8 <= p_hi);
+    const bool any_new = (pos0 < p_hi) && (pos0 + 8 > p_lo);
+    if (!full && !any_new) continue;
+    bf16_t vals[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) vals[j] = vs[kc * 8 + j][d];
+    bf16_t* dst = vt + d * 64 + kc * 8;
+    if (full) {
+      u32x4 w;
+      w.x = vals[0] | ((uint32_t)vals[1] << 16);
+      w.y = vals[2] | ((uint32_t)vals[3] << 16);
+      w.z = vals[4] | ((uint32_t)vals[5] << 16);
+      w.w = vals[6] | ((uint32_t)vals[7] << 16);
+      *(u32x4*)dst = w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int pos = pos0 + j;
+        if (pos >= p_lo && pos < p_hi) dst[j] = vals[j];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// attn_decode_kernel: one block (4 waves) per (head, sequence); q_len == 1. Waves take tiles round-robin, each keeps
+// an online-softmax partial (m, l, o[HD]); partials are merged through LDS.
+// ------------------------------------------------------------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ Q, int ldq,
+                                                          const bf16_t* __restrict__ Kt,
+                                                          const bf16_t* __restrict__ Vt,
+                                                          const int* __restrict__ tile_table,
+                                                          const VtAttnSeq* __restrict__ seqs, bf16_t* __restrict__ O,
+                                                          int ldo, int heads, float scale_log2e) {
+  constexpr int CH = HD / 8;        // 16-B chunks per K row; CH lanes cooperate on one key
+  constexpr int KPI = 64 / CH;      // keys per wave-instruction
+  constexpr int DPL = HD / 64;      // output dims per lane
+  __shared__ float sm_m[4], sm_l[4];
+  __shared__ float sm_o[4][HD];
+  __shared__ float sm_p[4][64];
+  const VtAttnSeq sq = seqs[blockIdx.y];
+  const int head = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ntiles = (sq.kv_len + 63) >> 6;
+  const bf16_t* qp = Q + (size_t)sq.q_row0 * ldq + head * HD;
+  // q chunk for this lane's position inside a key row
+  const int c = lane % CH;
+  const u32x4 qv = *(const u32x4*)(qp + c * 8);
+  float qf[8];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    qf[2 * w] = bf16lo_to_f32(qv[w]);
+    qf[2 * w + 1] = bf16hi_to_f32(qv[w]);
+  }
+  float m_run = -INFINITY, l_run = 0.f, o[DPL];
+#pragma unroll
+  for (int i = 0; i < DPL; ++i) o[i] = 0.f;
+
+  for (int t = wave; t < ntiles; t += 4) {
+    const size_t toff = ((size_t)tile_table[sq.table_off + t] * heads + head) * 64 * HD;
+    const bf16_t* kt = Kt + toff;
+    const bf16_t* vt = Vt + toff;
+    // scores for the 64 keys of the tile: iteration i handles keys i*KPI + lane/CH
+    float s_mine = -INFINITY;  // lane ends up owning key == lane
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int key = i * KPI + lane / CH;
+      const u32x4 kv = *(const u32x4*)(kt + key * HD + c * 8);
+      float part = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        part = fmaf(bf16lo_to_f32(kv[w]), qf[2 * w], part);
+        part = fmaf(bf16hi_to_f32(kv[w]), qf[2 * w + 1], part);
+      }
+#pragma unroll
+      for (int off = 1; off < CH; off <<= 1) part += __shfl_xor(part, off, 64);
+      // every lane of the CH-group now has the score of `key`; lane == key keeps it
+      const float sc = __shfl(part, (lane % KPI) * CH, 64);  // score of key i*KPI + lane%KPI
+      if ((lane / KPI) == i) s_mine = sc;
+    }
+    const int mykey = t * 64 + lane;
+    float s2 = (mykey < sq.kv_len) ? s_mine * scale_log2e : -INFINITY;
+    const float mx = wave_max(s2);
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = exp2f(m_run - m_new);
+    const float p = exp2f(s2 - m_new);
+    l_run = l_run * alpha + wave_sum(p);
+    m_run = m_new;
+    sm_p[wave][lane] = p;
+    __builtin_amdgcn_wave_barrier();  // DS ops of one wave are in order; only stop compiler reordering
+    // o[d] = o[d]*alpha + sum_key p[key] * V^T[d][key]; lane owns d = lane + 64*i
+#pragma unroll
+    for (int i = 0; i < DPL; ++i) {
+      const bf16_t* vr = vt + (lane + 64 * i) * 64;
+      float acc = 0.f;
+#pragma unroll
+      for (int kc = 0; kc < 8; ++kc) {
+        const u32x4 vv = *(const u32x4*)(vr + kc * 8);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          acc = fmaf(bf16lo_to_f32(vv[w]), sm_p[wave][kc * 8 + 2 * w], acc);
+          acc = fmaf(bf16hi_to_f32(vv[w]), sm_p[wave][kc * 8 + 2 * w + 1], acc);
+        }
+      }
+      o[i] = o[i] * alpha + acc;
+    }
+  }
+  if (lane == 0) {
+    sm_m[wave] = m_run;
+    sm_l[wave] = l_run;
+  }
+#pragma unroll
+  for (int i = 0; i < DPL; ++i) sm_o[wave][lane + 64 * i] = o[i];
+  __syncthreads();
+  if (wave == 0) {
+    float m = fmaxf(fmaxf(sm_m[0], sm_m[1]), fmaxf(sm_m[2], sm_m[3]));
+    float l = 0.f;
+    float w4[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      w4[w] = (sm_m[w] == -INFINITY) ? 0.f : exp2f(sm_m[w] - m);
+      l += sm_l[w] * w4[w];
+    }
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+#pragma unroll
+    for (int i = 0; i < DPL; ++i) {
+      const int d = lane + 64 * i;
+      float acc = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) acc += sm_o[w][d] * w4[w];
+      O[(size_t)sq.q_row0 * ldo + head * HD + d] = f32_to_bf16(acc * inv);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// attn_temporal_kernel: qkv bf16 [B*T*N][3D], row (b*T+t)*N+n; one wave per (b, n, head), lane = d (hd = 64).
+// q is pre-scaled by hd^-0.5 in the packed weights.
+// ------------------------------------------------------------------------------------------------------------------
+template <int T>
+__global__ __launch_bounds__(256) void attn_temporal_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                            int B, int N, int heads) {
+  const int D = heads * 64;
+  const int lane = threadIdx.x & 63;
+  const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long total = (long)B * N * heads;
+  if (wid >= total) return;
+  const int head = (int)(wid % heads);
+  const long bn = wid / heads;
+  const int n = (int)(bn % N), b = (int)(bn / N);
+  float q[T], k[T], v[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const size_t row = ((size_t)b * T + t) * N + n;
+    const bf16_t* p = qkv + row * (size_t)(3 * D) + head * 64 + lane;
+    q[t] = bf16_to_f32(p[0]);
+    k[t] = bf16_to_f32(p[D]);
+    v[t] = bf16_to_f32(p[2 * D]);
+  }
+#pragma unroll
+  for (int t1 = 0; t1 < T; ++t1) {
+    float s[T];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t2 = 0; t2 < T; ++t2) {
+      s[t2] = wave_sum(q[t1] * k[t2]);
+      mx = fmaxf(mx, s[t2]);
+    }
+    float den = 0.f, acc = 0.f;
+#pragma unroll
+    for (int t2 = 0; t2 < T; ++t2) {
+      const float p = __expf(s[t2] - mx);
+      den += p;
+      acc += p * v[t2];
+    }
+    const size_t row = ((size_t)b * T + t1) * N + n;
+    out[row * (size_t)D + head * 64 + lane] = f32_to_bf16(acc / den);
+  }
+}
+
+}  // namespace
+
+int vt_flash_attn_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf16_t* Vt, const int* tile_table,
+                         const VtAttnSeq* seqs, int nseq, int max_q_len, bf16_t* O, int ldo, int heads, int HD,
+                         int causal, float scale, hipStream_t s) {
+  VT_REQUIRE(Q && Kt && Vt && tile_table && seqs && O, "vt_flash_attn: null pointer");
+  VT_REQUIRE(HD == 64 || HD == 128, "vt_flash_attn: head_dim %d unsupported (64 or 128)", HD);
+  VT_REQUIRE(nseq > 0 && max_q_len > 0 && heads > 0, "vt_flash_attn: empty problem");
+  VT_REQUIRE(ldq % 8 == 0 && ldo % 4 == 0, "vt_flash_attn: ldq %% 8 and ldo %% 4 must be 0");
+  const float sl2 = scale * 1.4426950408889634f;
+  dim3 grid(cdiv(max_q_len, 128), heads, nseq), block(256);
+  const int smem = 2 * 2 * 64 * HD * 2;
+#define VT_FA(HDV, CV)                                                                                         \
+  do {                                                                                                         \
+    auto kern = flash_attn_kernel<HDV, CV>;                                                                    \
+    static bool done = false;                                                                                  \
+    if (!done) {                                                                                               \
+      VT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));        \
+      done = true;                                                                                             \
+    }                                                                                                          \
+    hipLaunchKernelGGL(kern, grid, block, smem, s, Q, ldq, Kt, Vt, tile_table, seqs, O, ldo, heads, sl2);      \
+  } while (0)
+  if (HD == 64) {
+    if (causal) VT_FA(64, true); else VT_FA(64, false);
+  } else {
+    if (causal) VT_FA(128, true); else VT_FA(128, false);
+  }
+#undef VT_FA
+  VT_LAUNCH_CHECK();
+  return VT_OK;
+}
+
+int vt_kv_tiles_launch(bf16_t* qkv, int ldqkv, int q_col0, int k_col0, int v_col0, bf16_t* Kt, bf16_t* Vt,
+                       const int* tile_table, const VtAttnSeq* seqs, int nseq, int max_new_tiles, int heads, int HD,
+                       const float* rope_cos, const float* rope_sin, const int* positions, hipStream_t s) {
+  VT_REQUIRE(qkv && Kt && Vt && tile_table && seqs, "vt_kv_tiles: null pointer");
+  VT_REQUIRE(HD == 64 || HD == 128, "vt_kv_tiles: head_dim %d unsupported", HD);
+  VT_REQUIRE(ldqkv % 8 == 0 && q_col0 % 8 == 0 && k_col0 % 8 == 0 && v_col0 % 8 == 0, "vt_kv_tiles: misaligned columns");
+  dim3 grid(max_new_tiles, heads, nseq), block(256);
+  const bool rope = rope_cos != nullptr;
+  if (rope) VT_REQUIRE(rope_sin && positions, "vt_kv_tiles: rope needs sin table and positions");
+  if (HD == 64) {
+    if (rope) hipLaunchKernelGGL((kv_tiles_kernel<64, true>), grid, block, 0, s, qkv, ldqkv, q_col0, k_col0, v_col0, Kt, Vt, tile_table, seqs, heads, rope_cos, rope_sin, positions);
+    else hipLaunchKernelGGL((kv_tiles_kernel<64, false>), grid, block, 0, s, qkv, ldqkv, q_col0, k_col0, v_col0, Kt, Vt, tile_table, seqs, heads, rope_cos, rope_sin, positions);
+  } else {
+    if (rope) hipLaunchKernelGGL((kv_tiles_kernel<128, true>), grid, block, 0, s, qkv, ldqkv, q_col0, k_col0, v_col0, Kt, Vt, tile_table, seqs, heads, rope_cos, rope_sin, positions);
+    else hipLaunchKernelGGL((kv_tiles_kernel<128, false>), grid, block, 0, s, qkv, ldqkv, q_col0, k_col0, v_col0, Kt, Vt, tile_table, seqs, heads, rope_cos, rope_sin, positions);
+  }
+  VT_LAUNCH_CHECK();
+  return VT_OK;
+}
+
+int vt_attn_decode_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf16_t* Vt, const int* tile_table,
+                          const VtAttnSeq* seqs, int nseq, bf16_t* O, int ldo, int heads, int HD, float scale,
+                          hipStream_t s) {
+  VT_REQUIRE(Q && Kt && Vt && tile_table && seqs && O, "vt_attn_decode: null pointer");
+  VT_REQUIRE(HD == 64 || HD == 128, "vt_attn_decode: head_dim %d unsupported", HD);
+  const float sl2 = scale * 1.4426950408889634f;
+  dim3 grid(heads, nseq), block(256);
+  if (HD == 64) hipLaunchKernelGGL((attn_decode_kernel<64>), grid, block, 0, s, Q, ldq, Kt, Vt, tile_table, seqs, O, ldo, heads, sl2);
+  else hipLaunchKernelGGL((attn_decode_kernel<128>), grid, block, 0, s, Q, ldq, Kt, Vt, tile_table, seqs, O, ldo, heads, sl2);
+  VT_LAUNCH_CHECK();
+  return VT_OK;
+}
+
+int vt_attn_temporal_launch(const bf16_t* qkv, bf16_t* out, int B, int T, int N, int heads, hipStream_t s) {
+  VT_REQUIRE(qkv && out, "vt_attn_temporal: null pointer");
+  VT_REQUIRE(T >= 1 && T <= 8, "vt_attn_temporal: T=%d unsupported (1..8)", T);
+  const long total = (long)B * N * heads;
+  dim3 grid((unsigned)((total + 3) / 4)), block(256);
+  switch (T) {
+#define VT_TC(TV) case TV: hipLaunchKernelGGL((attn_temporal_kernel<TV>), grid, block, 0, s, qkv, out, B, N, heads); break;
+    VT_TC(1) VT_TC(2) VT_TC(3) VT_TC(4) VT_TC(5) VT_TC(6) VT_TC(7) VT_TC(8)
+#undef VT_TC
+  }
+  VT_LAUNCH_CHECK();
+  return VT_OK;
+}

@@ -1,0 +1,109 @@
+// vt_common.h -- shared device/host helpers for libvitron_hip.so (gfx950 / CDNA4 only).
+//
+// Everything here is written for 64-lane wavefronts and the gfx950 MFMA shapes; there is no
+// other-architecture path on purpose.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits; all bf16 tensors cross the C-ABI as uint16_t*
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;   // 8 bf16 = one MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define VT_WAVE 64
+
+// ---- error plumbing (host) -------------------------------------------------------------------
+// Every extern "C" entry returns 0 on success or a negative code; the message is kept per thread.
+enum {
+  VT_OK = 0,
+  VT_ERR_ARG = -1,      // bad shape / null pointer / unsupported configuration
+  VT_ERR_HIP = -2,      // a HIP runtime call or kernel launch failed
+  VT_ERR_WORKSPACE = -3 // caller-provided workspace too small
+};
+void vt_set_error(const char* fmt, ...);
+
+#define VT_REQUIRE(cond, ...)            \
+  do {                                   \
+    if (!(cond)) {                       \
+      vt_set_error(__VA_ARGS__);         \
+      return VT_ERR_ARG;                 \
+    }                                    \
+  } while (0)
+
+#define VT_HIP(expr)                                                              \
+  do {                                                                            \
+    hipError_t _e = (expr);                                                       \
+    if (_e != hipSuccess) {                                                       \
+      vt_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return VT_ERR_HIP;                                                          \
+    }                                                                             \
+  } while (0)
+
+#define VT_LAUNCH_CHECK()                                                         \
+  do {                                                                            \
+    hipError_t _e = hipGetLastError();                                            \
+    if (_e != hipSuccess) {                                                       \
+      vt_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
+      return VT_ERR_HIP;                                                          \
+    }                                                                             \
+  } while (0)
+
+#define VT_TRY(expr)        \
+  do {                      \
+    int _r = (expr);        \
+    if (_r != VT_OK) return _r; \
+  } while (0)
+
+// ---- bf16 <-> f32 (device + host) ---------------------------------------------------------------
+__host__ __device__ __forceinline__ float bf16_to_f32(bf16_t h) {
+  union { uint32_t u; float f; } v;
+  v.u = ((uint32_t)h) << 16;
+  return v.f;
+}
+// round-to-nearest-even, NaN kept quiet
+__host__ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  union { uint32_t u; float f; } v;
+  v.f = f;
+  uint32_t u = v.u;
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+// two floats -> packed bf16x2 (lo in bits 0..15)
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+__device__ __forceinline__ float bf16lo_to_f32(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16hi_to_f32(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+// ---- wave-level reductions (64 lanes) -----------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- XCD-aware block id remap (bijective for any grid size) --------------------------------------
+// Blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b%8, observed, speed only).
+// Give each XCD a contiguous chunk of the logical tile order so neighbouring tiles share its L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int NX = 8;
+  int xcd = bid % NX, idx = bid / NX;
+  int q = nwg / NX, r = nwg % NX;
+  int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

@@ -1,0 +1,57 @@
+// vt_kernels.h -- internal launch prototypes shared by the .hip translation units and vt_api.hip.
+// Not part of the public C-ABI (that is include/vitron_hip.h).
+#pragma once
+#include "vt_common.h"
+#include "../../include/vitron_hip.h"
+
+struct VtAttnSeq {  // device-side view of one row of seq_desc (int32 x 4)
+  int q_row0;       // first row of this sequence's queries in the packed Q matrix
+  int q_len;        // number of query rows
+  int kv_len;       // number of valid keys (past + q_len)
+  int table_off;    // offset into the tile table of this sequence's first 64-key tile
+};
+
+// ---- vt_gemm.hip ----------------------------------------------------------------------------------
+int vt_gemm_pick_cfg(int M, int N, int K);
+int vt_gemm_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, const float* bias,
+                   int M, int N, int K, int epi, int cfg, void* skinny_scratch, hipStream_t s);
+
+// ---- vt_norm.hip ----------------------------------------------------------------------------------
+int vt_layernorm_launch(float* x, const float* temb, int T, int tokens_per_frame, const float* gamma,
+                        const float* beta, bf16_t* y, int rows, int D, float eps, hipStream_t s);
+int vt_rmsnorm_launch(const float* x, const int* idx, const float* w, bf16_t* y, int rows, int D, float eps,
+                      hipStream_t s);
+int vt_gather_f32_to_bf16_launch(const float* in, const int* idx, bf16_t* out, int rows, int D, hipStream_t s);
+int vt_bf16_to_f32_launch(const bf16_t* in, float* out, size_t n, hipStream_t s);
+int vt_add_f32_launch(float* dst, const float* a, size_t n, hipStream_t s);
+// drop the CLS row of every frame: out_bf16[f*G2+p] = bf16(x[f*(G2+1)+1+p])
+int vt_drop_cls_launch(const float* x, bf16_t* out, int F, int G2, int D, hipStream_t s);
+
+// ---- vt_vit.hip -----------------------------------------------------------------------------------
+int vt_im2col_launch(const void* pixels, int pix_dtype, bf16_t* patches, int B, int T, int H, int W, int P,
+                     int Kpad, int video_layout, hipStream_t s);
+int vt_vit_embed_launch(const float* patch_out, const float* cls, const float* pos, const float* g,
+                        const float* b, float* x, int F, int G2, int D, float eps, hipStream_t s);
+// seq_desc / tile table of the ViT's spatial attention: frame f = {f*N, N, N, f*ntiles}, table[i] = i
+int vt_vit_attn_meta_launch(int* seq_desc, int* tile_table, int F, int N, hipStream_t s);
+
+// ---- vt_attn.hip ----------------------------------------------------------------------------------
+int vt_flash_attn_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf16_t* Vt, const int* tile_table,
+                         const VtAttnSeq* seqs, int nseq, int max_q_len, bf16_t* O, int ldo, int heads, int HD,
+                         int causal, float scale, hipStream_t s);
+int vt_kv_tiles_launch(bf16_t* qkv, int ldqkv, int q_col0, int k_col0, int v_col0, bf16_t* Kt, bf16_t* Vt,
+                       const int* tile_table, const VtAttnSeq* seqs, int nseq, int max_new_tiles, int heads, int HD,
+                       const float* rope_cos, const float* rope_sin, const int* positions, hipStream_t s);
+int vt_attn_decode_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf16_t* Vt, const int* tile_table,
+                          const VtAttnSeq* seqs, int nseq, bf16_t* O, int ldo, int heads, int HD, float scale,
+                          hipStream_t s);
+int vt_attn_temporal_launch(const bf16_t* qkv, bf16_t* out, int B, int T, int N, int heads, hipStream_t s);
+
+// ---- vt_region.hip --------------------------------------------------------------------------------
+int vt_region_pool_launch(const bf16_t* feats, const int* slices, int B, int G, int image_size, int D,
+                          bf16_t* pooled, int* cell_mask, int* cell_count, hipStream_t s);
+
+// ---- vt_llama.hip ---------------------------------------------------------------------------------
+int vt_embed_splice_launch(const bf16_t* tok_table, const bf16_t* vis, const bf16_t* reg, const int* plan,
+                           int rows, int H, bf16_t* out, hipStream_t s);
+int vt_argmax_launch(const float* logits, int rows, int V, int ldl, int* out_ids, hipStream_t s);

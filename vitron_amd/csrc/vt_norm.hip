@@ -1,0 +1,210 @@
+// vt_norm.hip -- row normalisations and casts. All are HBM-bound: one wavefront per row, 16-byte
+// loads, statistics in fp32, a single pass over the row held in registers.
+//
+// The residual stream of both towers is kept in fp32 (the MFMA GEMM epilogue accumulates into it), so
+// the norms read fp32 and emit the bf16 operand of the next GEMM.
+//   LayerNorm : nn.LayerNorm(1024, eps) x4 per ViT layer -- reference
+//               vitron/model/multimodal_encoder/languagebind/video/modeling_video.py:70,72,82,604
+//               with the temporal-embedding add of :110-114 fused in front of temporal_layer_norm1.
+//   RMSNorm   : transformers-4.31 LlamaRMSNorm, used by the decoder the
+//               reference drives at vitron/model/language_model/llava_llama.py:91-102.
+#include "vt_common.h"
+#include "vt_kernels.h"
+
+namespace {
+
+template <int NCH>  // float4 chunks per lane; row fits when D <= NCH*256
+__global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, const float* __restrict__ temb,
+                                                        int T, int tokens_per_frame,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                        int rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float* xr = x + (size_t)row * D;
+  const float* te = nullptr;
+  if (temb) te = temb + (size_t)((row / tokens_per_frame) % T) * D;
+  f32x4 v[NCH];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (lane + i * 64) * 4;
+    if (c < D) {
+      v[i] = *(const f32x4*)(xr + c);
+      if (te) {
+        v[i] += *(const f32x4*)(te + c);
+        *(f32x4*)(xr + c) = v[i];
+      }
+      sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    } else {
+      v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  const float mean = wave_sum(sum) / (float)D;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (lane + i * 64) * 4;
+    if (c < D) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float d = v[i][r] - mean;
+        sq += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
+  bf16_t* yr = y + (size_t)row * D;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (lane + i * 64) * 4;
+    if (c < D) {
+      const f32x4 g = *(const f32x4*)(gamma + c);
+      const f32x4 b = *(const f32x4*)(beta + c);
+      u32x2 o;
+      o.x = pack_bf16x2((v[i][0] - mean) * rstd * g[0] + b[0], (v[i][1] - mean) * rstd * g[1] + b[1]);
+      o.y = pack_bf16x2((v[i][2] - mean) * rstd * g[2] + b[2], (v[i][3] - mean) * rstd * g[3] + b[3]);
+      *(u32x2*)(yr + c) = o;
+    }
+  }
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x, const int* __restrict__ idx,
+                                                      const float* __restrict__ w, bf16_t* __restrict__ y, int rows,
+                                                      int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + (size_t)(idx ? idx[row] : row) * D;
+  f32x4 v[NCH];
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (lane + i * 64) * 4;
+    if (c < D) {
+      v[i] = *(const f32x4*)(xr + c);
+      sq += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+    } else {
+      v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
+  bf16_t* yr = y + (size_t)row * D;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (lane + i * 64) * 4;
+    if (c < D) {
+      const f32x4 g = *(const f32x4*)(w + c);
+      u32x2 o;
+      o.x = pack_bf16x2(v[i][0] * rstd * g[0], v[i][1] * rstd * g[1]);
+      o.y = pack_bf16x2(v[i][2] * rstd * g[2], v[i][3] * rstd * g[3]);
+      *(u32x2*)(yr + c) = o;
+    }
+  }
+}
+
+__global__ void gather_f32_to_bf16_kernel(const float* __restrict__ in, const int* __restrict__ idx,
+                                          bf16_t* __restrict__ out, int rows, int D) {
+  const int per_row = D >> 2;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)rows * per_row) return;
+  const int r = (int)(i / per_row), c = (int)(i % per_row) * 4;
+  const int src = idx ? idx[r] : r;
+  const f32x4 v = *(const f32x4*)(in + (size_t)src * D + c);
+  u32x2 o;
+  o.x = pack_bf16x2(v[0], v[1]);
+  o.y = pack_bf16x2(v[2], v[3]);
+  *(u32x2*)(out + (size_t)r * D + c) = o;
+}
+
+__global__ void drop_cls_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, int F, int G2, int D) {
+  const int per_row = D >> 2;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)F * G2 * per_row) return;
+  const size_t r = i / per_row;
+  const int c = (int)(i % per_row) * 4;
+  const size_t f = r / G2, p = r % G2;
+  const f32x4 v = *(const f32x4*)(x + (f * (G2 + 1) + 1 + p) * D + c);
+  u32x2 o;
+  o.x = pack_bf16x2(v[0], v[1]);
+  o.y = pack_bf16x2(v[2], v[3]);
+  *(u32x2*)(out + r * D + c) = o;
+}
+
+__global__ void bf16_to_f32_kernel(const bf16_t* __restrict__ in, float* __restrict__ out, size_t n4) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const u32x2 w = *(const u32x2*)(in + i * 4);
+  f32x4 v = {bf16lo_to_f32(w.x), bf16hi_to_f32(w.x), bf16lo_to_f32(w.y), bf16hi_to_f32(w.y)};
+  *(f32x4*)(out + i * 4) = v;
+}
+
+__global__ void add_f32_kernel(float* __restrict__ dst, const float* __restrict__ a, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] += a[i];
+}
+
+}  // namespace
+
+#define VT_NORM_DISPATCH(KERN, D, ...)                                                                   \
+  do {                                                                                                   \
+    const int nch = cdiv(D, 256);                                                                        \
+    if (nch <= 1) hipLaunchKernelGGL((KERN<1>), grid, dim3(256), 0, s, __VA_ARGS__);                      \
+    else if (nch <= 2) hipLaunchKernelGGL((KERN<2>), grid, dim3(256), 0, s, __VA_ARGS__);                 \
+    else if (nch <= 4) hipLaunchKernelGGL((KERN<4>), grid, dim3(256), 0, s, __VA_ARGS__);                 \
+    else if (nch <= 8) hipLaunchKernelGGL((KERN<8>), grid, dim3(256), 0, s, __VA_ARGS__);                 \
+    else hipLaunchKernelGGL((KERN<16>), grid, dim3(256), 0, s, __VA_ARGS__);                              \
+  } while (0)
+
+int vt_layernorm_launch(float* x, const float* temb, int T, int tokens_per_frame, const float* gamma,
+                        const float* beta, bf16_t* y, int rows, int D, float eps, hipStream_t s) {
+  VT_REQUIRE(x && gamma && beta && y, "vt_layernorm: null pointer");
+  VT_REQUIRE(rows > 0 && D > 0 && D % 4 == 0 && D <= 4096, "vt_layernorm: D=%d must be a multiple of 4, <= 4096", D);
+  if (temb) VT_REQUIRE(T > 0 && tokens_per_frame > 0, "vt_layernorm: temporal embedding needs T and tokens_per_frame");
+  dim3 grid(cdiv(rows, 4));
+  VT_NORM_DISPATCH(layernorm_kernel, D, x, temb, T, tokens_per_frame, gamma, beta, y, rows, D, eps);
+  VT_LAUNCH_CHECK();
+  return VT_OK;
+}
+
+int vt_rmsnorm_launch(const float* x, const int* idx, const float* w, bf16_t* y, int rows, int D, float eps,
+                      hipStream_t s) {
+  VT_REQUIRE(x && w && y, "vt_rmsnorm: null pointer");
+  VT_REQUIRE(rows > 0 && D > 0 && D % 4 == 0 && D <= 4096, "vt_rmsnorm: D=%d must be a multiple of 4, <= 4096", D);
+  dim3 grid(cdiv(rows, 4));
+  VT_NORM_DISPATCH(rmsnorm_kernel, D, x, idx, w, y, rows, D, eps);
+  VT_LAUNCH_CHECK();
+  return VT_OK;
+}
+
+int vt_gather_f32_to_bf16_launch(const float* in, const int* idx, bf16_t* out, int rows, int D, hipStream_t s) {
+  VT_REQUIRE(in && out && rows > 0 && D % 4 == 0, "vt_gather_f32_to_bf16: bad arguments");
+  const size_t n = (size_t)rows * (D / 4);
+  hipLaunchKernelGGL(gather_f32_to_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, idx, out, rows, D);
+  VT_LAUNCH_CHECK();
+  return VT_OK;
+}
+
+int vt_bf16_to_f32_launch(const bf16_t* in, float* out, size_t n, hipStream_t s) {
+  VT_REQUIRE(in && out && n % 4 == 0, "vt_bf16_to_f32: n must be a multiple of 4");
+  const size_t n4 = n / 4;
+  hipLaunchKernelGGL(bf16_to_f32_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, in, out, n4);
+  VT_LAUNCH_CHECK();
+  return VT_OK;
+}
+
+int vt_add_f32_launch(float* dst, const float* a, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(add_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dst, a, n);
+  VT_LAUNCH_CHECK();
+  return VT_OK;
+}
+
+int vt_drop_cls_launch(const float* x, bf16_t* out, int F, int G2, int D, hipStream_t s) {
+  VT_REQUIRE(x && out && D % 4 == 0, "vt_drop_cls: bad arguments");
+  const size_t n = (size_t)F * G2 * (D / 4);
+  hipLaunchKernelGGL(drop_cls_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, out, F, G2, D);
+  VT_LAUNCH_CHECK();
+  return VT_OK;
+}
