@@ -1,0 +1,228 @@
+"""bench.py -- end-to-end multimodal prefill throughput on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one synthetic clip: pixels already in HBM -> LanguageBind video tower
+(ViT-L/14 @336, temporal attention over 8 frames, the 23 layers hidden_states[-2] needs) -> mm_projector -> splice
+with the 512-token prompt (S = 8*576 + 512 = 5120) -> 32-layer Vicuna-7B-shaped decoder prefill on a paged KV cache ->
+last-position logits -> greedy first token. Everything runs through libvitron_hip.so.
+
+  python bench.py --gpus 1 --steps 5 --warmup 2
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+N > 1: one process per GPU, one clip per rank (weak scaling). Clips are encoded on the rank that owns them, the
+visual tokens are exchanged with ONE RCCL all-gather over xGMI (BASELINE config 4), then every rank prefills its
+own sequence. value = (tokens of all ranks) / (max over ranks of the timed region).
+
+Prints ONE JSON line (rank 0) with the driver's contract + "roofline" (dominant kernel class = the MFMA tile GEMM,
+timed live with HIP events on the kernel's stream) + "cpu_baseline" (the CPU oracle on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def algorithmic_flops(S, n_vis_tokens, frames, N_vit, image_tokens):
+    """SURVEY.md 8(d) accounting: 2 FLOP/MAC, ViT 23 layers, causal attention S(S+1)/2, lm_head last row only."""
+    D, I_v, H, I, L, V = 1024, 4096, 4096, 11008, 32, 32000
+    rows = frames * N_vit
+    vit_lin = rows * 23 * (24 * D * D + 8 * D * D)            # spatial qkv/o + mlp (24 D^2) + temporal qkv/o (8 D^2)
+    vit_att = rows * 23 * (4 * N_vit * D + 4 * frames * D)
+    patch = frames * image_tokens * 2 * 588 * D
+    proj = n_vis_tokens * 2 * (D * H + H * H)
+    llm_lin = S * L * 2 * (4 * H * H + 3 * H * I)
+    llm_att = L * 4 * H * S * (S + 1) / 2
+    head = 2 * H * V
+    return dict(vit=vit_lin + vit_att + patch, projector=proj, llm_linear=llm_lin, llm_attention=llm_att, lm_head=head,
+                total=vit_lin + vit_att + patch + proj + llm_lin + llm_att + head)
+
+
+def cpu_baseline(image_size, frames, text_len, seed):
+    """The CPU oracle (a port of the reference's algorithm, fp32, all host cores) on a bounded sample of the same
+    workload; extrapolated to the full step. See DESIGN.md 'Measurement'."""
+    import torch
+
+    from oracle import vitron_oracle as O
+    from vitron_amd import synth
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    gen = synth.make_generator(seed)
+    G = image_size // 14
+    n_vis = frames * G * G
+    S = n_vis + text_len
+    vcfg = dict(synth.VIT_L14, image_size=image_size, add_time_attn=True, num_frames=frames, num_hidden_layers=1)
+    vsd = {k: v.float() for k, v in synth.vit_state(vcfg, gen).items()}
+    clip = torch.randn((1, 3, frames, image_size, image_size), generator=gen).to(torch.bfloat16).float()
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        O.vit_forward(vsd, vcfg, clip, 0)
+        t1 = time.perf_counter()
+        O.vit_forward(vsd, vcfg, clip, 1)
+        t2 = time.perf_counter()
+        t_vit = (t1 - t0) + 23 * max((t2 - t1) - (t1 - t0), 0.0)
+        psd = {k: v.float() for k, v in synth.projector_state(1024, 4096, gen).items()}
+        feats = torch.randn((n_vis, 1024), generator=gen)
+        t3 = time.perf_counter()
+        O.projector_forward(psd, feats)
+        t_proj = time.perf_counter() - t3
+        lcfg = dict(synth.VICUNA_7B, num_hidden_layers=1)
+        lsd = {k: v.float() for k, v in synth.llama_state(lcfg, gen).items()}
+        Ss = 1024
+        emb = torch.randn((1, Ss, 4096), generator=gen) * 0.02
+        t4 = time.perf_counter()
+        O.llama_forward(lsd, lcfg, emb, num_layers=0)        # final norm + lm_head on every position (as the reference does)
+        t5 = time.perf_counter()
+        O.llama_forward(lsd, lcfg, emb, num_layers=1)
+        t6 = time.perf_counter()
+        t_head = (t5 - t4) * (S / Ss)
+        t_layer = max((t6 - t5) - (t5 - t4), 0.0) * (S / Ss)
+        t_llm = t_head + 32 * t_layer
+    total = t_vit + t_proj + t_llm
+    return {"value": S / total, "unit": "tokens/s", "cores": cores, "kind": "port",
+            "sample": (f"oracle fp32 on {cores} host threads: ViT embeddings + 1 of 23 layers on the full {frames}-frame {image_size}px clip, "
+                       f"projector on all {n_vis} visual tokens, final-norm+lm_head and 1 of 32 decoder layers on the first {Ss} of {S} "
+                       "positions; extrapolated linearly in depth and sequence length (attention's quadratic term is under-counted, "
+                       "which flatters the CPU)"),
+            "est_seconds_per_step": total, "measured_seconds": time.perf_counter() - t0}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--image-size", type=int, default=336)
+    ap.add_argument("--frames", type=int, default=8)
+    ap.add_argument("--text-len", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=1234)
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from vitron_amd import _lib, ops, synth
+    from vitron_amd.engine import SequenceState, llama_forward
+    from vitron_amd.model import LlavaConfig, LlavaLlamaForCausalLM
+
+    _lib.load()
+    G = args.image_size // 14
+    n_vis = args.frames * G * G
+    S = n_vis + args.text_len
+    vit_video = dict(synth.VIT_L14, image_size=args.image_size, add_time_attn=True, num_frames=args.frames)
+    cfg = LlavaConfig(**synth.VICUNA_7B, mm_hidden_size=1024)
+    model = LlavaLlamaForCausalLM(cfg)
+    model.init_synthetic(dev, seed=args.seed, vit_image=None, vit_video=vit_video)
+
+    # synthetic inputs (seed 4321 + rank): pixels N(0,1) in HBM, ids uniform in [3, 31999], BOS first, 8 x <image>
+    gen = synth.make_generator(4321 + rank, dev)
+    clip = torch.randn((3, args.frames, args.image_size, args.image_size), generator=gen, device=dev).to(torch.bfloat16)
+    text = torch.randint(3, 32000, (args.text_len - 1,), generator=gen, device=dev)
+    ids = torch.cat([torch.tensor([1], device=dev), torch.full((args.frames,), -200, device=dev), text]).unsqueeze(0)
+    assert ids.shape[1] == args.text_len + args.frames
+
+    if world > 1:  # clip-per-rank encode, ONE all-gather of visual tokens, then data-parallel prefill
+        orig = model.encode_videos
+        gathered = torch.empty((world, args.frames, G * G, 4096), dtype=torch.bfloat16, device=dev)
+
+        def encode_videos_dist(videos):
+            f = orig(videos)
+            dist.all_gather_into_tensor(gathered, f.contiguous())
+            return gathered[rank:rank + 1]
+        model.encode_videos = encode_videos_dist
+
+    llama = model.get_model().llama
+    model._ensure_kv((S + 63) // 64 + 4)
+
+    def step():
+        (_, _, _, _, embeds, _) = model.prepare_inputs_labels_for_multimodal(ids, None, None, None, None, [clip], None)
+        seq = SequenceState()
+        logits = llama_forward(llama, model.kv, [seq], embeds[0], [embeds.shape[1]])
+        tok = ops.argmax(logits)
+        model.kv.release(seq.pages)
+        return tok, embeds.shape[1]
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        tok, s_len = step()
+    assert s_len == S, (s_len, S)
+    fence()
+    _lib.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tok, _ = step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = _lib.profile_end()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = world * S * args.steps / dt
+
+    if rank == 0:
+        gt = prof["gemm_tile"]
+        achieved = gt["work"] / (gt["ms"] * 1e-3) / 1e12 if gt["ms"] > 0 else 0.0
+        fl = algorithmic_flops(S, n_vis, args.frames, G * G + 1, G * G)
+        out = {
+            "metric": "visual-tokens+text-tokens/sec end-to-end prefill, 8-frame 336px clip, 1/2/4/8 GPU",
+            "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {
+                "workload": (f"BASELINE configs[2]: {args.frames}-frame {args.image_size}x{args.image_size} clip "
+                             f"({n_vis} visual tokens) + {args.text_len}-token prompt -> S={S}; LanguageBind video ViT-L/14 "
+                             "(23 of 24 layers, temporal attention) + mlp2x_gelu projector + Vicuna-7B-shaped decoder prefill "
+                             "(32 layers, paged KV), last-position logits + greedy token; random-init weights"),
+                "clips_per_gpu": 1, "tokens_per_step_per_gpu": S, "parallelism": f"clip-parallel x{world} + all-gather of visual tokens" if world > 1 else "single GPU",
+                "algorithmic_tflop_per_step": fl["total"] / 1e12,
+                "end_to_end_tflops_per_gpu": fl["total"] / 1e12 / (ms_per_step * 1e-3),
+                "end_to_end_frac_of_mfma_peak": fl["total"] / 1e12 / (ms_per_step * 1e-3) / MFMA_BF16_PEAK_TFLOPS,
+                "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items() if v["launches"]},
+            },
+            "roofline": {"bound": "mfma", "kernel": "gemm_bt_kernel (bf16 MFMA tile GEMM, all tile configs/epilogues)",
+                         "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                         "launches_per_step": gt["launches"] / args.steps,
+                         "avg_launch_ms": gt["ms"] / max(gt["launches"], 1),
+                         "algorithmic_gflop_per_launch": gt["work"] / max(gt["launches"], 1) / 1e9},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.image_size, args.frames, args.text_len, args.seed)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

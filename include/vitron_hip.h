@@ -240,6 +240,17 @@ int vt_llama_forward(const vt_llama_model* m, const vt_kv_cache* kv, const uint1
                      const int* tile_table, const int* logit_rows, int n_logit_rows, float* logits,
                      float* out_hidden, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Per-kernel-class timing (the reference has no tracing on this path). Between vt_profile_begin and
+ * vt_profile_end every launch of the instrumented kernel classes is bracketed by hipEvents recorded on the SAME
+ * stream as the kernel, so the durations are device-side launch durations inside the caller's timed region.
+ * vt_profile_end synchronises on the recorded events and fills, per class: launches, total milliseconds, total
+ * algorithmic work (FLOP for MFMA kernels, bytes for the weight-streaming kernel). Arrays hold VT_PROF_CLASSES items.
+ * ---------------------------------------------------------------------------------------------------------- */
+enum { VT_PROF_GEMM_TILE = 0, VT_PROF_FLASH_ATTN = 1, VT_PROF_GEMM_SKINNY = 2, VT_PROF_ATTN_DECODE = 3, VT_PROF_CLASSES = 4 };
+int vt_profile_begin(void);
+int vt_profile_end(int* launches, double* total_ms, double* total_work);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,159 @@
+"""CPU tests of the host-side logic of the product (no GPU, no kernels launched): prompt plumbing, the integer
+splice plan, region slice resolution, weight packing layouts, and that the C-ABI library loads and exports every
+symbol include/vitron_hip.h declares."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vitron_oracle as O
+from tests.golden import cases
+from tests.test_oracle_golden import StubTok
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_mm_utils_match_reference_goldens():
+    from vitron_amd import mm_utils
+    g = np.load(os.path.join(G, "mm_utils.npz"))
+    tok = StubTok()
+    for i, p in enumerate(cases.PROMPTS):
+        assert mm_utils.tokenizer_image_token(p, tok) == g[f"image_token_{i}"].tolist()
+        assert mm_utils.tokenizer_image_region_token(p, tok) == g[f"region_token_{i}"].tolist()
+        assert mm_utils.tokenizer_image_region_token(p, tok, return_tensors="pt").tolist() == g[f"region_token_{i}"].tolist()
+    for i, (r, isz, tsz) in enumerate(cases.REGION_RESCALE):
+        assert mm_utils.preprocess_region(r, isz, tsz) == g[f"preprocess_region_{i}"].tolist()
+    with pytest.raises(ValueError):
+        mm_utils.tokenizer_image_token("a", tok, return_tensors="np")
+    assert mm_utils.get_model_name_from_path("/a/b/checkpoint-12/") == "b_checkpoint-12"
+
+
+def test_constants_match_reference_values():
+    from vitron_amd import constants as c
+    assert (c.IGNORE_INDEX, c.IMAGE_TOKEN_INDEX, c.OBJS_TOKEN_INDEX) == (-100, -200, -300)
+    assert (O.IGNORE_INDEX, O.IMAGE_TOKEN_INDEX, O.OBJS_TOKEN_INDEX) == (-100, -200, -300)
+
+
+def _materialise(plan, tok, vis, reg):
+    rows = []
+    for kind, idx in plan:
+        rows.append({0: lambda: tok[idx], 1: lambda: vis[idx], 2: lambda: reg[idx], 3: lambda: torch.zeros(tok.shape[1])}[kind]())
+    return torch.stack(rows)
+
+
+@pytest.mark.parametrize("name", list(cases.glue_cases()))
+def test_splice_plan_matches_reference_layout(name):
+    """The integer plan reproduces the reference's spliced layout: same shape/mask as the golden produced by the
+    reference's prepare_inputs_labels_for_multimodal, and the same rows as the oracle's list surgery."""
+    from vitron_amd.model.llava_arch import build_splice_plan
+    g = np.load(os.path.join(G, "glue_llm.npz"))
+    case = cases.glue_cases()[name]
+    H, P, T = 8, 16, cases.VIT_VIDEO["num_frames"]
+    tok = torch.arange(cases.LLM["vocab_size"] * H, dtype=torch.float32).reshape(-1, H)
+    blocks, regs, vis_rows, flat_f, flat_r = [], [], 0, [], []
+    use_regions = case["regions"] is not None and len(case["regions"]) > 0
+    image_idx = [i for i, im in enumerate(case["images"]) if im.dim() == 3]
+    nreg = 0
+    per = {}
+    for j, i in enumerate(image_idx):
+        per[i] = ([(vis_rows + j * P, P)], [j])
+    vis_rows += len(image_idx) * P
+    for j, i in enumerate([i for i, im in enumerate(case["images"]) if im.dim() == 4]):
+        per[i] = ([(vis_rows + (j * T + t) * P, P) for t in range(T)], [-1] * T)
+    nvid = sum(1 for im in case["images"] if im.dim() == 4)
+    vis = -1.0 - torch.arange((vis_rows + nvid * T * P) * H, dtype=torch.float32).reshape(-1, H)
+    reg = 1e6 + torch.arange(max(len(image_idx), 1) * H, dtype=torch.float32).reshape(-1, H)
+    for i in range(len(case["images"])):
+        blocks += per[i][0]
+        regs += per[i][1]
+    for (first, n), r in zip(blocks, regs):
+        flat_f.append(vis[first:first + n])
+        flat_r.append(reg[r:r + 1] if r >= 0 else None)
+    am = None if case["attention_mask"] is None else case["attention_mask"].tolist()
+    plan, mask, pos, lengths = build_splice_plan(case["input_ids"].tolist(), am, blocks, regs if use_regions else None,
+                                                 case.get("max_length"), case.get("padding_side", "right"))
+    ref_m = g[f"{name}_mask"]
+    assert np.array_equal(np.array(mask, dtype=np.int32), ref_m)                          # vs the REFERENCE
+    e, m2, p2 = O.splice_embeddings(case["input_ids"], case["attention_mask"], tok, flat_f, flat_r if use_regions else None,
+                                    case.get("max_length"), case.get("padding_side", "right"))
+    got = torch.stack([_materialise(p, tok, vis, reg) for p in plan])
+    assert torch.equal(got, e) and torch.equal(torch.tensor(mask).bool(), m2) and torch.equal(torch.tensor(pos), p2)
+    assert lengths == [int(r.sum()) for r in ref_m]
+
+
+def test_splice_plan_errors_and_quirks():
+    from vitron_amd.model.llava_arch import build_splice_plan
+    # a sample without <image> still consumes a feature slot (llava_arch.py:317-324)
+    plan, mask, pos, lens = build_splice_plan([[1, 5, 6], [1, -200, 7]], None, [(0, 2), (2, 2)], None)
+    assert plan[1][1:3] == [(1, 2), (1, 3)] and lens == [3, 4] and mask[0] == [1, 1, 1, 0]
+    with pytest.raises(ValueError):
+        build_splice_plan([[1, -200, -200]], None, [(0, 2)], None)          # more sentinels than features
+    with pytest.raises(ValueError):
+        build_splice_plan([[1, -200, -300]], None, [(0, 2)], None)          # <objs> without regions
+    with pytest.raises(ValueError):
+        build_splice_plan([[1, -200, -300]], None, [(0, 2)], [-1])          # <objs> bound to a video frame
+    # empty prompt edge: zero-length sample
+    plan, mask, pos, lens = build_splice_plan([[1]], [[0]], [(0, 2)], None)
+    assert lens == [0]
+
+
+def test_region_slice_resolution_is_python_exact():
+    from vitron_amd.engine import resolve_region_slices
+    boxes = cases.BOXES + [[-10, 5.9, 300, 7.2], [50, 60, 40, 70], [223.99999, 0, 224.5, 1e9]]
+    got = resolve_region_slices(boxes, 224)
+    for (x1, y1, x2, y2), (r0, r1, c0, c1) in zip(boxes, got):
+        m = torch.zeros(224, 224)
+        m[int(x1):int(x2), int(y1):int(y2)] = 1
+        rows = m.any(1).nonzero().flatten()
+        cols = m.any(0).nonzero().flatten()
+        exp = torch.zeros(224, 224)
+        exp[r0:r1, c0:c1] = 1
+        assert torch.equal(m, exp), (x1, y1, x2, y2)
+
+
+def test_weight_packing_layouts():
+    from vitron_amd.engine import interleave_gate_up, merge_lora
+    g = torch.arange(64 * 3, dtype=torch.float32).reshape(64, 3)
+    u = -g
+    w = interleave_gate_up(g, u)
+    assert w.shape == (128, 3)
+    assert torch.equal(w[0:16], g[0:16]) and torch.equal(w[16:32], u[0:16]) and torch.equal(w[32:48], g[16:32])
+    base = torch.randn(8, 6)
+    a, b = torch.randn(2, 6), torch.randn(8, 2)
+    sd = {"encoder.layers.0.self_attn.q_proj.base_layer.weight": base, "encoder.layers.0.self_attn.q_proj.base_layer.bias": torch.zeros(8),
+          "encoder.layers.0.self_attn.q_proj.lora_A.default.weight": a, "encoder.layers.0.self_attn.q_proj.lora_B.default.weight": b,
+          "pre_layrnorm.weight": torch.ones(6)}
+    m = merge_lora(sd, lora_alpha=16.0)
+    assert set(m) == {"encoder.layers.0.self_attn.q_proj.weight", "encoder.layers.0.self_attn.q_proj.bias", "pre_layrnorm.weight"}
+    assert torch.allclose(m["encoder.layers.0.self_attn.q_proj.weight"], base + 8.0 * (b @ a))
+
+
+def test_cabi_library_loads_and_exports_header_symbols():
+    """Every function declared in include/vitron_hip.h is exported by libvitron_hip.so and bound in _lib.SIGNATURES."""
+    from vitron_amd import _lib
+    lib = _lib.load()
+    hdr = open(os.path.join(ROOT, "include", "vitron_hip.h")).read()
+    declared = set(re.findall(r"^(?:int|size_t)\s+(vt_\w+)\s*\(", hdr, flags=re.M))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.vt_version() >= 100
+    # error convention: bad arguments come back as a negative status + message, nothing throws, no GPU needed
+    st = lib.vt_gemm_bf16(None, 8, None, 8, None, 8, None, 4, 4, 8, 0, 0, None, None)
+    assert st == -1 and "null" in _lib.last_error()
+    assert lib.vt_projector_workspace_bytes(100, 4096) >= 100 * 4096 * 2
+
+
+def test_ops_refuse_cpu_tensors():
+    from vitron_amd import _lib, ops
+    with pytest.raises(_lib.VitronHipError):
+        ops.gemm(torch.zeros(4, 8, dtype=torch.bfloat16), torch.zeros(4, 8, dtype=torch.bfloat16))
+    from vitron_amd.model import load_pretrained_model
+    with pytest.raises(RuntimeError):
+        load_pretrained_model("synthetic", None, "x", device="cpu")
+    with pytest.raises(NotImplementedError):
+        load_pretrained_model("synthetic", None, "x", load_8bit=True)

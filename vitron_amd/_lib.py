@@ -82,7 +82,10 @@ SIGNATURES = {
     "vt_llama_workspace_bytes": (_sz, [C.POINTER(VtLlamaModel), _i, _i]),
     "vt_llama_forward": (_i, [C.POINTER(VtLlamaModel), C.POINTER(VtKvCache), vp, _i, vp, vp, _i, _i, _i, vp, vp,
                               _i, vp, vp, vp, _sz, vp]),
+    "vt_profile_begin": (_i, []),
+    "vt_profile_end": (_i, [C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
+PROF_CLASSES = ("gemm_tile", "flash_attn", "gemm_skinny", "attn_decode")
 
 _lib = None
 
@@ -134,3 +137,15 @@ def last_error() -> str:
 def check(status: int, what: str = "") -> None:
     if status != 0:
         raise VitronHipError(f"{what or 'libvitron_hip'} failed (status {status}): {last_error()}")
+
+
+def profile_begin() -> None:
+    check(load().vt_profile_begin(), "vt_profile_begin")
+
+
+def profile_end() -> dict:
+    """{class: {'launches', 'ms', 'work'}} for the launches since profile_begin (device-side event timing)."""
+    n = len(PROF_CLASSES)
+    launches, ms, work = (C.c_int * n)(), (C.c_double * n)(), (C.c_double * n)()
+    check(load().vt_profile_end(launches, ms, work), "vt_profile_end")
+    return {PROF_CLASSES[i]: {"launches": launches[i], "ms": ms[i], "work": work[i]} for i in range(n)}

@@ -18,6 +18,43 @@ void vt_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+// ---- profiling ---------------------------------------------------------------------------------------------------
+#include <mutex>
+#include <vector>
+namespace {
+struct ProfRec {
+  hipEvent_t a, b;
+  int cls;
+  double work;
+};
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof_recs;
+std::vector<hipEvent_t> g_prof_pool;
+hipEvent_t prof_event() {
+  if (!g_prof_pool.empty()) {
+    hipEvent_t e = g_prof_pool.back();
+    g_prof_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+}  // namespace
+bool vt_prof_enabled() { return g_prof_on; }
+void vt_prof_start(int cls, double work, hipStream_t s) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  ProfRec r{prof_event(), prof_event(), cls, work};
+  if (!r.a || !r.b) return;
+  hipEventRecord(r.a, s);
+  g_prof_recs.push_back(r);
+}
+void vt_prof_stop(hipStream_t s) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (!g_prof_recs.empty()) hipEventRecord(g_prof_recs.back().b, s);
+}
+
 namespace {
 struct Carver {  // bump allocator over the caller's workspace
   char* base;
@@ -46,6 +83,41 @@ int vt_last_error(char* buf, size_t buf_len) {
     buf[c] = 0;
   }
   return (int)n;
+}
+
+int vt_profile_begin(void) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (auto& r : g_prof_recs) {
+    g_prof_pool.push_back(r.a);
+    g_prof_pool.push_back(r.b);
+  }
+  g_prof_recs.clear();
+  g_prof_on = true;
+  return VT_OK;
+}
+
+int vt_profile_end(int* launches, double* total_ms, double* total_work) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof_on = false;
+  for (int c = 0; c < VT_PROF_CLASSES; ++c) {
+    if (launches) launches[c] = 0;
+    if (total_ms) total_ms[c] = 0.0;
+    if (total_work) total_work[c] = 0.0;
+  }
+  for (auto& r : g_prof_recs) {
+    float ms = 0.f;
+    VT_HIP(hipEventSynchronize(r.b));
+    VT_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+    if (r.cls >= 0 && r.cls < VT_PROF_CLASSES) {
+      if (launches) launches[r.cls] += 1;
+      if (total_ms) total_ms[r.cls] += ms;
+      if (total_work) total_work[r.cls] += r.work;
+    }
+    g_prof_pool.push_back(r.a);
+    g_prof_pool.push_back(r.b);
+  }
+  g_prof_recs.clear();
+  return VT_OK;
 }
 
 // ---- primitives -----------------------------------------------------------------------------------------------------

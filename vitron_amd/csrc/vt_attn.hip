@@ -519,6 +519,8 @@ int vt_flash_attn_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf16_
   VT_REQUIRE(nseq > 0 && max_q_len > 0 && heads > 0, "vt_flash_attn: empty problem");
   VT_REQUIRE(ldq % 8 == 0 && ldo % 4 == 0, "vt_flash_attn: ldq %% 8 and ldo %% 4 must be 0");
   const float sl2 = scale * 1.4426950408889634f;
+  // algorithmic FLOP are not known here without reading seq_desc back; the caller-side bench computes them.
+  VtProfScope prof(VT_PROF_FLASH_ATTN, 0.0, s);
   dim3 grid(cdiv(max_q_len, 128), heads, nseq), block(256);
   const int smem = 2 * 2 * 64 * HD * 2;
 #define VT_FA(HDV, CV)                                                                                         \
@@ -567,6 +569,7 @@ int vt_attn_decode_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf16
   VT_REQUIRE(Q && Kt && Vt && tile_table && seqs && O, "vt_attn_decode: null pointer");
   VT_REQUIRE(HD == 64 || HD == 128, "vt_attn_decode: head_dim %d unsupported", HD);
   const float sl2 = scale * 1.4426950408889634f;
+  VtProfScope prof(VT_PROF_ATTN_DECODE, 0.0, s);
   dim3 grid(heads, nseq), block(256);
   if (HD == 64) hipLaunchKernelGGL((attn_decode_kernel<64>), grid, block, 0, s, Q, ldq, Kt, Vt, tile_table, seqs, O, ldo, heads, sl2);
   else hipLaunchKernelGGL((attn_decode_kernel<128>), grid, block, 0, s, Q, ldq, Kt, Vt, tile_table, seqs, O, ldo, heads, sl2);

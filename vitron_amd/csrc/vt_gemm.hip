@@ -353,6 +353,10 @@ int vt_gemm_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, 
              "vt_gemm: A/W/C must be 16-byte aligned");
   VT_REQUIRE(ldc % 4 == 0, "vt_gemm: ldc must be a multiple of 4");
   GemmP p{A, W, C, bias, M, N, K, lda, ldw, ldc};
+  const bool skinny_path = (M <= 16) && (cfg == VT_GEMM_CFG_AUTO || cfg == VT_GEMM_CFG_SKINNY);
+  // algorithmic work: 2*M*N*K FLOP for the MFMA tile kernel; weight bytes for the weight-streaming kernel
+  VtProfScope prof(skinny_path ? VT_PROF_GEMM_SKINNY : VT_PROF_GEMM_TILE,
+                   skinny_path ? 2.0 * (double)N * (double)K : 2.0 * (double)M * (double)N * (double)K, s);
   const bool skinny = (M <= 16) && (cfg == VT_GEMM_CFG_AUTO || cfg == VT_GEMM_CFG_SKINNY);
   if (skinny) {
     VT_REQUIRE((K % 8) == 0, "vt_gemm(skinny): K=%d must be a multiple of 8", K);

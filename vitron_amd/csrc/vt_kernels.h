@@ -55,3 +55,19 @@ int vt_region_pool_launch(const bf16_t* feats, const int* slices, int B, int G, 
 int vt_embed_splice_launch(const bf16_t* tok_table, const bf16_t* vis, const bf16_t* reg, const int* plan,
                            int rows, int H, bf16_t* out, hipStream_t s);
 int vt_argmax_launch(const float* logits, int rows, int V, int ldl, int* out_ids, hipStream_t s);
+
+// ---- profiling (vt_api.hip) -----------------------------------------------------------------------------
+// RAII bracket: records start/stop events on `s` around a launch when profiling is enabled.
+bool vt_prof_enabled();
+void vt_prof_start(int cls, double work, hipStream_t s);
+void vt_prof_stop(hipStream_t s);
+struct VtProfScope {
+  hipStream_t s;
+  bool on;
+  VtProfScope(int cls, double work, hipStream_t st) : s(st), on(vt_prof_enabled()) {
+    if (on) vt_prof_start(cls, work, s);
+  }
+  ~VtProfScope() {
+    if (on) vt_prof_stop(s);
+  }
+};

@@ -1,0 +1,434 @@
+"""Weight packing and the composite operators (ViT tower, projector, region extractor, LLaMA decoder + paged KV).
+
+This is the "weight loader" side of the boundary: it takes state dicts in the REFERENCE's
+parameter naming (what vitron/model/builder.py:53-86,149-163 would load from disk) and lays them out the way the
+HIP kernels want them:
+  * q/k/v projections fused into one [3D][D] matrix (ViT: q rows and bias pre-scaled by head_dim^-0.5, an exact
+    power-of-two scaling in bf16),
+  * LLaMA gate/up fused and row-interleaved in blocks of 16 so SwiGLU is a lane-local GEMM epilogue,
+  * the patch-embedding conv flattened to [D][3*P*P] in (c,py,px) order and zero padded to a multiple of 64,
+  * image-tower LoRA deltas (reference image/modeling_image.py:772-793) merged into the base weights,
+  * biases / norm parameters / embeddings tables upcast to fp32 once.
+Each Packed* object owns its device tensors and the ctypes struct that points at them, and exposes one
+`forward` that is a single C-ABI call.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import PAGE_TOKENS
+
+SD = Dict[str, torch.Tensor]
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _bf(t: torch.Tensor, device) -> torch.Tensor:
+    return t.to(device=device, dtype=torch.bfloat16).contiguous()
+
+
+def _f32(t: torch.Tensor, device) -> torch.Tensor:
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+def merge_lora(sd: SD, lora_alpha: float = 16.0) -> SD:
+    """Fold peft LoRA adapters (`X.base_layer.weight`, `X.lora_A.default.weight`, `X.lora_B.default.weight`) into
+    plain `X.weight` entries: W += (alpha / r) * B @ A. Keys without adapters pass through."""
+    out: SD = {}
+    for k, v in sd.items():
+        if ".lora_A." in k or ".lora_B." in k:
+            continue
+        k2 = k.replace("base_model.model.", "")
+        if k2.endswith(".base_layer.weight"):
+            stem = k[: -len(".base_layer.weight")]
+            a = sd.get(stem + ".lora_A.default.weight")
+            b = sd.get(stem + ".lora_B.default.weight")
+            w = v.float()
+            if a is not None and b is not None:
+                w = w + (lora_alpha / a.shape[0]) * (b.float() @ a.float())
+            out[k2[: -len(".base_layer.weight")] + ".weight"] = w.to(v.dtype)
+        elif k2.endswith(".base_layer.bias"):
+            out[k2[: -len(".base_layer.bias")] + ".bias"] = v
+        else:
+            out[k2] = v
+    return out
+
+
+class Workspace:
+    """A grow-only device scratch buffer shared by the composite operators of one model."""
+
+    def __init__(self, device):
+        self.device = device
+        self.buf: Optional[torch.Tensor] = None
+
+    def get(self, nbytes: int) -> torch.Tensor:
+        if self.buf is None or self.buf.numel() < nbytes:
+            self.buf = None
+            self.buf = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        return self.buf
+
+
+# =====================================================================================================================
+class PackedVit:
+    """LanguageBind CLIP vision transformer in kernel layout (vt_vit_model)."""
+
+    def __init__(self, sd: SD, cfg: dict, device, select_layer: int = -2):
+        sd = merge_lora(sd) if any(".lora_" in k for k in sd) else sd
+        self.cfg = dict(cfg)
+        self.device = torch.device(device)
+        D, heads, P = cfg["hidden_size"], cfg["num_attention_heads"], cfg["patch_size"]
+        if D != heads * 64:
+            raise _lib.VitronHipError("PackedVit: kernels are specialised for head_dim 64")
+        self.D, self.heads, self.P, self.I = D, heads, P, cfg["intermediate_size"]
+        self.image_size = cfg["image_size"]
+        self.G = self.image_size // P
+        self.time_attn = bool(cfg.get("add_time_attn", False))
+        self.num_frames = int(cfg.get("num_frames", 1))
+        nl = cfg["num_hidden_layers"]
+        self.run_layers = select_layer if select_layer >= 0 else nl + 1 + select_layer
+        if not 0 <= self.run_layers <= nl:
+            raise _lib.VitronHipError(f"PackedVit: select_layer {select_layer} out of range")
+        self.k_pad = (3 * P * P + 63) // 64 * 64
+        self._keep: List[torch.Tensor] = []
+        dev = self.device
+        scale = 64 ** -0.5
+
+        def keep(t):
+            self._keep.append(t)
+            return t
+
+        wp = torch.zeros((D, self.k_pad), dtype=torch.bfloat16, device=dev)
+        wp[:, : 3 * P * P] = _bf(sd["embeddings.patch_embedding.weight"].reshape(D, 3 * P * P), dev)
+        self.w_patch = keep(wp)
+        self.cls = keep(_f32(sd["embeddings.class_embedding"].reshape(D), dev))
+        pos = sd["embeddings.position_embedding.weight"]
+        if pos.shape[0] != self.G * self.G + 1:
+            raise _lib.VitronHipError(f"PackedVit: position table has {pos.shape[0]} rows, need {self.G * self.G + 1}")
+        self.pos = keep(_f32(pos, dev))
+        self.pre_g = keep(_f32(sd["pre_layrnorm.weight"], dev))
+        self.pre_b = keep(_f32(sd["pre_layrnorm.bias"], dev))
+
+        def fuse_qkv(prefix):
+            w = torch.cat([sd[prefix + "q_proj.weight"].float() * scale, sd[prefix + "k_proj.weight"].float(),
+                           sd[prefix + "v_proj.weight"].float()], 0)
+            b = torch.cat([sd[prefix + "q_proj.bias"].float() * scale, sd[prefix + "k_proj.bias"].float(),
+                           sd[prefix + "v_proj.bias"].float()], 0)
+            return keep(_bf(w, dev)), keep(_f32(b, dev))
+
+        self.layers = (_lib.VtVitLayer * max(self.run_layers, 1))()
+        for l in range(self.run_layers):
+            p = f"encoder.layers.{l}."
+            L = self.layers[l]
+            if self.time_attn:
+                L.t_ln_g = keep(_f32(sd[p + "temporal_layer_norm1.weight"], dev)).data_ptr()
+                L.t_ln_b = keep(_f32(sd[p + "temporal_layer_norm1.bias"], dev)).data_ptr()
+                if self.num_frames != 1:
+                    L.t_embed = keep(_f32(sd[p + "temporal_embedding"].reshape(-1, D)[: self.num_frames], dev)).data_ptr()
+                w, b = fuse_qkv(p + "temporal_attn.")
+                L.t_wqkv, L.t_bqkv = w.data_ptr(), b.data_ptr()
+                L.t_wo = keep(_bf(sd[p + "temporal_attn.out_proj.weight"], dev)).data_ptr()
+                L.t_bo = keep(_f32(sd[p + "temporal_attn.out_proj.bias"], dev)).data_ptr()
+            L.ln1_g = keep(_f32(sd[p + "layer_norm1.weight"], dev)).data_ptr()
+            L.ln1_b = keep(_f32(sd[p + "layer_norm1.bias"], dev)).data_ptr()
+            w, b = fuse_qkv(p + "self_attn.")
+            L.wqkv, L.bqkv = w.data_ptr(), b.data_ptr()
+            L.wo = keep(_bf(sd[p + "self_attn.out_proj.weight"], dev)).data_ptr()
+            L.bo = keep(_f32(sd[p + "self_attn.out_proj.bias"], dev)).data_ptr()
+            L.ln2_g = keep(_f32(sd[p + "layer_norm2.weight"], dev)).data_ptr()
+            L.ln2_b = keep(_f32(sd[p + "layer_norm2.bias"], dev)).data_ptr()
+            L.w1 = keep(_bf(sd[p + "mlp.fc1.weight"], dev)).data_ptr()
+            L.b1 = keep(_f32(sd[p + "mlp.fc1.bias"], dev)).data_ptr()
+            L.w2 = keep(_bf(sd[p + "mlp.fc2.weight"], dev)).data_ptr()
+            L.b2 = keep(_f32(sd[p + "mlp.fc2.bias"], dev)).data_ptr()
+        act = cfg.get("hidden_act", "quick_gelu")
+        if act not in ("gelu", "quick_gelu"):
+            raise _lib.VitronHipError(f"PackedVit: unsupported hidden_act {act}")
+        m = _lib.VtVitModel()
+        m.image_size, m.patch, m.hidden, m.heads, m.intermediate = self.image_size, P, D, heads, self.I
+        m.num_layers, m.num_frames, m.add_time_attn = self.run_layers, self.num_frames, int(self.time_attn)
+        m.act = _lib.ACT_GELU if act == "gelu" else _lib.ACT_QUICK_GELU
+        m.ln_eps = float(cfg.get("layer_norm_eps", 1e-5))
+        m.k_pad = self.k_pad
+        m.w_patch, m.cls, m.pos = self.w_patch.data_ptr(), self.cls.data_ptr(), self.pos.data_ptr()
+        m.pre_ln_g, m.pre_ln_b = self.pre_g.data_ptr(), self.pre_b.data_ptr()
+        m.layers = C.cast(self.layers, C.POINTER(_lib.VtVitLayer))
+        self.model = m
+        self.ws = Workspace(dev)
+
+    def forward(self, pixels: torch.Tensor, return_hidden: bool = False):
+        """pixels [B,3,H,W] or [B,3,T,H,W] (bf16/fp32, on device) -> patch features bf16 [B(,T),G*G,D]
+        (= feature_select of hidden_states[select_layer]); optionally also the full fp32 hidden state."""
+        lib = _lib.load()
+        if not pixels.is_cuda:
+            raise _lib.VitronHipError("PackedVit.forward: pixels must live on the GPU")
+        video = pixels.dim() == 5
+        if video:
+            B, Cc, T, H, W = pixels.shape
+        else:
+            B, Cc, H, W = pixels.shape
+            T = 1
+        if Cc != 3 or H != self.image_size or W != self.image_size:
+            raise _lib.VitronHipError(f"PackedVit.forward: expected 3x{self.image_size}x{self.image_size} pixels, got {tuple(pixels.shape)}")
+        if pixels.dtype not in (torch.bfloat16, torch.float32):
+            pixels = pixels.to(torch.bfloat16)
+        pixels = pixels.contiguous()
+        dt = _lib.DTYPE_BF16 if pixels.dtype == torch.bfloat16 else _lib.DTYPE_F32
+        G2 = self.G * self.G
+        out = torch.empty((B * T * G2, self.D), device=self.device, dtype=torch.bfloat16)
+        hidden = torch.empty((B * T * (G2 + 1), self.D), device=self.device, dtype=torch.float32) if return_hidden else None
+        nbytes = lib.vt_vit_workspace_bytes(C.byref(self.model), B, T)
+        ws = self.ws.get(nbytes)
+        _lib.check(lib.vt_vit_forward(C.byref(self.model), pixels.data_ptr(), dt, B, T, int(video), out.data_ptr(),
+                                      None if hidden is None else hidden.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+                   "vt_vit_forward")
+        feats = out.view(B, T, G2, self.D) if video else out.view(B, G2, self.D)
+        if return_hidden:
+            return feats, hidden.view(B * T, G2 + 1, self.D)
+        return feats
+
+
+# =====================================================================================================================
+class PackedProjector:
+    """mm_projector ('mlp2x_gelu' or 'linear'), reference multimodal_projector/builder.py:33-51."""
+
+    def __init__(self, sd: SD, device):
+        self.device = torch.device(device)
+        if "0.weight" in sd:
+            self.w1, self.b1 = _bf(sd["0.weight"], device), _f32(sd["0.bias"], device)
+            self.w2, self.b2 = _bf(sd["2.weight"], device), _f32(sd["2.bias"], device)
+            self.dout = self.w2.shape[0]
+        else:
+            self.w1, self.b1 = _bf(sd["weight"], device), _f32(sd["bias"], device)
+            self.w2 = self.b2 = None
+            self.dout = self.w1.shape[0]
+        self.din, self.dh = self.w1.shape[1], self.w1.shape[0]
+        self.ws = Workspace(device)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        lib = _lib.load()
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1]).to(torch.bfloat16).contiguous()
+        M = x2.shape[0]
+        out = torch.empty((M, self.dout), device=self.device, dtype=torch.bfloat16)
+        ws = self.ws.get(lib.vt_projector_workspace_bytes(M, self.dh))
+        _lib.check(lib.vt_projector_forward(x2.data_ptr(), M, self.din, self.w1.data_ptr(), self.b1.data_ptr(), self.dh,
+                                            None if self.w2 is None else self.w2.data_ptr(),
+                                            None if self.b2 is None else self.b2.data_ptr(), self.dout, out.data_ptr(),
+                                            ws.data_ptr(), ws.numel(), _stream()), "vt_projector_forward")
+        return out.view(*shp[:-1], self.dout)
+
+
+# =====================================================================================================================
+def resolve_region_slices(regions: Sequence[Sequence[float]], image_size: int) -> List[List[int]]:
+    """Host half of transform_bbox_2_mask (reference region_extractor/layer.py:77-85): the mask assignment
+    mask[int(x1):int(x2), int(y1):int(y2)] = 1 resolved with Python's own int() and slice semantics, so the
+    integer bounds handed to the kernel are exactly the reference's (x -> rows, y -> columns)."""
+    out = []
+    for x1, y1, x2, y2 in regions:
+        r0, r1, _ = slice(int(x1), int(x2)).indices(image_size)
+        c0, c1, _ = slice(int(y1), int(y2)).indices(image_size)
+        out.append([r0, max(r1, r0), c0, max(c1, c0)])
+    return out
+
+
+class PackedRegion:
+    """RegionExtractor (reference region_extractor/layer.py:58-130) in kernel layout."""
+
+    def __init__(self, sd: SD, device, image_size: int = 224, patch_size: int = 14):
+        self.device = torch.device(device)
+        self.image_size, self.patch_size = image_size, patch_size
+        self._keep = []
+        w = _lib.VtRegionWeights()
+        self.in_dim = sd["region_linear.layers.0.weight"].shape[1]
+        self.out_dim = sd["region_linear.layers.2.weight"].shape[0]
+        w.in_dim, w.out_dim = self.in_dim, self.out_dim
+        for i in range(3):
+            wt, bt = _bf(sd[f"region_linear.layers.{i}.weight"], device), _f32(sd[f"region_linear.layers.{i}.bias"], device)
+            self._keep += [wt, bt]
+            w.mlp_w[i], w.mlp_b[i] = wt.data_ptr(), bt.data_ptr()
+        l0 = torch.zeros((self.out_dim // 2, 8), dtype=torch.bfloat16, device=device)  # K padded 4 -> 8
+        l0[:, :4] = _bf(sd["loc_encoder.loc_encoder.0.weight"], device)
+        l0b = _f32(sd["loc_encoder.loc_encoder.0.bias"], device)
+        l1, l1b = _bf(sd["loc_encoder.loc_encoder.2.weight"], device), _f32(sd["loc_encoder.loc_encoder.2.bias"], device)
+        self._keep += [l0, l0b, l1, l1b]
+        w.loc_w[0], w.loc_b[0], w.loc_w[1], w.loc_b[1] = l0.data_ptr(), l0b.data_ptr(), l1.data_ptr(), l1b.data_ptr()
+        self.weights = w
+        self.ws = Workspace(device)
+
+    def forward(self, feats: torch.Tensor, regions: Sequence[Sequence[float]], return_mask: bool = False):
+        """feats [B,G*G,C] bf16 (pre-projector patch features), regions: B boxes -> [B,1,H] bf16."""
+        lib = _lib.load()
+        B, n, c = feats.shape
+        G = int(math.sqrt(n))
+        if len(regions) != B:  # the reference prints and carries on (layer.py:101-107); there is nothing sane to compute
+            raise _lib.VitronHipError(f"region_extractor: {B} feature maps but {len(regions)} regions")
+        feats = feats.to(torch.bfloat16).contiguous()
+        out = torch.empty((B, self.out_dim), device=self.device, dtype=torch.bfloat16)
+        mask = torch.empty((B, n), device=self.device, dtype=torch.int32) if return_mask else None
+        count = torch.empty((B,), device=self.device, dtype=torch.int32) if return_mask else None
+        for s in range(0, B, 16):
+            e = min(B, s + 16)
+            sl = torch.tensor(resolve_region_slices(regions[s:e], self.image_size), dtype=torch.int32, device=self.device)
+            co = torch.zeros((e - s, 8), dtype=torch.float32)
+            co[:, :4] = torch.tensor([list(map(float, r)) for r in regions[s:e]], dtype=torch.float32)
+            co = co.to(device=self.device, dtype=torch.bfloat16)  # torch.tensor(regions, dtype=model dtype), layer.py:126
+            ws = self.ws.get(lib.vt_region_workspace_bytes(e - s, self.in_dim, self.out_dim))
+            _lib.check(lib.vt_region_forward(C.byref(self.weights), feats[s:e].data_ptr(), sl.data_ptr(), co.data_ptr(),
+                                             e - s, G, self.image_size, out[s:e].data_ptr(),
+                                             None if mask is None else mask[s:e].data_ptr(),
+                                             None if count is None else count[s:e].data_ptr(), ws.data_ptr(), ws.numel(),
+                                             _stream()), "vt_region_forward")
+        if return_mask:
+            return out.unsqueeze(1), mask, count
+        return out.unsqueeze(1)
+
+
+# =====================================================================================================================
+def rope_tables(head_dim: int, max_pos: int, theta: float, device):
+    """cos/sin [max_pos, head_dim/2] fp32, computed exactly as LlamaRotaryEmbedding does (fp32 outer product)."""
+    inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
+    t = torch.arange(max_pos, dtype=torch.float32)
+    freqs = torch.outer(t, inv_freq)
+    return freqs.cos().to(device).contiguous(), freqs.sin().to(device).contiguous()
+
+
+def interleave_gate_up(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
+    """[I,H] gate, [I,H] up -> [2I,H] with rows gate[0:16], up[0:16], gate[16:32], up[16:32], ..."""
+    I, H = gate.shape
+    return torch.stack([gate.reshape(I // 16, 16, H), up.reshape(I // 16, 16, H)], dim=1).reshape(2 * I, H)
+
+
+class PackedLlama:
+    """LLaMA decoder weights in kernel layout (vt_llama_model) + embedding table."""
+
+    def __init__(self, sd: SD, cfg: dict, device, rope_len: Optional[int] = None):
+        self.cfg = dict(cfg)
+        self.device = torch.device(device)
+        H, heads = cfg["hidden_size"], cfg["num_attention_heads"]
+        self.H, self.heads, self.hd = H, heads, H // heads
+        self.I, self.V, self.L = cfg["intermediate_size"], cfg["vocab_size"], cfg["num_hidden_layers"]
+        if self.hd not in (64, 128):
+            raise _lib.VitronHipError("PackedLlama: head_dim must be 64 or 128")
+        if self.I % 16:
+            raise _lib.VitronHipError("PackedLlama: intermediate_size must be a multiple of 16")
+        dev = self.device
+        self._keep: List[torch.Tensor] = []
+
+        def keep(t):
+            self._keep.append(t)
+            return t
+
+        self.embed = keep(_bf(sd["model.embed_tokens.weight"], dev))
+        self.final_norm = keep(_f32(sd["model.norm.weight"], dev))
+        self.lm_head = keep(_bf(sd["lm_head.weight"], dev))
+        self.rope_len = int(rope_len or max(cfg.get("max_position_embeddings", 4096), 8192))
+        self.rope_cos, self.rope_sin = rope_tables(self.hd, self.rope_len, float(cfg.get("rope_theta", 10000.0)), dev)
+        self.layers = (_lib.VtLlamaLayer * self.L)()
+        for l in range(self.L):
+            p = f"model.layers.{l}."
+            Ly = self.layers[l]
+            Ly.rms1 = keep(_f32(sd[p + "input_layernorm.weight"], dev)).data_ptr()
+            Ly.rms2 = keep(_f32(sd[p + "post_attention_layernorm.weight"], dev)).data_ptr()
+            wqkv = torch.cat([_bf(sd[p + "self_attn.q_proj.weight"], dev), _bf(sd[p + "self_attn.k_proj.weight"], dev),
+                              _bf(sd[p + "self_attn.v_proj.weight"], dev)], 0)
+            Ly.wqkv = keep(wqkv).data_ptr()
+            Ly.wo = keep(_bf(sd[p + "self_attn.o_proj.weight"], dev)).data_ptr()
+            Ly.wgu = keep(interleave_gate_up(_bf(sd[p + "mlp.gate_proj.weight"], dev), _bf(sd[p + "mlp.up_proj.weight"], dev)).contiguous()).data_ptr()
+            Ly.wdown = keep(_bf(sd[p + "mlp.down_proj.weight"], dev)).data_ptr()
+        m = _lib.VtLlamaModel()
+        m.hidden, m.heads, m.head_dim, m.intermediate, m.num_layers, m.vocab = H, heads, self.hd, self.I, self.L, self.V
+        m.rms_eps = float(cfg.get("rms_norm_eps", 1e-5))
+        m.final_norm, m.lm_head = self.final_norm.data_ptr(), self.lm_head.data_ptr()
+        m.rope_cos, m.rope_sin, m.rope_len = self.rope_cos.data_ptr(), self.rope_sin.data_ptr(), self.rope_len
+        m.layers = C.cast(self.layers, C.POINTER(_lib.VtLlamaLayer))
+        self.model = m
+        self.ws = Workspace(dev)
+
+
+class PagedKVCache:
+    """Paged KV pool: K pages [L][pages][heads][64][hd], V^T pages [L][pages][heads][hd][64]; 64 tokens per page.
+    A free list hands out pages; sequences own a list of page ids (their block table)."""
+
+    def __init__(self, llama: PackedLlama, num_pages: int):
+        self.llama = llama
+        self.num_pages = int(num_pages)
+        n = llama.L * self.num_pages * llama.heads * PAGE_TOKENS * llama.hd
+        self.k = torch.zeros(n, dtype=torch.bfloat16, device=llama.device)
+        self.vt = torch.zeros(n, dtype=torch.bfloat16, device=llama.device)
+        self.free = list(range(self.num_pages - 1, -1, -1))
+        c = _lib.VtKvCache()
+        c.k, c.vt, c.num_pages = self.k.data_ptr(), self.vt.data_ptr(), self.num_pages
+        self.struct = c
+
+    def alloc(self, n: int) -> List[int]:
+        if n > len(self.free):
+            raise _lib.VitronHipError(f"PagedKVCache: out of pages (want {n}, have {len(self.free)})")
+        return [self.free.pop() for _ in range(n)]
+
+    def release(self, pages: Sequence[int]) -> None:
+        self.free.extend(pages)
+
+
+class SequenceState:
+    """Host-side bookkeeping of one sequence in the paged cache."""
+
+    def __init__(self):
+        self.pages: List[int] = []
+        self.length = 0  # tokens already in the cache
+
+
+def llama_forward(llama: PackedLlama, kv: PagedKVCache, seqs: Sequence[SequenceState], embeds: torch.Tensor,
+                  q_lens: Sequence[int], positions: Optional[torch.Tensor] = None, logit_rows: Optional[Sequence[int]] = None,
+                  return_hidden: bool = False):
+    """One decoder pass over packed rows. embeds bf16 [sum(q_lens), H]: the new tokens of every sequence, sequence by
+    sequence. Appends their K/V to the cache, returns fp32 logits for `logit_rows` (default: last row of each
+    sequence). positions default to cache position (length + i). Prefill and decode are the same call."""
+    lib = _lib.load()
+    dev = llama.device
+    rows = int(sum(q_lens))
+    if embeds.shape[0] != rows or embeds.shape[1] != llama.H:
+        raise _lib.VitronHipError(f"llama_forward: embeds {tuple(embeds.shape)} vs rows={rows}, H={llama.H}")
+    embeds = embeds.to(torch.bfloat16).contiguous()
+    desc, table, pos_host = [], [], []
+    row0 = 0
+    max_new_tiles = 1
+    for s, q in zip(seqs, q_lens):
+        kv_len = s.length + q
+        need = (kv_len + PAGE_TOKENS - 1) // PAGE_TOKENS
+        if need > len(s.pages):
+            s.pages += kv.alloc(need - len(s.pages))
+        desc.append([row0, q, kv_len, len(table)])
+        table += s.pages[:need]
+        pos_host += list(range(s.length, kv_len))
+        max_new_tiles = max(max_new_tiles, (kv_len - 1) // PAGE_TOKENS - s.length // PAGE_TOKENS + 1)
+        row0 += q
+    if max(pos_host) >= llama.rope_len and positions is None:
+        raise _lib.VitronHipError(f"llama_forward: position {max(pos_host)} beyond rope table ({llama.rope_len})")
+    desc_t = torch.tensor(desc, dtype=torch.int32, device=dev)
+    table_t = torch.tensor(table, dtype=torch.int32, device=dev)
+    pos_t = torch.tensor(pos_host, dtype=torch.int32, device=dev) if positions is None else positions.to(device=dev, dtype=torch.int32).contiguous()
+    if logit_rows is None:
+        logit_rows = [d[0] + d[1] - 1 for d in desc]
+    n_logit = len(logit_rows)
+    lr_t = torch.tensor(list(logit_rows), dtype=torch.int32, device=dev) if n_logit else None
+    logits = torch.empty((n_logit, llama.V), dtype=torch.float32, device=dev) if n_logit else None
+    hidden = torch.empty((rows, llama.H), dtype=torch.float32, device=dev) if return_hidden else None
+    ws = llama.ws.get(lib.vt_llama_workspace_bytes(C.byref(llama.model), rows, n_logit))
+    _lib.check(lib.vt_llama_forward(C.byref(llama.model), C.byref(kv.struct), embeds.data_ptr(), rows, pos_t.data_ptr(),
+                                    desc_t.data_ptr(), len(desc), int(max(q_lens)), int(max_new_tiles), table_t.data_ptr(),
+                                    None if lr_t is None else lr_t.data_ptr(), n_logit,
+                                    None if logits is None else logits.data_ptr(),
+                                    None if hidden is None else hidden.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+               "vt_llama_forward")
+    for s, q in zip(seqs, q_lens):
+        s.length += q
+    if return_hidden:
+        return logits, hidden
+    return logits

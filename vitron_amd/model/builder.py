@@ -1,0 +1,139 @@
+"""load_pretrained_model -- mirror of the reference's vitron/model/builder.py:27-171 (same arguments, same 4-tuple).
+
+Differences that are inherent to this implementation:
+  * weights end up packed for the HIP kernels (vitron_amd.engine) in bf16 -- the reference loads fp16 (builder.py:47);
+  * load_8bit / load_4bit (bitsandbytes, builder.py:36-45) are rejected: there is no quantised kernel path;
+  * device must be a GPU: there is no CPU execution path;
+  * `model_path="synthetic"` (or a path that does not exist, with `synthetic_ok=True`) builds random-init weights of
+    the configured architecture -- the only thing available offline (checkpoints/ holds only download scripts).
+LoRA checkpoints follow the reference's layout (builder.py:53-86): base weights from `model_base`, projector /
+region_extractor from `non_lora_trainables.bin`, adapters from `adapter_model.bin|safetensors`, merged here as
+W += (lora_alpha / r) * B @ A.
+"""
+from __future__ import annotations
+
+import glob
+import json
+import os
+from types import SimpleNamespace
+
+import torch
+
+from .language_model.llava_llama import LlavaConfig, LlavaLlamaForCausalLM
+from .multimodal_encoder.languagebind import VisionConfig
+
+DEFAULT_IMAGE_PATCH_TOKEN = "<im_patch>"
+DEFAULT_IM_START_TOKEN = "<im_start>"
+DEFAULT_IM_END_TOKEN = "<im_end>"
+
+
+def _load_weight_files(path):
+    sd = {}
+    files = sorted(glob.glob(os.path.join(path, "*.safetensors")))
+    if files:
+        from safetensors.torch import load_file
+        for f in files:
+            if "adapter" in os.path.basename(f):
+                continue
+            sd.update(load_file(f))
+        return sd
+    for f in sorted(glob.glob(os.path.join(path, "pytorch_model*.bin"))):
+        sd.update(torch.load(f, map_location="cpu"))
+    return sd
+
+
+def _merge_llm_lora(base_sd, adapter_sd, lora_alpha, r=None):
+    """peft naming: base_model.model.<name>.lora_A.weight / lora_B.weight (optionally '.default')."""
+    out = dict(base_sd)
+    for k, a in adapter_sd.items():
+        if "lora_A" not in k:
+            continue
+        kb = k.replace("lora_A", "lora_B")
+        name = k.split(".lora_A")[0].replace("base_model.model.", "", 1) + ".weight"
+        if name not in out or kb not in adapter_sd:
+            continue
+        b = adapter_sd[kb]
+        rr = a.shape[0] if r is None else r
+        out[name] = (out[name].float() + (lora_alpha / rr) * (b.float() @ a.float())).to(out[name].dtype)
+    return out
+
+
+class ImageProcessorInfo(SimpleNamespace):
+    """What app.py / mm_utils read from the image processor: crop_size (app.py:556), image_mean (mm_utils.py:70)."""
+
+
+def _processors(model):
+    from .multimodal_encoder.languagebind import OPENAI_DATASET_MEAN, OPENAI_DATASET_STD
+    proc = {"image": None, "video": None}
+    it, vt = model.get_image_tower(), model.get_video_tower()
+    if it is not None and it.config is not None:
+        s = it.config.image_size
+        proc["image"] = it.image_processor or ImageProcessorInfo(crop_size={"height": s, "width": s}, image_mean=list(OPENAI_DATASET_MEAN),
+                                                                 image_std=list(OPENAI_DATASET_STD), size=s)
+    if vt is not None and vt.config is not None:
+        s = vt.config.image_size
+        proc["video"] = vt.video_processor or ImageProcessorInfo(crop_size={"height": s, "width": s}, image_mean=list(OPENAI_DATASET_MEAN),
+                                                                 image_std=list(OPENAI_DATASET_STD), size=s, num_frames=vt.config.num_frames)
+    return proc
+
+
+def load_pretrained_model(model_path, model_base, model_name, load_8bit=False, load_4bit=False, device_map="auto",
+                          device="cuda", **kwargs):
+    if load_8bit or load_4bit:
+        raise NotImplementedError("bitsandbytes 8/4-bit loading has no MI355X kernel path in vitron_amd")
+    if torch.device(device).type != "cuda":
+        raise RuntimeError("vitron_amd runs on the GPU only (device must be 'cuda'); there is no CPU path")
+    synthetic = kwargs.pop("synthetic", None)
+    tokenizer = kwargs.pop("tokenizer", None)
+    if model_path == "synthetic" or synthetic is not None:
+        spec = synthetic or {}
+        cfg = LlavaConfig(**spec.get("llm", {}), mm_hidden_size=spec.get("image", spec.get("video", {})).get("hidden_size", 1024))
+        model = LlavaLlamaForCausalLM(cfg)
+        model.init_synthetic(device, seed=spec.get("seed", 1234), vit_image=spec.get("image"), vit_video=spec.get("video"),
+                             w_std=spec.get("w_std", 0.02))
+        context_len = getattr(cfg, "max_sequence_length", 2048)
+        return tokenizer, model, _processors(model), context_len
+
+    with open(os.path.join(model_path, "config.json")) as f:
+        cfg = LlavaConfig(**json.load(f))
+    if "lora" in model_name.lower() and model_base is None:
+        raise ValueError("LoRA checkpoints need `model_base` (reference builder.py:51-52)")
+    if tokenizer is None:
+        from transformers import AutoTokenizer
+        tokenizer = AutoTokenizer.from_pretrained(model_base or model_path, use_fast=False)
+    model = LlavaLlamaForCausalLM(cfg)
+    if "lora" in model_name.lower() and model_base is not None:
+        sd = _load_weight_files(model_base)
+        nl = os.path.join(model_path, "non_lora_trainables.bin")
+        if os.path.exists(nl):
+            extra = torch.load(nl, map_location="cpu")
+            extra = {(k[11:] if k.startswith("base_model.") else k): v for k, v in extra.items()}
+            if any(k.startswith("model.model.") for k in extra):
+                extra = {(k[6:] if k.startswith("model.") else k): v for k, v in extra.items()}
+            sd.update(extra)
+        ad = {}
+        for f in ("adapter_model.safetensors", "adapter_model.bin"):
+            p = os.path.join(model_path, f)
+            if os.path.exists(p):
+                if f.endswith(".bin"):
+                    ad = torch.load(p, map_location="cpu")
+                else:
+                    from safetensors.torch import load_file
+                    ad = load_file(p)
+                break
+        acfg = {}
+        if os.path.exists(os.path.join(model_path, "adapter_config.json")):
+            with open(os.path.join(model_path, "adapter_config.json")) as f:
+                acfg = json.load(f)
+        sd = _merge_llm_lora(sd, ad, float(acfg.get("lora_alpha", 16)), acfg.get("r"))
+    else:
+        sd = _load_weight_files(model_path)
+    model.load_state_dict(sd, strict=False)
+    # towers (reference builder.py:149-163): LanguageBind checkpoint directories named by the config
+    for get in (model.get_image_tower, model.get_video_tower):
+        t = get()
+        if t is not None and not t.is_loaded:
+            t.load_model()
+    model.to(device)
+    context_len = getattr(cfg, "max_sequence_length", 2048)   # reference builder.py:166-169
+    return tokenizer, model, _processors(model), context_len

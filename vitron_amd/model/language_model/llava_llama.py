@@ -1,0 +1,342 @@
+"""LlavaLlamaForCausalLM on HIP kernels -- mirror of the reference's vitron/model/language_model/llava_llama.py.
+
+Same class names (LlavaConfig, LlavaLlamaModel, LlavaLlamaForCausalLM) and the same forward / generate /
+prepare_inputs_for_generation signatures (llava_llama.py:57-114), so app.py:562-571 and
+inference_image.py:53-61 call it unchanged. The decoder itself (transformers-4.31 LlamaForCausalLM in the
+reference) is vt_llama_forward: one C call per pass over a paged KV cache; `generate` is a greedy / top-p loop on
+top of it (the reference gets its loop from GenerationMixin).
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import List, Optional, Sequence
+
+import torch
+
+from ... import ops, synth
+from ...engine import PackedLlama, PagedKVCache, SequenceState, llama_forward
+from ..llava_arch import KIND_TOKEN, LlavaMetaForCausalLM, LlavaMetaModel
+from ..multimodal_encoder.builder import build_image_tower, build_video_tower
+from ..multimodal_projector.builder import build_vision_projector
+from ..region_extractor.builder import build_region_extractor
+
+
+class LlavaConfig(SimpleNamespace):
+    """LlamaConfig fields + the mm_* fields the reference reads (llava_arch.py:33-40,363,379)."""
+    model_type = "llava"
+
+    def __init__(self, **kw):
+        base = dict(hidden_size=4096, intermediate_size=11008, num_hidden_layers=32, num_attention_heads=32,
+                    vocab_size=32000, rms_norm_eps=1e-5, rope_theta=10000.0, max_position_embeddings=4096,
+                    bos_token_id=1, eos_token_id=2, pad_token_id=0, mm_image_tower=None, mm_video_tower=None,
+                    mm_projector_type="mlp2x_gelu", mm_vision_select_layer=-2, mm_vision_select_feature="patch",
+                    mm_hidden_size=1024, tokenizer_model_max_length=None, tokenizer_padding_side="right",
+                    pretraining_tp=1, use_cache=True)
+        base.update(kw)
+        super().__init__(**base)
+
+    def to_dict(self):
+        return dict(self.__dict__)
+
+
+class CausalLMOutputWithPast(SimpleNamespace):
+    def __getitem__(self, i):
+        return [v for v in (self.loss, self.logits, self.past_key_values) if v is not None][i]
+
+
+class PagedPast:
+    """past_key_values of this implementation: per-sequence page lists in the model's paged KV pool."""
+
+    def __init__(self, kv: PagedKVCache, seqs: List[SequenceState], padded_len: int):
+        self.kv, self.seqs, self.padded_len = kv, seqs, padded_len
+
+    def seq_length(self) -> int:  # what the reference reads as past_key_values[-1][-1].shape[-2] (llava_arch.py:198)
+        return self.padded_len
+
+    def release(self):
+        for s in self.seqs:
+            self.kv.release(s.pages)
+            s.pages = []
+
+
+class LlavaLlamaModel(LlavaMetaModel):
+    """reference llava_llama.py:33-37 + LlavaMetaModel.__init__ (llava_arch.py:30-40)."""
+
+    def __init__(self, config: LlavaConfig):
+        self.config = config
+        self.llama: Optional[PackedLlama] = None
+        if getattr(config, "mm_image_tower", None) is not None:
+            self.image_tower = build_image_tower(config, delay_load=True)
+        if getattr(config, "mm_video_tower", None) is not None:
+            self.video_tower = build_video_tower(config, delay_load=True)
+        if getattr(config, "mm_image_tower", None) is not None or getattr(config, "mm_video_tower", None) is not None:
+            self.mm_projector = build_vision_projector(config)
+            self.region_extractor = build_region_extractor(config)
+
+    @property
+    def embed_tokens_weight(self) -> torch.Tensor:
+        return self.llama.embed
+
+    def embed_tokens(self, ids: torch.Tensor) -> torch.Tensor:
+        flat = ids.reshape(-1).to(device=self.llama.device, dtype=torch.int32)
+        plan = torch.stack([torch.zeros_like(flat), flat], dim=1).contiguous()
+        return ops.embed_splice(self.llama.embed, None, None, plan).view(*ids.shape, -1)
+
+
+class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
+    config_class = LlavaConfig
+
+    def __init__(self, config: LlavaConfig):
+        self.config = config
+        self.model = LlavaLlamaModel(config)
+        self.vocab_size = config.vocab_size
+        self._device = torch.device("cpu")
+        self._llama_sd = None
+        self.kv: Optional[PagedKVCache] = None
+        self.kv_pages = getattr(config, "kv_pages", None)
+
+    # ---- module-like plumbing -----------------------------------------------------------------------------------
+    def get_model(self):
+        return self.model
+
+    @property
+    def device(self):
+        return self._device
+
+    @property
+    def dtype(self):
+        return torch.bfloat16
+
+    def eval(self):
+        return self
+
+    def requires_grad_(self, flag=False):
+        return self
+
+    def load_state_dict(self, sd, strict=True):
+        """Accepts the reference checkpoint naming: LLaMA weights (`model.layers.*`, `model.embed_tokens.weight`,
+        `model.norm.weight`, `lm_head.weight`) and the non-LoRA trainables `model.mm_projector.*`,
+        `model.region_extractor.*` (reference builder.py:64-79)."""
+        proj = {k[len("model.mm_projector."):]: v for k, v in sd.items() if k.startswith("model.mm_projector.")}
+        reg = {k[len("model.region_extractor."):]: v for k, v in sd.items() if k.startswith("model.region_extractor.")}
+        llm = {k: v for k, v in sd.items() if not k.startswith(("model.mm_projector.", "model.region_extractor.",
+                                                                "model.image_tower.", "model.video_tower."))}
+        if proj and self.model.mm_projector is not None:
+            self.model.mm_projector.load_state_dict(proj, strict)
+        if reg and self.model.region_extractor is not None:
+            self.model.region_extractor.load_state_dict(reg, strict)
+        if llm:
+            self._llama_sd = llm
+            self.model.llama = None
+        return [], []
+
+    def to(self, device=None, dtype=None):
+        if device is None:
+            return self
+        dev = torch.device(device)
+        if dev.type == "cuda":
+            if self._llama_sd is not None:
+                self.model.llama = PackedLlama(self._llama_sd, self.config.to_dict(), dev)
+                self._llama_sd = None
+            for m in (self.model.mm_projector, self.model.region_extractor, self.model.image_tower, self.model.video_tower):
+                if m is not None:
+                    m.to(dev)
+        self._device = dev
+        return self
+
+    def cuda(self):
+        return self.to("cuda")
+
+    def init_synthetic(self, device, seed=1234, vit_image: Optional[dict] = None, vit_video: Optional[dict] = None,
+                       w_std=0.02):
+        """Random-init weights of the configured architecture, generated on `device` (no checkpoints exist offline)."""
+        gen = synth.make_generator(seed, device)
+        cfg = self.config
+        self._llama_sd = synth.llama_state(cfg.to_dict(), gen, device, w_std)
+        if vit_image is not None:
+            self.model.image_tower = build_image_tower(SimpleNamespace(mm_image_tower="synthetic/LanguageBind_Image",
+                                                                       mm_vision_select_layer=cfg.mm_vision_select_layer), delay_load=True)
+            self.model.image_tower.init_synthetic(vit_image, gen, device, w_std)
+        if vit_video is not None:
+            self.model.video_tower = build_video_tower(SimpleNamespace(mm_video_tower="synthetic/LanguageBind_Video_merge",
+                                                                       mm_vision_select_layer=cfg.mm_vision_select_layer), delay_load=True)
+            self.model.video_tower.init_synthetic(vit_video, gen, device, w_std)
+        if self.model.mm_projector is None:
+            self.model.mm_projector = build_vision_projector(cfg)
+            self.model.region_extractor = build_region_extractor(cfg)
+        self.model.mm_projector.init_synthetic(gen, device, w_std)
+        self.model.region_extractor.init_synthetic(gen, device, w_std)
+        return self.to(device)
+
+    # ---- KV pool ----------------------------------------------------------------------------------------------
+    def _ensure_kv(self, pages_needed: int):
+        if self.kv is not None and len(self.kv.free) >= pages_needed:
+            return
+        if self.kv is not None and len(self.kv.free) != self.kv.num_pages:
+            raise RuntimeError("KV pool exhausted while sequences are live; release past_key_values or raise config.kv_pages")
+        n = max(pages_needed, int(self.kv_pages or 0))
+        self.kv = None
+        self.kv = PagedKVCache(self.model.llama, n)
+
+    # ---- reference llava_llama.py:57-102 ----------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None,
+                labels=None, use_cache=None, output_attentions=None, output_hidden_states=None, images=None,
+                regions=None, return_dict=None):
+        splice = None
+        if inputs_embeds is None:
+            (input_ids, position_ids, attention_mask, past_key_values, inputs_embeds, labels) = \
+                self.prepare_inputs_labels_for_multimodal(input_ids, position_ids, attention_mask, past_key_values,
+                                                          labels, images, regions)
+            splice = getattr(self, "_last_splice", None) if inputs_embeds is not None else None
+        llama = self.model.llama
+        if inputs_embeds is None:
+            inputs_embeds = self.model.embed_tokens(input_ids)
+        B, S, H = inputs_embeds.shape
+        # valid rows of every sample (padding rows never enter the decoder: the batch is packed)
+        if splice is not None:
+            mask_host = splice[0]
+        elif attention_mask is not None and past_key_values is None:
+            mask_host = attention_mask.to(torch.int32).tolist()
+        else:
+            mask_host = [[1] * S for _ in range(B)]
+        if past_key_values is None:
+            lens = [sum(r) for r in mask_host]
+            seqs = [SequenceState() for _ in range(B)]
+            need = sum((l + 63) // 64 + 1 for l in lens)
+            if use_cache:
+                self._ensure_kv(need + B * 2)
+            else:
+                self._ensure_kv(need)
+            past = PagedPast(self.kv, seqs, S)
+            idx = [b * S + j for b in range(B) for j in range(S) if mask_host[b][j]]
+        else:
+            past = past_key_values
+            seqs = past.seqs
+            lens = [S] * B
+            idx = list(range(B * S))
+            past.padded_len += S
+        flat = inputs_embeds.reshape(B * S, H)
+        if len(idx) != B * S:
+            flat = flat.index_select(0, torch.tensor(idx, device=flat.device))
+        rows = flat.shape[0]
+        logits_p, hidden = llama_forward(llama, past.kv, seqs, flat, lens, logit_rows=list(range(rows)), return_hidden=True)
+        if len(idx) != B * S:
+            logits = torch.zeros((B * S, llama.V), dtype=torch.float32, device=flat.device)
+            logits.index_copy_(0, torch.tensor(idx, device=flat.device), logits_p)
+        else:
+            logits = logits_p
+        logits = logits.view(B, S, llama.V)
+        loss = None
+        if labels is not None:  # shifted cross entropy, ignore_index -100 (LlamaForCausalLM.forward)
+            loss = torch.nn.functional.cross_entropy(logits[:, :-1].reshape(-1, llama.V), labels[:, 1:].reshape(-1).to(logits.device),
+                                                     ignore_index=-100)
+        if not use_cache and past_key_values is None:
+            past.release()
+            past = None
+        return CausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=past,
+                                      hidden_states=(hidden.view(-1, H),) if output_hidden_states else None, attentions=None)
+
+    __call__ = forward
+
+    # ---- reference llava_llama.py:104-114 ----------------------------------------------------------------------
+    def prepare_inputs_for_generation(self, input_ids, past_key_values=None, inputs_embeds=None, **kwargs):
+        images = kwargs.pop("images", None)
+        regions = kwargs.pop("regions", None)
+        if past_key_values is not None:
+            input_ids = input_ids[:, -1:]
+        inputs = {"input_ids": input_ids, "past_key_values": past_key_values, "use_cache": kwargs.get("use_cache", True),
+                  "attention_mask": kwargs.get("attention_mask", None)}
+        if inputs_embeds is not None and past_key_values is None:
+            inputs = {"inputs_embeds": inputs_embeds, **{k: v for k, v in inputs.items() if k != "input_ids"}}
+        if images is not None:
+            inputs["images"] = images
+        if regions is not None:
+            inputs["regions"] = regions
+        return inputs
+
+    # ---- GenerationMixin.generate / sample, as app.py:562-571 drives it ----------------------------------------
+    @torch.no_grad()
+    def generate(self, input_ids=None, images=None, regions=None, attention_mask=None, do_sample=False,
+                 temperature=1.0, top_p=1.0, top_k=0, max_new_tokens=None, max_length=None, use_cache=True,
+                 stopping_criteria=None, eos_token_id=None, pad_token_id=None, num_beams=1, seed=None,
+                 return_logits=False, **kwargs):
+        if num_beams != 1:
+            raise NotImplementedError("beam search is not implemented (the reference entry points sample or go greedy)")
+        dev = self.device
+        input_ids = input_ids.to(dev)
+        B = input_ids.shape[0]
+        eos = self.config.eos_token_id if eos_token_id is None else eos_token_id
+        eos_set = set(eos) if isinstance(eos, (list, tuple)) else ({eos} if eos is not None else set())
+        pad = pad_token_id if pad_token_id is not None else (self.config.pad_token_id if self.config.pad_token_id is not None else 0)
+        if max_new_tokens is None:
+            max_new_tokens = (max_length - input_ids.shape[1]) if max_length else 20
+        gen = None
+        if do_sample:
+            gen = torch.Generator(device=dev)
+            gen.manual_seed(int(seed) if seed is not None else int(torch.seed() % (2 ** 31)))
+
+        (_, _, _, _, embeds, _) = self.prepare_inputs_labels_for_multimodal(input_ids, None, attention_mask, None, None,
+                                                                            images, regions)
+        llama = self.model.llama
+        if embeds is None:
+            embeds = self.model.embed_tokens(input_ids)
+            mask_host = attention_mask.to(torch.int32).tolist() if attention_mask is not None else [[1] * input_ids.shape[1]] * B
+        else:
+            mask_host = self._last_splice[0]
+        S, H = embeds.shape[1], embeds.shape[2]
+        lens = [sum(r) for r in mask_host]
+        idx = [b * S + j for b in range(B) for j in range(S) if mask_host[b][j]]
+        flat = embeds.reshape(B * S, H)
+        if len(idx) != B * S:
+            flat = flat.index_select(0, torch.tensor(idx, device=dev))
+        self._ensure_kv(sum((l + max_new_tokens + 63) // 64 + 1 for l in lens))
+        seqs = [SequenceState() for _ in range(B)]
+        logits = llama_forward(llama, self.kv, seqs, flat, lens)             # [B, V]: last position of every sequence
+        out = input_ids
+        finished = torch.zeros(B, dtype=torch.bool, device=dev)
+        all_logits = []
+        try:
+            for step in range(max_new_tokens):
+                if return_logits:
+                    all_logits.append(logits.clone())
+                nxt = self._sample(logits, do_sample, temperature, top_p, top_k, gen)
+                nxt = torch.where(finished, torch.full_like(nxt, pad), nxt)
+                out = torch.cat([out, nxt.unsqueeze(1)], dim=1)
+                for e in eos_set:
+                    finished |= nxt == e
+                if bool(finished.all()):
+                    break
+                if stopping_criteria is not None and all(c(out, logits) for c in stopping_criteria):
+                    break
+                if step + 1 == max_new_tokens:
+                    break
+                plan = torch.stack([torch.full_like(nxt, KIND_TOKEN), nxt], dim=1).to(torch.int32).contiguous()
+                x = ops.embed_splice(llama.embed, None, None, plan)
+                logits = llama_forward(llama, self.kv, seqs, x, [1] * B)
+        finally:
+            for s in seqs:
+                self.kv.release(s.pages)
+        if return_logits:
+            return out, all_logits
+        return out
+
+    @staticmethod
+    def _sample(logits, do_sample, temperature, top_p, top_k, gen):
+        if not do_sample:
+            return ops.argmax(logits).to(torch.long)
+        lg = logits / max(float(temperature), 1e-5)
+        if top_k and top_k > 0:
+            kth = torch.topk(lg, min(top_k, lg.shape[-1]), dim=-1).values[..., -1, None]
+            lg = lg.masked_fill(lg < kth, float("-inf"))
+        if top_p is not None and top_p < 1.0:  # TopPLogitsWarper: drop the lowest-probability tail whose mass <= 1 - top_p
+            sl, si = torch.sort(lg, descending=False, dim=-1)
+            cp = sl.softmax(dim=-1).cumsum(dim=-1)
+            rm = cp <= (1.0 - top_p)
+            rm[..., -1:] = False
+            lg = lg.masked_fill(rm.scatter(1, si, rm), float("-inf"))
+        probs = torch.softmax(lg, dim=-1)
+        return torch.multinomial(probs, 1, generator=gen).squeeze(1)
+
+
+VitronLlamaForCausalLM = LlavaLlamaForCausalLM  # name used by BASELINE.json's north_star; the reference class is LlavaLlamaForCausalLM

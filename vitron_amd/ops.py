@@ -1,0 +1,162 @@
+"""Torch-tensor front end of the primitive C-ABI operators (include/vitron_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; every function below checks its tensors,
+passes raw device pointers + the current stream to libvitron_hip.so and returns torch tensors. There is no
+torch-op fallback: without the shared library, or on a CPU tensor, these raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import (CFG_AUTO, EPI_BF16, EPI_BF16_GELU, EPI_BF16_QGELU, EPI_BF16_RELU, EPI_F32, EPI_F32_RESID,  # noqa: F401
+                   EPI_SWIGLU_BF16, PAGE_TOKENS)
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t: torch.Tensor, dtype, name: str):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.VitronHipError(f"{name}: expected a CUDA/HIP tensor (vitron_amd has no CPU path)")
+    if t.dtype != dtype:
+        raise _lib.VitronHipError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise _lib.VitronHipError(f"{name}: tensor must be contiguous")
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, epi: int = EPI_BF16,
+         out: Optional[torch.Tensor] = None, cfg: int = CFG_AUTO) -> torch.Tensor:
+    """out = epi(a[M,K] @ w[N,K]^T + bias). EPI_F32_RESID accumulates into `out` (fp32, required)."""
+    lib = _lib.load()
+    _chk(a, torch.bfloat16, "gemm.a")
+    _chk(w, torch.bfloat16, "gemm.w")
+    M, K = a.shape
+    N, K2 = w.shape
+    if K != K2:
+        raise _lib.VitronHipError(f"gemm: K mismatch {K} vs {K2}")
+    if bias is not None:
+        _chk(bias, torch.float32, "gemm.bias")
+    n_out = N // 2 if epi == EPI_SWIGLU_BF16 else N
+    odt = torch.float32 if epi in (EPI_F32, EPI_F32_RESID) else torch.bfloat16
+    if out is None:
+        if epi == EPI_F32_RESID:
+            raise _lib.VitronHipError("gemm: EPI_F32_RESID needs `out` (the fp32 residual stream)")
+        out = torch.empty((M, n_out), device=a.device, dtype=odt)
+    _chk(out, odt, "gemm.out")
+    scratch = None
+    if epi == EPI_SWIGLU_BF16 and M <= 16:
+        scratch = torch.empty((M, N), device=a.device, dtype=torch.float32)
+    _lib.check(lib.vt_gemm_bf16(_p(a), a.stride(0), _p(w), w.stride(0), _p(out), out.stride(0), _p(bias), M, N, K, epi,
+                                cfg, _p(scratch), _stream()), "vt_gemm_bf16")
+    return out
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, temb: Optional[torch.Tensor] = None,
+              tokens_per_frame: int = 0) -> torch.Tensor:
+    """bf16 LayerNorm of the fp32 rows of x; with temb ([T,D] fp32) x[row] += temb[(row//tokens_per_frame)%T] in place."""
+    lib = _lib.load()
+    _chk(x, torch.float32, "layernorm.x")
+    rows, D = x.shape
+    y = torch.empty((rows, D), device=x.device, dtype=torch.bfloat16)
+    T = 0 if temb is None else temb.shape[0]
+    _lib.check(lib.vt_layernorm(_p(x), _p(temb), T, tokens_per_frame, _p(gamma), _p(beta), _p(y), rows, D, eps, _stream()),
+               "vt_layernorm")
+    return y
+
+
+def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float, idx: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = _lib.load()
+    _chk(x, torch.float32, "rmsnorm.x")
+    rows = x.shape[0] if idx is None else idx.shape[0]
+    D = x.shape[1]
+    y = torch.empty((rows, D), device=x.device, dtype=torch.bfloat16)
+    _lib.check(lib.vt_rmsnorm(_p(x), _p(idx), _p(w), _p(y), rows, D, eps, _stream()), "vt_rmsnorm")
+    return y
+
+
+def seq_desc_tensor(rows: Sequence[Sequence[int]], device) -> torch.Tensor:
+    """int32 [nseq,4] = (q_row0, q_len, kv_len, table_off)."""
+    return torch.tensor(rows, dtype=torch.int32, device=device).reshape(-1, 4)
+
+
+def kv_tiles(qkv: torch.Tensor, q_col0: int, k_col0: int, v_col0: int, k_tiles: torch.Tensor, vt_tiles: torch.Tensor,
+             tile_table: torch.Tensor, seq_desc: torch.Tensor, max_new_tiles: int, heads: int, head_dim: int,
+             rope_cos: Optional[torch.Tensor] = None, rope_sin: Optional[torch.Tensor] = None,
+             positions: Optional[torch.Tensor] = None) -> None:
+    lib = _lib.load()
+    _chk(qkv, torch.bfloat16, "kv_tiles.qkv")
+    _lib.check(lib.vt_kv_tiles(_p(qkv), qkv.stride(0), q_col0, k_col0, v_col0, _p(k_tiles), _p(vt_tiles), _p(tile_table),
+                               _p(seq_desc), seq_desc.shape[0], max_new_tiles, heads, head_dim, _p(rope_cos), _p(rope_sin),
+                               _p(positions), _stream()), "vt_kv_tiles")
+
+
+def flash_attn(q: torch.Tensor, k_tiles: torch.Tensor, vt_tiles: torch.Tensor, tile_table: torch.Tensor,
+               seq_desc: torch.Tensor, max_q_len: int, heads: int, head_dim: int, causal: bool, scale: float,
+               out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """q: bf16 [rows, ldq] view whose first heads*head_dim columns are the queries (e.g. the fused QKV buffer)."""
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty((q.shape[0], heads * head_dim), device=q.device, dtype=torch.bfloat16)
+    _lib.check(lib.vt_flash_attn(_p(q), q.stride(0), _p(k_tiles), _p(vt_tiles), _p(tile_table), _p(seq_desc),
+                                 seq_desc.shape[0], max_q_len, _p(out), out.stride(0), heads, head_dim, int(causal),
+                                 float(scale), _stream()), "vt_flash_attn")
+    return out
+
+
+def attn_decode(q: torch.Tensor, k_tiles: torch.Tensor, vt_tiles: torch.Tensor, tile_table: torch.Tensor,
+                seq_desc: torch.Tensor, heads: int, head_dim: int, scale: float) -> torch.Tensor:
+    lib = _lib.load()
+    out = torch.empty((q.shape[0], heads * head_dim), device=q.device, dtype=torch.bfloat16)
+    _lib.check(lib.vt_attn_decode(_p(q), q.stride(0), _p(k_tiles), _p(vt_tiles), _p(tile_table), _p(seq_desc),
+                                  seq_desc.shape[0], _p(out), out.stride(0), heads, head_dim, float(scale), _stream()),
+               "vt_attn_decode")
+    return out
+
+
+def attn_temporal(qkv: torch.Tensor, B: int, T: int, N: int, heads: int) -> torch.Tensor:
+    lib = _lib.load()
+    _chk(qkv, torch.bfloat16, "attn_temporal.qkv")
+    out = torch.empty((qkv.shape[0], heads * 64), device=qkv.device, dtype=torch.bfloat16)
+    _lib.check(lib.vt_attn_temporal(_p(qkv), _p(out), B, T, N, heads, _stream()), "vt_attn_temporal")
+    return out
+
+
+def im2col(pixels: torch.Tensor, patch: int, k_pad: int) -> torch.Tensor:
+    lib = _lib.load()
+    video = pixels.dim() == 5
+    if video:
+        B, _, T, H, W = pixels.shape
+    else:
+        B, _, H, W = pixels.shape
+        T = 1
+    dt = {torch.bfloat16: _lib.DTYPE_BF16, torch.float32: _lib.DTYPE_F32}[pixels.dtype]
+    out = torch.empty((B * T * (H // patch) * (W // patch), k_pad), device=pixels.device, dtype=torch.bfloat16)
+    _lib.check(lib.vt_im2col(_p(pixels.contiguous()), dt, _p(out), B, T, H, W, patch, k_pad, int(video), _stream()), "vt_im2col")
+    return out
+
+
+def embed_splice(tok_table: torch.Tensor, vis: Optional[torch.Tensor], reg: Optional[torch.Tensor], plan: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    _chk(tok_table, torch.bfloat16, "embed_splice.tok_table")
+    rows, H = plan.shape[0], tok_table.shape[1]
+    out = torch.empty((rows, H), device=tok_table.device, dtype=torch.bfloat16)
+    _lib.check(lib.vt_embed_splice(_p(tok_table), _p(vis), _p(reg), _p(plan), rows, H, _p(out), _stream()), "vt_embed_splice")
+    return out
+
+
+def argmax(logits: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    _chk(logits, torch.float32, "argmax.logits")
+    rows, V = logits.shape
+    out = torch.empty((rows,), device=logits.device, dtype=torch.int32)
+    _lib.check(lib.vt_argmax(_p(logits), rows, V, logits.stride(0), _p(out), _stream()), "vt_argmax")
+    return out
