@@ -60,7 +60,7 @@ def quick_gelu(x):  # transformers ACT2FN['quick_gelu']
     return x * torch.sigmoid(1.702 * x)
 
 
-def clip_attention(x, sd: SD, prefix: str, heads: int, emulate: bool):
+def clip_attention(x, sd: SD, prefix: str, heads: int, emulate: bool, round_p: bool = True):
     """transformers-4.31 CLIPAttention.forward: q = q_proj(x)*hd^-0.5, bmm, softmax,
     bmm, out_proj -- no masks on the vision path (reference modeling_video.py:652-657 passes None)."""
     B, N, D = x.shape
@@ -72,7 +72,7 @@ def clip_attention(x, sd: SD, prefix: str, heads: int, emulate: bool):
     k = k.view(B, N, heads, hd).transpose(1, 2)
     v = v.view(B, N, heads, hd).transpose(1, 2)
     s = q @ k.transpose(-1, -2)
-    if emulate:  # kernel: P (relative to the row max) is rounded to bf16 for the PV MFMA, row sum stays fp32
+    if emulate and round_p:  # flash kernel: P (relative to the row max) is rounded to bf16 for the PV MFMA, row sum fp32
         p = torch.exp(s - s.amax(-1, keepdim=True))
         o = (bf16_round(p) @ v) / p.sum(-1, keepdim=True)
     else:
@@ -116,7 +116,7 @@ def vit_forward(sd: SD, cfg: dict, pixels: torch.Tensor, num_layers: Optional[in
             h = x.view(B, T, N, D).transpose(1, 2).reshape(B * N, T, D)  # '(b t) n d -> (b n) t d'
             h = _r(F.layer_norm(h, (D,), sd[p + "temporal_layer_norm1.weight"].float(),
                                 sd[p + "temporal_layer_norm1.bias"].float(), eps), emulate_bf16)
-            h = clip_attention(h, sd, p + "temporal_attn.", heads, emulate_bf16)
+            h = clip_attention(h, sd, p + "temporal_attn.", heads, emulate_bf16, round_p=False)  # temporal kernel keeps P in fp32
             h = _lin(h, sd[p + "temporal_attn.out_proj.weight"], sd[p + "temporal_attn.out_proj.bias"])
             x = res + h.view(B, N, T, D).transpose(1, 2).reshape(B * T, N, D)  # :127
         res = x  # spatial attention :136-146

@@ -119,6 +119,10 @@ def load(build_if_needed: bool = True):
     if not LIB_PATH.exists():
         raise VitronHipError(f"{LIB_PATH} not found: run `python -m vitron_amd.build` (needs hipcc). "
                              "vitron_amd has no CPU or PyTorch fallback for its operators.")
+    # PyTorch bundles its own HIP runtime (torch/lib/libamdhip64.so, same SONAME as /opt/rocm's). It must be the
+    # one already mapped when libvitron_hip.so resolves libamdhip64.so.7, or the process ends up with two runtimes
+    # ("no ROCm-capable device is detected" at the first launch). Importing torch first guarantees that.
+    import torch  # noqa: F401
     lib = C.CDLL(str(LIB_PATH))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here == header/library mismatch
