@@ -145,13 +145,12 @@ def main():
     assert ids.shape[1] == args.text_len + args.frames
 
     if world > 1:  # clip-per-rank encode, ONE all-gather of visual tokens, then data-parallel prefill
+        from vitron_amd.parallel import all_gather_visual_tokens
         orig = model.encode_videos
-        gathered = torch.empty((world, args.frames, G * G, 4096), dtype=torch.bfloat16, device=dev)
 
         def encode_videos_dist(videos):
-            f = orig(videos)
-            dist.all_gather_into_tensor(gathered, f.contiguous())
-            return gathered[rank:rank + 1]
+            f = orig(videos)                                    # this rank's clip: [1, T, P, H]
+            return all_gather_visual_tokens(f, world)[rank:rank + 1]   # every rank receives all clips' tokens
         model.encode_videos = encode_videos_dist
 
     llama = model.get_model().llama

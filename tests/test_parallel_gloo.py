@@ -1,0 +1,68 @@
+"""world_size-2 gloo tests (CPU) of the clip-parallel path: sharding, the visual-token all-gather (even and uneven
+shards), and that every rank ends up with the same tokens a single process would compute."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from vitron_amd.parallel import all_gather_visual_tokens, encode_clips_parallel, shard_range
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _stub_encode(batch):  # [n,3,T,H,W] -> [n,T,P,Hd] deterministic function of the pixels
+    n, _, T, H, W = batch.shape
+    base = batch.float().mean(dim=(1, 3, 4))  # [n, T]
+    return (base[:, :, None, None] + torch.arange(4)[None, None, :, None] * 10 + torch.arange(3)[None, None, None, :]).to(torch.bfloat16)
+
+
+def _worker(rank, world, port, n_clips, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        clips = [torch.full((3, 2, 4, 4), float(i + 1)) for i in range(n_clips)]
+        out = encode_clips_parallel(_stub_encode, clips)
+        ref = _stub_encode(torch.stack(clips))
+        ok = out.shape == ref.shape and torch.equal(out, ref)
+        s, e = shard_range(n_clips, world, rank)
+        loc = torch.arange(s, e, dtype=torch.float32).reshape(-1, 1)
+        g = all_gather_visual_tokens(loc, n_clips)
+        ok = ok and torch.equal(g.flatten(), torch.arange(n_clips, dtype=torch.float32))
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_clips", [2, 3, 8, 1])
+def test_clip_parallel_all_gather_gloo(n_clips):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_clips, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_shard_range_partitions():
+    for n in range(0, 20):
+        for w in (1, 2, 4, 8):
+            spans = [shard_range(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            sizes = [e - s for s, e in spans]
+            assert max(sizes) - min(sizes) <= 1

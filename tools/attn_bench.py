@@ -1,0 +1,49 @@
+"""Micro-benchmark of the flash attention kernel on the C3 shapes (LLM causal prefill S=5120, ViT spatial N=577)."""
+import json
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vitron_amd import _lib, ops  # noqa: E402
+
+
+def timeit(fn, iters=10):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+def run(S, heads, hd, nseq, causal):
+    dev = torch.device("cuda:0")
+    D = heads * hd
+    qkv = torch.randn((nseq * S, 3 * D), device=dev).bfloat16()
+    nt = (S + 63) // 64
+    desc = torch.tensor([[i * S, S, S, i * nt] for i in range(nseq)], dtype=torch.int32, device=dev)
+    table = torch.arange(nseq * nt, dtype=torch.int32, device=dev)
+    kt = torch.zeros(nseq * nt * heads * 64 * hd, dtype=torch.bfloat16, device=dev)
+    vt = torch.zeros_like(kt)
+    ops.kv_tiles(qkv, 0, D, 2 * D, kt, vt, table, desc, nt, heads, hd)
+    out = torch.empty((nseq * S, D), dtype=torch.bfloat16, device=dev)
+    ms = timeit(lambda: ops.flash_attn(qkv, kt, vt, table, desc, S, heads, hd, causal, 1 / math.sqrt(hd), out=out))
+    flops = nseq * heads * 4 * hd * (S * (S + 1) / 2 if causal else S * S)
+    ms_kv = timeit(lambda: ops.kv_tiles(qkv, 0, D, 2 * D, kt, vt, table, desc, nt, heads, hd))
+    print(json.dumps({"S": S, "heads": heads, "hd": hd, "nseq": nseq, "causal": causal, "ms": round(ms, 4),
+                      "tflops": round(flops / ms / 1e9, 1), "kv_tiles_ms": round(ms_kv, 4)}), flush=True)
+
+
+if __name__ == "__main__":
+    _lib.load()
+    run(5120, 32, 128, 1, True)
+    run(1088, 32, 128, 1, True)
+    run(577, 16, 64, 8, False)
+    run(2048, 32, 128, 4, True)

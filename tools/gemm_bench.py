@@ -16,9 +16,11 @@ SHAPES = [  # (M, N, K, epi, label)
     (5120, 12288, 4096, "BF16", "llm qkv"), (5120, 4096, 4096, "F32_RESID", "llm o_proj"),
     (5120, 22016, 4096, "SWIGLU_BF16", "llm gate_up"), (5120, 4096, 11008, "F32_RESID", "llm down"),
     (4616, 3072, 1024, "BF16", "vit qkv"), (4616, 4096, 1024, "BF16_GELU", "vit fc1"), (4616, 1024, 4096, "F32_RESID", "vit fc2"),
-    (4608, 4096, 1024, "BF16_GELU", "proj 1"), (1088, 12288, 4096, "BF16", "llm qkv C2"), (577, 3072, 1024, "BF16", "vit qkv image"),
+    (4608, 4096, 1024, "BF16_GELU", "proj 1"), (4096, 4096, 4096, "F32_RESID", "o_proj rows 0..4095"),
+    (1024, 4096, 4096, "F32_RESID", "o_proj rows 4096.."), (4096, 4096, 11008, "F32_RESID", "down rows 0..4095"),
+    (1024, 4096, 11008, "F32_RESID", "down rows 4096.."), (4608, 1024, 4096, "F32_RESID", "vit fc2 4608"), (4608, 3072, 1024, "BF16", "vit qkv 4608"), (1088, 12288, 4096, "BF16", "llm qkv C2"), (577, 3072, 1024, "BF16", "vit qkv image"),
 ]
-CFGS = {"128x128": 2, "256x128": 3, "256x256": 4, "64x128": 5, "256x256_p8": 6}
+CFGS = {"auto": 0, "128x128": 2, "256x128": 3, "256x256": 4, "64x128": 5, "256x256_p8": 6}
 
 
 def timeit(fn, iters):

@@ -35,8 +35,10 @@ __device__ __forceinline__ int k_swz(int key) {
 }
 __device__ __forceinline__ int v_swz(int d) { return (d >> 1) & 7; }
 
+#define RESCALE_THR 8.0f
+
 template <int HD, bool CAUSAL>
-__global__ __launch_bounds__(256) void flash_attn_kernel(const bf16_t* __restrict__ Q, int ldq,
+__global__ __launch_bounds__(256, 2) void flash_attn_kernel(const bf16_t* __restrict__ Q, int ldq,
                                                          const bf16_t* __restrict__ Kt,
                                                          const bf16_t* __restrict__ Vt,
                                                          const int* __restrict__ tile_table,
@@ -163,42 +165,46 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const bf16_t* __restric
         }
     }
 
-    // ---- online softmax (log2 domain) ------------------------------------------------------------------------
-    float mx = sacc[0][0];
+    // ---- online softmax (log2 domain, deferred rescale) ------------------------------------------------------------
+    // The running max m_run only moves when some row's tile max exceeds it by more than RESCALE_THR (wave-uniform
+    // branch): P is then bounded by 2^RESCALE_THR instead of 1, which bf16's exponent range absorbs at unchanged
+    // relative precision, and the O / l rescale (the expensive VALU part) is skipped on almost every tile.
+    float mx = fmaxf(sacc[0][0], sacc[1][0]);
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[sub][r]);
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(sacc[0][r], sacc[1][r]));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx * scale_log2e);
-    const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = exp2f(m_run - m_safe);  // m_run = -inf -> 0
-    m_run = m_new;
+    const float m_tile = mx * scale_log2e;
+    if (__builtin_amdgcn_ballot_w64(m_tile > m_run + RESCALE_THR) != 0) {
+      const float m_new = fmaxf(m_run, m_tile);
+      const float alpha = (m_new == -INFINITY) ? 1.f : fast_exp2(m_run - m_new);  // m_run = -inf -> 0
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+    }
+    const float m_safe = (m_run == -INFINITY) ? 0.f : m_run;
     float psum = 0.f;
     bf16x8 pf[2][2];
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
-      float p[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        p[r] = exp2f(sacc[sub][r] * scale_log2e - m_safe);
-        psum += p[r];
+        sacc[sub][r] = fast_exp2(__builtin_fmaf(sacc[sub][r], scale_log2e, -m_safe));
+        psum += sacc[sub][r];
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         u32x4 w;
-        w.x = pack_bf16x2(p[8 * j + 0], p[8 * j + 1]);
-        w.y = pack_bf16x2(p[8 * j + 2], p[8 * j + 3]);
-        w.z = pack_bf16x2(p[8 * j + 4], p[8 * j + 5]);
-        w.w = pack_bf16x2(p[8 * j + 6], p[8 * j + 7]);
+        w.x = pack_bf16x2(sacc[sub][8 * j + 0], sacc[sub][8 * j + 1]);
+        w.y = pack_bf16x2(sacc[sub][8 * j + 2], sacc[sub][8 * j + 3]);
+        w.z = pack_bf16x2(sacc[sub][8 * j + 4], sacc[sub][8 * j + 5]);
+        w.w = pack_bf16x2(sacc[sub][8 * j + 6], sacc[sub][8 * j + 7]);
         pf[sub][j] = __builtin_bit_cast(bf16x8, w);
       }
     }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int db = 0; db < DB; ++db)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+    l_run += psum;
 
     // ---- O^T += V^T . P^T --------------------------------------------------------------------------------------
 #pragma unroll

@@ -75,10 +75,15 @@ __host__ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
   u += 0x7fffu + ((u >> 16) & 1u);
   return (bf16_t)(u >> 16);
 }
-// two floats -> packed bf16x2 (lo in bits 0..15)
+// two floats -> packed bf16x2 (lo in bits 0..15): one v_cvt_pk_bf16_f32 (round-to-nearest-even, same as f32_to_bf16)
+typedef __bf16 vt_bf16v2 __attribute__((ext_vector_type(2)));
+typedef float vt_f32v2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+  vt_f32v2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, vt_bf16v2));
 }
+// raw v_exp_f32 (no denormal-range fix-up): for softmax weights, whose arguments are <= ~8 and whose tiny results may flush
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float bf16lo_to_f32(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16hi_to_f32(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 

@@ -1,0 +1,309 @@
+// vt_gemm8.hip -- the large-shape bf16 GEMM: 256x256x64 tile, 8 wavefronts, 8-phase software pipeline.
+//
+// Same contract and epilogues as vt_gemm.hip's tile kernel (C = epi(A[M,K].W[N,K]^T + bias)); used for the
+// decoder's big projections where >92 % of the prefill FLOPs live.
+//
+// Structure (one workgroup = 512 threads = 8 waves as 2(M) x 4(N); two waves per SIMD):
+//   * The 256x64 A tile and the 256x64 B tile of one K step are staged as four 16-KiB "half tiles"
+//     A0 (rows 0..127), A1 (rows 128..255), B0, B1; LDS holds two K steps = 8 slots = 128 KiB.
+//   * Wave (wr, wc) owns four 64x32 output quadrants: rows {wr*64.., 128 + wr*64..} x cols {wc*32.., 128 + wc*32..}.
+//     One K step = 4 phases, one quadrant each: Q00 (reads A0, B0), Q01 (reads B1), Q11 (reads A1), Q10 (reads nothing:
+//     the B0 fragments stay in registers). So every half tile is needed at a different phase and is dead early.
+//   * Each phase also issues the LDS-DMA (global_load_lds_dwordx4) of ONE half tile, 6 phases ahead of its first use:
+//     stage of (K step u, slot j) goes out at global phase 4u + j - 6. Waits are counted, never drained:
+//     s_waitcnt vmcnt(6) leaves the three newest half tiles in flight across the barriers.
+//   * The two wave rows are staggered by one barrier (wr == 1 runs one s_barrier behind), so on every SIMD one wave is
+//     in its MFMA section while its partner issues ds_reads / DMA: the matrix pipe and the LDS pipe overlap.
+//   * LDS image is lane-linear per DMA piece, chunks XOR-swizzled by ((row>>1)&7) on the source address and on the
+//     ds_read_b128 address (conflict-free for the 16x16x32 fragment read pattern).
+//
+// Safety of the schedule (g = global phase, stage issued in the "load" section L(g), wait in the "MFMA" section M(g)):
+//   RAW  a slot staged at L(g) is first read at phase >= g+5. A read in L(p) needs every wave's DMA landed before the
+//        barrier that opens L(p): the reader's own group waited at M(p-1), the other group (half a phase behind) at
+//        M(p-2); both waits are vmcnt(6) = "everything but the 3 newest stages", i.e. stages <= p-5 for the laggard. OK.
+//   WAR  stage (u, j) overwrites K step u-2's slot j, whose last read was at phase 4(u-2) + {0,0,1,2}[j]; the stage is
+//        issued at 4(u-2) + j + 2 >= two phases later, after the readers' lgkmcnt wait and two barriers. OK.
+#include "vt_common.h"
+#include "vt_kernels.h"
+
+namespace {
+
+struct GemmP8 {
+  const bf16_t* A;
+  const bf16_t* W;
+  void* C;
+  const float* bias;
+  int M, N, K;
+  int lda, ldw, ldc;
+};
+
+__device__ __forceinline__ float gelu_erf8(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float quick_gelu8(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+__device__ __forceinline__ float silu8(float x) { return x / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst_wave_uniform) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_dst_wave_uniform, 16, 0, 0);
+}
+
+#define VT_VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+
+constexpr int HALF_BYTES = 128 * 64 * 2;        // 16 KiB
+constexpr int BUF_BYTES = 4 * HALF_BYTES;       // A0 A1 B0 B1
+constexpr int SLOT_A0 = 0, SLOT_B0 = 1, SLOT_B1 = 2, SLOT_A1 = 3;   // staging order within a K step
+__device__ __forceinline__ constexpr int slot_offset(int slot) {     // LDS placement of a slot inside a buffer
+  return (slot == SLOT_A0 ? 0 : slot == SLOT_A1 ? 1 : slot == SLOT_B0 ? 2 : 3) * HALF_BYTES;
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmP8 p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  // ---- tile order (XCD remap + groups of 8 M tiles), as in vt_gemm.hip ---------------------------------------------
+  const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 255) / 256;
+  const int nwg = tiles_m * tiles_n;
+  const int sid = xcd_remap(blockIdx.x, nwg);
+  constexpr int GROUP_M = 8;
+  const int per_group = GROUP_M * tiles_n;
+  const int first_m = (sid / per_group) * GROUP_M;
+  const int gsz = min(tiles_m - first_m, GROUP_M);
+  const int tm = first_m + (sid % per_group) % gsz;
+  const int tn = (sid % per_group) / gsz;
+  const int bm0 = tm * 256, bn0 = tn * 256;
+
+  // ---- DMA source pointers: slot s, piece i (this wave stages pieces 2*wave + i of every half tile) ------------------
+  const int lrow = lane >> 3, lchk = lane & 7;
+  const bf16_t* src[4][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (wave * 2 + i) * 8 + lrow;          // row inside the half tile
+    const int coff = (lchk ^ ((row >> 1) & 7)) * 8;
+    src[SLOT_A0][i] = p.A + (size_t)min(bm0 + row, p.M - 1) * p.lda + coff;
+    src[SLOT_A1][i] = p.A + (size_t)min(bm0 + 128 + row, p.M - 1) * p.lda + coff;
+    src[SLOT_B0][i] = p.W + (size_t)min(bn0 + row, p.N - 1) * p.ldw + coff;
+    src[SLOT_B1][i] = p.W + (size_t)min(bn0 + 128 + row, p.N - 1) * p.ldw + coff;
+  }
+  const int dma_off = wave * 2048;                      // this wave's two 1-KiB pieces inside a half tile
+
+#define STAGE(BUF, SLOT)                                                                        \
+  do {                                                                                          \
+    char* _d = smem + (BUF) * BUF_BYTES + slot_offset(SLOT) + dma_off;                          \
+    glds16(src[SLOT][0], _d);                                                                   \
+    glds16(src[SLOT][1], _d + 1024);                                                            \
+    src[SLOT][0] += 64;                                                                         \
+    src[SLOT][1] += 64;                                                                         \
+  } while (0)
+
+  // ---- fragment read offsets (same swizzle as the DMA side) ------------------------------------------------------------
+  const int f = (lane >> 1) & 7;
+  const int fo0 = (lane & 15) * 128 + (((lane >> 4) ^ f) << 4);
+  const int fo1 = (lane & 15) * 128 + ((((lane >> 4) | 4) ^ f) << 4);
+  const int a_row_off = wr * 64 * 128;                  // this wave's 64 rows inside an A half tile
+  const int b_row_off = wc * 32 * 128;                  // this wave's 32 cols (= rows of W) inside a B half tile
+
+  f32x4 acc[2][2][4][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[a][b][mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  bf16x8 af[4][2], b0f[2][2], b1f[2][2];
+
+#define READ_A(BUF, SLOT)                                                                      \
+  do {                                                                                         \
+    const char* _s = smem + (BUF) * BUF_BYTES + slot_offset(SLOT) + a_row_off;                 \
+    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) {                                         \
+      af[mi][0] = *(const bf16x8*)(_s + mi * 2048 + fo0);                                      \
+      af[mi][1] = *(const bf16x8*)(_s + mi * 2048 + fo1);                                      \
+    }                                                                                          \
+  } while (0)
+#define READ_B(BUF, SLOT, DST)                                                                 \
+  do {                                                                                         \
+    const char* _s = smem + (BUF) * BUF_BYTES + slot_offset(SLOT) + b_row_off;                 \
+    _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) {                                         \
+      DST[ni][0] = *(const bf16x8*)(_s + ni * 2048 + fo0);                                     \
+      DST[ni][1] = *(const bf16x8*)(_s + ni * 2048 + fo1);                                     \
+    }                                                                                          \
+  } while (0)
+#define MFMA_Q(QM, QN, BF)                                                                     \
+  do {                                                                                         \
+    __builtin_amdgcn_s_setprio(1);                                                             \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                           \
+      _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                         \
+        _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                       \
+          acc[QM][QN][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[ni][kk], af[mi][kk], acc[QM][QN][mi][ni], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                             \
+  } while (0)
+  // one phase = load section | barrier | MFMA section + counted wait | barrier
+#define SECTION_SPLIT()                        \
+  do {                                         \
+    __builtin_amdgcn_sched_barrier(0);         \
+    __builtin_amdgcn_s_barrier();              \
+    __builtin_amdgcn_sched_barrier(0);         \
+  } while (0)
+#define PHASE_END(G)                                              \
+  do {                                                            \
+    if ((G) < drain_from) VT_VMCNT(6); else VT_VMCNT(0);          \
+    SECTION_SPLIT();                                              \
+  } while (0)
+
+  const int nt = p.K >> 6;                 // K steps (even, >= 4: checked by the launcher)
+  const int total_phases = 4 * nt;
+  const int drain_from = total_phases - 6;  // phases g >= this did not all issue a stage in (g-2..g): drain instead
+
+  // ---- prologue: stages of global phases -6..-1 = K step 0 (A0 B0 B1 A1) + K step 1 (A0 B0) -----------------------------
+  STAGE(0, SLOT_A0);
+  STAGE(0, SLOT_B0);
+  STAGE(0, SLOT_B1);
+  STAGE(0, SLOT_A1);
+  STAGE(1, SLOT_A0);
+  STAGE(1, SLOT_B0);
+  VT_VMCNT(0);
+  SECTION_SPLIT();
+  if (wr == 1) __builtin_amdgcn_s_barrier();   // stagger: the second wave row runs one barrier behind
+  __builtin_amdgcn_sched_barrier(0);
+
+  for (int it = 0; it < nt / 2; ++it) {
+    const int g0 = it * 8;                     // global phase of this iteration's first phase
+    const int u = it * 2;                      // K step in buffer 0
+    // ===== K step u (buffer 0) =====
+    // phase 0: stage (u+1, B1) -> buffer 1; read A0,B0; Q00
+    if (u + 1 < nt) STAGE(1, SLOT_B1);
+    READ_B(0, SLOT_B0, b0f);
+    READ_A(0, SLOT_A0);
+    SECTION_SPLIT();
+    MFMA_Q(0, 0, b0f);
+    PHASE_END(g0 + 0);
+    // phase 1: stage (u+1, A1); read B1; Q01
+    if (u + 1 < nt) STAGE(1, SLOT_A1);
+    READ_B(0, SLOT_B1, b1f);
+    SECTION_SPLIT();
+    MFMA_Q(0, 1, b1f);
+    PHASE_END(g0 + 1);
+    // phase 2: stage (u+2, A0) -> buffer 0; read A1; Q11
+    if (u + 2 < nt) STAGE(0, SLOT_A0);
+    READ_A(0, SLOT_A1);
+    SECTION_SPLIT();
+    MFMA_Q(1, 1, b1f);
+    PHASE_END(g0 + 2);
+    // phase 3: stage (u+2, B0); no read; Q10
+    if (u + 2 < nt) STAGE(0, SLOT_B0);
+    SECTION_SPLIT();
+    MFMA_Q(1, 0, b0f);
+    PHASE_END(g0 + 3);
+    // ===== K step u+1 (buffer 1) =====
+    if (u + 2 < nt) STAGE(0, SLOT_B1);
+    READ_B(1, SLOT_B0, b0f);
+    READ_A(1, SLOT_A0);
+    SECTION_SPLIT();
+    MFMA_Q(0, 0, b0f);
+    PHASE_END(g0 + 4);
+    if (u + 2 < nt) STAGE(0, SLOT_A1);
+    READ_B(1, SLOT_B1, b1f);
+    SECTION_SPLIT();
+    MFMA_Q(0, 1, b1f);
+    PHASE_END(g0 + 5);
+    if (u + 3 < nt) STAGE(1, SLOT_A0);
+    READ_A(1, SLOT_A1);
+    SECTION_SPLIT();
+    MFMA_Q(1, 1, b1f);
+    PHASE_END(g0 + 6);
+    if (u + 3 < nt) STAGE(1, SLOT_B0);
+    SECTION_SPLIT();
+    MFMA_Q(1, 0, b0f);
+    PHASE_END(g0 + 7);
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();   // pairs with the stagger barrier of the second wave row
+
+  // ---- epilogue ------------------------------------------------------------------------------------------------------------
+#pragma unroll
+  for (int qm = 0; qm < 2; ++qm)
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const int m = bm0 + qm * 128 + wr * 64 + mi * 16 + (lane & 15);
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int qn = 0; qn < 2; ++qn) {
+        const int nbase = bn0 + qn * 128 + wc * 32;     // multiple of 32
+        if constexpr (EPI == VT_EPI_SWIGLU_BF16) {
+          if (nbase + ((lane >> 4) << 2) >= p.N) continue;
+          const f32x4 g = acc[qm][qn][mi][0], u2 = acc[qm][qn][mi][1];
+          u32x2 o;
+          o.x = pack_bf16x2(silu8(g[0]) * u2[0], silu8(g[1]) * u2[1]);
+          o.y = pack_bf16x2(silu8(g[2]) * u2[2], silu8(g[3]) * u2[3]);
+          *(u32x2*)((bf16_t*)p.C + (size_t)m * p.ldc + (nbase >> 1) + ((lane >> 4) << 2)) = o;
+        } else {
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) {
+            const int n = nbase + ni * 16 + ((lane >> 4) << 2);
+            if (n >= p.N) continue;
+            f32x4 v = acc[qm][qn][mi][ni];
+            if (p.bias) v += *(const f32x4*)(p.bias + n);
+            if constexpr (EPI == VT_EPI_BF16_GELU) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = gelu_erf8(v[r]);
+            } else if constexpr (EPI == VT_EPI_BF16_QGELU) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = quick_gelu8(v[r]);
+            } else if constexpr (EPI == VT_EPI_BF16_RELU) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            if constexpr (EPI == VT_EPI_F32_RESID) {
+              float* c = (float*)p.C + (size_t)m * p.ldc + n;
+              *(f32x4*)c = *(const f32x4*)c + v;
+            } else if constexpr (EPI == VT_EPI_F32) {
+              *(f32x4*)((float*)p.C + (size_t)m * p.ldc + n) = v;
+            } else {
+              u32x2 o;
+              o.x = pack_bf16x2(v[0], v[1]);
+              o.y = pack_bf16x2(v[2], v[3]);
+              *(u32x2*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
+            }
+          }
+        }
+      }
+    }
+}
+
+template <int EPI>
+int launch_p8(const GemmP8& p, hipStream_t s) {
+  constexpr int smem = 2 * BUF_BYTES;  // 128 KiB
+  auto kern = gemm_p8_kernel<EPI>;
+  static bool done = false;
+  if (!done) {
+    VT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    done = true;
+  }
+  const int nwg = cdiv(p.M, 256) * cdiv(p.N, 256);
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), smem, s, p);
+  VT_LAUNCH_CHECK();
+  return VT_OK;
+}
+
+}  // namespace
+
+bool vt_gemm_p8_supported(int M, int N, int K) { return (K % 128) == 0 && K >= 256 && N % 32 == 0; }
+
+int vt_gemm_p8_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, const float* bias, int M,
+                      int N, int K, int epi, hipStream_t s) {
+  VT_REQUIRE(vt_gemm_p8_supported(M, N, K), "vt_gemm(p8): needs K %% 128 == 0, K >= 256, N %% 32 == 0 (K=%d N=%d)", K, N);
+  GemmP8 p{A, W, C, bias, M, N, K, lda, ldw, ldc};
+  switch (epi) {
+    case VT_EPI_BF16: return launch_p8<VT_EPI_BF16>(p, s);
+    case VT_EPI_BF16_GELU: return launch_p8<VT_EPI_BF16_GELU>(p, s);
+    case VT_EPI_BF16_QGELU: return launch_p8<VT_EPI_BF16_QGELU>(p, s);
+    case VT_EPI_BF16_RELU: return launch_p8<VT_EPI_BF16_RELU>(p, s);
+    case VT_EPI_F32_RESID: return launch_p8<VT_EPI_F32_RESID>(p, s);
+    case VT_EPI_F32: return launch_p8<VT_EPI_F32>(p, s);
+    case VT_EPI_SWIGLU_BF16: return launch_p8<VT_EPI_SWIGLU_BF16>(p, s);
+    default: vt_set_error("vt_gemm(p8): unknown epilogue %d", epi); return VT_ERR_ARG;
+  }
+}

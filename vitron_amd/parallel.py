@@ -1,0 +1,58 @@
+"""Clip-parallel video encoding across the GPUs of one node (BASELINE config 4).
+
+The reference has no multi-GPU path (vitron/ contains no torch.distributed call). The natural shard unit is the CLIP
+(or image): the video tower's temporal attention couples the 8 frames of a clip in every layer
+(reference modeling_video.py:105-127), so frames of one clip never leave a GPU. Each rank encodes its clips, then ONE
+all-gather moves the projected visual tokens over xGMI (RCCL, `backend="nccl"`) so that every rank can prefill any
+sequence; prefill itself is data parallel. No other collective is on the path.
+
+Works with any torch.distributed backend: the tests run it under gloo on CPU tensors with a stub encoder.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous, balanced shard [start, stop) of n_items for `rank` (first n_items % world ranks get one more)."""
+    base, rem = divmod(n_items, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def all_gather_visual_tokens(local: torch.Tensor, n_items: int, group=None) -> torch.Tensor:
+    """local: [n_local, ...] tokens of this rank's shard (shard_range order) -> [n_items, ...] on every rank.
+    One all_gather_into_tensor when the shards are even (the benchmark case); padded to the largest shard otherwise."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    counts = [shard_range(n_items, world, r)[1] - shard_range(n_items, world, r)[0] for r in range(world)]
+    assert local.shape[0] == counts[rank], (local.shape, counts, rank)
+    mx = max(counts)
+    if mx == 0:
+        return local
+    send = local.contiguous()
+    if counts[rank] != mx:
+        pad = torch.zeros((mx - counts[rank], *local.shape[1:]), dtype=local.dtype, device=local.device)
+        send = torch.cat([send, pad], 0)
+    out = torch.empty((world * mx, *local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, send, group=group)
+    if all(c == mx for c in counts):
+        return out
+    return torch.cat([out[r * mx: r * mx + counts[r]] for r in range(world)], 0)
+
+
+def encode_clips_parallel(encode: Callable[[torch.Tensor], torch.Tensor], clips: Sequence[torch.Tensor], group=None) -> torch.Tensor:
+    """clips: the GLOBAL list of clips [3,T,H,W] (every rank holds the list, or at least its own shard's entries).
+    Each rank runs `encode` (tower + projector -> [n, T, P, H]) on its shard only; returns all clips' tokens."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    s, e = shard_range(len(clips), world, rank)
+    if e > s:
+        local = encode(torch.stack([clips[i] for i in range(s, e)]))
+    else:
+        probe = encode(torch.stack([clips[0]]))  # shape/dtype only (more ranks than clips)
+        local = probe[:0]
+    return all_gather_visual_tokens(local, len(clips), group)
