@@ -315,6 +315,7 @@ int launch_cfg(const GemmP& p, int cfg, hipStream_t s) {
     case VT_GEMM_CFG_256x128: return launch_tile<256, 128, 4, 2, EPI>(p, s);
     case VT_GEMM_CFG_256x256: return launch_tile<256, 256, 2, 4, EPI>(p, s);
     case VT_GEMM_CFG_64x128: return launch_tile<64, 128, 1, 4, EPI>(p, s);
+    case VT_GEMM_CFG_256x256_W4: return launch_tile<256, 256, 2, 2, EPI>(p, s);
     default: vt_set_error("vt_gemm: unknown tile config %d", cfg); return VT_ERR_ARG;
   }
 }
@@ -333,11 +334,14 @@ int launch_skinny(const GemmP& p, hipStream_t s) {
 }  // namespace
 
 int vt_gemm_pick_cfg(int M, int N, int K) {
-  (void)K;
+  // Measured on MI355X (tools/gemm_bench.py, profiles/): the 8-phase 256x256 kernel wins whenever its grid fills
+  // whole rounds of the 256 CUs (one 128-KiB-LDS workgroup per CU); when the last round would be mostly empty the
+  // 128x128 kernel (two workgroups per CU, 4x more tiles) quantises better.
   if (M <= 64) return VT_GEMM_CFG_64x128;
-  // enough 256x256 tiles to fill 256 CUs at least twice -> biggest tile (best operand reuse)
   const long t256 = (long)cdiv(M, 256) * cdiv(N, 256);
-  if (t256 >= 512 && (N % 256) == 0) return VT_GEMM_CFG_256x256;
+  const long rounds = (t256 + 255) / 256;
+  const double waste = 1.0 - (double)t256 / (double)(rounds * 256);
+  if (vt_gemm_p8_supported(M, N, K) && waste <= 0.15) return VT_GEMM_CFG_256x256_P8;
   const long t128 = (long)cdiv(M, 128) * cdiv(N, 128);
   if (t128 < 256 && M <= 640) return VT_GEMM_CFG_64x128;
   return VT_GEMM_CFG_128x128;

@@ -148,6 +148,14 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmP8 p) {
     __builtin_amdgcn_s_barrier();              \
     __builtin_amdgcn_sched_barrier(0);         \
   } while (0)
+  // end of a load section: the fragment reads must have LANDED before the barrier, so that the MFMA section that
+  // follows starts issuing at once (the partner wave on this SIMD is in its MFMA section while we wait here)
+#define LOAD_SECTION_END()                                   \
+  do {                                                       \
+    __builtin_amdgcn_sched_barrier(0);                       \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
+    SECTION_SPLIT();                                         \
+  } while (0)
 #define PHASE_END(G)                                              \
   do {                                                            \
     if ((G) < drain_from) VT_VMCNT(6); else VT_VMCNT(0);          \
@@ -178,45 +186,45 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmP8 p) {
     if (u + 1 < nt) STAGE(1, SLOT_B1);
     READ_B(0, SLOT_B0, b0f);
     READ_A(0, SLOT_A0);
-    SECTION_SPLIT();
+    LOAD_SECTION_END();
     MFMA_Q(0, 0, b0f);
     PHASE_END(g0 + 0);
     // phase 1: stage (u+1, A1); read B1; Q01
     if (u + 1 < nt) STAGE(1, SLOT_A1);
     READ_B(0, SLOT_B1, b1f);
-    SECTION_SPLIT();
+    LOAD_SECTION_END();
     MFMA_Q(0, 1, b1f);
     PHASE_END(g0 + 1);
     // phase 2: stage (u+2, A0) -> buffer 0; read A1; Q11
     if (u + 2 < nt) STAGE(0, SLOT_A0);
     READ_A(0, SLOT_A1);
-    SECTION_SPLIT();
+    LOAD_SECTION_END();
     MFMA_Q(1, 1, b1f);
     PHASE_END(g0 + 2);
     // phase 3: stage (u+2, B0); no read; Q10
     if (u + 2 < nt) STAGE(0, SLOT_B0);
-    SECTION_SPLIT();
+    LOAD_SECTION_END();
     MFMA_Q(1, 0, b0f);
     PHASE_END(g0 + 3);
     // ===== K step u+1 (buffer 1) =====
     if (u + 2 < nt) STAGE(0, SLOT_B1);
     READ_B(1, SLOT_B0, b0f);
     READ_A(1, SLOT_A0);
-    SECTION_SPLIT();
+    LOAD_SECTION_END();
     MFMA_Q(0, 0, b0f);
     PHASE_END(g0 + 4);
     if (u + 2 < nt) STAGE(0, SLOT_A1);
     READ_B(1, SLOT_B1, b1f);
-    SECTION_SPLIT();
+    LOAD_SECTION_END();
     MFMA_Q(0, 1, b1f);
     PHASE_END(g0 + 5);
     if (u + 3 < nt) STAGE(1, SLOT_A0);
     READ_A(1, SLOT_A1);
-    SECTION_SPLIT();
+    LOAD_SECTION_END();
     MFMA_Q(1, 1, b1f);
     PHASE_END(g0 + 6);
     if (u + 3 < nt) STAGE(1, SLOT_B0);
-    SECTION_SPLIT();
+    LOAD_SECTION_END();
     MFMA_Q(1, 0, b0f);
     PHASE_END(g0 + 7);
   }
