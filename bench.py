@@ -46,6 +46,26 @@ def algorithmic_flops(S, n_vis_tokens, frames, N_vit, image_tokens):
                 total=vit_lin + vit_att + patch + proj + llm_lin + llm_att + head)
 
 
+def pmc_traffic_per_launch():
+    """HBM-side bytes per launch of the MFMA tile GEMM class from the committed rocprofv3 PMC passes
+    (profiles/r1_pmc_traffic.json: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command, summarised by
+    tools/pmc_summarize.py). Units are KiB; FETCH_SIZE is doubled as /opt/skills/guides/MI355X_MICROARCH.md prescribes
+    for gfx950 (128-B requests tallied at 64 B); the counters sit on the L2's fabric side, so Infinity-Cache hits are
+    included. Returns None when the file is absent."""
+    path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        d = json.load(f)
+    tot, n = 0.0, 0
+    for k, v in d.items():
+        if k.startswith(("gemm_bt_kernel", "gemm_p8_kernel", "gemm_w4_kernel")) and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            l = v["FETCH_SIZE"]["launches"]
+            tot += l * (2.0 * v["FETCH_SIZE"]["mean_per_launch"] + v["WRITE_SIZE"]["mean_per_launch"]) * 1024.0
+            n += l
+    return tot / n if n else None
+
+
 def cpu_baseline(image_size, frames, text_len, seed):
     """The CPU oracle (a port of the reference's algorithm, fp32, all host cores) on a bounded sample of the same
     workload; extrapolated to the full step. See DESIGN.md 'Measurement'."""
@@ -210,7 +230,8 @@ def main():
             },
             "roofline": {"bound": "mfma", "kernel": "gemm_bt_kernel (bf16 MFMA tile GEMM, all tile configs/epilogues)",
                          "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": pmc_traffic_per_launch(),
+                         "traffic_note": "mean bytes per launch, FETCH_SIZE x2 + WRITE_SIZE (KiB) from profiles/r1_pmc_traffic.json; includes Infinity-Cache hits",
                          "launches_per_step": gt["launches"] / args.steps,
                          "avg_launch_ms": gt["ms"] / max(gt["launches"], 1),
                          "algorithmic_gflop_per_launch": gt["work"] / max(gt["launches"], 1) / 1e9},

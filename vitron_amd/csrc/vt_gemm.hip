@@ -315,7 +315,6 @@ int launch_cfg(const GemmP& p, int cfg, hipStream_t s) {
     case VT_GEMM_CFG_256x128: return launch_tile<256, 128, 4, 2, EPI>(p, s);
     case VT_GEMM_CFG_256x256: return launch_tile<256, 256, 2, 4, EPI>(p, s);
     case VT_GEMM_CFG_64x128: return launch_tile<64, 128, 1, 4, EPI>(p, s);
-    case VT_GEMM_CFG_256x256_W4: return launch_tile<256, 256, 2, 2, EPI>(p, s);
     default: vt_set_error("vt_gemm: unknown tile config %d", cfg); return VT_ERR_ARG;
   }
 }
@@ -391,6 +390,7 @@ int vt_gemm_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, 
   if (epi == VT_EPI_SWIGLU_BF16) VT_REQUIRE((N % 32) == 0, "vt_gemm(swiglu): N must be a multiple of 32");
   if (cfg == VT_GEMM_CFG_AUTO || cfg == VT_GEMM_CFG_SKINNY) cfg = vt_gemm_pick_cfg(M, N, K);
   if (cfg == VT_GEMM_CFG_256x256_P8) return vt_gemm_p8_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, epi, s);
+  if (cfg == VT_GEMM_CFG_256x256_W4) return vt_gemm_w4_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, epi, s);
   switch (epi) {
     case VT_EPI_BF16: return launch_cfg<VT_EPI_BF16>(p, cfg, s);
     case VT_EPI_BF16_GELU: return launch_cfg<VT_EPI_BF16_GELU>(p, cfg, s);
