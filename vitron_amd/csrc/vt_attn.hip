@@ -18,6 +18,8 @@
 //  * attn_decode_kernel<HD>: single-query attention over the paged tiles (HBM-bound).
 //  * attn_temporal_kernel: the video tower's attention over T frames at one token position
 //    (reference modeling_video.py:105-127) -- T<=8, one wavefront per (position, head).
+#include <stdlib.h>
+
 #include "vt_common.h"
 #include "vt_kernels.h"
 
@@ -37,8 +39,11 @@ __device__ __forceinline__ int v_swz(int d) { return (d >> 1) & 7; }
 
 #define RESCALE_THR 8.0f
 
-template <int HD, bool CAUSAL>
-__global__ __launch_bounds__(256, 2) void flash_attn_kernel(const bf16_t* __restrict__ Q, int ldq,
+// NWAVES waves x 32 query rows share one K / V^T tile ring of NSTAGES 64-key tiles (LDS-DMA, counted vmcnt):
+//   <4 waves, 2 stages>  128-row blocks, 64 KiB LDS (HD=128), two blocks per CU      -- ViT (many short sequences)
+//   <8 waves, 3 stages>  256-row blocks, 96 KiB LDS, one block per CU, two tiles of DMA lead -- long causal prefill
+template <int HD, bool CAUSAL, int NWAVES, int NSTAGES>
+__global__ __launch_bounds__(64 * NWAVES, (NWAVES == 8) ? 2 : 2) void flash_attn_kernel(const bf16_t* __restrict__ Q, int ldq,
                                                          const bf16_t* __restrict__ Kt,
                                                          const bf16_t* __restrict__ Vt,
                                                          const int* __restrict__ tile_table,
@@ -51,26 +56,30 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const bf16_t* __rest
   constexpr int TILE_BYTES = 64 * HD * 2;  // K tile == V^T tile == 64*HD bf16
   constexpr int STAGE_BYTES = 2 * TILE_BYTES;
   constexpr int PIECES = TILE_BYTES / 1024;  // 1-KiB DMA pieces per tile
-  constexpr int PPW = PIECES / 4;            // per wave
+  constexpr int PPW = PIECES / NWAVES;       // per wave
+  constexpr int QBLK = 32 * NWAVES;          // query rows per workgroup
+  static_assert(PIECES % NWAVES == 0, "tile pieces must split evenly over the waves");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const VtAttnSeq sq = seqs[blockIdx.z];
-  const int nqb = (sq.q_len + 127) >> 7;
-  const int qb = nqb - 1 - (int)blockIdx.x;  // heavy (late) blocks first
+  const int nqb = (sq.q_len + QBLK - 1) / QBLK;
+  // grid = (heads, q blocks, sequences): workgroups are dispatched x-fastest, so ALL heads' heaviest (latest) causal
+  // blocks start first and the light ones fill the tail (longest-processing-time order)
+  const int qb = nqb - 1 - (int)blockIdx.y;
   if (qb < 0) return;
-  const int head = blockIdx.y;
+  const int head = blockIdx.x;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ql = lane & 31, hh = lane >> 5;
   const int past = sq.kv_len - sq.q_len;
-  const int q0 = qb * 128;
+  const int q0 = qb * QBLK;
   const int qrow = q0 + wave * 32 + ql;             // row inside the sequence (may be >= q_len)
   const int qrow_c = min(qrow, sq.q_len - 1);
 
   // number of 64-key tiles this block needs
   int ntiles = (sq.kv_len + 63) >> 6;
   if (CAUSAL) {
-    const int last_key = past + min(q0 + 127, sq.q_len - 1);
+    const int last_key = past + min(q0 + QBLK - 1, sq.q_len - 1);
     ntiles = min(ntiles, (last_key >> 6) + 1);
   }
 
@@ -127,24 +136,46 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const bf16_t* __rest
     for (int r = 0; r < 16; ++r) oacc[db][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  stage(0, 0);
-  __syncthreads();
+  // counted wait: at the end of iteration t (prologue = t -1) tile t+1 must have landed; the stages of tiles
+  // t+2 .. t+NSTAGES-1 (PPW K pieces + PPW V pieces each) may stay in flight across the barrier
+#define FA_TILE_SYNC(T)                                                                              \
+  do {                                                                                               \
+    if ((NSTAGES == 3) && ((T) + 2 < ntiles)) {                                                      \
+      if constexpr (PPW == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                       \
+      else if constexpr (PPW == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                  \
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                          \
+    } else {                                                                                         \
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                               \
+    }                                                                                                \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                               \
+    __builtin_amdgcn_s_barrier();                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                               \
+  } while (0)
 
+#pragma unroll
+  for (int s0 = 0; s0 < NSTAGES - 1; ++s0)
+    if (s0 < ntiles) stage(s0, s0);
+  FA_TILE_SYNC(-1);
+
+  int slot = 0, pre_slot = NSTAGES - 1;
   for (int t = 0; t < ntiles; ++t) {
-    const int cur = t & 1;
-    if (t + 1 < ntiles) stage(cur ^ 1, t + 1);
-    const char* kb = smem + cur * STAGE_BYTES;
+    if (t + NSTAGES - 1 < ntiles) stage(pre_slot, t + NSTAGES - 1);
+    const char* kb = smem + slot * STAGE_BYTES;
     const char* vb = kb + TILE_BYTES;
 
     // ---- S^T = K . Q^T ---------------------------------------------------------------------------------
+    // (the two 32-key sub tiles alternate so consecutive MFMAs never depend on each other: a 32x32x16 result is
+    //  only available ~64 cycles after issue, twice its 32-cycle issue slot)
     f32x16 sacc[2];
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
+    for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
       for (int r = 0; r < 16; ++r) sacc[sub][r] = 0.f;
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const int chunk = (ks * 2 + hh) ^ k_sw0;
+    for (int ks = 0; ks < KS; ++ks) {
+      const int chunk = (ks * 2 + hh) ^ k_sw0;
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
         const bf16x8 kf = *(const bf16x8*)(kb + k_row_off[sub] + (chunk << 4));
         sacc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[sub], 0, 0, 0);
       }
@@ -208,19 +239,21 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(const bf16_t* __rest
 
     // ---- O^T += V^T . P^T --------------------------------------------------------------------------------------
 #pragma unroll
-    for (int db = 0; db < DB; ++db) {
-      const int vrow = (db * 32 + ql) * 128;
+    for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-      for (int sub = 0; sub < 2; ++sub)
+      for (int j = 0; j < 2; ++j) {
+        const int chunk = (sub * 4 + 2 * hh + j) ^ v_sw;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int chunk = (sub * 4 + 2 * hh + j) ^ v_sw;
-          const bf16x8 vf = *(const bf16x8*)(vb + vrow + (chunk << 4));
+        for (int db = 0; db < DB; ++db) {   // DB independent accumulators back to back
+          const bf16x8 vf = *(const bf16x8*)(vb + (db * 32 + ql) * 128 + (chunk << 4));
           oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[sub][j], oacc[db], 0, 0, 0);
         }
-    }
-    __syncthreads();
+      }
+    FA_TILE_SYNC(t);
+    slot = (slot + 1 == NSTAGES) ? 0 : slot + 1;
+    pre_slot = (pre_slot + 1 == NSTAGES) ? 0 : pre_slot + 1;
   }
+#undef FA_TILE_SYNC
 
   // ---- epilogue ------------------------------------------------------------------------------------------------
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -527,22 +560,29 @@ int vt_flash_attn_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf16_
   const float sl2 = scale * 1.4426950408889634f;
   // algorithmic FLOP are not known here without reading seq_desc back; the caller-side bench computes them.
   VtProfScope prof(VT_PROF_FLASH_ATTN, 0.0, s);
-  dim3 grid(cdiv(max_q_len, 128), heads, nseq), block(256);
-  const int smem = 2 * 2 * 64 * HD * 2;
-#define VT_FA(HDV, CV)                                                                                         \
+  // long sequences: 256-row blocks, 3-stage ring; short ones (ViT frames, small prefills): 128-row blocks
+  // measured (tools/attn_bench.py, S=5120 causal): 128-row blocks (2 per CU) 272 us vs 256-row blocks 288 us -- the finer
+  // causal granularity wins; the 8-wave / 3-stage variant stays selectable for experiments
+  static const int use_big = getenv("VT_FLASH_QBLK256") ? atoi(getenv("VT_FLASH_QBLK256")) : 0;
+  const bool big = max_q_len >= 1024 && use_big;
+#define VT_FA(HDV, CV, NW, NS)                                                                                 \
   do {                                                                                                         \
-    auto kern = flash_attn_kernel<HDV, CV>;                                                                    \
+    auto kern = flash_attn_kernel<HDV, CV, NW, NS>;                                                            \
+    const int smem = NS * 2 * 64 * HDV * 2;                                                                    \
     static bool done = false;                                                                                  \
     if (!done) {                                                                                               \
       VT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));        \
       done = true;                                                                                             \
     }                                                                                                          \
+    dim3 grid(heads, cdiv(max_q_len, 32 * NW), nseq), block(64 * NW);                                          \
     hipLaunchKernelGGL(kern, grid, block, smem, s, Q, ldq, Kt, Vt, tile_table, seqs, O, ldo, heads, sl2);      \
   } while (0)
   if (HD == 64) {
-    if (causal) VT_FA(64, true); else VT_FA(64, false);
+    if (causal) VT_FA(64, true, 4, 2); else VT_FA(64, false, 4, 2);
+  } else if (big) {
+    if (causal) VT_FA(128, true, 8, 3); else VT_FA(128, false, 8, 3);
   } else {
-    if (causal) VT_FA(128, true); else VT_FA(128, false);
+    if (causal) VT_FA(128, true, 4, 2); else VT_FA(128, false, 4, 2);
   }
 #undef VT_FA
   VT_LAUNCH_CHECK();
