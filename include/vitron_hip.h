@@ -86,9 +86,11 @@ int vt_rmsnorm(const float* x, const int* idx, const float* w, uint16_t* y, int 
 int vt_flash_attn(const uint16_t* Q, int ldq, const uint16_t* k_tiles, const uint16_t* vt_tiles, const int* tile_table,
                   const int* seq_desc, int nseq, int max_q_len, uint16_t* O, int ldo, int heads, int head_dim,
                   int causal, float scale, void* stream);
+/* single-query (q_len == 1) attention, split over the KV tiles; scratch >= vt_attn_decode_scratch_bytes(...) */
+size_t vt_attn_decode_scratch_bytes(int nseq, int heads, int head_dim, int max_kv_len);
 int vt_attn_decode(const uint16_t* Q, int ldq, const uint16_t* k_tiles, const uint16_t* vt_tiles, const int* tile_table,
                    const int* seq_desc, int nseq, uint16_t* O, int ldo, int heads, int head_dim, float scale,
-                   void* stream);
+                   int max_kv_len, void* scratch, size_t scratch_bytes, void* stream);
 /* fused-QKV rows -> K tiles / V^T tiles for the NEW tokens of each sequence; when rope_cos != NULL applies the
  * half-split rotary embedding (tables [rope_len][HD/2] fp32, row = positions[row]) to k and, in place, to q.
  * Replaces apply_rotary_pos_emb + the torch.cat KV-cache append of transformers-4.31 LlamaAttention. */
@@ -228,7 +230,7 @@ typedef struct vt_kv_cache {
   int num_pages;
 } vt_kv_cache;
 
-size_t vt_llama_workspace_bytes(const vt_llama_model* m, int rows, int n_logit_rows);
+size_t vt_llama_workspace_bytes(const vt_llama_model* m, int rows, int n_logit_rows, int nseq, int max_kv_len);
 /* x_embeds    bf16 [rows][H]   packed input embeddings of all sequences (no padding rows)
  * positions   int32 [rows]     rotary position of every row
  * seq_desc    int32 [nseq][4]  {q_row0, q_len, kv_len, table_off} ; kv_len = past + q_len
@@ -237,7 +239,7 @@ size_t vt_llama_workspace_bytes(const vt_llama_model* m, int rows, int n_logit_r
  * logits      fp32 [n_logit_rows][V]
  * The new tokens' K/V are appended to the cache pages; attention is causal over past + new tokens. */
 int vt_llama_forward(const vt_llama_model* m, const vt_kv_cache* kv, const uint16_t* x_embeds, int rows,
-                     const int* positions, const int* seq_desc, int nseq, int max_q_len, int max_new_tiles,
+                     const int* positions, const int* seq_desc, int nseq, int max_q_len, int max_new_tiles, int max_kv_len,
                      const int* tile_table, const int* logit_rows, int n_logit_rows, float* logits,
                      float* out_hidden, void* workspace, size_t workspace_bytes, void* stream);
 

@@ -192,7 +192,7 @@ def test_attention_with_past_rope_and_decode(dev):
         new_tiles = (done + chunk - 1) // 64 - done // 64 + 1
         ops.kv_tiles(x, 0, D, 2 * D, kt, vt, table, desc, new_tiles, heads, hd, cd, sd_, pos)
         if chunk == 1:
-            out = ops.attn_decode(x, kt, vt, table, desc, heads, hd, scale)
+            out = ops.attn_decode(x, kt, vt, table, desc, heads, hd, scale, done + chunk)
         else:
             out = ops.flash_attn(x, kt, vt, table, desc, chunk, heads, hd, True, scale)
         assert rel_l2(out.float(), bf16r(ref[done:done + chunk])) <= 3e-3, (done, chunk)

@@ -67,7 +67,8 @@ SIGNATURES = {
     "vt_layernorm": (_i, [vp, vp, _i, _i, vp, vp, vp, _i, _i, _f, vp]),
     "vt_rmsnorm": (_i, [vp, vp, vp, vp, _i, _i, _f, vp]),
     "vt_flash_attn": (_i, [vp, _i, vp, vp, vp, vp, _i, _i, vp, _i, _i, _i, _i, _f, vp]),
-    "vt_attn_decode": (_i, [vp, _i, vp, vp, vp, vp, _i, vp, _i, _i, _i, _f, vp]),
+    "vt_attn_decode_scratch_bytes": (_sz, [_i, _i, _i, _i]),
+    "vt_attn_decode": (_i, [vp, _i, vp, vp, vp, vp, _i, vp, _i, _i, _i, _f, _i, vp, _sz, vp]),
     "vt_kv_tiles": (_i, [vp, _i, _i, _i, _i, vp, vp, vp, vp, _i, _i, _i, _i, vp, vp, vp, vp]),
     "vt_attn_temporal": (_i, [vp, vp, _i, _i, _i, _i, vp]),
     "vt_im2col": (_i, [vp, _i, vp, _i, _i, _i, _i, _i, _i, _i, vp]),
@@ -79,8 +80,8 @@ SIGNATURES = {
     "vt_region_forward": (_i, [C.POINTER(VtRegionWeights), vp, vp, vp, _i, _i, _i, vp, vp, vp, vp, _sz, vp]),
     "vt_vit_workspace_bytes": (_sz, [C.POINTER(VtVitModel), _i, _i]),
     "vt_vit_forward": (_i, [C.POINTER(VtVitModel), vp, _i, _i, _i, _i, vp, vp, vp, _sz, vp]),
-    "vt_llama_workspace_bytes": (_sz, [C.POINTER(VtLlamaModel), _i, _i]),
-    "vt_llama_forward": (_i, [C.POINTER(VtLlamaModel), C.POINTER(VtKvCache), vp, _i, vp, vp, _i, _i, _i, vp, vp,
+    "vt_llama_workspace_bytes": (_sz, [C.POINTER(VtLlamaModel), _i, _i, _i, _i]),
+    "vt_llama_forward": (_i, [C.POINTER(VtLlamaModel), C.POINTER(VtKvCache), vp, _i, vp, vp, _i, _i, _i, _i, vp, vp,
                               _i, vp, vp, vp, _sz, vp]),
     "vt_profile_begin": (_i, []),
     "vt_profile_end": (_i, [C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),

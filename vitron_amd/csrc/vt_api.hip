@@ -142,11 +142,12 @@ int vt_flash_attn(const uint16_t* Q, int ldq, const uint16_t* k_tiles, const uin
                               ldo, heads, head_dim, causal, scale, S(stream));
 }
 
+size_t vt_attn_decode_scratch_bytes(int nseq, int heads, int head_dim, int max_kv_len);  // defined in vt_attn.hip (C++ linkage there)
 int vt_attn_decode(const uint16_t* Q, int ldq, const uint16_t* k_tiles, const uint16_t* vt_tiles, const int* tile_table,
                    const int* seq_desc, int nseq, uint16_t* O, int ldo, int heads, int head_dim, float scale,
-                   void* stream) {
+                   int max_kv_len, void* scratch, size_t scratch_bytes, void* stream) {
   return vt_attn_decode_launch(Q, ldq, k_tiles, vt_tiles, tile_table, (const VtAttnSeq*)seq_desc, nseq, O, ldo, heads,
-                               head_dim, scale, S(stream));
+                               head_dim, scale, max_kv_len, (float*)scratch, scratch_bytes, S(stream));
 }
 
 int vt_kv_tiles(uint16_t* qkv, int ldqkv, int q_col0, int k_col0, int v_col0, uint16_t* k_tiles, uint16_t* vt_tiles,
@@ -330,9 +331,11 @@ struct LlamaWs {
   float* x;
   bf16_t *y, *qkv, *att, *h, *yn;
   float* scratch;
+  float* attn_scratch;
+  size_t attn_scratch_bytes;
   size_t total;
 };
-LlamaWs llama_carve(const vt_llama_model* m, int rows, int n_logit, void* p, size_t n) {
+LlamaWs llama_carve(const vt_llama_model* m, int rows, int n_logit, int nseq, int max_kv_len, void* p, size_t n) {
   Carver ws(p, n);
   LlamaWs w;
   const int H = m->hidden, I = m->intermediate;
@@ -343,29 +346,31 @@ LlamaWs llama_carve(const vt_llama_model* m, int rows, int n_logit, void* p, siz
   w.h = (bf16_t*)ws.take((size_t)rows * I * 2);
   w.yn = (bf16_t*)ws.take((size_t)(n_logit > 0 ? n_logit : 1) * H * 2);
   w.scratch = (float*)ws.take((size_t)16 * 2 * I * 4);
+  w.attn_scratch_bytes = vt_attn_decode_scratch_bytes(nseq > 0 ? nseq : 1, m->heads, m->head_dim, max_kv_len > 0 ? max_kv_len : 64);
+  w.attn_scratch = (float*)ws.take(w.attn_scratch_bytes);
   w.total = ws.off + 256;
   return w;
 }
 }  // namespace
 
-size_t vt_llama_workspace_bytes(const vt_llama_model* m, int rows, int n_logit_rows) {
+size_t vt_llama_workspace_bytes(const vt_llama_model* m, int rows, int n_logit_rows, int nseq, int max_kv_len) {
   if (!m) return 0;
-  return llama_carve(m, rows, n_logit_rows, nullptr, 0).total;
+  return llama_carve(m, rows, n_logit_rows, nseq, max_kv_len, nullptr, 0).total;
 }
 
 int vt_llama_forward(const vt_llama_model* m, const vt_kv_cache* kv, const uint16_t* x_embeds, int rows,
-                     const int* positions, const int* seq_desc, int nseq, int max_q_len, int max_new_tiles,
+                     const int* positions, const int* seq_desc, int nseq, int max_q_len, int max_new_tiles, int max_kv_len,
                      const int* tile_table, const int* logit_rows, int n_logit_rows, float* logits,
                      float* out_hidden, void* workspace, size_t workspace_bytes, void* stream) {
   VT_REQUIRE(m && kv && x_embeds && positions && seq_desc && tile_table && workspace, "vt_llama_forward: null pointer");
-  VT_REQUIRE(rows > 0 && nseq > 0 && max_q_len > 0 && max_new_tiles > 0, "vt_llama_forward: empty batch");
+  VT_REQUIRE(rows > 0 && nseq > 0 && max_q_len > 0 && max_new_tiles > 0 && max_kv_len > 0, "vt_llama_forward: empty batch");
   VT_REQUIRE(m->head_dim == 128 || m->head_dim == 64, "vt_llama_forward: head_dim %d unsupported", m->head_dim);
   VT_REQUIRE(m->hidden == m->heads * m->head_dim, "vt_llama_forward: hidden != heads*head_dim");
   VT_REQUIRE(m->hidden % 64 == 0 && m->intermediate % 64 == 0, "vt_llama_forward: hidden/intermediate must be multiples of 64");
   VT_REQUIRE(m->rope_cos && m->rope_sin, "vt_llama_forward: rope tables missing");
   if (n_logit_rows > 0) VT_REQUIRE(logits && logit_rows, "vt_llama_forward: logits requested but pointer missing");
   hipStream_t s = S(stream);
-  LlamaWs w = llama_carve(m, rows, n_logit_rows, workspace, workspace_bytes);
+  LlamaWs w = llama_carve(m, rows, n_logit_rows, nseq, max_kv_len, workspace, workspace_bytes);
   if (w.total > workspace_bytes) {
     vt_set_error("vt_llama_forward: workspace too small (%zu < %zu)", workspace_bytes, w.total);
     return VT_ERR_WORKSPACE;
@@ -385,7 +390,8 @@ int vt_llama_forward(const vt_llama_model* m, const vt_kv_cache* kv, const uint1
     VT_TRY(vt_kv_tiles_launch(w.qkv, 3 * H, 0, H, 2 * H, kt, vt, tile_table, (const VtAttnSeq*)seq_desc, nseq,
                               max_new_tiles, heads, HD, m->rope_cos, m->rope_sin, positions, s));
     if (max_q_len == 1)
-      VT_TRY(vt_attn_decode_launch(w.qkv, 3 * H, kt, vt, tile_table, (const VtAttnSeq*)seq_desc, nseq, w.att, H, heads, HD, scale, s));
+      VT_TRY(vt_attn_decode_launch(w.qkv, 3 * H, kt, vt, tile_table, (const VtAttnSeq*)seq_desc, nseq, w.att, H, heads, HD, scale,
+                                   max_kv_len, w.attn_scratch, w.attn_scratch_bytes, s));
     else
       VT_TRY(vt_flash_attn_launch(w.qkv, 3 * H, kt, vt, tile_table, (const VtAttnSeq*)seq_desc, nseq, max_q_len, w.att, H,
                                   heads, HD, 1, scale, s));

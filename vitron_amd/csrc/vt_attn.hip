@@ -392,28 +392,32 @@ __global__ __launch_bounds__(256) void kv_tiles_kernel(bf16_t* __restrict__ qkv,
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// attn_decode_kernel: one block (4 waves) per (head, sequence); q_len == 1. Waves take tiles round-robin, each keeps
-// an online-softmax partial (m, l, o[HD]); partials are merged through LDS.
+// attn_decode_kernel: single-query attention over the paged tiles, flash-decoding style. HBM-bound: the whole job is
+// to stream K and V^T tiles once, fully coalesced, with enough waves in flight.
+//   grid (head, sequence, split); 4 waves per block; wave w of split s owns tiles t = 4*s + w, 4*s + w + 4*nsplit, ...
+//   scores : 16 (HD=128) lanes cooperate on one 256-B K row, 4 rows per wave-instruction, shuffle-reduce per row
+//   PV     : 8 lanes cooperate on one 128-B V^T row (8 rows per wave-instruction = 8 full cache lines); every lane
+//            keeps HD/8 partial accumulators and the cross-lane reduction happens ONCE after the last tile
+//   each block writes an online-softmax partial (m, l, o[HD]) to scratch; attn_decode_combine_kernel merges the splits.
 // ------------------------------------------------------------------------------------------------------------------
 template <int HD>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ Q, int ldq,
                                                           const bf16_t* __restrict__ Kt,
                                                           const bf16_t* __restrict__ Vt,
                                                           const int* __restrict__ tile_table,
-                                                          const VtAttnSeq* __restrict__ seqs, bf16_t* __restrict__ O,
-                                                          int ldo, int heads, float scale_log2e) {
+                                                          const VtAttnSeq* __restrict__ seqs, int heads,
+                                                          float scale_log2e, float* __restrict__ part, int nsplit) {
   constexpr int CH = HD / 8;        // 16-B chunks per K row; CH lanes cooperate on one key
   constexpr int KPI = 64 / CH;      // keys per wave-instruction
-  constexpr int DPL = HD / 64;      // output dims per lane
+  constexpr int NACC = HD / 8;      // V^T rows handled per lane (one per PV instruction)
   __shared__ float sm_m[4], sm_l[4];
   __shared__ float sm_o[4][HD];
-  __shared__ float sm_p[4][64];
+  __shared__ __attribute__((aligned(16))) float sm_p[4][64];
   const VtAttnSeq sq = seqs[blockIdx.y];
-  const int head = blockIdx.x;
+  const int head = blockIdx.x, split = blockIdx.z;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ntiles = (sq.kv_len + 63) >> 6;
   const bf16_t* qp = Q + (size_t)sq.q_row0 * ldq + head * HD;
-  // q chunk for this lane's position inside a key row
   const int c = lane % CH;
   const u32x4 qv = *(const u32x4*)(qp + c * 8);
   float qf[8];
@@ -422,85 +426,121 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
     qf[2 * w] = bf16lo_to_f32(qv[w]);
     qf[2 * w + 1] = bf16hi_to_f32(qv[w]);
   }
-  float m_run = -INFINITY, l_run = 0.f, o[DPL];
+  float m_run = -INFINITY, l_run = 0.f, acc[NACC];
 #pragma unroll
-  for (int i = 0; i < DPL; ++i) o[i] = 0.f;
+  for (int i = 0; i < NACC; ++i) acc[i] = 0.f;
+  const int vrow = lane >> 3, vchk = lane & 7;
 
-  for (int t = wave; t < ntiles; t += 4) {
+  for (int t = split * 4 + wave; t < ntiles; t += 4 * nsplit) {
     const size_t toff = ((size_t)tile_table[sq.table_off + t] * heads + head) * 64 * HD;
     const bf16_t* kt = Kt + toff;
     const bf16_t* vt = Vt + toff;
-    // scores for the 64 keys of the tile: iteration i handles keys i*KPI + lane/CH
+    // issue the V^T loads early: they do not depend on the scores
+    u32x4 vv[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) vv[i] = __builtin_nontemporal_load((const u32x4*)(vt + (i * 8 + vrow) * 64 + vchk * 8));
     float s_mine = -INFINITY;  // lane ends up owning key == lane
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
       const int key = i * KPI + lane / CH;
-      const u32x4 kv = *(const u32x4*)(kt + key * HD + c * 8);
-      float part = 0.f;
+      const u32x4 kv = __builtin_nontemporal_load((const u32x4*)(kt + key * HD + c * 8));
+      float part_s = 0.f;
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
-        part = fmaf(bf16lo_to_f32(kv[w]), qf[2 * w], part);
-        part = fmaf(bf16hi_to_f32(kv[w]), qf[2 * w + 1], part);
+        part_s = fmaf(bf16lo_to_f32(kv[w]), qf[2 * w], part_s);
+        part_s = fmaf(bf16hi_to_f32(kv[w]), qf[2 * w + 1], part_s);
       }
 #pragma unroll
-      for (int off = 1; off < CH; off <<= 1) part += __shfl_xor(part, off, 64);
-      // every lane of the CH-group now has the score of `key`; lane == key keeps it
-      const float sc = __shfl(part, (lane % KPI) * CH, 64);  // score of key i*KPI + lane%KPI
+      for (int off = 1; off < CH; off <<= 1) part_s += __shfl_xor(part_s, off, 64);
+      const float sc = __shfl(part_s, (lane % KPI) * CH, 64);  // score of key i*KPI + lane%KPI
       if ((lane / KPI) == i) s_mine = sc;
     }
     const int mykey = t * 64 + lane;
-    float s2 = (mykey < sq.kv_len) ? s_mine * scale_log2e : -INFINITY;
-    const float mx = wave_max(s2);
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = exp2f(m_run - m_new);
-    const float p = exp2f(s2 - m_new);
+    const float s2 = (mykey < sq.kv_len) ? s_mine * scale_log2e : -INFINITY;
+    const float m_new = fmaxf(m_run, wave_max(s2));
+    const float alpha = fast_exp2(m_run - m_new);
+    const float p = fast_exp2(s2 - m_new);
     l_run = l_run * alpha + wave_sum(p);
     m_run = m_new;
     sm_p[wave][lane] = p;
     __builtin_amdgcn_wave_barrier();  // DS ops of one wave are in order; only stop compiler reordering
-    // o[d] = o[d]*alpha + sum_key p[key] * V^T[d][key]; lane owns d = lane + 64*i
+    const f32x4 pa = *(const f32x4*)(&sm_p[wave][vchk * 8]);
+    const f32x4 pb = *(const f32x4*)(&sm_p[wave][vchk * 8 + 4]);
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int i = 0; i < DPL; ++i) {
-      const bf16_t* vr = vt + (lane + 64 * i) * 64;
-      float acc = 0.f;
-#pragma unroll
-      for (int kc = 0; kc < 8; ++kc) {
-        const u32x4 vv = *(const u32x4*)(vr + kc * 8);
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-          acc = fmaf(bf16lo_to_f32(vv[w]), sm_p[wave][kc * 8 + 2 * w], acc);
-          acc = fmaf(bf16hi_to_f32(vv[w]), sm_p[wave][kc * 8 + 2 * w + 1], acc);
-        }
-      }
-      o[i] = o[i] * alpha + acc;
+    for (int i = 0; i < NACC; ++i) {
+      float a = acc[i] * alpha;
+      a = fmaf(bf16lo_to_f32(vv[i][0]), pa[0], a);
+      a = fmaf(bf16hi_to_f32(vv[i][0]), pa[1], a);
+      a = fmaf(bf16lo_to_f32(vv[i][1]), pa[2], a);
+      a = fmaf(bf16hi_to_f32(vv[i][1]), pa[3], a);
+      a = fmaf(bf16lo_to_f32(vv[i][2]), pb[0], a);
+      a = fmaf(bf16hi_to_f32(vv[i][2]), pb[1], a);
+      a = fmaf(bf16lo_to_f32(vv[i][3]), pb[2], a);
+      a = fmaf(bf16hi_to_f32(vv[i][3]), pb[3], a);
+      acc[i] = a;
     }
+  }
+  // reduce the 8 lanes of every V^T row, then combine the 4 waves through LDS
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) {
+    float a = acc[i];
+    a += __shfl_xor(a, 1, 64);
+    a += __shfl_xor(a, 2, 64);
+    a += __shfl_xor(a, 4, 64);
+    if (vchk == 0) sm_o[wave][i * 8 + vrow] = a;
   }
   if (lane == 0) {
     sm_m[wave] = m_run;
     sm_l[wave] = l_run;
   }
-#pragma unroll
-  for (int i = 0; i < DPL; ++i) sm_o[wave][lane + 64 * i] = o[i];
   __syncthreads();
   if (wave == 0) {
-    float m = fmaxf(fmaxf(sm_m[0], sm_m[1]), fmaxf(sm_m[2], sm_m[3]));
-    float l = 0.f;
-    float w4[4];
+    const float m = fmaxf(fmaxf(sm_m[0], sm_m[1]), fmaxf(sm_m[2], sm_m[3]));
+    float l = 0.f, w4[4];
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
-      w4[w] = (sm_m[w] == -INFINITY) ? 0.f : exp2f(sm_m[w] - m);
+      w4[w] = (sm_m[w] == -INFINITY) ? 0.f : fast_exp2(sm_m[w] - m);
       l += sm_l[w] * w4[w];
     }
-    const float inv = l > 0.f ? 1.f / l : 0.f;
+    float* dst = part + (((size_t)blockIdx.y * heads + head) * nsplit + split) * (HD + 2);
+    if (lane == 0) {
+      dst[0] = m;
+      dst[1] = l;
+    }
 #pragma unroll
-    for (int i = 0; i < DPL; ++i) {
+    for (int i = 0; i < HD / 64; ++i) {
       const int d = lane + 64 * i;
-      float acc = 0.f;
+      float o = 0.f;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) acc += sm_o[w][d] * w4[w];
-      O[(size_t)sq.q_row0 * ldo + head * HD + d] = f32_to_bf16(acc * inv);
+      for (int w = 0; w < 4; ++w) o += sm_o[w][d] * w4[w];
+      dst[2 + d] = o;
     }
   }
+}
+
+template <int HD>
+__global__ __launch_bounds__(64) void attn_decode_combine_kernel(const float* __restrict__ part,
+                                                                 const VtAttnSeq* __restrict__ seqs,
+                                                                 bf16_t* __restrict__ O, int ldo, int heads, int nsplit) {
+  const int head = blockIdx.x, seq = blockIdx.y, lane = threadIdx.x;
+  const float* src = part + ((size_t)seq * heads + head) * nsplit * (HD + 2);
+  float m = -INFINITY;
+  for (int s = 0; s < nsplit; ++s) m = fmaxf(m, src[s * (HD + 2)]);
+  float l = 0.f, o[HD / 64];
+#pragma unroll
+  for (int i = 0; i < HD / 64; ++i) o[i] = 0.f;
+  for (int s = 0; s < nsplit; ++s) {
+    const float ms = src[s * (HD + 2)];
+    const float w = (ms == -INFINITY) ? 0.f : fast_exp2(ms - m);
+    l += src[s * (HD + 2) + 1] * w;
+#pragma unroll
+    for (int i = 0; i < HD / 64; ++i) o[i] += src[s * (HD + 2) + 2 + lane + 64 * i] * w;
+  }
+  const float inv = l > 0.f ? 1.f / l : 0.f;
+  bf16_t* op = O + (size_t)seqs[seq].q_row0 * ldo + head * HD;
+#pragma unroll
+  for (int i = 0; i < HD / 64; ++i) op[lane + 64 * i] = f32_to_bf16(o[i] * inv);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -609,16 +649,37 @@ int vt_kv_tiles_launch(bf16_t* qkv, int ldqkv, int q_col0, int k_col0, int v_col
   return VT_OK;
 }
 
+size_t vt_attn_decode_scratch_bytes(int nseq, int heads, int HD, int max_kv_len) {
+  const int ntiles = (max_kv_len + 63) / 64;
+  int nsplit = (ntiles + 3) / 4;
+  nsplit = nsplit < 1 ? 1 : (nsplit > 32 ? 32 : nsplit);
+  return (size_t)nseq * heads * nsplit * (HD + 2) * sizeof(float);
+}
+
 int vt_attn_decode_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf16_t* Vt, const int* tile_table,
                           const VtAttnSeq* seqs, int nseq, bf16_t* O, int ldo, int heads, int HD, float scale,
-                          hipStream_t s) {
-  VT_REQUIRE(Q && Kt && Vt && tile_table && seqs && O, "vt_attn_decode: null pointer");
+                          int max_kv_len, float* scratch, size_t scratch_bytes, hipStream_t s) {
+  VT_REQUIRE(Q && Kt && Vt && tile_table && seqs && O && scratch, "vt_attn_decode: null pointer");
   VT_REQUIRE(HD == 64 || HD == 128, "vt_attn_decode: head_dim %d unsupported", HD);
+  VT_REQUIRE(max_kv_len > 0, "vt_attn_decode: max_kv_len must be > 0");
+  const int ntiles = (max_kv_len + 63) / 64;
+  int nsplit = (ntiles + 3) / 4;
+  nsplit = nsplit < 1 ? 1 : (nsplit > 32 ? 32 : nsplit);
+  const size_t need = (size_t)nseq * heads * nsplit * (HD + 2) * sizeof(float);
+  if (scratch_bytes < need) {
+    vt_set_error("vt_attn_decode: scratch too small (%zu < %zu)", scratch_bytes, need);
+    return VT_ERR_WORKSPACE;
+  }
   const float sl2 = scale * 1.4426950408889634f;
   VtProfScope prof(VT_PROF_ATTN_DECODE, 0.0, s);
-  dim3 grid(heads, nseq), block(256);
-  if (HD == 64) hipLaunchKernelGGL((attn_decode_kernel<64>), grid, block, 0, s, Q, ldq, Kt, Vt, tile_table, seqs, O, ldo, heads, sl2);
-  else hipLaunchKernelGGL((attn_decode_kernel<128>), grid, block, 0, s, Q, ldq, Kt, Vt, tile_table, seqs, O, ldo, heads, sl2);
+  dim3 grid(heads, nseq, nsplit), block(256);
+  if (HD == 64) {
+    hipLaunchKernelGGL((attn_decode_kernel<64>), grid, block, 0, s, Q, ldq, Kt, Vt, tile_table, seqs, heads, sl2, scratch, nsplit);
+    hipLaunchKernelGGL((attn_decode_combine_kernel<64>), dim3(heads, nseq), dim3(64), 0, s, scratch, seqs, O, ldo, heads, nsplit);
+  } else {
+    hipLaunchKernelGGL((attn_decode_kernel<128>), grid, block, 0, s, Q, ldq, Kt, Vt, tile_table, seqs, heads, sl2, scratch, nsplit);
+    hipLaunchKernelGGL((attn_decode_combine_kernel<128>), dim3(heads, nseq), dim3(64), 0, s, scratch, seqs, O, ldo, heads, nsplit);
+  }
   VT_LAUNCH_CHECK();
   return VT_OK;
 }

@@ -212,39 +212,75 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bt_kernel(GemmP p
 }
 
 // ------------------------------------------------------------------------------------------------
-// skinny GEMM: M <= 16. One wave computes NPW output columns; lanes split K in 16-byte chunks.
+// skinny GEMM: M <= 16 (decode steps, region MLP, last-position lm_head). Pure weight streaming:
+//   * a block of 4 waves owns 16 output columns (4 per wave); the M activation rows are staged once in LDS as fp32
+//     (converted on the way in), K split in slabs of KSLAB so any K fits,
+//   * every lane streams 16-byte chunks of its wave's 4 weight rows with non-temporal loads, 2 K-chunks unrolled
+//     (8 independent 16-B loads in flight per lane), fp32 FMA, one wave reduction per (column, row) at the end.
+// Roofline: HBM (2*N*K weight bytes per launch, read exactly once).
 // ------------------------------------------------------------------------------------------------
 template <int MROWS, int EPI>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmP p) {
-  constexpr int NPW = 2;  // output columns per wave
+  constexpr int NPW = 2;        // output columns per wave
+  constexpr int UNR = 4;        // K chunks in flight per column  -> NPW*UNR = 8 independent 16-B loads per lane
+  constexpr int KSLAB = 2048;   // activation slab staged in LDS: MROWS * KSLAB * 4 B (<= 128 KiB at MROWS = 16)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* xs = (float*)smem;     // [MROWS][KSLAB]
   const int lane = threadIdx.x & 63;
-  const int wave = (blockIdx.x * (blockDim.x >> 6)) + (threadIdx.x >> 6);
-  const int n0 = wave * NPW;
-  if (n0 >= p.N) return;
+  const int wave = threadIdx.x >> 6;
+  const int n0 = (blockIdx.x * 4 + wave) * NPW;
   float acc[NPW][MROWS];
 #pragma unroll
   for (int j = 0; j < NPW; ++j)
 #pragma unroll
     for (int m = 0; m < MROWS; ++m) acc[j][m] = 0.f;
+  const bf16_t* wrow[NPW];
+#pragma unroll
+  for (int j = 0; j < NPW; ++j) wrow[j] = p.W + (size_t)min(n0 + j, p.N - 1) * p.ldw;
 
-  const int kchunks = p.K >> 3;  // K % 8 == 0
-  for (int c = lane; c < kchunks; c += 64) {
-    u32x4 w[NPW];
-#pragma unroll
-    for (int j = 0; j < NPW; ++j) {
-      const int n = min(n0 + j, p.N - 1);
-      w[j] = __builtin_nontemporal_load((const u32x4*)(p.W + (size_t)n * p.ldw + c * 8));
+  for (int k0 = 0; k0 < p.K; k0 += KSLAB) {
+    const int kw = min(KSLAB, p.K - k0);   // multiple of 8
+    __syncthreads();                       // previous slab fully consumed
+    for (int i = threadIdx.x; i < MROWS * (kw >> 3); i += 256) {
+      const int m = i / (kw >> 3), c = i % (kw >> 3);
+      u32x4 x = {0u, 0u, 0u, 0u};
+      if (m < p.M) x = *(const u32x4*)(p.A + (size_t)m * p.lda + k0 + c * 8);
+      float* d = xs + m * KSLAB + c * 8;
+      *(f32x4*)d = (f32x4){bf16lo_to_f32(x[0]), bf16hi_to_f32(x[0]), bf16lo_to_f32(x[1]), bf16hi_to_f32(x[1])};
+      *(f32x4*)(d + 4) = (f32x4){bf16lo_to_f32(x[2]), bf16hi_to_f32(x[2]), bf16lo_to_f32(x[3]), bf16hi_to_f32(x[3])};
     }
+    __syncthreads();
+    const int chunks = kw >> 3;
+    for (int c = lane; c < chunks; c += 64 * UNR) {
+      u32x4 w[UNR][NPW];
 #pragma unroll
-    for (int m = 0; m < MROWS; ++m) {
-      const int mr = min(m, p.M - 1);  // rows >= M recompute the last row; their results are never stored
-      const u32x4 x = *(const u32x4*)(p.A + (size_t)mr * p.lda + c * 8);
+      for (int u = 0; u < UNR; ++u) {
+        const int cu = c + 64 * u;
 #pragma unroll
-      for (int j = 0; j < NPW; ++j) {
+        for (int j = 0; j < NPW; ++j)
+          w[u][j] = (cu < chunks) ? __builtin_nontemporal_load((const u32x4*)(wrow[j] + k0 + cu * 8)) : (u32x4){0u, 0u, 0u, 0u};
+      }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          acc[j][m] = fmaf(bf16lo_to_f32(w[j][q]), bf16lo_to_f32(x[q]), acc[j][m]);
-          acc[j][m] = fmaf(bf16hi_to_f32(w[j][q]), bf16hi_to_f32(x[q]), acc[j][m]);
+      for (int u = 0; u < UNR; ++u) {
+        const int cu = min(c + 64 * u, chunks - 1);   // out-of-range chunks carry zero weights
+#pragma unroll
+        for (int m = 0; m < MROWS; ++m) {
+          const f32x4 xa = *(const f32x4*)(xs + m * KSLAB + cu * 8);
+          const f32x4 xb = *(const f32x4*)(xs + m * KSLAB + cu * 8 + 4);
+#pragma unroll
+          for (int j = 0; j < NPW; ++j) {
+            const u32x4 ww = w[u][j];
+            float a = acc[j][m];
+            a = fmaf(bf16lo_to_f32(ww[0]), xa[0], a);
+            a = fmaf(bf16hi_to_f32(ww[0]), xa[1], a);
+            a = fmaf(bf16lo_to_f32(ww[1]), xa[2], a);
+            a = fmaf(bf16hi_to_f32(ww[1]), xa[3], a);
+            a = fmaf(bf16lo_to_f32(ww[2]), xb[0], a);
+            a = fmaf(bf16hi_to_f32(ww[2]), xb[1], a);
+            a = fmaf(bf16lo_to_f32(ww[3]), xb[2], a);
+            a = fmaf(bf16hi_to_f32(ww[3]), xb[3], a);
+            acc[j][m] = a;
+          }
         }
       }
     }
@@ -319,15 +355,25 @@ int launch_cfg(const GemmP& p, int cfg, hipStream_t s) {
   }
 }
 
-template <int EPI>
-int launch_skinny(const GemmP& p, hipStream_t s) {
-  const int waves = cdiv(p.N, 2);
-  const int blocks = cdiv(waves, 4);
-  if (p.M <= 4) hipLaunchKernelGGL((gemm_skinny_kernel<4, EPI>), dim3(blocks), dim3(256), 0, s, p);
-  else if (p.M <= 8) hipLaunchKernelGGL((gemm_skinny_kernel<8, EPI>), dim3(blocks), dim3(256), 0, s, p);
-  else hipLaunchKernelGGL((gemm_skinny_kernel<16, EPI>), dim3(blocks), dim3(256), 0, s, p);
+template <int MR, int EPI>
+int launch_skinny_m(const GemmP& p, hipStream_t s) {
+  constexpr int smem = MR * 2048 * 4;
+  auto kern = gemm_skinny_kernel<MR, EPI>;
+  static bool done = false;
+  if (!done) {
+    VT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(cdiv(p.N, 8)), dim3(256), smem, s, p);
   VT_LAUNCH_CHECK();
   return VT_OK;
+}
+
+template <int EPI>
+int launch_skinny(const GemmP& p, hipStream_t s) {
+  if (p.M <= 4) return launch_skinny_m<4, EPI>(p, s);
+  if (p.M <= 8) return launch_skinny_m<8, EPI>(p, s);
+  return launch_skinny_m<16, EPI>(p, s);
 }
 
 }  // namespace
@@ -388,7 +434,26 @@ int vt_gemm_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, 
   }
   VT_REQUIRE((K % 64) == 0, "vt_gemm(tile): K=%d must be a multiple of 64", K);
   if (epi == VT_EPI_SWIGLU_BF16) VT_REQUIRE((N % 32) == 0, "vt_gemm(swiglu): N must be a multiple of 32");
-  if (cfg == VT_GEMM_CFG_AUTO || cfg == VT_GEMM_CFG_SKINNY) cfg = vt_gemm_pick_cfg(M, N, K);
+  if (cfg == VT_GEMM_CFG_AUTO || cfg == VT_GEMM_CFG_SKINNY) {
+    cfg = vt_gemm_pick_cfg(M, N, K);
+    // Wave quantisation: when the 256x256 grid would leave most of its last round of CUs idle (e.g. M=5120, N=4096:
+    // 320 tiles = 1.25 rounds), run the rows that fill WHOLE rounds on the 8-phase kernel and the remaining rows on the
+    // small-tile kernel (4x more, 4x shorter tiles fill the CUs again). Both launches are plain row ranges of the same GEMM.
+    if (cfg != VT_GEMM_CFG_256x256_P8 && vt_gemm_p8_supported(M, N, K) && K >= 2048 && M > 256) {
+      const int tiles_n = cdiv(N, 256);
+      int g = tiles_n, b = 256;
+      while (b) { const int t = g % b; g = b; b = t; }   // gcd(tiles_n, 256)
+      const long unit = 256L * (256 / g);                 // rows per whole round
+      const long M1 = (M / unit) * unit;
+      if (M1 >= unit && M1 < M) {
+        const size_t esz = (epi == VT_EPI_F32 || epi == VT_EPI_F32_RESID) ? 4 : 2;
+        prof.on = false;  // the two halves are profiled by the recursive calls
+        VT_TRY(vt_gemm_launch(A, lda, W, ldw, C, ldc, bias, (int)M1, N, K, epi, VT_GEMM_CFG_256x256_P8, skinny_scratch, s));
+        return vt_gemm_launch(A + (size_t)M1 * lda, lda, W, ldw, (char*)C + (size_t)M1 * ldc * esz, ldc, bias, M - (int)M1, N, K,
+                              epi, VT_GEMM_CFG_AUTO, skinny_scratch, s);
+      }
+    }
+  }
   if (cfg == VT_GEMM_CFG_256x256_P8) return vt_gemm_p8_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, epi, s);
   if (cfg == VT_GEMM_CFG_256x256_W4) return vt_gemm_w4_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, epi, s);
   switch (epi) {

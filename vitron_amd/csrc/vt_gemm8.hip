@@ -387,10 +387,12 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmP8 p) {
     const int cur = t & 1;                                                                \
     W4_READ(fa1, fb1, cur, 1);                                                            \
     W4_MFMA(fa0, fb0);                                                                    \
+    /* front-load the 16 fragment reads (1 per MFMA), the last 16 MFMAs cover their latency */ \
     _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                      \
-      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                  \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                  \
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                  \
     }                                                                                     \
+    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);                                   \
     __builtin_amdgcn_sched_barrier(0);                                                    \
     VT_VMCNT(0);                                                                          \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                    \
@@ -400,10 +402,11 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmP8 p) {
     if (READ_ON) W4_READ(fa0, fb0, cur ^ 1, 0);                                           \
     W4_MFMA(fa1, fb1);                                                                    \
     _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                      \
-      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                  \
-      if (STAGE_ON) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);                    \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                  \
       if (READ_ON) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                     \
+      if (STAGE_ON) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);                    \
     }                                                                                     \
+    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);                                   \
     __builtin_amdgcn_sched_barrier(0);                                                    \
   } while (0)
 

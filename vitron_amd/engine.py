@@ -420,9 +420,10 @@ def llama_forward(llama: PackedLlama, kv: PagedKVCache, seqs: Sequence[SequenceS
     lr_t = torch.tensor(list(logit_rows), dtype=torch.int32, device=dev) if n_logit else None
     logits = torch.empty((n_logit, llama.V), dtype=torch.float32, device=dev) if n_logit else None
     hidden = torch.empty((rows, llama.H), dtype=torch.float32, device=dev) if return_hidden else None
-    ws = llama.ws.get(lib.vt_llama_workspace_bytes(C.byref(llama.model), rows, n_logit))
+    max_kv = max(d[2] for d in desc)
+    ws = llama.ws.get(lib.vt_llama_workspace_bytes(C.byref(llama.model), rows, n_logit, len(desc), max_kv))
     _lib.check(lib.vt_llama_forward(C.byref(llama.model), C.byref(kv.struct), embeds.data_ptr(), rows, pos_t.data_ptr(),
-                                    desc_t.data_ptr(), len(desc), int(max(q_lens)), int(max_new_tiles), table_t.data_ptr(),
+                                    desc_t.data_ptr(), len(desc), int(max(q_lens)), int(max_new_tiles), int(max_kv), table_t.data_ptr(),
                                     None if lr_t is None else lr_t.data_ptr(), n_logit,
                                     None if logits is None else logits.data_ptr(),
                                     None if hidden is None else hidden.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),

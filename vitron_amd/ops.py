@@ -113,12 +113,14 @@ def flash_attn(q: torch.Tensor, k_tiles: torch.Tensor, vt_tiles: torch.Tensor, t
 
 
 def attn_decode(q: torch.Tensor, k_tiles: torch.Tensor, vt_tiles: torch.Tensor, tile_table: torch.Tensor,
-                seq_desc: torch.Tensor, heads: int, head_dim: int, scale: float) -> torch.Tensor:
+                seq_desc: torch.Tensor, heads: int, head_dim: int, scale: float, max_kv_len: int) -> torch.Tensor:
     lib = _lib.load()
     out = torch.empty((q.shape[0], heads * head_dim), device=q.device, dtype=torch.bfloat16)
-    _lib.check(lib.vt_attn_decode(_p(q), q.stride(0), _p(k_tiles), _p(vt_tiles), _p(tile_table), _p(seq_desc),
-                                  seq_desc.shape[0], _p(out), out.stride(0), heads, head_dim, float(scale), _stream()),
-               "vt_attn_decode")
+    nseq = seq_desc.shape[0]
+    scratch = torch.empty(lib.vt_attn_decode_scratch_bytes(nseq, heads, head_dim, int(max_kv_len)), dtype=torch.uint8, device=q.device)
+    _lib.check(lib.vt_attn_decode(_p(q), q.stride(0), _p(k_tiles), _p(vt_tiles), _p(tile_table), _p(seq_desc), nseq, _p(out),
+                                  out.stride(0), heads, head_dim, float(scale), int(max_kv_len), _p(scratch), scratch.numel(),
+                                  _stream()), "vt_attn_decode")
     return out
 
 
