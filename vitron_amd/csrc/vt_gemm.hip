@@ -228,7 +228,11 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmP p) {
   float* xs = (float*)smem;     // [MROWS][KSLAB]
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int n0 = (blockIdx.x * 4 + wave) * NPW;
+  // plain epilogues: the wave owns columns n0, n0+1. SwiGLU: it owns the (gate, up) pair of output column q -- rows
+  // 32*(q/16) + q%16 and +16 of the block-interleaved weight -- so silu(gate)*up is formed in the same lane.
+  const int q = blockIdx.x * 4 + wave;
+  const int n0 = (EPI == VT_EPI_SWIGLU_BF16) ? ((q >> 4) * 32 + (q & 15)) : q * NPW;
+  constexpr int NSTEP = (EPI == VT_EPI_SWIGLU_BF16) ? 16 : 1;
   float acc[NPW][MROWS];
 #pragma unroll
   for (int j = 0; j < NPW; ++j)
@@ -236,7 +240,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmP p) {
     for (int m = 0; m < MROWS; ++m) acc[j][m] = 0.f;
   const bf16_t* wrow[NPW];
 #pragma unroll
-  for (int j = 0; j < NPW; ++j) wrow[j] = p.W + (size_t)min(n0 + j, p.N - 1) * p.ldw;
+  for (int j = 0; j < NPW; ++j) wrow[j] = p.W + (size_t)min(n0 + j * NSTEP, p.N - 1) * p.ldw;
 
   for (int k0 = 0; k0 < p.K; k0 += KSLAB) {
     const int kw = min(KSLAB, p.K - k0);   // multiple of 8
@@ -290,6 +294,14 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmP p) {
 #pragma unroll
     for (int m = 0; m < MROWS; ++m) acc[j][m] = wave_sum(acc[j][m]);
 
+  if constexpr (EPI == VT_EPI_SWIGLU_BF16) {
+    if (lane == 0 && n0 + 16 < p.N) {
+#pragma unroll
+      for (int m = 0; m < MROWS; ++m)
+        if (m < p.M) ((bf16_t*)p.C)[(size_t)m * p.ldc + q] = f32_to_bf16(silu(acc[0][m]) * acc[1][m]);
+    }
+    return;
+  }
   if (lane == 0) {
 #pragma unroll
     for (int j = 0; j < NPW; ++j) {
@@ -364,7 +376,8 @@ int launch_skinny_m(const GemmP& p, hipStream_t s) {
     VT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     done = true;
   }
-  hipLaunchKernelGGL(kern, dim3(cdiv(p.N, 8)), dim3(256), smem, s, p);
+  const int waves = (EPI == VT_EPI_SWIGLU_BF16) ? p.N / 2 : cdiv(p.N, 2);
+  hipLaunchKernelGGL(kern, dim3(cdiv(waves, 4)), dim3(256), smem, s, p);
   VT_LAUNCH_CHECK();
   return VT_OK;
 }
@@ -416,19 +429,9 @@ int vt_gemm_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, 
       case VT_EPI_BF16_RELU: return launch_skinny<VT_EPI_BF16_RELU>(p, s);
       case VT_EPI_F32_RESID: return launch_skinny<VT_EPI_F32_RESID>(p, s);
       case VT_EPI_F32: return launch_skinny<VT_EPI_F32>(p, s);
-      case VT_EPI_SWIGLU_BF16: {
-        VT_REQUIRE(skinny_scratch, "vt_gemm(skinny, swiglu): needs an fp32 scratch of M*N floats");
+      case VT_EPI_SWIGLU_BF16:
         VT_REQUIRE((N % 32) == 0, "vt_gemm(swiglu): N must be a multiple of 32");
-        GemmP q = p;
-        q.C = skinny_scratch;
-        q.ldc = N;
-        VT_TRY(launch_skinny<VT_EPI_F32>(q, s));
-        const int total = M * (N / 2);
-        hipLaunchKernelGGL(swiglu_pair_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s,
-                           (const float*)skinny_scratch, (bf16_t*)C, M, N, ldc);
-        VT_LAUNCH_CHECK();
-        return VT_OK;
-      }
+        return launch_skinny<VT_EPI_SWIGLU_BF16>(p, s);
       default: vt_set_error("vt_gemm: unknown epilogue %d", epi); return VT_ERR_ARG;
     }
   }

@@ -105,6 +105,41 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
   }
 }
 
+// few rows (decode steps): one 256-thread block per row so the row's 16 KiB are fetched by 4 waves at once
+__global__ __launch_bounds__(256) void rmsnorm_row_block_kernel(const float* __restrict__ x, const int* __restrict__ idx,
+                                                                const float* __restrict__ w, bf16_t* __restrict__ y,
+                                                                int D, float eps) {
+  __shared__ float red[4];
+  const int row = blockIdx.x;
+  const float* xr = x + (size_t)(idx ? idx[row] : row) * D;
+  f32x4 v[4];
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = (threadIdx.x + i * 256) * 4;
+    if (c < D) {
+      v[i] = *(const f32x4*)(xr + c);
+      sq += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+    }
+  }
+  sq = wave_sum(sq);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sq;
+  __syncthreads();
+  const float rstd = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)D + eps);
+  bf16_t* yr = y + (size_t)row * D;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = (threadIdx.x + i * 256) * 4;
+    if (c < D) {
+      const f32x4 g = *(const f32x4*)(w + c);
+      u32x2 o;
+      o.x = pack_bf16x2(v[i][0] * rstd * g[0], v[i][1] * rstd * g[1]);
+      o.y = pack_bf16x2(v[i][2] * rstd * g[2], v[i][3] * rstd * g[3]);
+      *(u32x2*)(yr + c) = o;
+    }
+  }
+}
+
 __global__ void gather_f32_to_bf16_kernel(const float* __restrict__ in, const int* __restrict__ idx,
                                           bf16_t* __restrict__ out, int rows, int D) {
   const int per_row = D >> 2;
@@ -173,6 +208,11 @@ int vt_rmsnorm_launch(const float* x, const int* idx, const float* w, bf16_t* y,
                       hipStream_t s) {
   VT_REQUIRE(x && w && y, "vt_rmsnorm: null pointer");
   VT_REQUIRE(rows > 0 && D > 0 && D % 4 == 0 && D <= 4096, "vt_rmsnorm: D=%d must be a multiple of 4, <= 4096", D);
+  if (rows <= 64) {
+    hipLaunchKernelGGL(rmsnorm_row_block_kernel, dim3(rows), dim3(256), 0, s, x, idx, w, y, D, eps);
+    VT_LAUNCH_CHECK();
+    return VT_OK;
+  }
   dim3 grid(cdiv(rows, 4));
   VT_NORM_DISPATCH(rmsnorm_kernel, D, x, idx, w, y, rows, D, eps);
   VT_LAUNCH_CHECK();
