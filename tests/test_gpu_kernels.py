@@ -229,3 +229,21 @@ def test_im2col_splice_argmax(dev):
     lg = randn((5, 32000), 55)
     lg[2, 777] = lg[2, 31999] = 50.0  # tie -> lowest index
     assert ops.argmax(lg.to(dev)).cpu().tolist() == lg.argmax(-1).tolist() and ops.argmax(lg.to(dev))[2].item() == 777
+
+
+def test_profile_api_counts_split_gemm(dev):
+    """vt_profile_begin/end bracket every launch with events on the kernel's stream; the auto-split GEMM (whole rounds on the
+    8-phase kernel + remainder on the small-tile kernel) must show up as two timed launches with the full 2*M*N*K work."""
+    from vitron_amd import _lib, ops
+    M, N, K = 4352, 4096, 2048   # 17 x 16 tiles of 256: one whole round (4096 rows) + 256 remainder rows
+    a, w = randn((M, K), 61), randn((N, K), 62, 0.05)
+    ad, wd = a.to(dev).bfloat16(), w.to(dev).bfloat16()
+    _lib.profile_begin()
+    out = ops.gemm(ad, wd, None, ops.EPI_BF16)
+    ops.gemm(ad[:4], wd, None, ops.EPI_BF16)          # skinny class
+    prof = _lib.profile_end()
+    assert prof["gemm_tile"]["launches"] == 2 and prof["gemm_skinny"]["launches"] == 1
+    assert prof["gemm_tile"]["work"] == 2.0 * M * N * K and prof["gemm_tile"]["ms"] > 0
+    ref = bf16r((a.double() @ w.double().t()).float())
+    assert rel_l2(out.float(), ref) <= TOL
+    assert _lib.profile_end()["gemm_tile"]["launches"] == 0   # idempotent when nothing was recorded

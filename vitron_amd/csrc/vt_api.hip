@@ -106,9 +106,10 @@ int vt_profile_end(int* launches, double* total_ms, double* total_work) {
   }
   for (auto& r : g_prof_recs) {
     float ms = 0.f;
-    VT_HIP(hipEventSynchronize(r.b));
-    VT_HIP(hipEventElapsedTime(&ms, r.a, r.b));
-    if (r.cls >= 0 && r.cls < VT_PROF_CLASSES) {
+    // a record whose stop event was never recorded (a launch that bailed out early) is dropped, not an error
+    const bool ok = hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess;
+    if (!ok) (void)hipGetLastError();
+    if (ok && r.cls >= 0 && r.cls < VT_PROF_CLASSES) {
       if (launches) launches[r.cls] += 1;
       if (total_ms) total_ms[r.cls] += ms;
       if (total_work) total_work[r.cls] += r.work;

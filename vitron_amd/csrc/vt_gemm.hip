@@ -416,6 +416,28 @@ int vt_gemm_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, 
   VT_REQUIRE(ldc % 4 == 0, "vt_gemm: ldc must be a multiple of 4");
   GemmP p{A, W, C, bias, M, N, K, lda, ldw, ldc};
   const bool skinny_path = (M <= 16) && (cfg == VT_GEMM_CFG_AUTO || cfg == VT_GEMM_CFG_SKINNY);
+  if (!skinny_path) {
+    VT_REQUIRE((K % 64) == 0, "vt_gemm(tile): K=%d must be a multiple of 64", K);
+  if (cfg == VT_GEMM_CFG_AUTO || cfg == VT_GEMM_CFG_SKINNY) {
+      cfg = vt_gemm_pick_cfg(M, N, K);
+      // Wave quantisation: when the 256x256 grid would leave most of its last round of CUs idle (e.g. M=5120, N=4096:
+      // 320 tiles = 1.25 rounds), run the rows that fill WHOLE rounds on the 8-phase kernel and the remaining rows on the
+      // small-tile kernel (4x more, 4x shorter tiles fill the CUs again). Both launches are plain row ranges of the same GEMM.
+      if (cfg != VT_GEMM_CFG_256x256_P8 && vt_gemm_p8_supported(M, N, K) && K >= 2048 && M > 256) {
+        const int tiles_n = cdiv(N, 256);
+        int g = tiles_n, b = 256;
+        while (b) { const int t = g % b; g = b; b = t; }   // gcd(tiles_n, 256)
+        const long unit = 256L * (256 / g);                 // rows per whole round
+        const long M1 = (M / unit) * unit;
+        if (M1 >= unit && M1 < M) {
+          const size_t esz = (epi == VT_EPI_F32 || epi == VT_EPI_F32_RESID) ? 4 : 2;
+          VT_TRY(vt_gemm_launch(A, lda, W, ldw, C, ldc, bias, (int)M1, N, K, epi, VT_GEMM_CFG_256x256_P8, skinny_scratch, s));
+          return vt_gemm_launch(A + (size_t)M1 * lda, lda, W, ldw, (char*)C + (size_t)M1 * ldc * esz, ldc, bias, M - (int)M1, N, K,
+                                epi, VT_GEMM_CFG_AUTO, skinny_scratch, s);
+        }
+      }
+    }
+  }
   // algorithmic work: 2*M*N*K FLOP for the MFMA tile kernel; weight bytes for the weight-streaming kernel
   VtProfScope prof(skinny_path ? VT_PROF_GEMM_SKINNY : VT_PROF_GEMM_TILE,
                    skinny_path ? 2.0 * (double)N * (double)K : 2.0 * (double)M * (double)N * (double)K, s);
@@ -437,26 +459,6 @@ int vt_gemm_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, 
   }
   VT_REQUIRE((K % 64) == 0, "vt_gemm(tile): K=%d must be a multiple of 64", K);
   if (epi == VT_EPI_SWIGLU_BF16) VT_REQUIRE((N % 32) == 0, "vt_gemm(swiglu): N must be a multiple of 32");
-  if (cfg == VT_GEMM_CFG_AUTO || cfg == VT_GEMM_CFG_SKINNY) {
-    cfg = vt_gemm_pick_cfg(M, N, K);
-    // Wave quantisation: when the 256x256 grid would leave most of its last round of CUs idle (e.g. M=5120, N=4096:
-    // 320 tiles = 1.25 rounds), run the rows that fill WHOLE rounds on the 8-phase kernel and the remaining rows on the
-    // small-tile kernel (4x more, 4x shorter tiles fill the CUs again). Both launches are plain row ranges of the same GEMM.
-    if (cfg != VT_GEMM_CFG_256x256_P8 && vt_gemm_p8_supported(M, N, K) && K >= 2048 && M > 256) {
-      const int tiles_n = cdiv(N, 256);
-      int g = tiles_n, b = 256;
-      while (b) { const int t = g % b; g = b; b = t; }   // gcd(tiles_n, 256)
-      const long unit = 256L * (256 / g);                 // rows per whole round
-      const long M1 = (M / unit) * unit;
-      if (M1 >= unit && M1 < M) {
-        const size_t esz = (epi == VT_EPI_F32 || epi == VT_EPI_F32_RESID) ? 4 : 2;
-        prof.on = false;  // the two halves are profiled by the recursive calls
-        VT_TRY(vt_gemm_launch(A, lda, W, ldw, C, ldc, bias, (int)M1, N, K, epi, VT_GEMM_CFG_256x256_P8, skinny_scratch, s));
-        return vt_gemm_launch(A + (size_t)M1 * lda, lda, W, ldw, (char*)C + (size_t)M1 * ldc * esz, ldc, bias, M - (int)M1, N, K,
-                              epi, VT_GEMM_CFG_AUTO, skinny_scratch, s);
-      }
-    }
-  }
   if (cfg == VT_GEMM_CFG_256x256_P8) return vt_gemm_p8_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, epi, s);
   if (cfg == VT_GEMM_CFG_256x256_W4) return vt_gemm_w4_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, epi, s);
   switch (epi) {
