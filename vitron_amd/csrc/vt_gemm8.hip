@@ -55,7 +55,8 @@ __device__ __forceinline__ constexpr int slot_offset(int slot) {     // LDS plac
   return (slot == SLOT_A0 ? 0 : slot == SLOT_A1 ? 1 : slot == SLOT_B0 ? 2 : 3) * HALF_BYTES;
 }
 
-template <int EPI>
+// ABL (timing ablations, results are garbage): bit0 = no fragment reads, bit1 = no LDS-DMA in the loop, bit2 = no MFMA
+template <int EPI, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmP8 p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -90,6 +91,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmP8 p) {
 
 #define STAGE(BUF, SLOT)                                                                        \
   do {                                                                                          \
+    if ((ABL & 2) && in_loop) break;                                                            \
     char* _d = smem + (BUF) * BUF_BYTES + slot_offset(SLOT) + dma_off;                          \
     glds16(src[SLOT][0], _d);                                                                   \
     glds16(src[SLOT][1], _d + 1024);                                                            \
@@ -118,6 +120,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmP8 p) {
 
 #define READ_A(BUF, SLOT)                                                                      \
   do {                                                                                         \
+    if ((ABL & 1) && in_loop) break;                                                           \
     const char* _s = smem + (BUF) * BUF_BYTES + slot_offset(SLOT) + a_row_off;                 \
     _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) {                                         \
       af[mi][0] = *(const bf16x8*)(_s + mi * 2048 + fo0);                                      \
@@ -126,6 +129,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmP8 p) {
   } while (0)
 #define READ_B(BUF, SLOT, DST)                                                                 \
   do {                                                                                         \
+    if ((ABL & 1) && in_loop) break;                                                           \
     const char* _s = smem + (BUF) * BUF_BYTES + slot_offset(SLOT) + b_row_off;                 \
     _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) {                                         \
       DST[ni][0] = *(const bf16x8*)(_s + ni * 2048 + fo0);                                     \
@@ -134,6 +138,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmP8 p) {
   } while (0)
 #define MFMA_Q(QM, QN, BF)                                                                     \
   do {                                                                                         \
+    if (ABL & 4) break;                                                                        \
     __builtin_amdgcn_s_setprio(1);                                                             \
     _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                           \
       _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                         \
@@ -162,6 +167,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmP8 p) {
     SECTION_SPLIT();                                              \
   } while (0)
 
+  bool in_loop = false;
   const int nt = p.K >> 6;                 // K steps (even, >= 4: checked by the launcher)
   const int total_phases = 4 * nt;
   const int drain_from = total_phases - 6;  // phases g >= this did not all issue a stage in (g-2..g): drain instead
@@ -178,6 +184,9 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmP8 p) {
   if (wr == 1) __builtin_amdgcn_s_barrier();   // stagger: the second wave row runs one barrier behind
   __builtin_amdgcn_sched_barrier(0);
 
+  // ablation builds need the fragments initialised once from valid LDS
+  if (ABL & 1) { READ_B(0, SLOT_B0, b0f); READ_B(0, SLOT_B1, b1f); READ_A(0, SLOT_A0); }
+  in_loop = true;
   for (int it = 0; it < nt / 2; ++it) {
     const int g0 = it * 8;                     // global phase of this iteration's first phase
     const int u = it * 2;                      // K step in buffer 0
@@ -290,7 +299,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmP8 p) {
 //                 vmcnt(0) (K step t+1 landed, issued one K step ago) ; lgkmcnt(0) ; barrier
 //                 second half: DMA K step t+2 -> buffer t&1 (dead)  ; read F0 <- (t+1, k 0..31) | MFMA on F1
 // ------------------------------------------------------------------------------------------------------------------
-template <int EPI>
+template <int EPI, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmP8 p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int TILE_BYTES = 256 * 64 * 2;   // 32 KiB per operand per K step
@@ -327,6 +336,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmP8 p) {
   const int dma_off = wave * 8192;
 #define W4_STAGE(BUF)                                                        \
   do {                                                                       \
+    if ((ABL & 2) && w4_in_loop) break;                                      \
     char* _d = smem + (BUF) * STAGE + dma_off;                               \
     _Pragma("unroll") for (int i = 0; i < 8; ++i) {                          \
       glds16(a_ptr + a_src[i], _d + i * 1024);                               \
@@ -357,6 +367,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmP8 p) {
 
 #define W4_READ(FA, FB, BUF, HALF)                                                         \
   do {                                                                                     \
+    if ((ABL & 1) && w4_in_loop) break;                                                    \
     const char* _s = smem + (BUF) * STAGE;                                                 \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                          \
       _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                   \
@@ -366,12 +377,14 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmP8 p) {
   } while (0)
 #define W4_MFMA(FA, FB)                                                                    \
   do {                                                                                     \
+    if (ABL & 4) break;                                                                    \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                       \
       _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                     \
         _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                   \
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FB[ni][ks], FA[mi][ks], acc[mi][ni], 0, 0, 0); \
   } while (0)
 
+  bool w4_in_loop = false;
   const int nt = p.K >> 6;
   W4_STAGE(0);
   if (nt > 1) W4_STAGE(1);
@@ -410,6 +423,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmP8 p) {
     __builtin_amdgcn_sched_barrier(0);                                                    \
   } while (0)
 
+  if (ABL & 1) W4_READ(fa1, fb1, 0, 1);
+  w4_in_loop = true;
   int t = 0;
   for (; t + 2 < nt; ++t) W4_ITER(true, true);
   if (t + 1 < nt) {
@@ -471,10 +486,10 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmP8 p) {
   }
 }
 
-template <int EPI>
+template <int EPI, int ABL = 0>
 int launch_w4(const GemmP8& p, hipStream_t s) {
   constexpr int smem = 2 * 2 * 256 * 64 * 2;  // 128 KiB
-  auto kern = gemm_w4_kernel<EPI>;
+  auto kern = gemm_w4_kernel<EPI, ABL>;
   static bool done = false;
   if (!done) {
     VT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -486,10 +501,10 @@ int launch_w4(const GemmP8& p, hipStream_t s) {
   return VT_OK;
 }
 
-template <int EPI>
+template <int EPI, int ABL = 0>
 int launch_p8(const GemmP8& p, hipStream_t s) {
   constexpr int smem = 2 * BUF_BYTES;  // 128 KiB
-  auto kern = gemm_p8_kernel<EPI>;
+  auto kern = gemm_p8_kernel<EPI, ABL>;
   static bool done = false;
   if (!done) {
     VT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -510,6 +525,17 @@ int vt_gemm_w4_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* 
   VT_REQUIRE((K % 64) == 0 && N % 32 == 0, "vt_gemm(w4): needs K %% 64 == 0 and N %% 32 == 0 (K=%d N=%d)", K, N);
   VT_REQUIRE((size_t)M * lda * 2 < (1ull << 32) && (size_t)N * ldw * 2 < (1ull << 32), "vt_gemm(w4): operands must be < 4 GiB");
   GemmP8 p{A, W, C, bias, M, N, K, lda, ldw, ldc};
+  if (epi >= 0x100) {  // timing ablations
+    switch (epi >> 8) {
+      case 1: return launch_w4<VT_EPI_BF16, 1>(p, s);
+      case 2: return launch_w4<VT_EPI_BF16, 2>(p, s);
+      case 3: return launch_w4<VT_EPI_BF16, 3>(p, s);
+      case 4: return launch_w4<VT_EPI_BF16, 4>(p, s);
+      case 5: return launch_w4<VT_EPI_BF16, 5>(p, s);
+      case 6: return launch_w4<VT_EPI_BF16, 6>(p, s);
+      default: return launch_w4<VT_EPI_BF16, 7>(p, s);
+    }
+  }
   switch (epi) {
     case VT_EPI_BF16: return launch_w4<VT_EPI_BF16>(p, s);
     case VT_EPI_BF16_GELU: return launch_w4<VT_EPI_BF16_GELU>(p, s);
@@ -526,6 +552,17 @@ int vt_gemm_p8_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* 
                       int N, int K, int epi, hipStream_t s) {
   VT_REQUIRE(vt_gemm_p8_supported(M, N, K), "vt_gemm(p8): needs K %% 128 == 0, K >= 256, N %% 32 == 0 (K=%d N=%d)", K, N);
   GemmP8 p{A, W, C, bias, M, N, K, lda, ldw, ldc};
+  if (epi >= 0x100) {  // timing ablations (tools/gemm_ablate.py); not reachable through the public enums
+    switch (epi >> 8) {
+      case 1: return launch_p8<VT_EPI_BF16, 1>(p, s);
+      case 2: return launch_p8<VT_EPI_BF16, 2>(p, s);
+      case 3: return launch_p8<VT_EPI_BF16, 3>(p, s);
+      case 4: return launch_p8<VT_EPI_BF16, 4>(p, s);
+      case 5: return launch_p8<VT_EPI_BF16, 5>(p, s);
+      case 6: return launch_p8<VT_EPI_BF16, 6>(p, s);
+      default: return launch_p8<VT_EPI_BF16, 7>(p, s);
+    }
+  }
   switch (epi) {
     case VT_EPI_BF16: return launch_p8<VT_EPI_BF16>(p, s);
     case VT_EPI_BF16_GELU: return launch_p8<VT_EPI_BF16_GELU>(p, s);

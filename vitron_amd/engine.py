@@ -406,14 +406,19 @@ def llama_forward(llama: PackedLlama, kv: PagedKVCache, seqs: Sequence[SequenceS
             s.pages += kv.alloc(need - len(s.pages))
         desc.append([row0, q, kv_len, len(table)])
         table += s.pages[:need]
-        pos_host += list(range(s.length, kv_len))
+        pos_host.append((s.length, kv_len))
         max_new_tiles = max(max_new_tiles, (kv_len - 1) // PAGE_TOKENS - s.length // PAGE_TOKENS + 1)
         row0 += q
-    if max(pos_host) >= llama.rope_len and positions is None:
-        raise _lib.VitronHipError(f"llama_forward: position {max(pos_host)} beyond rope table ({llama.rope_len})")
+    max_pos = max(e for _, e in pos_host) - 1
+    if max_pos >= llama.rope_len and positions is None:
+        raise _lib.VitronHipError(f"llama_forward: position {max_pos} beyond rope table ({llama.rope_len})")
     desc_t = torch.tensor(desc, dtype=torch.int32, device=dev)
     table_t = torch.tensor(table, dtype=torch.int32, device=dev)
-    pos_t = torch.tensor(pos_host, dtype=torch.int32, device=dev) if positions is None else positions.to(device=dev, dtype=torch.int32).contiguous()
+    if positions is None:
+        import numpy as np
+        pos_t = torch.from_numpy(np.concatenate([np.arange(a, e, dtype=np.int32) for a, e in pos_host])).to(dev, non_blocking=True)
+    else:
+        pos_t = positions.to(device=dev, dtype=torch.int32).contiguous()
     if logit_rows is None:
         logit_rows = [d[0] + d[1] - 1 for d in desc]
     n_logit = len(logit_rows)

@@ -9,6 +9,7 @@ from __future__ import annotations
 
 from typing import List, Optional, Sequence, Tuple
 
+import numpy as np
 import torch
 
 from .. import ops
@@ -17,66 +18,82 @@ from ..constants import IGNORE_INDEX, IMAGE_TOKEN_INDEX, OBJS_TOKEN_INDEX
 KIND_TOKEN, KIND_VISUAL, KIND_REGION, KIND_ZERO = 0, 1, 2, 3
 
 
-def build_splice_plan(input_ids: Sequence[Sequence[int]], attention_mask: Optional[Sequence[Sequence[int]]],
-                      feature_blocks: Sequence[Tuple[int, int]], region_rows: Optional[Sequence[int]],
-                      max_length: Optional[int] = None, padding_side: str = "right"):
-    """Integer plan of prepare_inputs_labels_for_multimodal (reference llava_arch.py:300-398 / :474-558).
+def build_splice_plan_np(input_ids, attention_mask, feature_blocks: Sequence[Tuple[int, int]],
+                         region_rows: Optional[Sequence[int]], max_length: Optional[int] = None,
+                         padding_side: str = "right"):
+    """Integer plan of prepare_inputs_labels_for_multimodal (reference llava_arch.py:300-398 / :474-558), numpy form.
 
     input_ids       [B][L] ints with -200 / -300 sentinels; attention_mask [B][L] (None = all ones)
     feature_blocks  one (first_row, n_rows) per flat visual feature (one per image, T per video) in list order
     region_rows     per flat feature: row of its region feature (or -1), None when the caller passed no regions
-    Returns (plan [B][S][2] int, mask [B][S] int, position_ids [B][S] int, lengths [B]).
+    Returns (plan int32 [B,S,2] = (kind, index), mask int32 [B,S], position_ids int64 [B,S], lengths list[B]).
     Quirks kept from the reference: a sample without <image> still consumes one feature slot (:317-324);
     <objs> takes the region of the most recently consumed feature (:350-351); truncate before padding (:363-366).
     """
+    ids_all = np.asarray(input_ids, dtype=np.int64)
+    am_all = None if attention_mask is None else np.asarray(attention_mask).astype(bool)
     use_regions = region_rows is not None
-    samples: List[List[Tuple[int, int]]] = []
+    samples = []
     cur = 0
-    for b, row in enumerate(input_ids):
-        ids = [int(t) for j, t in enumerate(row) if attention_mask is None or int(attention_mask[b][j])]
-        plan: List[Tuple[int, int]] = []
-        if not any(t == IMAGE_TOKEN_INDEX for t in ids):
-            for t in ids:
-                if t < 0:
-                    raise ValueError(f"sample {b}: sentinel {t} in a sample without <image> (the reference would index embed_tokens with it)")
-                plan.append((KIND_TOKEN, t))
-            samples.append(plan)
+    for b in range(ids_all.shape[0]):
+        ids = ids_all[b] if am_all is None else ids_all[b][am_all[b]]
+        specials = np.nonzero(ids < 0)[0]
+        if not np.any(ids == IMAGE_TOKEN_INDEX):
+            if specials.size:
+                raise ValueError(f"sample {b}: sentinel {int(ids[specials[0]])} in a sample without <image> "
+                                 "(the reference would index embed_tokens with it)")
+            samples.append(np.stack([np.zeros(ids.shape[0], np.int64), ids], 1))
             cur += 1
             continue
-        for t in ids:
+        parts = []
+        prev = 0
+        for sp in specials.tolist():
+            if sp > prev:
+                seg = ids[prev:sp]
+                parts.append(np.stack([np.zeros(seg.shape[0], np.int64), seg], 1))
+            t = int(ids[sp])
             if t == IMAGE_TOKEN_INDEX:
                 if cur >= len(feature_blocks):
                     raise ValueError(f"sample {b}: more <image> sentinels than visual features ({len(feature_blocks)})")
                 first, n = feature_blocks[cur]
-                plan.extend((KIND_VISUAL, first + r) for r in range(n))
+                parts.append(np.stack([np.full(n, KIND_VISUAL, np.int64), np.arange(first, first + n, dtype=np.int64)], 1))
                 cur += 1
             elif t == OBJS_TOKEN_INDEX and use_regions:
                 rr = region_rows[cur - 1] if cur >= 1 else -1
                 if rr < 0:
                     raise ValueError(f"sample {b}: <objs> follows a video frame or no image (no region feature to bind)")
-                plan.append((KIND_REGION, rr))
-            elif t < 0:
-                raise ValueError(f"sample {b}: sentinel {t} but no regions were passed")
+                parts.append(np.array([[KIND_REGION, rr]], dtype=np.int64))
             else:
-                plan.append((KIND_TOKEN, t))
-        samples.append(plan)
+                raise ValueError(f"sample {b}: sentinel {t} but no regions were passed")
+            prev = sp + 1
+        if prev < ids.shape[0]:
+            seg = ids[prev:]
+            parts.append(np.stack([np.zeros(seg.shape[0], np.int64), seg], 1))
+        samples.append(np.concatenate(parts, 0) if parts else np.zeros((0, 2), np.int64))
     if max_length is not None:
         samples = [p[:max_length] for p in samples]
-    lengths = [len(p) for p in samples]
+    lengths = [int(p.shape[0]) for p in samples]
     S = max(lengths) if lengths else 0
-    plan_out, mask, pos = [], [], []
-    for p in samples:
-        n = len(p)
-        padn = S - n
-        if padding_side == "left":
-            plan_out.append([(KIND_ZERO, 0)] * padn + p)
-            mask.append([0] * padn + [1] * n)
-            pos.append([0] * padn + list(range(n)))
-        else:
-            plan_out.append(p + [(KIND_ZERO, 0)] * padn)
-            mask.append([1] * n + [0] * padn)
-            pos.append(list(range(n)) + [0] * padn)
-    return plan_out, mask, pos, lengths
+    B = len(samples)
+    plan = np.zeros((B, S, 2), dtype=np.int32)
+    plan[:, :, 0] = KIND_ZERO
+    mask = np.zeros((B, S), dtype=np.int32)
+    pos = np.zeros((B, S), dtype=np.int64)
+    for b, p in enumerate(samples):
+        n = p.shape[0]
+        if n == 0:
+            continue
+        sl = slice(S - n, S) if padding_side == "left" else slice(0, n)
+        plan[b, sl] = p
+        mask[b, sl] = 1
+        pos[b, sl] = np.arange(n)
+    return plan, mask, pos, lengths
+
+
+def build_splice_plan(input_ids, attention_mask, feature_blocks, region_rows, max_length=None, padding_side="right"):
+    """List-of-tuples view of build_splice_plan_np: (plan [B][S] of (kind, index), mask [B][S], position_ids [B][S], lengths)."""
+    plan, mask, pos, lengths = build_splice_plan_np(input_ids, attention_mask, feature_blocks, region_rows, max_length, padding_side)
+    return [[(int(k), int(i)) for k, i in row] for row in plan.tolist()], mask.tolist(), pos.tolist(), lengths
 
 
 class LlavaMetaModel:
@@ -152,47 +169,61 @@ class LlavaMetaForCausalLM:
         image_idx = [i for i, im in enumerate(images) if im.ndim == 3]
         video_idx = [i for i, im in enumerate(images) if im.ndim == 4]
         dev = self.device
-        vis_chunks: List[torch.Tensor] = []
+        if image_idx and image_tower is None:
+            raise ValueError("images were passed but the model has no image tower")
+        if video_idx and video_tower is None:
+            raise ValueError("videos were passed but the model has no video tower")
+
+        # ---- host side first: the integer plan only needs token ids and feature-block SIZES (known from the tower
+        # configs), so it is built and uploaded before any GPU work is queued and never stalls the device ----------------
         blocks: List[Optional[List[Tuple[int, int]]]] = [None] * len(images)
         reg_rows: List[Optional[List[int]]] = [None] * len(images)
         nvis = 0
-        region_buf = None
         if image_idx:
-            if image_tower is None:
-                raise ValueError("images were passed but the model has no image tower")
-            batch = torch.stack([images[i] for i in image_idx]).to(dev)
-            rb = [regions[i] for i in image_idx] if use_regions else None         # :241
-            feats, region_buf = self.encode_images(batch, rb)
-            P = feats.shape[1]
-            vis_chunks.append(feats.reshape(-1, feats.shape[-1]))
+            P = image_tower.num_patches
             for j, i in enumerate(image_idx):
                 blocks[i] = [(nvis + j * P, P)]
                 reg_rows[i] = [j]
-            nvis += feats.shape[0] * P
-            region_buf = region_buf.reshape(-1, region_buf.shape[-1]) if use_regions else None
+            nvis += len(image_idx) * P
         if video_idx:
-            if video_tower is None:
-                raise ValueError("videos were passed but the model has no video tower")
-            batch = torch.stack([images[i] for i in video_idx]).to(dev)
-            feats = self.encode_videos(batch)                                     # [b, T, P, H]
-            b, T, P, H = feats.shape
-            vis_chunks.append(feats.reshape(-1, H))
+            P = video_tower.num_patches
             for j, i in enumerate(video_idx):
+                T = images[i].shape[1]
                 blocks[i] = [(nvis + (j * T + t) * P, P) for t in range(T)]       # each frame = one "image" (:255-258)
                 reg_rows[i] = [-1] * T
-            nvis += b * T * P
+                nvis_end = nvis + (j + 1) * T * P
+            nvis = nvis_end
         flat_blocks = [blk for bl in blocks for blk in bl]
         flat_regs = [r for rl in reg_rows for r in rl] if use_regions else None
-        vis = torch.cat(vis_chunks, 0) if len(vis_chunks) > 1 else vis_chunks[0]
-
-        ids_host = input_ids.tolist()
-        am_host = None if attention_mask is None else attention_mask.tolist()
-        plan, mask, pos, lengths = build_splice_plan(
+        ids_host = input_ids.cpu().numpy()
+        am_host = None if attention_mask is None else attention_mask.cpu().numpy()
+        plan, mask, pos, lengths = build_splice_plan_np(
             ids_host, am_host, flat_blocks, flat_regs, getattr(self.config, "tokenizer_model_max_length", None),
             getattr(self.config, "tokenizer_padding_side", "right"))
-        B, S = len(plan), len(plan[0])
-        plan_t = torch.tensor(plan, dtype=torch.int32, device=dev).reshape(B * S, 2)
+        B, S = plan.shape[0], plan.shape[1]
+        plan_t = torch.from_numpy(plan.reshape(B * S, 2)).to(dev, non_blocking=True)
+
+        # ---- device side: towers -> region extractor -> projector -> gather/splice ------------------------------------------
+        vis_chunks: List[torch.Tensor] = []
+        region_buf = None
+        if image_idx:
+            batch = torch.stack([images[i] for i in image_idx]).to(dev)
+            rb = [regions[i] for i in image_idx] if use_regions else None         # :241
+            feats, region_buf = self.encode_images(batch, rb)
+            vis_chunks.append(feats.reshape(-1, feats.shape[-1]))
+            region_buf = region_buf.reshape(-1, region_buf.shape[-1]) if use_regions else None
+        if video_idx:
+            batch = torch.stack([images[i] for i in video_idx]).to(dev)
+            feats = self.encode_videos(batch)                                     # [b, T, P, H]
+            vis_chunks.append(feats.reshape(-1, feats.shape[-1]))
+        vis = torch.cat(vis_chunks, 0) if len(vis_chunks) > 1 else vis_chunks[0]
+        if vis.shape[0] != nvis:
+            raise RuntimeError(f"visual token count mismatch: planned {nvis}, encoded {vis.shape[0]}")
         embeds = ops.embed_splice(self.get_model().embed_tokens_weight, vis.contiguous(), region_buf, plan_t).view(B, S, -1)
+        ids_host = ids_host.tolist()
+        am_host = None if am_host is None else am_host.tolist()
+        mask, pos = mask.tolist(), pos.tolist()
+        plan = [[(int(k), int(i)) for k, i in row] for row in plan.tolist()] if labels is not None else None
 
         new_labels = None
         if labels is not None:  # labels follow the same layout: text keeps its label, visual rows are IGNORE_INDEX
