@@ -113,6 +113,11 @@ int vt_embed_splice(const uint16_t* tok_table, const uint16_t* vis, const uint16
 
 /* greedy next token: first index of the row maximum (GenerationMixin greedy search). */
 int vt_argmax(const float* logits, int rows, int V, int ldl, int* out_ids, void* stream);
+/* one sampled token per row: softmax(logits / temperature), transformers' TopPLogitsWarper keep-set (top_p >= 1 keeps all),
+ * inverse-CDF draw with a counter-based uniform of (seed, step, row). kept_count (optional) = size of the keep-set per row.
+ * Replaces GenerationMixin.sample's temperature / top-p / multinomial step (reference app.py:562-571, do_sample=True). */
+int vt_sample_top_p(const float* logits, int rows, int V, int ldl, float temperature, float top_p, uint64_t seed,
+                    uint64_t step, int* out_ids, int* kept_count, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * mm_projector: Linear(Din,Dh) -> GELU(erf) -> Linear(Dh,Dout)   ('mlp2x_gelu';  w2 == NULL -> 'linear')

@@ -1,0 +1,122 @@
+"""The weight-loader side of the boundary: load_pretrained_model on a checkpoint laid out like
+the reference's (builder.py:53-86,149-163): base LLaMA shards, non_lora_trainables.bin, a peft LoRA adapter, and
+LanguageBind tower directories (the image tower peft-wrapped, modeling_image.py:772-793). Synthetic weights, tiny widths."""
+import json
+import os
+
+import pytest
+import torch
+
+from tests.golden import cases
+from vitron_amd import synth
+
+
+def _write_checkpoint(tmp, with_lora=True):
+    from safetensors.torch import save_file
+    L = cases.LLM
+    base = os.path.join(tmp, "vicuna-base")
+    ckpt = os.path.join(tmp, "vitron-lora")
+    img = os.path.join(tmp, "LanguageBind_Image")
+    vid = os.path.join(tmp, "LanguageBind_Video_merge")
+    for d in (base, ckpt, img, vid):
+        os.makedirs(d)
+    llm = synth.llama_state(L, synth.make_generator(cases.SEED_LLM), **cases.LLM_INIT)
+    keys = sorted(llm)
+    save_file({k: llm[k].contiguous() for k in keys[: len(keys) // 2]}, os.path.join(base, "model-00001-of-00002.safetensors"))
+    save_file({k: llm[k].contiguous() for k in keys[len(keys) // 2:]}, os.path.join(base, "model-00002-of-00002.safetensors"))
+    cfg = dict(L, mm_hidden_size=cases.MM_HIDDEN, mm_image_tower=img, mm_video_tower=vid, mm_projector_type="mlp2x_gelu",
+               mm_vision_select_layer=-2)
+    json.dump(cfg, open(os.path.join(ckpt, "config.json"), "w"))
+    proj = synth.projector_state(cases.MM_HIDDEN, L["hidden_size"], synth.make_generator(cases.SEED_PROJ), **cases.MLP_INIT)
+    reg = synth.region_state(cases.MM_HIDDEN, L["hidden_size"], synth.make_generator(cases.SEED_REGION), **cases.MLP_INIT)
+    extra = {"base_model.model.model.mm_projector." + k: v for k, v in proj.items()}
+    extra.update({"base_model.model.model.region_extractor." + k: v for k, v in reg.items()})
+    torch.save(extra, os.path.join(ckpt, "non_lora_trainables.bin"))
+    g = synth.make_generator(99)
+    adapter, merged = {}, {k: v.float().clone() for k, v in llm.items()}
+    r, alpha = 4, 8
+    for l in range(L["num_hidden_layers"]):
+        for proj_name in ("self_attn.q_proj", "mlp.down_proj"):
+            name = f"model.layers.{l}.{proj_name}"
+            o, i = llm[name + ".weight"].shape
+            a = (torch.randn((r, i), generator=g) * 0.05).bfloat16()
+            b = (torch.randn((o, r), generator=g) * 0.05).bfloat16()
+            adapter[f"base_model.model.{name}.lora_A.weight"] = a
+            adapter[f"base_model.model.{name}.lora_B.weight"] = b
+            merged[name + ".weight"] = merged[name + ".weight"] + (alpha / r) * (b.float() @ a.float())
+    torch.save(adapter, os.path.join(ckpt, "adapter_model.bin"))
+    json.dump({"r": r, "lora_alpha": alpha}, open(os.path.join(ckpt, "adapter_config.json"), "w"))
+    # towers: video plain, image peft-wrapped (base_layer + lora_A/B on q_proj of layer 0)
+    vsd = synth.vit_state(cases.VIT_VIDEO, synth.make_generator(cases.SEED_VIT), **cases.VIT_INIT)
+    torch.save({"vision_model." + k: v for k, v in vsd.items()}, os.path.join(vid, "pytorch_model.bin"))
+    json.dump({"vision_config": dict(cases.VIT_VIDEO)}, open(os.path.join(vid, "config.json"), "w"))
+    isd = synth.vit_state(cases.VIT_IMAGE, synth.make_generator(cases.SEED_VIT), **cases.VIT_INIT)
+    iref = {k: v.float().clone() for k, v in isd.items()}
+    disk = {}
+    D = cases.VIT_IMAGE["hidden_size"]
+    for k, v in isd.items():
+        if k.startswith("encoder.") and k.endswith("q_proj.weight"):
+            stem = k[: -len(".weight")].replace("encoder.", "encoder.base_model.model.", 1)
+            a = (torch.randn((2, D), generator=g) * 0.05).bfloat16()
+            b = (torch.randn((D, 2), generator=g) * 0.05).bfloat16()
+            disk["vision_model." + stem + ".base_layer.weight"] = v
+            disk["vision_model." + stem + ".lora_A.default.weight"] = a
+            disk["vision_model." + stem + ".lora_B.default.weight"] = b
+            iref[k] = iref[k] + (16.0 / 2) * (b.float() @ a.float())
+        elif k.startswith("encoder.") and k.endswith("q_proj.bias"):
+            stem = k[: -len(".bias")].replace("encoder.", "encoder.base_model.model.", 1)
+            disk["vision_model." + stem + ".base_layer.bias"] = v
+        elif k.startswith("encoder."):
+            disk["vision_model." + k.replace("encoder.", "encoder.base_model.model.", 1)] = v
+        else:
+            disk["vision_model." + k] = v
+    torch.save(disk, os.path.join(img, "pytorch_model.bin"))
+    json.dump({"vision_config": dict(cases.VIT_IMAGE, lora_r=2, lora_alpha=16)}, open(os.path.join(img, "config.json"), "w"))
+    return dict(base=base, ckpt=ckpt, merged_llm=merged, image_ref=iref, video=vsd, proj=proj, reg=reg)
+
+
+def test_checkpoint_parsing_and_lora_merge_cpu(tmp_path):
+    """No GPU: file discovery, key remapping and both LoRA merges reproduce W + alpha/r * B@A."""
+    from vitron_amd.engine import merge_lora
+    from vitron_amd.model import builder
+    from vitron_amd.model.multimodal_encoder.languagebind import _load_dir_state
+    ck = _write_checkpoint(str(tmp_path))
+    sd = builder._load_weight_files(ck["base"])
+    assert set(sd) == set(ck["merged_llm"])
+    ad = torch.load(os.path.join(ck["ckpt"], "adapter_model.bin"))
+    merged = builder._merge_llm_lora(sd, ad, 8.0, 4)
+    for k, v in ck["merged_llm"].items():
+        assert torch.allclose(merged[k].float(), v.to(merged[k].dtype).float(), atol=1e-6), k
+    vcfg, isd = _load_dir_state(os.path.join(str(tmp_path), "LanguageBind_Image"))
+    im = merge_lora(isd, lora_alpha=16.0)
+    assert set(im) == set(ck["image_ref"])
+    for k, v in ck["image_ref"].items():
+        assert torch.allclose(im[k].float(), v.to(im[k].dtype).float(), atol=1e-6), k
+    assert vcfg["hidden_size"] == cases.VIT_IMAGE["hidden_size"]
+
+
+@pytest.mark.gpu
+def test_load_pretrained_model_matches_direct_construction(tmp_path):
+    from vitron_amd.model import LlavaConfig, LlavaLlamaForCausalLM, load_pretrained_model
+    from tests.util import rel_l2
+    ck = _write_checkpoint(str(tmp_path))
+    dev = torch.device("cuda:0")
+    tok, model, procs, ctx = load_pretrained_model(ck["ckpt"], ck["base"], "vitron-7b-lora", device="cuda", tokenizer=object())
+    assert ctx == 2048 and procs["image"].crop_size == {"height": 56, "width": 56} and procs["video"].num_frames == 4
+    # reference construction straight from the merged tensors
+    cfg = LlavaConfig(**cases.LLM, mm_hidden_size=cases.MM_HIDDEN, mm_image_tower="x/LanguageBind_Image", mm_video_tower="x/LanguageBind_Video_merge")
+    ref = LlavaLlamaForCausalLM(cfg)
+    ref.get_image_tower().load_state(cases.VIT_IMAGE, {k: v.bfloat16() for k, v in ck["image_ref"].items()})
+    ref.get_video_tower().load_state(cases.VIT_VIDEO, ck["video"])
+    sd = {k: v.bfloat16() for k, v in ck["merged_llm"].items()}
+    sd.update({"model.mm_projector." + k: v for k, v in ck["proj"].items()})
+    sd.update({"model.region_extractor." + k: v for k, v in ck["reg"].items()})
+    ref.load_state_dict(sd)
+    ref.to(dev)
+    case = cases.glue_cases()["image_region"]
+    ids = case["input_ids"].to(dev)
+    images = [im.to(dev).bfloat16() for im in case["images"]]
+    a = model(input_ids=ids, images=images, regions=case["regions"], use_cache=False).logits
+    b = ref(input_ids=ids, images=images, regions=case["regions"], use_cache=False).logits
+    assert rel_l2(a, b) <= 2e-2   # merged weights are re-rounded to bf16 on both paths, in a different order
+    assert float((a.argmax(-1) == b.argmax(-1)).float().mean()) >= 0.9

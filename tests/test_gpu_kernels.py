@@ -247,3 +247,40 @@ def test_profile_api_counts_split_gemm(dev):
     ref = bf16r((a.double() @ w.double().t()).float())
     assert rel_l2(out.float(), ref) <= TOL
     assert _lib.profile_end()["gemm_tile"]["launches"] == 0   # idempotent when nothing was recorded
+
+
+def test_sample_top_p_keep_set_and_distribution(dev):
+    """Keep-set size must equal transformers' TopPLogitsWarper rule (restated on CPU); samples must come from the keep-set
+    and follow the renormalised distribution; the draw is a pure function of (seed, step, row)."""
+    from vitron_amd import ops
+    V, rows = 32000, 6
+    g = torch.Generator().manual_seed(71)
+    logits = torch.randn((rows, V), generator=g) * 3.0
+    logits[0, 123] = 40.0                                  # one dominant token -> keep-set of size 1
+    for temperature, top_p in ((0.7, 0.9), (1.0, 0.5), (0.2, 0.95), (1.3, 1.0)):
+        ld = logits.to(dev)
+        ids, kept = ops.sample_top_p(ld, temperature, top_p, seed=5, step=3, return_kept=True)
+        probs = torch.softmax(logits.double() / temperature, -1)
+        sp, si = torch.sort(probs, descending=False, dim=-1)
+        remove = sp.cumsum(-1) <= (1.0 - top_p)
+        remove[:, -1] = False
+        keep_n = (~remove).sum(-1)
+        kn = kept.cpu().long()
+        assert ((kn - keep_n).abs() <= torch.clamp(keep_n // 1000, min=1)).all(), (temperature, top_p, kn.tolist(), keep_n.tolist())
+        assert int(ids[0]) == 123 and (int(kn[0]) == 1 or top_p >= 1.0)
+        mask = torch.zeros_like(probs, dtype=torch.bool).scatter(1, si, ~remove)
+        lo = torch.where(mask, probs, torch.ones_like(probs)).amin(-1)   # smallest kept probability
+        for r in range(rows):
+            assert probs[r, int(ids[r])] >= lo[r] * (1 - 1e-3)
+        ids2 = ops.sample_top_p(ld, temperature, top_p, seed=5, step=3)
+        assert torch.equal(ids, ids2)                      # deterministic in (seed, step, row)
+    # distribution: 4-token toy vocabulary padded with -inf-like logits, many independent draws
+    V2 = 64
+    lg = torch.full((1, V2), -1e4)
+    lg[0, :4] = torch.log(torch.tensor([0.5, 0.25, 0.15, 0.10]))
+    ld = lg.repeat(2048, 1).contiguous().to(dev)
+    ids = ops.sample_top_p(ld, 1.0, 1.0, seed=11, step=0).cpu().long()
+    freq = torch.bincount(ids, minlength=V2)[:4].double() / 2048
+    assert (freq - torch.tensor([0.5, 0.25, 0.15, 0.10], dtype=torch.float64)).abs().max() < 0.04 and int((ids >= 4).sum()) == 0
+    ids = ops.sample_top_p(ld, 1.0, 0.7, seed=11, step=0).cpu().long()   # keep-set {0,1}: mass .75 >= .7
+    assert int((ids >= 2).sum()) == 0 and abs(float((ids == 0).double().mean()) - 2 / 3) < 0.04

@@ -177,6 +177,11 @@ int vt_argmax(const float* logits, int rows, int V, int ldl, int* out_ids, void*
   return vt_argmax_launch(logits, rows, V, ldl, out_ids, S(stream));
 }
 
+int vt_sample_top_p(const float* logits, int rows, int V, int ldl, float temperature, float top_p, uint64_t seed,
+                    uint64_t step, int* out_ids, int* kept_count, void* stream) {
+  return vt_sample_top_p_launch(logits, rows, V, ldl, temperature, top_p, seed, step, out_ids, kept_count, S(stream));
+}
+
 // ---- mm_projector ---------------------------------------------------------------------------------------------------
 size_t vt_projector_workspace_bytes(int M, int Dh) { return align_up((size_t)M * Dh * 2, 256) + 256; }
 

@@ -64,6 +64,8 @@ int vt_region_pool_launch(const bf16_t* feats, const int* slices, int B, int G, 
 int vt_embed_splice_launch(const bf16_t* tok_table, const bf16_t* vis, const bf16_t* reg, const int* plan,
                            int rows, int H, bf16_t* out, hipStream_t s);
 int vt_argmax_launch(const float* logits, int rows, int V, int ldl, int* out_ids, hipStream_t s);
+int vt_sample_top_p_launch(const float* logits, int rows, int V, int ldl, float temperature, float top_p, uint64_t seed,
+                           uint64_t step, int* out_ids, int* kept_count, hipStream_t s);
 
 // ---- profiling (vt_api.hip) -----------------------------------------------------------------------------
 // RAII bracket: records start/stop events on `s` around a launch when profiling is enabled.

@@ -70,7 +70,140 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ l
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Temperature / top-k-free top-p sampling of one token per row, entirely on the device (no logits copy, no host sync):
+//   p = softmax(logits / T);  keep the smallest set of highest-probability tokens whose mass reaches top_p -- exactly
+//   transformers' TopPLogitsWarper rule (sort ascending, drop while cumulative mass <= 1 - top_p, always keep one) --
+//   found by bisection on the probability threshold instead of a sort; then inverse-CDF sampling over the kept tokens in
+//   index order with a counter-based uniform (splitmix64 of seed, step, row). One 1024-thread block per row.
+// Replaces GenerationMixin.sample's warper + torch.multinomial (app.py:562-571 passes do_sample=True, temperature, top_p).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum_1024(float v, float* sh) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < 16; ++i) t += sh[i];
+  return t;
+}
+__device__ __forceinline__ float block_max_1024(float v, float* sh) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = sh[0];
+  for (int i = 1; i < 16; ++i) t = fmaxf(t, sh[i]);
+  return t;
+}
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+  x += 0x9e3779b97f4a7c15ull;
+  x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
+  x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
+  return x ^ (x >> 31);
+}
+
+__global__ __launch_bounds__(1024) void sample_top_p_kernel(const float* __restrict__ logits, int V, int ldl,
+                                                            float inv_temp, float top_p, uint64_t seed, uint64_t step,
+                                                            int* __restrict__ out_ids, int* __restrict__ kept_count) {
+  __shared__ float sh[16];
+  __shared__ float sh_scan[16];
+  const float* row = logits + (size_t)blockIdx.x * ldl;
+  const int tid = threadIdx.x;
+  float mx = -INFINITY;
+  for (int i = tid; i < V; i += 1024) mx = fmaxf(mx, row[i] * inv_temp);
+  mx = block_max_1024(mx, sh);
+  float z = 0.f;
+  for (int i = tid; i < V; i += 1024) z += __expf(row[i] * inv_temp - mx);
+  z = block_sum_1024(z, sh);
+  const float inv_z = 1.f / z;
+  // bisection on the threshold t in (0, 1]: mass(t) = sum of p_i with p_i >= t is non-increasing in t.
+  // keep-set of the warper = {i : mass of tokens strictly above p_i < top_p}  <=>  largest t with mass(t) >= top_p.
+  float lo = 0.f, hi = 1.f;   // invariant: mass(lo) >= top_p, mass(hi) < top_p (or hi == 1 when a single token has p >= top_p)
+  for (int it = 0; it < 30; ++it) {
+    const float mid = 0.5f * (lo + hi);
+    float m = 0.f;
+    for (int i = tid; i < V; i += 1024) {
+      const float p = __expf(row[i] * inv_temp - mx) * inv_z;
+      if (p >= mid) m += p;
+    }
+    m = block_sum_1024(m, sh);
+    if (m >= top_p) lo = mid; else hi = mid;
+  }
+  const float thr = (top_p >= 1.f) ? 0.f : fminf(lo, inv_z);   // inv_z = probability of the arg-max token: always kept
+  float kept = 0.f, cnt = 0.f;
+  for (int i = tid; i < V; i += 1024) {
+    const float p = __expf(row[i] * inv_temp - mx) * inv_z;
+    if (p >= thr) {
+      kept += p;
+      cnt += 1.f;
+    }
+  }
+  kept = block_sum_1024(kept, sh);
+  cnt = block_sum_1024(cnt, sh);
+  if (tid == 0 && kept_count) kept_count[blockIdx.x] = (int)cnt;
+  // inverse CDF over the kept tokens in index order: thread t owns the contiguous index range [t*chunk, (t+1)*chunk)
+  const uint64_t r = splitmix64(seed ^ splitmix64(step * 0x632be59bd9b4e019ull + blockIdx.x));
+  const float u = (float)((r >> 40) + 0.5) * (1.0f / 16777216.0f) * kept;
+  const int chunk = (V + 1023) / 1024;
+  const int i0 = tid * chunk, i1 = min(V, i0 + chunk);
+  float mine = 0.f;
+  for (int i = i0; i < i1; ++i) {
+    const float p = __expf(row[i] * inv_temp - mx) * inv_z;
+    if (p >= thr) mine += p;
+  }
+  // exclusive prefix over threads: wave scan + scan of the 16 wave totals
+  float incl = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float v = __shfl_up(incl, o, 64);
+    if ((tid & 63) >= o) incl += v;
+  }
+  __syncthreads();
+  if ((tid & 63) == 63) sh_scan[tid >> 6] = incl;
+  __syncthreads();
+  float base = 0.f;
+  for (int w = 0; w < (tid >> 6); ++w) base += sh_scan[w];
+  const float excl = base + incl - mine;
+  // the owner of u is the thread with excl <= u < excl + mine; fall back to the last kept token against rounding
+  __shared__ int chosen;
+  if (tid == 0) chosen = -1;
+  __syncthreads();
+  if (mine > 0.f && u >= excl && u < excl + mine) {
+    float c = excl;
+    int pick = -1;
+    for (int i = i0; i < i1; ++i) {
+      const float p = __expf(row[i] * inv_temp - mx) * inv_z;
+      if (p >= thr) {
+        pick = i;
+        c += p;
+        if (u < c) break;
+      }
+    }
+    atomicMax(&chosen, pick);
+  }
+  __syncthreads();
+  if (chosen < 0 && mine > 0.f) {  // u landed on a rounding seam: take the last kept token of the highest owning range
+    int last = -1;
+    for (int i = i0; i < i1; ++i)
+      if (__expf(row[i] * inv_temp - mx) * inv_z >= thr) last = i;
+    atomicMax(&chosen, last);
+  }
+  __syncthreads();
+  if (tid == 0) out_ids[blockIdx.x] = chosen;
+}
+
 }  // namespace
+
+int vt_sample_top_p_launch(const float* logits, int rows, int V, int ldl, float temperature, float top_p, uint64_t seed,
+                           uint64_t step, int* out_ids, int* kept_count, hipStream_t s) {
+  VT_REQUIRE(logits && out_ids && rows > 0 && V > 0, "vt_sample_top_p: bad arguments");
+  VT_REQUIRE(temperature > 0.f && top_p > 0.f, "vt_sample_top_p: temperature and top_p must be > 0");
+  hipLaunchKernelGGL(sample_top_p_kernel, dim3(rows), dim3(1024), 0, s, logits, V, ldl, 1.0f / temperature, top_p, seed, step,
+                     out_ids, kept_count);
+  VT_LAUNCH_CHECK();
+  return VT_OK;
+}
 
 int vt_embed_splice_launch(const bf16_t* tok_table, const bf16_t* vis, const bf16_t* reg, const int* plan, int rows,
                            int H, bf16_t* out, hipStream_t s) {

@@ -80,7 +80,7 @@ class PackedVit:
     """LanguageBind CLIP vision transformer in kernel layout (vt_vit_model)."""
 
     def __init__(self, sd: SD, cfg: dict, device, select_layer: int = -2):
-        sd = merge_lora(sd) if any(".lora_" in k for k in sd) else sd
+        sd = merge_lora(sd, float(cfg.get("lora_alpha", 16.0))) if any(".lora_" in k for k in sd) else sd
         self.cfg = dict(cfg)
         self.device = torch.device(device)
         D, heads, P = cfg["hidden_size"], cfg["num_attention_heads"], cfg["patch_size"]

@@ -272,9 +272,10 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
         if max_new_tokens is None:
             max_new_tokens = (max_length - input_ids.shape[1]) if max_length else 20
         gen = None
+        sample_seed = int(seed) if seed is not None else int(torch.seed() % (2 ** 31))
         if do_sample:
             gen = torch.Generator(device=dev)
-            gen.manual_seed(int(seed) if seed is not None else int(torch.seed() % (2 ** 31)))
+            gen.manual_seed(sample_seed)
 
         (_, _, _, _, embeds, _) = self.prepare_inputs_labels_for_multimodal(input_ids, None, attention_mask, None, None,
                                                                             images, regions)
@@ -300,7 +301,10 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
             for step in range(max_new_tokens):
                 if return_logits:
                     all_logits.append(logits.clone())
-                nxt = self._sample(logits, do_sample, temperature, top_p, top_k, gen)
+                if do_sample and not top_k:   # device-side temperature + top-p sampler (no host sync, counter-based RNG)
+                    nxt = ops.sample_top_p(logits, temperature, top_p if top_p else 1.0, sample_seed, step).to(torch.long)
+                else:
+                    nxt = self._sample(logits, do_sample, temperature, top_p, top_k, gen)
                 nxt = torch.where(finished, torch.full_like(nxt, pad), nxt)
                 out = torch.cat([out, nxt.unsqueeze(1)], dim=1)
                 for e in eos_set:

@@ -162,3 +162,15 @@ def argmax(logits: torch.Tensor) -> torch.Tensor:
     out = torch.empty((rows,), device=logits.device, dtype=torch.int32)
     _lib.check(lib.vt_argmax(_p(logits), rows, V, logits.stride(0), _p(out), _stream()), "vt_argmax")
     return out
+
+
+def sample_top_p(logits: torch.Tensor, temperature: float, top_p: float, seed: int, step: int, return_kept: bool = False):
+    """One sampled token id per row (int32), on device; see vt_sample_top_p in include/vitron_hip.h."""
+    lib = _lib.load()
+    _chk(logits, torch.float32, "sample_top_p.logits")
+    rows, V = logits.shape
+    out = torch.empty((rows,), device=logits.device, dtype=torch.int32)
+    kept = torch.empty((rows,), device=logits.device, dtype=torch.int32) if return_kept else None
+    _lib.check(lib.vt_sample_top_p(_p(logits), rows, V, logits.stride(0), float(temperature), float(top_p if top_p else 1.0),
+                                   int(seed) & (2 ** 64 - 1), int(step), _p(out), _p(kept), _stream()), "vt_sample_top_p")
+    return (out, kept) if return_kept else out
