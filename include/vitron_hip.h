@@ -106,6 +106,15 @@ int vt_attn_temporal(const uint16_t* qkv, uint16_t* out, int B, int T, int N, in
 int vt_im2col(const void* pixels, int pix_dtype, uint16_t* patches, int B, int T, int H, int W, int P, int k_pad,
               int video_layout, void* stream);
 
+/* Pre-processing of decoded frames on the device, fused: short-side resize to S (bicubic = torchvision tensor Resize,
+ * reference image/processing_image.py:15-25; bilinear = pytorchvideo ShortSideScale, video/processing_video.py:45-53),
+ * centre crop SxS, *1/255 for uint8 sources, (x - mean) / std, optional horizontal flip.
+ * src: F frames, [F][H][W][3] (hwc=1) or [F][3][H][W]; uint8 (src_u8=1) or fp32. mean/std: HOST float[3].
+ * dst element (c, f, y, x) at c*dst_stride_c + f*dst_stride_f + y*S + x  (images: sc=S*S, sf=3*S*S; clips [3][T][S][S]:
+ * sc=T*S*S, sf=S*S); bf16 or fp32. */
+int vt_preprocess(const void* src, int src_u8, int hwc, int F, int H, int W, int bicubic, int S, const float* mean,
+                  const float* std, int flip, void* dst, int dst_dtype, long dst_stride_c, long dst_stride_f, void* stream);
+
 /* embed_tokens gather + visual / region splice (reference llava_arch.py:306-398, 479-558).
  * plan: device int32 [rows][2] = {kind, index}; kind 0 = token id, 1 = row of vis, 2 = row of reg, 3 = zero row. */
 int vt_embed_splice(const uint16_t* tok_table, const uint16_t* vis, const uint16_t* reg, const int* plan, int rows,

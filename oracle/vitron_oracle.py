@@ -467,3 +467,48 @@ def multimodal_forward(weights: dict, cfgs: dict, input_ids, attention_mask, ima
     logits, _ = llama_forward(weights["llama"], cfgs["llama"], embeds, pos if attention_mask is not None else None,
                               am, None, emulate_bf16)
     return logits, embeds, mask, pos
+
+
+# =====================================================================================================================
+# pre-processing (reference languagebind/image/processing_image.py:15-25, video/processing_video.py:45-53)
+# NOTE parity unpinned for this stage: the reference's transforms need torchvision / pytorchvideo, which are not
+# installed, so no golden could be generated from the reference itself; this restates the documented algorithm of the
+# two libraries (both call torch.nn.functional.interpolate) on top of the same PyTorch build.
+# =====================================================================================================================
+OPENAI_DATASET_MEAN = (0.48145466, 0.4578275, 0.40821073)
+OPENAI_DATASET_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def preprocess_image(img_u8_hwc: torch.Tensor, size: int = 224) -> torch.Tensor:
+    """ToTensor -> Resize(size, BICUBIC) [tensor path: F.interpolate bicubic, align_corners=False, no antialias; short
+    side -> size, long side int(size*long/short)] -> CenterCrop(size) -> Normalize.  [H,W,3] uint8 -> [3,size,size]."""
+    x = img_u8_hwc.permute(2, 0, 1).float() / 255.0
+    h, w = x.shape[1:]
+    if w <= h:
+        nw, nh = size, int(size * h / w)
+    else:
+        nh, nw = size, int(size * w / h)
+    x = F.interpolate(x[None], size=(nh, nw), mode="bicubic", align_corners=False)[0]
+    top, left = int(round((nh - size) / 2.0)), int(round((nw - size) / 2.0))
+    x = x[:, top:top + size, left:left + size]
+    mean = torch.tensor(OPENAI_DATASET_MEAN)[:, None, None]
+    std = torch.tensor(OPENAI_DATASET_STD)[:, None, None]
+    return (x - mean) / std
+
+
+def preprocess_video(frames_u8_thwc: torch.Tensor, size: int = 224, flip: bool = False) -> torch.Tensor:
+    """x/255 -> NormalizeVideo -> ShortSideScale(size) [bilinear, long side floor(long/short*size)] -> CenterCropVideo
+    [-> horizontal flip].  [T,H,W,3] uint8 -> [3,T,size,size]."""
+    x = frames_u8_thwc.permute(3, 0, 1, 2).float() / 255.0          # (C,T,H,W)
+    mean = torch.tensor(OPENAI_DATASET_MEAN)[:, None, None, None]
+    std = torch.tensor(OPENAI_DATASET_STD)[:, None, None, None]
+    x = (x - mean) / std
+    h, w = x.shape[2:]
+    if w < h:
+        nh, nw = int(math.floor((float(h) / w) * size)), size
+    else:
+        nh, nw = size, int(math.floor((float(w) / h) * size))
+    x = F.interpolate(x, size=(nh, nw), mode="bilinear", align_corners=False)
+    top, left = int(round((nh - size) / 2.0)), int(round((nw - size) / 2.0))
+    x = x[:, :, top:top + size, left:left + size]
+    return x.flip(-1) if flip else x

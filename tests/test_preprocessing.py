@@ -1,0 +1,59 @@
+"""GPU pre-processing kernel (vt_preprocess) against the oracle's restatement of the torchvision / pytorchvideo
+transforms the reference composes. Real COCO-like content is not needed: smooth + noisy synthetic uint8 frames."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vitron_oracle as O
+
+
+def _frames(shape, seed):
+    g = torch.Generator().manual_seed(seed)
+    F_, H, W = shape
+    yy, xx = torch.meshgrid(torch.linspace(0, 3.0, H), torch.linspace(0, 5.0, W), indexing="ij")
+    base = 127 + 90 * torch.sin(yy[None] * 2.1 + torch.arange(F_)[:, None, None]) * torch.cos(xx[None] * 1.3)
+    img = base[..., None] + torch.randn((F_, H, W, 3), generator=g) * 25
+    return img.clamp(0, 255).to(torch.uint8)
+
+
+def test_oracle_preprocess_shapes_and_identity():
+    x = _frames((1, 224, 224), 1)[0]
+    y = O.preprocess_image(x, 224)
+    ref = (x.permute(2, 0, 1).float() / 255 - torch.tensor(O.OPENAI_DATASET_MEAN)[:, None, None]) / torch.tensor(O.OPENAI_DATASET_STD)[:, None, None]
+    assert y.shape == (3, 224, 224) and torch.allclose(y, ref, atol=1e-5)      # same size: resize is the identity
+    v = O.preprocess_video(_frames((4, 120, 200), 2), 56)
+    assert v.shape == (3, 4, 56, 56)
+    from vitron_amd.processing import sample_frame_indices
+    assert sample_frame_indices(100, 8).tolist() == np.linspace(0, 99, 8, dtype=int).tolist()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,size", [((1, 480, 640), 224), ((1, 500, 333), 336), ((2, 224, 224), 224), ((1, 97, 131), 56)])
+def test_image_preprocess_matches_oracle(shape, size):
+    from vitron_amd.processing import LanguageBindImageProcessor, preprocess_frames
+    dev = torch.device("cuda:0")
+    fr = _frames(shape, 3)
+    got = preprocess_frames(fr.to(dev), size, True, False, dtype=torch.float32).cpu()
+    ref = torch.stack([O.preprocess_image(f, size) for f in fr])
+    assert got.shape == ref.shape
+    assert float((got - ref).abs().max()) <= 2e-4          # fp32 tap weights in a different summation order
+    proc = LanguageBindImageProcessor(image_size=size)
+    pv = proc.preprocess([fr[0].numpy()], return_tensors="pt")["pixel_values"]
+    assert pv.shape == (1, 3, size, size) and pv.dtype == torch.bfloat16 and proc.crop_size == {"height": size, "width": size}
+    assert float((pv[0].float().cpu() - ref[0]).abs().max()) <= 2e-2   # bf16 output
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,size,flip", [((8, 360, 640), 224, False), ((8, 300, 200), 336, True), ((20, 64, 64), 56, False)])
+def test_video_preprocess_matches_oracle(shape, size, flip):
+    from vitron_amd.processing import LanguageBindVideoProcessor, preprocess_frames, sample_frame_indices
+    dev = torch.device("cuda:0")
+    fr = _frames(shape, 4)
+    sel = fr[torch.from_numpy(sample_frame_indices(shape[0], 8))]
+    got = preprocess_frames(sel.to(dev), size, False, True, flip=flip, dtype=torch.float32).cpu()
+    ref = O.preprocess_video(sel, size, flip)
+    assert got.shape == ref.shape == (3, 8, size, size)
+    assert float((got - ref).abs().max()) <= 2e-4
+    pv = LanguageBindVideoProcessor(image_size=size, num_frames=8, flip=flip)(fr)["pixel_values"]
+    assert pv.shape == (1, 3, 8, size, size)
+    assert float((pv[0].float().cpu() - ref).abs().max()) <= 2e-2

@@ -72,6 +72,8 @@ SIGNATURES = {
     "vt_kv_tiles": (_i, [vp, _i, _i, _i, _i, vp, vp, vp, vp, _i, _i, _i, _i, vp, vp, vp, vp]),
     "vt_attn_temporal": (_i, [vp, vp, _i, _i, _i, _i, vp]),
     "vt_im2col": (_i, [vp, _i, vp, _i, _i, _i, _i, _i, _i, _i, vp]),
+    "vt_preprocess": (_i, [vp, _i, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _i, vp, _i, C.c_long,
+                           C.c_long, vp]),
     "vt_embed_splice": (_i, [vp, vp, vp, vp, _i, _i, vp, vp]),
     "vt_argmax": (_i, [vp, _i, _i, _i, vp, vp]),
     "vt_sample_top_p": (_i, [vp, _i, _i, _i, _f, _f, C.c_uint64, C.c_uint64, vp, vp, vp]),

@@ -17,7 +17,7 @@ PKG_DIR = Path(__file__).resolve().parent
 CSRC = PKG_DIR / "csrc"
 INCLUDE = PKG_DIR.parent / "include"
 LIB_PATH = PKG_DIR / "libvitron_hip.so"
-SOURCES = ["vt_api.hip", "vt_gemm.hip", "vt_gemm8.hip", "vt_norm.hip", "vt_attn.hip", "vt_vit.hip", "vt_region.hip", "vt_llama.hip"]
+SOURCES = ["vt_api.hip", "vt_gemm.hip", "vt_gemm8.hip", "vt_norm.hip", "vt_attn.hip", "vt_vit.hip", "vt_region.hip", "vt_llama.hip", "vt_preproc.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
          "-Wno-unused-but-set-variable", "-Wno-unused-variable"]

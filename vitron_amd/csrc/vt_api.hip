@@ -69,6 +69,7 @@ struct Carver {  // bump allocator over the caller's workspace
   bool ok() const { return off <= cap; }
 };
 inline hipStream_t S(void* s) { return (hipStream_t)s; }
+inline hipStream_t S_(void* s) { return (hipStream_t)s; }
 }  // namespace
 
 extern "C" {
@@ -175,6 +176,12 @@ int vt_embed_splice(const uint16_t* tok_table, const uint16_t* vis, const uint16
 
 int vt_argmax(const float* logits, int rows, int V, int ldl, int* out_ids, void* stream) {
   return vt_argmax_launch(logits, rows, V, ldl, out_ids, S(stream));
+}
+
+int vt_preprocess(const void* src, int src_u8, int hwc, int F, int H, int W, int bicubic, int S, const float* mean,
+                  const float* std, int flip, void* dst, int dst_dtype, long dst_stride_c, long dst_stride_f, void* stream) {
+  return vt_preprocess_launch(src, src_u8, hwc, F, H, W, bicubic, S, mean, std, flip, dst, dst_dtype, dst_stride_c, dst_stride_f,
+                              S_(stream));
 }
 
 int vt_sample_top_p(const float* logits, int rows, int V, int ldl, float temperature, float top_p, uint64_t seed,

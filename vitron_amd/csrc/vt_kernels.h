@@ -67,6 +67,10 @@ int vt_argmax_launch(const float* logits, int rows, int V, int ldl, int* out_ids
 int vt_sample_top_p_launch(const float* logits, int rows, int V, int ldl, float temperature, float top_p, uint64_t seed,
                            uint64_t step, int* out_ids, int* kept_count, hipStream_t s);
 
+// ---- vt_preproc.hip -------------------------------------------------------------------------------
+int vt_preprocess_launch(const void* src, int src_u8, int hwc, int F, int H, int W, int bicubic, int S, const float* mean,
+                         const float* std, int flip, void* dst, int dst_dtype, long dst_sc, long dst_sf, hipStream_t s);
+
 // ---- profiling (vt_api.hip) -----------------------------------------------------------------------------
 // RAII bracket: records start/stop events on `s` around a launch when profiling is enabled.
 bool vt_prof_enabled();

@@ -58,22 +58,19 @@ def _merge_llm_lora(base_sd, adapter_sd, lora_alpha, r=None):
     return out
 
 
-class ImageProcessorInfo(SimpleNamespace):
-    """What app.py / mm_utils read from the image processor: crop_size (app.py:556), image_mean (mm_utils.py:70)."""
-
-
 def _processors(model):
-    from .multimodal_encoder.languagebind import OPENAI_DATASET_MEAN, OPENAI_DATASET_STD
+    """{'image': processor, 'video': processor} like the reference's builder (builder.py:149-171): device-side processors
+    (vitron_amd.processing) exposing what app.py / mm_utils read -- preprocess(...)['pixel_values'], crop_size, image_mean."""
+    from ..processing import LanguageBindImageProcessor, LanguageBindVideoProcessor
     proc = {"image": None, "video": None}
     it, vt = model.get_image_tower(), model.get_video_tower()
     if it is not None and it.config is not None:
-        s = it.config.image_size
-        proc["image"] = it.image_processor or ImageProcessorInfo(crop_size={"height": s, "width": s}, image_mean=list(OPENAI_DATASET_MEAN),
-                                                                 image_std=list(OPENAI_DATASET_STD), size=s)
+        it.image_processor = it.image_processor or LanguageBindImageProcessor(image_size=it.config.image_size, device=model.device)
+        proc["image"] = it.image_processor
     if vt is not None and vt.config is not None:
-        s = vt.config.image_size
-        proc["video"] = vt.video_processor or ImageProcessorInfo(crop_size={"height": s, "width": s}, image_mean=list(OPENAI_DATASET_MEAN),
-                                                                 image_std=list(OPENAI_DATASET_STD), size=s, num_frames=vt.config.num_frames)
+        vt.video_processor = vt.video_processor or LanguageBindVideoProcessor(image_size=vt.config.image_size,
+                                                                              num_frames=vt.config.num_frames, device=model.device)
+        proc["video"] = vt.video_processor
     return proc
 
 
