@@ -59,7 +59,7 @@ def pmc_traffic_per_launch():
         d = json.load(f)
     tot, n = 0.0, 0
     for k, v in d.items():
-        if k.startswith(("gemm_bt_kernel", "gemm_p8_kernel", "gemm_w4_kernel")) and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+        if k.startswith(("gemm_bt_kernel", "gemm_p8_kernel", "gemm_w4_kernel", "gemm_rp_kernel")) and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
             l = v["FETCH_SIZE"]["launches"]
             tot += l * (2.0 * v["FETCH_SIZE"]["mean_per_launch"] + v["WRITE_SIZE"]["mean_per_launch"]) * 1024.0
             n += l

@@ -46,7 +46,8 @@ enum {
   VT_GEMM_CFG_256x256 = 4,
   VT_GEMM_CFG_64x128 = 5,
   VT_GEMM_CFG_256x256_P8 = 6, /* 256x256 tile, 8 waves, 8-phase pipelined main loop */
-  VT_GEMM_CFG_256x256_W4 = 7  /* 256x256 tile, 4 waves (one per SIMD, 128x128 register tile each) */
+  VT_GEMM_CFG_256x256_W4 = 7, /* 256x256 tile, 4 waves (one per SIMD, 128x128 register tile each) */
+  VT_GEMM_CFG_256x256_RP = 8  /* 256x256 tile, 8 waves, register-pipelined 32x32x16 main loop, one barrier per K tile */
 };
 enum { VT_DTYPE_BF16 = 0, VT_DTYPE_F32 = 1 };
 enum { VT_ACT_GELU = 0, VT_ACT_QUICK_GELU = 1 };

@@ -394,7 +394,9 @@ int launch_skinny(const GemmP& p, hipStream_t s) {
 int vt_gemm_pick_cfg(int M, int N, int K) {
   // Measured on MI355X (tools/gemm_bench.py, profiles/): the 8-phase 256x256 kernel wins whenever its grid fills
   // whole rounds of the 256 CUs (one 128-KiB-LDS workgroup per CU); when the last round would be mostly empty the
-  // 128x128 kernel (two workgroups per CU, 4x more tiles) quantises better.
+  // 128x128 kernel (two workgroups per CU, 4x more tiles) quantises better. The register-pipelined variant
+  // (VT_GEMM_CFG_256x256_RP) is 3-8% faster than the 8-phase kernel on isolated back-to-back launches but measured
+  // equal (bf16 epilogue) to 9% slower (fp32 residual epilogue) inside the full prefill step, so it stays opt-in.
   if (M <= 64) return VT_GEMM_CFG_64x128;
   const long t256 = (long)cdiv(M, 256) * cdiv(N, 256);
   const long rounds = (t256 + 255) / 256;
@@ -421,7 +423,7 @@ int vt_gemm_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, 
   if (cfg == VT_GEMM_CFG_AUTO || cfg == VT_GEMM_CFG_SKINNY) {
       cfg = vt_gemm_pick_cfg(M, N, K);
       // Wave quantisation: when the 256x256 grid would leave most of its last round of CUs idle (e.g. M=5120, N=4096:
-      // 320 tiles = 1.25 rounds), run the rows that fill WHOLE rounds on the 8-phase kernel and the remaining rows on the
+      // 320 tiles = 1.25 rounds), run the rows that fill WHOLE rounds on the 256x256 kernel and the remaining rows on the
       // small-tile kernel (4x more, 4x shorter tiles fill the CUs again). Both launches are plain row ranges of the same GEMM.
       if (cfg != VT_GEMM_CFG_256x256_P8 && vt_gemm_p8_supported(M, N, K) && K >= 2048 && M > 256) {
         const int tiles_n = cdiv(N, 256);
@@ -461,7 +463,9 @@ int vt_gemm_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, 
   if (epi == VT_EPI_SWIGLU_BF16) VT_REQUIRE((N % 32) == 0, "vt_gemm(swiglu): N must be a multiple of 32");
   if (cfg == VT_GEMM_CFG_256x256_P8) return vt_gemm_p8_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, epi, s);
   if (cfg >= 100 && cfg < 108) return vt_gemm_p8_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, (cfg - 100) << 8, s);
+  if (cfg >= 301 && cfg <= 303) return vt_gemm_rp_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, (cfg - 300) << 8, s);
   if (cfg >= 200 && cfg < 208) return vt_gemm_w4_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, (cfg - 200) << 8, s);
+  if (cfg == VT_GEMM_CFG_256x256_RP) return vt_gemm_rp_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, epi, s);
   if (cfg == VT_GEMM_CFG_256x256_W4) return vt_gemm_w4_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, epi, s);
   switch (epi) {
     case VT_EPI_BF16: return launch_cfg<VT_EPI_BF16>(p, cfg, s);

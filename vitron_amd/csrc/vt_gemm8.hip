@@ -501,6 +501,221 @@ int launch_w4(const GemmP8& p, hipStream_t s) {
   return VT_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// gemm_rp_kernel ("register-pipelined"): 256x256x64 tile, 8 waves (2 x 4, two per SIMD), 128x64 per wave as 4 x 2
+// fragments of v_mfma_f32_32x32x16_bf16. No load/compute phase split: inside every wave the fragment reads of k-step
+// j+1 (6 ds_read_b128) are in flight while the 8 MFMAs of k-step j issue (8 independent accumulators, no dependent
+// back-to-back MFMAs), fragments double-buffered in registers. Two LDS stages, LDS-DMA of K tile t+1 issued right after
+// the barrier, ONE barrier per K tile placed before the last k-step so the first fragments of tile t+1 are read under the
+// last MFMAs of tile t.
+// ------------------------------------------------------------------------------------------------------------------
+// VAR bit0: fragment reads 2 per MFMA (front-loaded) instead of 1 per MFMA; bit1: DMA of tile t+2 right after the barrier of
+// tile t (a full K tile ahead) instead of tile t+1 at the top of iteration t. (A/B knobs: tools/gemm_bench.py)
+template <int EPI, int VAR = 0>
+__global__ __launch_bounds__(512, 2) void gemm_rp_kernel(GemmP8 p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int TILE_BYTES = 256 * 64 * 2;
+  constexpr int STAGE = 2 * TILE_BYTES;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 255) / 256;
+  const int nwg = tiles_m * tiles_n;
+  const int sid = xcd_remap(blockIdx.x, nwg);
+  constexpr int GROUP_M = 8;
+  const int per_group = GROUP_M * tiles_n;
+  const int first_m = (sid / per_group) * GROUP_M;
+  const int gsz = min(tiles_m - first_m, GROUP_M);
+  const int tm = first_m + (sid % per_group) % gsz;
+  const int tn = (sid % per_group) / gsz;
+  const int bm0 = tm * 256, bn0 = tn * 256;
+
+  // DMA: 32 pieces (8 rows each) per operand tile; wave w stages pieces 4w..4w+3 of A and of B
+  const int lrow = lane >> 3, lchk = lane & 7;
+  unsigned a_src[4], b_src[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave * 4 + i) * 8 + lrow;
+    const int coff = (lchk ^ ((row >> 1) & 7)) * 8;
+    a_src[i] = (unsigned)(((size_t)min(bm0 + row, p.M - 1) * p.lda + coff) * 2);
+    b_src[i] = (unsigned)(((size_t)min(bn0 + row, p.N - 1) * p.ldw + coff) * 2);
+  }
+  const char* a_ptr = (const char*)p.A;
+  const char* b_ptr = (const char*)p.W;
+  const int dma_off = wave * 4096;
+#define RP_STAGE(BUF)                                                        \
+  do {                                                                       \
+    char* _d = smem + (BUF) * STAGE + dma_off;                               \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                          \
+      glds16(a_ptr + a_src[i], _d + i * 1024);                               \
+      a_src[i] += 128;                                                       \
+    }                                                                        \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                          \
+      glds16(b_ptr + b_src[i], _d + TILE_BYTES + i * 1024);                  \
+      b_src[i] += 128;                                                       \
+    }                                                                        \
+  } while (0)
+
+  const int f = ((lane & 31) >> 1) & 7;
+  int fo[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) fo[ks] = (lane & 31) * 128 + ((((2 * ks) | (lane >> 5)) ^ f) << 4);
+  const int a_base = wr * 128 * 128;
+  const int b_base = TILE_BYTES + wc * 64 * 128;
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+  bf16x8 fa0[4], fb0[2], fa1[4], fb1[2];
+
+#define RP_READ(FA, FB, BUF, KS)                                                          \
+  do {                                                                                    \
+    const char* _s = smem + (BUF) * STAGE;                                                \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) FA[i] = *(const bf16x8*)(_s + a_base + i * 4096 + fo[KS]); \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) FB[i] = *(const bf16x8*)(_s + b_base + i * 4096 + fo[KS]); \
+  } while (0)
+#define RP_MFMA(FA, FB)                                                                   \
+  do {                                                                                    \
+    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                      \
+      _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                    \
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FB[ni], FA[mi], acc[mi][ni], 0, 0, 0); \
+  } while (0)
+  // one k-step: reads of the next fragments interleaved 1:1 behind the first MFMAs
+#define RP_STEP(FA_CUR, FB_CUR, FA_NXT, FB_NXT, BUF, KS_NXT)                              \
+  do {                                                                                    \
+    RP_READ(FA_NXT, FB_NXT, BUF, KS_NXT);                                                 \
+    RP_MFMA(FA_CUR, FB_CUR);                                                              \
+    if (VAR & 1) {                                                                        \
+      _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                     \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                \
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                \
+      }                                                                                   \
+      __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);                                  \
+    } else {                                                                              \
+      _Pragma("unroll") for (int i = 0; i < 6; ++i) {                                     \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                \
+      }                                                                                   \
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                  \
+    }                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+  } while (0)
+
+  const int nt = p.K >> 6;
+  constexpr bool EARLY = (VAR & 2) != 0;
+  RP_STAGE(0);
+  if (EARLY && nt > 1) RP_STAGE(1);
+  if (EARLY && nt > 1) VT_VMCNT(8); else VT_VMCNT(0);   // K tile 0 landed (EARLY: tile 1's 8 DMAs may still be in flight)
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  RP_READ(fa0, fb0, 0, 0);
+
+  // K tile t: k-steps 1..3 read buffer t&1; then "tile t+1 landed" wait + barrier (buffer t&1 is dead from here on) and the
+  // last k-step already reads tile t+1's first fragments. DMA: EARLY -> tile t+2 into the dead buffer right after the barrier
+  // (a full K tile of lead); otherwise tile t+1 at the top of iteration t (three k-steps of lead).
+  // STAGE_ON / NEXT_ON are compile-time: the steady-state body has no branches.
+#define RP_TILE(STAGE_ON, NEXT_ON)                                                         \
+  do {                                                                                    \
+    const int cur = t & 1;                                                                \
+    if (!EARLY && NEXT_ON) RP_STAGE(cur ^ 1);                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+    RP_STEP(fa0, fb0, fa1, fb1, cur, 1);                                                  \
+    RP_STEP(fa1, fb1, fa0, fb0, cur, 2);                                                  \
+    RP_STEP(fa0, fb0, fa1, fb1, cur, 3);                                                  \
+    if (NEXT_ON) {                                                                        \
+      VT_VMCNT(0);                                                                        \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                  \
+      __builtin_amdgcn_s_barrier();                                                       \
+      __builtin_amdgcn_sched_barrier(0);                                                  \
+      if (EARLY && STAGE_ON) RP_STAGE(cur);                                               \
+      __builtin_amdgcn_sched_barrier(0);                                                  \
+      RP_STEP(fa1, fb1, fa0, fb0, cur ^ 1, 0);                                            \
+    } else {                                                                              \
+      RP_MFMA(fa1, fb1);                                                                  \
+    }                                                                                     \
+  } while (0)
+  int t = 0;
+  for (; t + 2 < nt; ++t) RP_TILE(true, true);
+  if (t + 1 < nt) {
+    RP_TILE(false, true);
+    ++t;
+  }
+  RP_TILE(false, false);
+#undef RP_TILE
+
+  // ---- epilogue: lane (m = ..+(lane&31)) holds n = nfrag + 8*g + 4*(lane>>5) + {0..3}, g = reg>>2 -------------------------
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const int m = bm0 + wr * 128 + mi * 32 + (lane & 31);
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int nfrag = bn0 + wc * 64 + ni * 32;
+      const f32x16 a = acc[mi][ni];
+      if constexpr (EPI == VT_EPI_SWIGLU_BF16) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const int nl = 8 * g + 4 * (lane >> 5);
+          if (nfrag + nl >= p.N) continue;
+          u32x2 o;
+          o.x = pack_bf16x2(silu8(a[4 * g + 0]) * a[4 * g + 8], silu8(a[4 * g + 1]) * a[4 * g + 9]);
+          o.y = pack_bf16x2(silu8(a[4 * g + 2]) * a[4 * g + 10], silu8(a[4 * g + 3]) * a[4 * g + 11]);
+          *(u32x2*)((bf16_t*)p.C + (size_t)m * p.ldc + (nfrag >> 1) + nl) = o;
+        }
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = nfrag + 8 * g + 4 * (lane >> 5);
+          if (n >= p.N) continue;
+          f32x4 v = {a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]};
+          if (p.bias) v += *(const f32x4*)(p.bias + n);
+          if constexpr (EPI == VT_EPI_BF16_GELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = gelu_erf8(v[r]);
+          } else if constexpr (EPI == VT_EPI_BF16_QGELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = quick_gelu8(v[r]);
+          } else if constexpr (EPI == VT_EPI_BF16_RELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+          }
+          if constexpr (EPI == VT_EPI_F32_RESID) {
+            float* c = (float*)p.C + (size_t)m * p.ldc + n;
+            *(f32x4*)c = *(const f32x4*)c + v;
+          } else if constexpr (EPI == VT_EPI_F32) {
+            *(f32x4*)((float*)p.C + (size_t)m * p.ldc + n) = v;
+          } else {
+            u32x2 o;
+            o.x = pack_bf16x2(v[0], v[1]);
+            o.y = pack_bf16x2(v[2], v[3]);
+            *(u32x2*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int EPI, int VAR = 0>
+int launch_rp(const GemmP8& p, hipStream_t s) {
+  constexpr int smem = 2 * 2 * 256 * 64 * 2;  // 128 KiB
+  auto kern = gemm_rp_kernel<EPI, VAR>;
+  static bool done = false;
+  if (!done) {
+    VT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    done = true;
+  }
+  const int nwg = cdiv(p.M, 256) * cdiv(p.N, 256);
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), smem, s, p);
+  VT_LAUNCH_CHECK();
+  return VT_OK;
+}
+
 template <int EPI, int ABL = 0>
 int launch_p8(const GemmP8& p, hipStream_t s) {
   constexpr int smem = 2 * BUF_BYTES;  // 128 KiB
@@ -519,6 +734,30 @@ int launch_p8(const GemmP8& p, hipStream_t s) {
 }  // namespace
 
 bool vt_gemm_p8_supported(int M, int N, int K) { return (K % 128) == 0 && K >= 256 && N % 32 == 0; }
+
+int vt_gemm_rp_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, const float* bias, int M,
+                      int N, int K, int epi, hipStream_t s) {
+  VT_REQUIRE((K % 64) == 0 && N % 32 == 0, "vt_gemm(rp): needs K %% 64 == 0 and N %% 32 == 0 (K=%d N=%d)", K, N);
+  VT_REQUIRE((size_t)M * lda * 2 < (1ull << 32) && (size_t)N * ldw * 2 < (1ull << 32), "vt_gemm(rp): operands must be < 4 GiB");
+  GemmP8 p{A, W, C, bias, M, N, K, lda, ldw, ldc};
+  if (epi >= 0x100) {  // A/B variants of the main loop (bf16 epilogue only)
+    switch (epi >> 8) {
+      case 1: return launch_rp<VT_EPI_BF16, 1>(p, s);
+      case 2: return launch_rp<VT_EPI_BF16, 2>(p, s);
+      default: return launch_rp<VT_EPI_BF16, 3>(p, s);
+    }
+  }
+  switch (epi) {
+    case VT_EPI_BF16: return launch_rp<VT_EPI_BF16>(p, s);
+    case VT_EPI_BF16_GELU: return launch_rp<VT_EPI_BF16_GELU>(p, s);
+    case VT_EPI_BF16_QGELU: return launch_rp<VT_EPI_BF16_QGELU>(p, s);
+    case VT_EPI_BF16_RELU: return launch_rp<VT_EPI_BF16_RELU>(p, s);
+    case VT_EPI_F32_RESID: return launch_rp<VT_EPI_F32_RESID>(p, s);
+    case VT_EPI_F32: return launch_rp<VT_EPI_F32>(p, s);
+    case VT_EPI_SWIGLU_BF16: return launch_rp<VT_EPI_SWIGLU_BF16>(p, s);
+    default: vt_set_error("vt_gemm(rp): unknown epilogue %d", epi); return VT_ERR_ARG;
+  }
+}
 
 int vt_gemm_w4_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, const float* bias, int M,
                       int N, int K, int epi, hipStream_t s) {

@@ -21,6 +21,8 @@ bool vt_gemm_p8_supported(int M, int N, int K);
 int vt_gemm_p8_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, const float* bias, int M,
                       int N, int K, int epi, hipStream_t s);
 
+int vt_gemm_rp_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, const float* bias, int M,
+                      int N, int K, int epi, hipStream_t s);
 int vt_gemm_w4_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, const float* bias, int M,
                       int N, int K, int epi, hipStream_t s);
 
