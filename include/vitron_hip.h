@@ -40,14 +40,15 @@ enum {
 /* tile configurations of the MFMA GEMM (VT_GEMM_CFG_AUTO lets the library choose) */
 enum {
   VT_GEMM_CFG_AUTO = 0,
-  VT_GEMM_CFG_SKINNY = 1,   /* M <= 16 weight-streaming kernel */
+  VT_GEMM_CFG_SKINNY = 1,   /* M <= 16 weight-streaming kernel (per-wave LDS-DMA ring -> MFMA, split-K inside the block) */
   VT_GEMM_CFG_128x128 = 2,
   VT_GEMM_CFG_256x128 = 3,
   VT_GEMM_CFG_256x256 = 4,
   VT_GEMM_CFG_64x128 = 5,
   VT_GEMM_CFG_256x256_P8 = 6, /* 256x256 tile, 8 waves, 8-phase pipelined main loop */
   VT_GEMM_CFG_256x256_W4 = 7, /* 256x256 tile, 4 waves (one per SIMD, 128x128 register tile each) */
-  VT_GEMM_CFG_256x256_RP = 8  /* 256x256 tile, 8 waves, register-pipelined 32x32x16 main loop, one barrier per K tile */
+  VT_GEMM_CFG_256x256_RP = 8, /* 256x256 tile, 8 waves, register-pipelined 32x32x16 main loop, one barrier per K tile */
+  VT_GEMM_CFG_SKINNY_REG = 9  /* M <= 16: weight rows loaded straight into MFMA operand registers; fallback when K % 64 != 0 */
 };
 enum { VT_DTYPE_BF16 = 0, VT_DTYPE_F32 = 1 };
 enum { VT_ACT_GELU = 0, VT_ACT_QUICK_GELU = 1 };
@@ -63,7 +64,7 @@ int vt_last_error(char* buf, size_t buf_len);
  * ---------------------------------------------------------------------------------------------------------- */
 
 /* nn.Linear: C = epi(A[M,K] . W[N,K]^T + bias[N]).  bias may be NULL. C is bf16 or fp32 per `epi`.
- * `scratch` (fp32, >= M*N floats) is only needed for VT_EPI_SWIGLU_BF16 with M <= 16.
+ * `scratch` is reserved (no kernel needs it any more); pass NULL.
  * Replaces every torch.nn.Linear on the path (transformers-4.31 CLIPAttention/CLIPMLP/LlamaAttention/LlamaMLP,
  * reference call sites modeling_video.py:69,71,81; llava_llama.py:49,91-102; multimodal_projector/builder.py:33-51). */
 int vt_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, void* C, int ldc, const float* bias, int M,

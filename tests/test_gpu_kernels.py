@@ -72,6 +72,22 @@ def test_gemm_epilogues_auto(dev, epi_name, M):
     assert rel_l2(got.float(), ref) <= TOL
 
 
+@pytest.mark.parametrize("cfg", [1, 9])
+@pytest.mark.parametrize("M,N,K", [(1, 64, 64), (4, 4096, 4096), (3, 96, 1376), (16, 320, 200), (9, 320, 448), (7, 4096 + 32, 11008), (4, 2048, 8)])
+def test_gemm_skinny_kernels(dev, cfg, M, N, K):
+    """M <= 16 weight-streaming kernels: LDS-DMA ring (cfg 1, default when K % 64 == 0) and register-operand MFMA (cfg 9, also the ragged-K fallback); ragged N/K tails, all epilogues."""
+    from vitron_amd import ops
+    a, w, b = randn((M, K), 21), randn((N, K), 22, 0.05), randn((N,), 23)
+    resid = randn((M, N), 24)
+    for epi in (ops.EPI_BF16, ops.EPI_F32, ops.EPI_BF16_GELU, ops.EPI_BF16_QGELU, ops.EPI_BF16_RELU, ops.EPI_F32_RESID, ops.EPI_SWIGLU_BF16):
+        bias = None if epi == ops.EPI_SWIGLU_BF16 else b.to(dev)
+        out = resid.to(dev).clone() if epi == ops.EPI_F32_RESID else None
+        got = ops.gemm(a.to(dev).bfloat16(), w.to(dev).bfloat16(), bias, epi, out=out, cfg=cfg)
+        ref = _gemm_ref(a, w, None if bias is None else b, epi, resid)
+        assert got.shape == ref.shape
+        assert rel_l2(got.float(), ref) <= TOL, (cfg, epi)
+
+
 def test_gemm_transpose_detecting(dev):
     """A = I-like selector with an ASYMMETRIC W catches row/col swaps of the MFMA C layout."""
     from vitron_amd import ops

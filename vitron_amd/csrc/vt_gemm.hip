@@ -25,8 +25,8 @@
 //     lane-local epilogues (bias, GELU, residual, SwiGLU pairing).
 //   * 1-D grid, XCD-aware + grouped tile order so the 32 CUs of an XCD work on neighbouring tiles.
 //
-// "skinny" kernel: M <= 16 rows (decode steps, region MLP, last-position lm_head): pure weight
-// streaming, one wave per group of output columns, fp32 FMA, wave reduction. HBM-bound.
+// "skinny" kernels: M <= 16 rows (decode steps, region MLP, last-position lm_head): pure weight streaming through a
+// per-wave LDS-DMA ring into 16x16x32 MFMAs, split-K inside the block. HBM-bound.
 #include "vt_common.h"
 #include "vt_kernels.h"
 
@@ -212,133 +212,223 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bt_kernel(GemmP p
 }
 
 // ------------------------------------------------------------------------------------------------
-// skinny GEMM: M <= 16 (decode steps, region MLP, last-position lm_head). Pure weight streaming:
-//   * a block of 4 waves owns 16 output columns (4 per wave); the M activation rows are staged once in LDS as fp32
-//     (converted on the way in), K split in slabs of KSLAB so any K fits,
-//   * every lane streams 16-byte chunks of its wave's 4 weight rows with non-temporal loads, 2 K-chunks unrolled
-//     (8 independent 16-B loads in flight per lane), fp32 FMA, one wave reduction per (column, row) at the end.
-// Roofline: HBM (2*N*K weight bytes per launch, read exactly once).
+// skinny GEMM, register-operand variant (VT_GEMM_CFG_SKINNY_REG; the fallback when K % 64 != 0): M <= 16 rows (decode
+// steps, region MLP, last-position lm_head), pure weight streaming on the matrix cores.
+//   * a block of 8 waves owns 16 output columns (32 = one gate block + one up block for SwiGLU) and splits K eight
+//     ways; partial 16x16 tiles are reduced through 8 KiB of LDS at the end,
+//   * the weight rows are the MFMA "A" operand straight from HBM: lane (i = lane&15, g = lane>>4) loads the 16 bytes
+//     W[n0+i][k + 8g .. +8) -- 64 contiguous bytes per row and instruction, UNR K-steps (32 wide) in flight per lane
+//     and a second group prefetched before the first is consumed,
+//   * the activations are the "B" operand, 16-B loads from L2 by the lanes whose row (lane&15) < M only,
+//   * v_mfma_f32_16x16x32_bf16: lane ends with D[n = 4*(lane>>4)+r][m = lane&15].
+// Roofline: HBM (2*N*K weight bytes per launch, read exactly once); the MFMA pipe idles (one 16x16x32 per KiB).
 // ------------------------------------------------------------------------------------------------
-template <int MROWS, int EPI>
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmP p) {
-  constexpr int NPW = 2;        // output columns per wave
-  constexpr int UNR = 4;        // K chunks in flight per column  -> NPW*UNR = 8 independent 16-B loads per lane
-  constexpr int KSLAB = 2048;   // activation slab staged in LDS: MROWS * KSLAB * 4 B (<= 128 KiB at MROWS = 16)
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* xs = (float*)smem;     // [MROWS][KSLAB]
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_skinny_mfma_kernel(GemmP p) {
+  constexpr int NT = (EPI == VT_EPI_SWIGLU_BF16) ? 2 : 1;   // 16-row weight tiles per block
+  constexpr int NWAVE = 8;
+  constexpr int UNR = (NT == 2) ? 4 : 8;
+  __shared__ float red[NWAVE][NT][256];
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  // plain epilogues: the wave owns columns n0, n0+1. SwiGLU: it owns the (gate, up) pair of output column q -- rows
-  // 32*(q/16) + q%16 and +16 of the block-interleaved weight -- so silu(gate)*up is formed in the same lane.
-  const int q = blockIdx.x * 4 + wave;
-  const int n0 = (EPI == VT_EPI_SWIGLU_BF16) ? ((q >> 4) * 32 + (q & 15)) : q * NPW;
-  constexpr int NSTEP = (EPI == VT_EPI_SWIGLU_BF16) ? 16 : 1;
-  float acc[NPW][MROWS];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, g = lane >> 4;
+  const int n_base = blockIdx.x * 16 * NT;
+  const int steps = (p.K + 31) >> 5;
+  const int s0 = (int)((long)steps * wave / NWAVE), s1 = (int)((long)steps * (wave + 1) / NWAVE);
+  const bf16_t* wp[NT];
 #pragma unroll
-  for (int j = 0; j < NPW; ++j)
+  for (int t = 0; t < NT; ++t) wp[t] = p.W + (size_t)min(n_base + t * 16 + i, p.N - 1) * p.ldw + g * 8;
+  const bf16_t* xp = p.A + (size_t)min(i, p.M - 1) * p.lda + g * 8;
+  const bool xact = i < p.M;
+  f32x4 acc[NT];
 #pragma unroll
-    for (int m = 0; m < MROWS; ++m) acc[j][m] = 0.f;
-  const bf16_t* wrow[NPW];
-#pragma unroll
-  for (int j = 0; j < NPW; ++j) wrow[j] = p.W + (size_t)min(n0 + j * NSTEP, p.N - 1) * p.ldw;
+  for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (int k0 = 0; k0 < p.K; k0 += KSLAB) {
-    const int kw = min(KSLAB, p.K - k0);   // multiple of 8
-    __syncthreads();                       // previous slab fully consumed
-    for (int i = threadIdx.x; i < MROWS * (kw >> 3); i += 256) {
-      const int m = i / (kw >> 3), c = i % (kw >> 3);
-      u32x4 x = {0u, 0u, 0u, 0u};
-      if (m < p.M) x = *(const u32x4*)(p.A + (size_t)m * p.lda + k0 + c * 8);
-      float* d = xs + m * KSLAB + c * 8;
-      *(f32x4*)d = (f32x4){bf16lo_to_f32(x[0]), bf16hi_to_f32(x[0]), bf16lo_to_f32(x[1]), bf16hi_to_f32(x[1])};
-      *(f32x4*)(d + 4) = (f32x4){bf16lo_to_f32(x[2]), bf16hi_to_f32(x[2]), bf16lo_to_f32(x[3]), bf16hi_to_f32(x[3])};
-    }
-    __syncthreads();
-    const int chunks = kw >> 3;
-    for (int c = lane; c < chunks; c += 64 * UNR) {
-      u32x4 w[UNR][NPW];
-#pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        const int cu = c + 64 * u;
-#pragma unroll
-        for (int j = 0; j < NPW; ++j)
-          w[u][j] = (cu < chunks) ? __builtin_nontemporal_load((const u32x4*)(wrow[j] + k0 + cu * 8)) : (u32x4){0u, 0u, 0u, 0u};
-      }
-#pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        const int cu = min(c + 64 * u, chunks - 1);   // out-of-range chunks carry zero weights
-#pragma unroll
-        for (int m = 0; m < MROWS; ++m) {
-          const f32x4 xa = *(const f32x4*)(xs + m * KSLAB + cu * 8);
-          const f32x4 xb = *(const f32x4*)(xs + m * KSLAB + cu * 8 + 4);
-#pragma unroll
-          for (int j = 0; j < NPW; ++j) {
-            const u32x4 ww = w[u][j];
-            float a = acc[j][m];
-            a = fmaf(bf16lo_to_f32(ww[0]), xa[0], a);
-            a = fmaf(bf16hi_to_f32(ww[0]), xa[1], a);
-            a = fmaf(bf16lo_to_f32(ww[1]), xa[2], a);
-            a = fmaf(bf16hi_to_f32(ww[1]), xa[3], a);
-            a = fmaf(bf16lo_to_f32(ww[2]), xb[0], a);
-            a = fmaf(bf16hi_to_f32(ww[2]), xb[1], a);
-            a = fmaf(bf16lo_to_f32(ww[3]), xb[2], a);
-            a = fmaf(bf16hi_to_f32(ww[3]), xb[3], a);
-            acc[j][m] = a;
-          }
-        }
-      }
-    }
+  u32x4 wa[UNR][NT], xa[UNR], wb[UNR][NT], xb[UNR];
+#define SK_LOAD(W_, X_, S_)                                                                               \
+  _Pragma("unroll") for (int u = 0; u < UNR; ++u) {                                                       \
+    const int st = (S_) + u;                                                                              \
+    const bool ok = st < s1 && (st * 32 + g * 8) < p.K;                                                   \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                        \
+      W_[u][t] = ok ? __builtin_nontemporal_load((const u32x4*)(wp[t] + (size_t)st * 32)) : (u32x4){0u, 0u, 0u, 0u}; \
+    X_[u] = (ok && xact) ? *(const u32x4*)(xp + (size_t)st * 32) : (u32x4){0u, 0u, 0u, 0u};              \
   }
-#pragma unroll
-  for (int j = 0; j < NPW; ++j)
-#pragma unroll
-    for (int m = 0; m < MROWS; ++m) acc[j][m] = wave_sum(acc[j][m]);
+#define SK_MFMA(W_, X_)                                                                                   \
+  _Pragma("unroll") for (int u = 0; u < UNR; ++u)                                                         \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                        \
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, W_[u][t]),              \
+                                                       __builtin_bit_cast(bf16x8, X_[u]), acc[t], 0, 0, 0);
+  SK_LOAD(wa, xa, s0);
+  for (int s = s0; s < s1; s += 2 * UNR) {
+    SK_LOAD(wb, xb, s + UNR);
+    SK_MFMA(wa, xa);
+    SK_LOAD(wa, xa, s + 2 * UNR);
+    SK_MFMA(wb, xb);
+  }
+#undef SK_LOAD
+#undef SK_MFMA
 
+#pragma unroll
+  for (int t = 0; t < NT; ++t) *(f32x4*)&red[wave][t][lane * 4] = acc[t];
+  __syncthreads();
+  if (threadIdx.x >= 256) return;
+  const int m = threadIdx.x >> 4, nn = threadIdx.x & 15;
+  if (m >= p.M) return;
+  const int e = (((nn >> 2) * 16 + m) << 2) + (nn & 3);   // lane (m, g = nn>>2) register nn&3
+  float v[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    v[t] = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWAVE; ++w) v[t] += red[w][t][e];
+  }
   if constexpr (EPI == VT_EPI_SWIGLU_BF16) {
-    if (lane == 0 && n0 + 16 < p.N) {
-#pragma unroll
-      for (int m = 0; m < MROWS; ++m)
-        if (m < p.M) ((bf16_t*)p.C)[(size_t)m * p.ldc + q] = f32_to_bf16(silu(acc[0][m]) * acc[1][m]);
-    }
-    return;
-  }
-  if (lane == 0) {
-#pragma unroll
-    for (int j = 0; j < NPW; ++j) {
-      const int n = n0 + j;
-      if (n >= p.N) continue;
-      const float b = p.bias ? p.bias[n] : 0.f;
-#pragma unroll
-      for (int m = 0; m < MROWS; ++m) {
-        if (m >= p.M) continue;
-        float v = acc[j][m] + b;
-        if constexpr (EPI == VT_EPI_BF16_GELU) v = gelu_erf(v);
-        if constexpr (EPI == VT_EPI_BF16_QGELU) v = quick_gelu(v);
-        if constexpr (EPI == VT_EPI_BF16_RELU) v = fmaxf(v, 0.f);
-        if constexpr (EPI == VT_EPI_F32_RESID) {
-          float* c = (float*)p.C + (size_t)m * p.ldc + n;
-          *c = *c + v;
-        } else if constexpr (EPI == VT_EPI_F32) {
-          ((float*)p.C)[(size_t)m * p.ldc + n] = v;
-        } else {
-          ((bf16_t*)p.C)[(size_t)m * p.ldc + n] = f32_to_bf16(v);
-        }
-      }
+    const int q = blockIdx.x * 16 + nn;                      // output column; gate row n_base+nn, up row n_base+16+nn
+    if (n_base + 16 + nn < p.N) ((bf16_t*)p.C)[(size_t)m * p.ldc + q] = f32_to_bf16(silu(v[0]) * v[NT - 1]);
+  } else {
+    const int n = n_base + nn;
+    if (n >= p.N) return;
+    float r = v[0] + (p.bias ? p.bias[n] : 0.f);
+    if constexpr (EPI == VT_EPI_BF16_GELU) r = gelu_erf(r);
+    if constexpr (EPI == VT_EPI_BF16_QGELU) r = quick_gelu(r);
+    if constexpr (EPI == VT_EPI_BF16_RELU) r = fmaxf(r, 0.f);
+    if constexpr (EPI == VT_EPI_F32_RESID) {
+      float* c = (float*)p.C + (size_t)m * p.ldc + n;
+      *c = *c + r;
+    } else if constexpr (EPI == VT_EPI_F32) {
+      ((float*)p.C)[(size_t)m * p.ldc + n] = r;
+    } else {
+      ((bf16_t*)p.C)[(size_t)m * p.ldc + n] = f32_to_bf16(r);
     }
   }
 }
 
-// SwiGLU for the skinny path: gate/up come out of the interleaved weight as separate columns, so the
-// skinny kernel writes fp32 [M][N] to scratch and this kernel pairs them.
-__global__ void swiglu_pair_kernel(const float* gu, bf16_t* out, int M, int N, int ldo) {
-  const int half = N >> 1;
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= M * half) return;
-  const int m = idx / half, j = idx % half;
-  const int blk = j >> 4, r = j & 15;
-  const float g = gu[(size_t)m * N + blk * 32 + r];
-  const float u = gu[(size_t)m * N + blk * 32 + 16 + r];
-  out[(size_t)m * ldo + j] = f32_to_bf16(silu(g) * u);
+// ------------------------------------------------------------------------------------------------
+// skinny GEMM, LDS-DMA weight stream (default for M <= 16 when K % 64 == 0):
+//   * a block of NWAVE waves owns 16*NT weight rows (NT = 2 for SwiGLU: one gate block + one up block) and splits K;
+//     every wave runs ALONE on a private ring of R slots in LDS -- no block barrier until the final split-K reduce,
+//   * one slot = one 64-wide K step: NT*2 `global_load_lds` instructions of 8 rows x 128 B for the weights (nt policy:
+//     read once) + 1 (M <= 8) or 2 for the activation rows, all XOR-swizzled on the source side exactly like the tile
+//     kernel, so the 16-B MFMA fragment reads are conflict-free,
+//   * counted `s_waitcnt vmcnt` keeps (R-1) K steps of DMA in flight per wave while the oldest slot is consumed by
+//     two v_mfma_f32_16x16x32_bf16 per weight tile (weights = "A" operand, activations = "B": lane ends with
+//     D[n = 4*(lane>>4)+r][m = lane&15]); activation rows >= M hold whatever the ring held -- they only reach output
+//     columns m >= M, which are never stored.
+// Roofline: HBM (2*N*K weight bytes per launch, read exactly once).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void glds16_nt(const void* gsrc, void* lds_dst_wave_uniform) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_dst_wave_uniform, 16, 0, 2);
+}
+template <int N>
+__device__ __forceinline__ void vmcnt_wait() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int EPI, int XI, int NWAVE, int R>
+__global__ __launch_bounds__(64 * NWAVE) void gemm_skinny_dma_kernel(GemmP p) {
+  constexpr int NT = (EPI == VT_EPI_SWIGLU_BF16) ? 2 : 1;   // 16-row weight tiles per block
+  constexpr int PS = NT * 2 + XI;                            // DMA instructions per K step
+  constexpr int SLOT = PS * 1024;
+  static_assert((R & (R - 1)) == 0 && (R - 1) * PS <= 63, "ring depth");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ float red[NWAVE][NT][256];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  char* ring = smem + wave * (R * SLOT);
+  const int n_base = blockIdx.x * 16 * NT;
+  const int steps = p.K >> 6;
+  const int s0 = (int)((long)steps * wave / NWAVE), s1 = (int)((long)steps * (wave + 1) / NWAVE);
+  const int n = s1 - s0;
+
+  // DMA sources at K step 0: lane -> (row = lane>>3 of an 8-row piece, 16-B chunk lane&7, swizzled on the source side)
+  const int lrow = lane >> 3, lchk = lane & 7;
+  const bf16_t* wsrc[NT * 2];
+#pragma unroll
+  for (int q = 0; q < NT * 2; ++q) {
+    const int row = (q & 1) * 8 + lrow;                      // row inside the 16-row tile
+    const int csrc = lchk ^ ((row >> 1) & 7);
+    wsrc[q] = p.W + (size_t)min(n_base + (q >> 1) * 16 + row, p.N - 1) * p.ldw + csrc * 8;
+  }
+  const bf16_t* xsrc[XI];
+#pragma unroll
+  for (int q = 0; q < XI; ++q) {
+    const int row = q * 8 + lrow;
+    const int csrc = lchk ^ ((row >> 1) & 7);
+    xsrc[q] = p.A + (size_t)min(row, p.M - 1) * p.lda + csrc * 8;
+  }
+  auto issue = [&](int step, int slot) {
+    char* base = ring + slot * SLOT;
+    const size_t ko = (size_t)step * 64;
+#pragma unroll
+    for (int q = 0; q < NT * 2; ++q) glds16_nt(wsrc[q] + ko, base + q * 1024);
+#pragma unroll
+    for (int q = 0; q < XI; ++q) glds16(xsrc[q] + ko, base + (NT * 2 + q) * 1024);
+  };
+  const int f = (lane >> 1) & 7;
+  const int frag_off0 = (lane & 15) * 128 + (((lane >> 4) ^ f) << 4);
+  const int frag_off1 = (lane & 15) * 128 + ((((lane >> 4) | 4) ^ f) << 4);
+
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+    if (r < n) issue(s0 + r, r);
+  for (int i = 0; i < n; ++i) {
+    if (i + R <= n) vmcnt_wait<(R - 1) * PS>(); else vmcnt_wait<0>();
+    const char* sb = ring + (i & (R - 1)) * SLOT;
+    bf16x8 wf[NT][2], xf[2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      wf[t][0] = *(const bf16x8*)(sb + t * 2048 + frag_off0);
+      wf[t][1] = *(const bf16x8*)(sb + t * 2048 + frag_off1);
+    }
+    xf[0] = *(const bf16x8*)(sb + NT * 2048 + frag_off0);   // XI == 1: rows >= 8 read past the 8-row piece (next slot / reduce
+    xf[1] = *(const bf16x8*)(sb + NT * 2048 + frag_off1);   // buffer): garbage confined to output columns m >= 8 > M
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (i + R < n) issue(s0 + i + R, i & (R - 1));
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][0], xf[0], acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][1], xf[1], acc[t], 0, 0, 0);
+    }
+  }
+
+#pragma unroll
+  for (int t = 0; t < NT; ++t) *(f32x4*)&red[wave][t][lane * 4] = acc[t];
+  __syncthreads();
+  if (threadIdx.x >= 256) return;
+  const int m = threadIdx.x >> 4, nn = threadIdx.x & 15;
+  if (m >= p.M) return;
+  const int e = (((nn >> 2) * 16 + m) << 2) + (nn & 3);   // lane (m, g = nn>>2), register nn&3
+  float v[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    v[t] = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWAVE; ++w) v[t] += red[w][t][e];
+  }
+  if constexpr (EPI == VT_EPI_SWIGLU_BF16) {
+    const int q = blockIdx.x * 16 + nn;                      // output column; gate row n_base+nn, up row n_base+16+nn
+    if (n_base + 16 + nn < p.N) ((bf16_t*)p.C)[(size_t)m * p.ldc + q] = f32_to_bf16(silu(v[0]) * v[NT - 1]);
+  } else {
+    const int nc = n_base + nn;
+    if (nc >= p.N) return;
+    float r = v[0] + (p.bias ? p.bias[nc] : 0.f);
+    if constexpr (EPI == VT_EPI_BF16_GELU) r = gelu_erf(r);
+    if constexpr (EPI == VT_EPI_BF16_QGELU) r = quick_gelu(r);
+    if constexpr (EPI == VT_EPI_BF16_RELU) r = fmaxf(r, 0.f);
+    if constexpr (EPI == VT_EPI_F32_RESID) {
+      float* c = (float*)p.C + (size_t)m * p.ldc + nc;
+      *c = *c + r;
+    } else if constexpr (EPI == VT_EPI_F32) {
+      ((float*)p.C)[(size_t)m * p.ldc + nc] = r;
+    } else {
+      ((bf16_t*)p.C)[(size_t)m * p.ldc + nc] = f32_to_bf16(r);
+    }
+  }
 }
 
 template <int BM, int BN, int WM, int WN, int EPI>
@@ -367,26 +457,36 @@ int launch_cfg(const GemmP& p, int cfg, hipStream_t s) {
   }
 }
 
-template <int MR, int EPI>
-int launch_skinny_m(const GemmP& p, hipStream_t s) {
-  constexpr int smem = MR * 2048 * 4;
-  auto kern = gemm_skinny_kernel<MR, EPI>;
+template <int EPI>
+int launch_skinny_mfma(const GemmP& p, hipStream_t s) {
+  const int rows_per_block = (EPI == VT_EPI_SWIGLU_BF16) ? 32 : 16;
+  hipLaunchKernelGGL(gemm_skinny_mfma_kernel<EPI>, dim3(cdiv(p.N, rows_per_block)), dim3(512), 0, s, p);
+  VT_LAUNCH_CHECK();
+  return VT_OK;
+}
+
+template <int EPI, int XI, int NWAVE, int R>
+int launch_skinny_dma_cfg(const GemmP& p, hipStream_t s) {
+  constexpr int NT = (EPI == VT_EPI_SWIGLU_BF16) ? 2 : 1;
+  constexpr int smem = NWAVE * R * (NT * 2 + XI) * 1024 + ((XI == 1) ? 1024 : 0);  // + slack for the XI == 1 over-read of the last slot
+  static_assert(smem + NWAVE * NT * 1024 <= 160 * 1024, "ring does not fit the 160 KiB LDS");
+  auto kern = gemm_skinny_dma_kernel<EPI, XI, NWAVE, R>;
   static bool done = false;
   if (!done) {
     VT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     done = true;
   }
-  const int waves = (EPI == VT_EPI_SWIGLU_BF16) ? p.N / 2 : cdiv(p.N, 2);
-  hipLaunchKernelGGL(kern, dim3(cdiv(waves, 4)), dim3(256), smem, s, p);
+  hipLaunchKernelGGL(kern, dim3(cdiv(p.N, 16 * NT)), dim3(64 * NWAVE), smem, s, p);
   VT_LAUNCH_CHECK();
   return VT_OK;
 }
 
 template <int EPI>
-int launch_skinny(const GemmP& p, hipStream_t s) {
-  if (p.M <= 4) return launch_skinny_m<4, EPI>(p, s);
-  if (p.M <= 8) return launch_skinny_m<8, EPI>(p, s);
-  return launch_skinny_m<16, EPI>(p, s);
+int launch_skinny(const GemmP& p, hipStream_t s, bool reg_operands) {
+  // measured on MI355X (tools/skinny_bench.py): 4 waves x 4-slot rings beat 8x4, 4x8 and 2x8 on every decode shape
+  if (reg_operands || (p.K % 64) != 0) return launch_skinny_mfma<EPI>(p, s);
+  if (p.M <= 8) return launch_skinny_dma_cfg<EPI, 1, 4, 4>(p, s);
+  return launch_skinny_dma_cfg<EPI, 2, 4, 4>(p, s);
 }
 
 }  // namespace
@@ -417,10 +517,10 @@ int vt_gemm_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, 
              "vt_gemm: A/W/C must be 16-byte aligned");
   VT_REQUIRE(ldc % 4 == 0, "vt_gemm: ldc must be a multiple of 4");
   GemmP p{A, W, C, bias, M, N, K, lda, ldw, ldc};
-  const bool skinny_path = (M <= 16) && (cfg == VT_GEMM_CFG_AUTO || cfg == VT_GEMM_CFG_SKINNY);
+  const bool skinny_path = (M <= 16) && (cfg == VT_GEMM_CFG_AUTO || cfg == VT_GEMM_CFG_SKINNY || cfg == VT_GEMM_CFG_SKINNY_REG);
   if (!skinny_path) {
     VT_REQUIRE((K % 64) == 0, "vt_gemm(tile): K=%d must be a multiple of 64", K);
-  if (cfg == VT_GEMM_CFG_AUTO || cfg == VT_GEMM_CFG_SKINNY) {
+  if (cfg == VT_GEMM_CFG_AUTO || cfg == VT_GEMM_CFG_SKINNY || cfg == VT_GEMM_CFG_SKINNY_REG) {
       cfg = vt_gemm_pick_cfg(M, N, K);
       // Wave quantisation: when the 256x256 grid would leave most of its last round of CUs idle (e.g. M=5120, N=4096:
       // 320 tiles = 1.25 rounds), run the rows that fill WHOLE rounds on the 256x256 kernel and the remaining rows on the
@@ -443,19 +543,19 @@ int vt_gemm_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, 
   // algorithmic work: 2*M*N*K FLOP for the MFMA tile kernel; weight bytes for the weight-streaming kernel
   VtProfScope prof(skinny_path ? VT_PROF_GEMM_SKINNY : VT_PROF_GEMM_TILE,
                    skinny_path ? 2.0 * (double)N * (double)K : 2.0 * (double)M * (double)N * (double)K, s);
-  const bool skinny = (M <= 16) && (cfg == VT_GEMM_CFG_AUTO || cfg == VT_GEMM_CFG_SKINNY);
-  if (skinny) {
+  if (skinny_path) {
+    const bool fma = cfg == VT_GEMM_CFG_SKINNY_REG;   // register-operand kernel on request; it is also the ragged-K fallback
     VT_REQUIRE((K % 8) == 0, "vt_gemm(skinny): K=%d must be a multiple of 8", K);
     switch (epi) {
-      case VT_EPI_BF16: return launch_skinny<VT_EPI_BF16>(p, s);
-      case VT_EPI_BF16_GELU: return launch_skinny<VT_EPI_BF16_GELU>(p, s);
-      case VT_EPI_BF16_QGELU: return launch_skinny<VT_EPI_BF16_QGELU>(p, s);
-      case VT_EPI_BF16_RELU: return launch_skinny<VT_EPI_BF16_RELU>(p, s);
-      case VT_EPI_F32_RESID: return launch_skinny<VT_EPI_F32_RESID>(p, s);
-      case VT_EPI_F32: return launch_skinny<VT_EPI_F32>(p, s);
+      case VT_EPI_BF16: return launch_skinny<VT_EPI_BF16>(p, s, fma);
+      case VT_EPI_BF16_GELU: return launch_skinny<VT_EPI_BF16_GELU>(p, s, fma);
+      case VT_EPI_BF16_QGELU: return launch_skinny<VT_EPI_BF16_QGELU>(p, s, fma);
+      case VT_EPI_BF16_RELU: return launch_skinny<VT_EPI_BF16_RELU>(p, s, fma);
+      case VT_EPI_F32_RESID: return launch_skinny<VT_EPI_F32_RESID>(p, s, fma);
+      case VT_EPI_F32: return launch_skinny<VT_EPI_F32>(p, s, fma);
       case VT_EPI_SWIGLU_BF16:
         VT_REQUIRE((N % 32) == 0, "vt_gemm(swiglu): N must be a multiple of 32");
-        return launch_skinny<VT_EPI_SWIGLU_BF16>(p, s);
+        return launch_skinny<VT_EPI_SWIGLU_BF16>(p, s, fma);
       default: vt_set_error("vt_gemm: unknown epilogue %d", epi); return VT_ERR_ARG;
     }
   }

@@ -52,11 +52,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
             raise _lib.VitronHipError("gemm: EPI_F32_RESID needs `out` (the fp32 residual stream)")
         out = torch.empty((M, n_out), device=a.device, dtype=odt)
     _chk(out, odt, "gemm.out")
-    scratch = None
-    if epi == EPI_SWIGLU_BF16 and M <= 16:
-        scratch = torch.empty((M, N), device=a.device, dtype=torch.float32)
     _lib.check(lib.vt_gemm_bf16(_p(a), a.stride(0), _p(w), w.stride(0), _p(out), out.stride(0), _p(bias), M, N, K, epi,
-                                cfg, _p(scratch), _stream()), "vt_gemm_bf16")
+                                cfg, None, _stream()), "vt_gemm_bf16")
     return out
 
 
