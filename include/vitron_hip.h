@@ -88,6 +88,16 @@ int vt_rmsnorm(const float* x, const int* idx, const float* w, uint16_t* y, int 
 int vt_flash_attn(const uint16_t* Q, int ldq, const uint16_t* k_tiles, const uint16_t* vt_tiles, const int* tile_table,
                   const int* seq_desc, int nseq, int max_q_len, uint16_t* O, int ldo, int heads, int head_dim,
                   int causal, float scale, void* stream);
+/* One decode step's attention in one launch (every sequence has q_len == 1; kv_len counts the new token): rotary
+ * embedding of the new q/k rows (rope tables may be NULL), append of the new k row / v column to the paged tiles (a tile
+ * that starts with the new token is zero-filled around it), single-query attention over the cache. qkv is not modified.
+ * Equivalent to vt_kv_tiles + vt_attn_decode; replaces LlamaAttention's cached single-token step
+ * (transformers 4.31 LlamaAttention.forward as called from vitron/model/language_model/llava_llama.py:91-102). */
+int vt_attn_decode_fused(const uint16_t* qkv, int ldqkv, int q_col0, int k_col0, int v_col0, uint16_t* k_tiles,
+                         uint16_t* vt_tiles, const int* tile_table, const int* seq_desc, int nseq, uint16_t* O, int ldo,
+                         int heads, int head_dim, float scale, const float* rope_cos, const float* rope_sin,
+                         const int* positions, void* stream);
+
 /* single-query (q_len == 1) attention, split over the KV tiles; scratch >= vt_attn_decode_scratch_bytes(...) */
 size_t vt_attn_decode_scratch_bytes(int nseq, int heads, int head_dim, int max_kv_len);
 int vt_attn_decode(const uint16_t* Q, int ldq, const uint16_t* k_tiles, const uint16_t* vt_tiles, const int* tile_table,

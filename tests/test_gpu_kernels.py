@@ -215,6 +215,66 @@ def test_attention_with_past_rope_and_decode(dev):
         done += chunk
 
 
+@pytest.mark.parametrize("hd", [64, 128])
+def test_attn_decode_fused_matches_unfused(dev, hd):
+    """vt_attn_decode_fused == vt_kv_tiles + vt_attn_decode: same outputs, bit-identical K / V^T tiles; covers a new token that
+    starts a page (the page is poisoned with NaN first: the kernel must zero-fill it), page ends, multi-page contexts, batch 3."""
+    from oracle import vitron_oracle as O
+    from vitron_amd import ops
+    heads = 4
+    D = heads * hd
+    cos, sin = O.rope_tables(hd, 2048)
+    cd, sd_ = cos.to(dev).contiguous(), sin.to(dev).contiguous()
+    scale = 1.0 / math.sqrt(hd)
+    npages = 40
+    pasts = [0, 63, 64, 127, 700, 1024]
+    for trial, past_set in enumerate([pasts[:3], pasts[3:], [5, 64, 1300]]):
+        nseq = len(past_set)
+        nan = float("nan")
+        kt_a = torch.full((npages * heads * 64 * hd,), nan, dtype=torch.bfloat16, device=dev)
+        vt_a = torch.full_like(kt_a, nan)
+        # page tables: disjoint shuffled pages per sequence
+        perm = torch.randperm(npages, generator=torch.Generator().manual_seed(50 + trial)).tolist()
+        tables, descs, off = [], [], 0
+        for i, past in enumerate(past_set):
+            nt = past // 64 + 1
+            tables += perm[off:off + nt]
+            descs.append((off, past))
+            off += nt
+        table = torch.tensor(tables, dtype=torch.int32, device=dev)
+        # fill the past with a prefill through kv_tiles (zero-fills the padding of every touched page)
+        for i, (toff, past) in enumerate(descs):
+            if past == 0:
+                continue
+            x = randn((past, 3 * D), 60 + i + 10 * trial).to(dev).bfloat16()
+            pos = torch.arange(0, past, dtype=torch.int32, device=dev)
+            d = torch.tensor([[0, past, past, toff]], dtype=torch.int32, device=dev)
+            ops.kv_tiles(x, 0, D, 2 * D, kt_a, vt_a, table, d, (past - 1) // 64 + 1, heads, hd, cd, sd_, pos)
+        kt_b, vt_b = kt_a.clone(), vt_a.clone()
+        # one decode step for all sequences at once
+        x = randn((nseq, 3 * D), 90 + trial).to(dev).bfloat16()
+        pos = torch.tensor([p for _, p in descs], dtype=torch.int32, device=dev)
+        desc = torch.tensor([[i, 1, p + 1, toff] for i, (toff, p) in enumerate(descs)], dtype=torch.int32, device=dev)
+        xa = x.clone()
+        ops.kv_tiles(xa, 0, D, 2 * D, kt_a, vt_a, table, desc, 1, heads, hd, cd, sd_, pos)   # rotates q in place
+        ref = ops.attn_decode(xa, kt_a, vt_a, table, desc, heads, hd, scale, max(p for _, p in descs) + 1)
+        xb = x.clone()
+        got = ops.attn_decode_fused(xb, 0, D, 2 * D, kt_b, vt_b, table, desc, heads, hd, scale, cd, sd_, pos)
+        torch.cuda.synchronize()
+        assert torch.equal(xb, x), "fused kernel must not modify qkv"
+        assert torch.isfinite(got.float()).all()
+        assert rel_l2(got.float(), ref.float()) <= 2e-3, (trial, rel_l2(got.float(), ref.float()))
+        # every page of every sequence: identical bits (incl. zero padding of a freshly started page)
+        used = torch.zeros(npages, dtype=torch.bool)
+        used[tables] = True
+        ka = kt_a.view(npages, -1)[used.to(dev)]
+        kb = kt_b.view(npages, -1)[used.to(dev)]
+        va = vt_a.view(npages, -1)[used.to(dev)]
+        vb = vt_b.view(npages, -1)[used.to(dev)]
+        assert torch.equal(ka.view(torch.int16), kb.view(torch.int16))
+        assert torch.equal(va.view(torch.int16), vb.view(torch.int16))
+
+
 def test_temporal_attention(dev):
     from vitron_amd import ops
     B, T, N, heads = 2, 8, 5, 2

@@ -152,6 +152,15 @@ int vt_attn_decode(const uint16_t* Q, int ldq, const uint16_t* k_tiles, const ui
                                head_dim, scale, max_kv_len, (float*)scratch, scratch_bytes, S(stream));
 }
 
+int vt_attn_decode_fused(const uint16_t* qkv, int ldqkv, int q_col0, int k_col0, int v_col0, uint16_t* k_tiles,
+                         uint16_t* vt_tiles, const int* tile_table, const int* seq_desc, int nseq, uint16_t* O, int ldo,
+                         int heads, int head_dim, float scale, const float* rope_cos, const float* rope_sin,
+                         const int* positions, void* stream) {
+  return vt_attn_decode_fused_launch(qkv, ldqkv, q_col0, k_col0, v_col0, k_tiles, vt_tiles, tile_table,
+                                     (const VtAttnSeq*)seq_desc, nseq, O, ldo, heads, head_dim, scale, rope_cos, rope_sin,
+                                     positions, S(stream));
+}
+
 int vt_kv_tiles(uint16_t* qkv, int ldqkv, int q_col0, int k_col0, int v_col0, uint16_t* k_tiles, uint16_t* vt_tiles,
                 const int* tile_table, const int* seq_desc, int nseq, int max_new_tiles, int heads, int head_dim,
                 const float* rope_cos, const float* rope_sin, const int* positions, void* stream) {
@@ -400,14 +409,15 @@ int vt_llama_forward(const vt_llama_model* m, const vt_kv_cache* kv, const uint1
     bf16_t* vt = kv->vt + l * layer_stride;
     VT_TRY(vt_rmsnorm_launch(w.x, nullptr, L.rms1, w.y, rows, H, m->rms_eps, s));
     VT_TRY(vt_gemm_launch(w.y, H, L.wqkv, H, w.qkv, 3 * H, nullptr, rows, 3 * H, H, VT_EPI_BF16, AUTO, nullptr, s));
-    VT_TRY(vt_kv_tiles_launch(w.qkv, 3 * H, 0, H, 2 * H, kt, vt, tile_table, (const VtAttnSeq*)seq_desc, nseq,
-                              max_new_tiles, heads, HD, m->rope_cos, m->rope_sin, positions, s));
-    if (max_q_len == 1)
-      VT_TRY(vt_attn_decode_launch(w.qkv, 3 * H, kt, vt, tile_table, (const VtAttnSeq*)seq_desc, nseq, w.att, H, heads, HD, scale,
-                                   max_kv_len, w.attn_scratch, w.attn_scratch_bytes, s));
-    else
+    if (max_q_len == 1) {   // decode step: rotary + append + attention + combine in one launch
+      VT_TRY(vt_attn_decode_fused_launch(w.qkv, 3 * H, 0, H, 2 * H, kt, vt, tile_table, (const VtAttnSeq*)seq_desc, nseq, w.att, H,
+                                         heads, HD, scale, m->rope_cos, m->rope_sin, positions, s));
+    } else {
+      VT_TRY(vt_kv_tiles_launch(w.qkv, 3 * H, 0, H, 2 * H, kt, vt, tile_table, (const VtAttnSeq*)seq_desc, nseq,
+                                max_new_tiles, heads, HD, m->rope_cos, m->rope_sin, positions, s));
       VT_TRY(vt_flash_attn_launch(w.qkv, 3 * H, kt, vt, tile_table, (const VtAttnSeq*)seq_desc, nseq, max_q_len, w.att, H,
                                   heads, HD, 1, scale, s));
+    }
     VT_TRY(vt_gemm_launch(w.att, H, L.wo, H, w.x, H, nullptr, rows, H, H, VT_EPI_F32_RESID, AUTO, nullptr, s));
     VT_TRY(vt_rmsnorm_launch(w.x, nullptr, L.rms2, w.y, rows, H, m->rms_eps, s));
     VT_TRY(vt_gemm_launch(w.y, H, L.wgu, H, w.h, I, nullptr, rows, 2 * I, H, VT_EPI_SWIGLU_BF16, AUTO, w.scratch, s));

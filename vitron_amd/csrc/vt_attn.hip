@@ -391,11 +391,51 @@ __global__ __launch_bounds__(256) void kv_tiles_kernel(bf16_t* __restrict__ qkv,
   }
 }
 
+// lane ^ MASK exchange inside groups of 16 lanes without an LDS address: DPP quad_perm (1, 2), row_ror:8 (8), ds_swizzle (4)
+template <int MASK>
+__device__ __forceinline__ float lane_xor16(float v) {
+  int x = __builtin_bit_cast(int, v);
+  if constexpr (MASK == 1) x = __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true);
+  else if constexpr (MASK == 2) x = __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true);
+  else if constexpr (MASK == 8) x = __builtin_amdgcn_update_dpp(0, x, 0x128, 0xF, 0xF, true);
+  else x = __builtin_amdgcn_ds_swizzle(x, (MASK << 10) | 0x1F);
+  return __builtin_bit_cast(float, x);
+}
+// CH lanes (c = lane % CH) each hold CH partial sums part[i]; on return part[0] is the FULL sum of value i == c.
+// Recursive halving: CH - 1 exchanges instead of CH * log2(CH) for one butterfly per value.
+template <int CH>
+__device__ __forceinline__ float reduce_scatter_lanes(float (&part)[CH], int c) {
+#define VT_RS_STEP(N)                                                   \
+  if constexpr (CH >= 2 * (N)) {                                        \
+    const bool up = (c & (N)) != 0;                                     \
+    _Pragma("unroll") for (int j = 0; j < (N); ++j) {                   \
+      const float send = up ? part[j] : part[j + (N)];                  \
+      const float mine = up ? part[j + (N)] : part[j];                  \
+      part[j] = mine + lane_xor16<(N)>(send);                           \
+    }                                                                   \
+  }
+  VT_RS_STEP(8)
+  VT_RS_STEP(4)
+  VT_RS_STEP(2)
+  VT_RS_STEP(1)
+#undef VT_RS_STEP
+  return part[0];
+}
+template <int CH>
+__device__ __forceinline__ float allreduce_lanes(float v) {
+  if constexpr (CH >= 16) v += lane_xor16<8>(v);
+  if constexpr (CH >= 8) v += lane_xor16<4>(v);
+  v += lane_xor16<2>(v);
+  v += lane_xor16<1>(v);
+  return v;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // attn_decode_kernel: single-query attention over the paged tiles, flash-decoding style. HBM-bound: the whole job is
 // to stream K and V^T tiles once, fully coalesced, with enough waves in flight.
 //   grid (head, sequence, split); 4 waves per block; wave w of split s owns tiles t = 4*s + w, 4*s + w + 4*nsplit, ...
-//   scores : 16 (HD=128) lanes cooperate on one 256-B K row, 4 rows per wave-instruction, shuffle-reduce per row
+//   scores : 16 (HD=128) lanes cooperate on one 256-B K row, 4 rows per wave-instruction; the 16 partial sums per lane are
+//            reduce-scattered over the 16 lanes (15 DPP/swizzle exchanges per tile), lane ends up owning key (lane%16)*4 + lane/16
 //   PV     : 8 lanes cooperate on one 128-B V^T row (8 rows per wave-instruction = 8 full cache lines); every lane
 //            keeps HD/8 partial accumulators and the cross-lane reduction happens ONCE after the last tile
 //   each block writes an online-softmax partial (m, l, o[HD]) to scratch; attn_decode_combine_kernel merges the splits.
@@ -430,39 +470,40 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
 #pragma unroll
   for (int i = 0; i < NACC; ++i) acc[i] = 0.f;
   const int vrow = lane >> 3, vchk = lane & 7;
+  const int key_of_lane = c * KPI + lane / CH;   // the key (inside a tile) whose score this lane ends up owning
 
   for (int t = split * 4 + wave; t < ntiles; t += 4 * nsplit) {
     const size_t toff = ((size_t)tile_table[sq.table_off + t] * heads + head) * 64 * HD;
     const bf16_t* kt = Kt + toff;
     const bf16_t* vt = Vt + toff;
-    // issue the V^T loads early: they do not depend on the scores
-    u32x4 vv[NACC];
+    // the whole tile (16 KiB of K + 16 KiB of V^T) is requested before anything is consumed
+    u32x4 kk[CH], vv[NACC];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) kk[i] = __builtin_nontemporal_load((const u32x4*)(kt + (i * KPI + lane / CH) * HD + c * 8));
 #pragma unroll
     for (int i = 0; i < NACC; ++i) vv[i] = __builtin_nontemporal_load((const u32x4*)(vt + (i * 8 + vrow) * 64 + vchk * 8));
-    float s_mine = -INFINITY;  // lane ends up owning key == lane
+    __builtin_amdgcn_sched_barrier(0);
+    float part[CH];
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
-      const int key = i * KPI + lane / CH;
-      const u32x4 kv = __builtin_nontemporal_load((const u32x4*)(kt + key * HD + c * 8));
+      const u32x4 kv = kk[i];
       float part_s = 0.f;
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
         part_s = fmaf(bf16lo_to_f32(kv[w]), qf[2 * w], part_s);
         part_s = fmaf(bf16hi_to_f32(kv[w]), qf[2 * w + 1], part_s);
       }
-#pragma unroll
-      for (int off = 1; off < CH; off <<= 1) part_s += __shfl_xor(part_s, off, 64);
-      const float sc = __shfl(part_s, (lane % KPI) * CH, 64);  // score of key i*KPI + lane%KPI
-      if ((lane / KPI) == i) s_mine = sc;
+      part[i] = part_s;
     }
-    const int mykey = t * 64 + lane;
+    const float s_mine = reduce_scatter_lanes<CH>(part, c);   // full score of key c*KPI + lane/CH
+    const int mykey = t * 64 + key_of_lane;
     const float s2 = (mykey < sq.kv_len) ? s_mine * scale_log2e : -INFINITY;
     const float m_new = fmaxf(m_run, wave_max(s2));
     const float alpha = fast_exp2(m_run - m_new);
     const float p = fast_exp2(s2 - m_new);
     l_run = l_run * alpha + wave_sum(p);
     m_run = m_new;
-    sm_p[wave][lane] = p;
+    sm_p[wave][key_of_lane] = p;
     __builtin_amdgcn_wave_barrier();  // DS ops of one wave are in order; only stop compiler reordering
     const f32x4 pa = *(const f32x4*)(&sm_p[wave][vchk * 8]);
     const f32x4 pb = *(const f32x4*)(&sm_p[wave][vchk * 8 + 4]);
@@ -541,6 +582,223 @@ __global__ __launch_bounds__(64) void attn_decode_combine_kernel(const float* __
   bf16_t* op = O + (size_t)seqs[seq].q_row0 * ldo + head * HD;
 #pragma unroll
   for (int i = 0; i < HD / 64; ++i) op[lane + 64 * i] = f32_to_bf16(o[i] * inv);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// attn_decode_fused_kernel: the whole attention part of one decode step of one layer in ONE launch (q_len == 1):
+//   rotary embedding of the new q and k rows, append of the new k row / v column to the paged tiles, single-query
+//   attention over the cache, combine. Replaces kv_tiles + attn_decode + attn_decode_combine (3 launches, 2 boundaries).
+//   grid (head, sequence), 8 waves per block: wave w owns tiles w, w + 8, ... of its (sequence, head) and streams them
+//   exactly like attn_decode_kernel (K rows by 16-lane groups, V^T rows by 8-lane groups, everything of a tile in
+//   flight at once); the 8 online-softmax partials meet in LDS -- no scratch, no cross-block traffic. One head of one
+//   sequence is <= 1 MiB of K/V^T at 2048 tokens, which one CU streams in a few microseconds.
+//   The wave that owns the LAST tile also owns the new token: it rotates k, scores it from registers, stores the k row
+//   and the v column, and adds p_new * v_new to its accumulators. A tile that STARTS with the new token is zero-filled
+//   around it (same invariant as kv_tiles_kernel: padding rows/columns of a tile are zero, never garbage).
+// ------------------------------------------------------------------------------------------------------------------
+template <int HD, bool ROPE>
+__global__ __launch_bounds__(512) void attn_decode_fused_kernel(
+    const bf16_t* __restrict__ qkv, int ldqkv, int q_col0, int k_col0, int v_col0, bf16_t* __restrict__ Kt,
+    bf16_t* __restrict__ Vt, const int* __restrict__ tile_table, const VtAttnSeq* __restrict__ seqs, int heads,
+    const float* __restrict__ rope_cos, const float* __restrict__ rope_sin, const int* __restrict__ positions,
+    float scale_log2e, bf16_t* __restrict__ O, int ldo) {
+  constexpr int NW = 8;
+  constexpr int CH = HD / 8;        // 16-B chunks per K row; CH lanes cooperate on one key
+  constexpr int KPI = 64 / CH;      // keys per wave-instruction
+  constexpr int NACC = HD / 8;      // V^T rows handled per lane
+  __shared__ float sm_m[NW], sm_l[NW];
+  __shared__ float sm_o[NW][HD];
+  __shared__ __attribute__((aligned(16))) float sm_p[NW][64];
+  __shared__ __attribute__((aligned(16))) bf16_t sm_v[HD];
+  const VtAttnSeq sq = seqs[blockIdx.y];
+  const int head = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int past = sq.kv_len - 1;
+  const int t_last = past >> 6, r_new = past & 63, ntiles = t_last + 1;
+  const bf16_t* qrow = qkv + (size_t)sq.q_row0 * ldqkv;
+  const int c = lane % CH, ch = c % (CH / 2);
+  const bool upper = c >= CH / 2;
+  constexpr bool rope = ROPE;
+  const int vrow = lane >> 3, vchk = lane & 7;
+  const int key_of_lane = c * KPI + lane / CH;   // the key (inside a tile) whose score this lane ends up owning
+  float m_run = -INFINITY, l_run = 0.f, acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) acc[i] = 0.f;
+
+  // the whole tile (16 KiB of K + 16 KiB of V^T) is requested before anything is consumed; the first tile's requests go
+  // out before the rotary prologue so that its three dependent look-ups (positions -> tables, q row) overlap the K/V latency
+  u32x4 kk[CH], vv[NACC];
+  auto issue = [&](int t) {
+    const size_t toff = ((size_t)tile_table[sq.table_off + t] * heads + head) * 64 * HD;
+    if (t == t_last && r_new == 0) {   // tile starts with the new token: nothing to read (it is zero-filled below)
+#pragma unroll
+      for (int i = 0; i < CH; ++i) kk[i] = (u32x4){0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int i = 0; i < NACC; ++i) vv[i] = (u32x4){0u, 0u, 0u, 0u};
+    } else {
+#pragma unroll
+      for (int i = 0; i < CH; ++i)
+        kk[i] = __builtin_nontemporal_load((const u32x4*)(Kt + toff + (i * KPI + lane / CH) * HD + c * 8));
+#pragma unroll
+      for (int i = 0; i < NACC; ++i)
+        vv[i] = __builtin_nontemporal_load((const u32x4*)(Vt + toff + (i * 8 + vrow) * 64 + vchk * 8));
+    }
+    return toff;
+  };
+  float cs[8], sn[8];
+  if (rope) {
+    const int rp = positions[sq.q_row0];
+    const float* cp = rope_cos + (size_t)rp * (HD / 2) + ch * 8;
+    const float* sp = rope_sin + (size_t)rp * (HD / 2) + ch * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      cs[j] = cp[j];
+      sn[j] = sp[j];
+    }
+  }
+  // this lane's 16-B chunk c of a head row, rotated (half-split rotary, same arithmetic and bf16 rounding as kv_tiles_kernel)
+  auto rotate = [&](const u32x4 lo, const u32x4 hi) -> u32x4 {
+    u32x4 o;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float a0 = bf16lo_to_f32(lo[w]), a1 = bf16hi_to_f32(lo[w]);
+      const float b0 = bf16lo_to_f32(hi[w]), b1 = bf16hi_to_f32(hi[w]);
+      const float c0 = cs[2 * w], c1 = cs[2 * w + 1], s0 = sn[2 * w], s1 = sn[2 * w + 1];
+      o[w] = upper ? pack_bf16x2(b0 * c0 + a0 * s0, b1 * c1 + a1 * s1) : pack_bf16x2(a0 * c0 - b0 * s0, a1 * c1 - b1 * s1);
+    }
+    return o;
+  };
+  auto head_chunk = [&](const bf16_t* base) -> u32x4 {
+    if (!rope) return *(const u32x4*)(base + c * 8);
+    return rotate(*(const u32x4*)(base + ch * 8), *(const u32x4*)(base + HD / 2 + ch * 8));
+  };
+  // raw q chunk(s) first, then the first tile's 32 requests, then the rotary arithmetic: loads complete in issue order, so
+  // the prologue only ever waits for its own small look-ups while the tile is in flight
+  const bf16_t* qbase = qrow + q_col0 + head * HD;
+  const u32x4 q_lo = *(const u32x4*)(qbase + (rope ? ch : c) * 8);
+  const u32x4 q_hi = *(const u32x4*)(qbase + (rope ? HD / 2 + ch * 8 : c * 8));
+  __builtin_amdgcn_sched_barrier(0);
+  int t = wave;
+  size_t toff = 0;
+  if (t < ntiles) toff = issue(t);
+  __builtin_amdgcn_sched_barrier(0);
+  const u32x4 qv = rope ? rotate(q_lo, q_hi) : q_lo;
+  float qf[8];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    qf[2 * w] = bf16lo_to_f32(qv[w]);
+    qf[2 * w + 1] = bf16hi_to_f32(qv[w]);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+
+  while (t < ntiles) {
+    const bool is_last = t == t_last;
+    const bool fresh = is_last && r_new == 0;
+    bf16_t* kt = Kt + toff;
+    bf16_t* vt = Vt + toff;
+    float part[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const u32x4 kv = kk[i];
+      float part_s = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        part_s = fmaf(bf16lo_to_f32(kv[w]), qf[2 * w], part_s);
+        part_s = fmaf(bf16hi_to_f32(kv[w]), qf[2 * w + 1], part_s);
+      }
+      part[i] = part_s;
+    }
+    float s_mine = reduce_scatter_lanes<CH>(part, c);   // full score of key_of_lane = c*KPI + lane/CH
+    if (is_last) {
+      // ---- the new token: key r_new of this tile ----
+      const u32x4 kr = head_chunk(qrow + k_col0 + head * HD);
+      float part_s = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        part_s = fmaf(bf16lo_to_f32(kr[w]), qf[2 * w], part_s);
+        part_s = fmaf(bf16hi_to_f32(kr[w]), qf[2 * w + 1], part_s);
+      }
+      part_s = allreduce_lanes<CH>(part_s);
+      if (key_of_lane == r_new) s_mine = part_s;
+      if (lane < CH) {
+        *(u32x4*)(kt + r_new * HD + lane * 8) = kr;                                       // lane < CH: c == lane
+        *(u32x4*)(&sm_v[lane * 8]) = *(const u32x4*)(qrow + v_col0 + head * HD + lane * 8);
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (!fresh) {
+#pragma unroll
+        for (int i = 0; i < HD / 64; ++i) vt[(lane + 64 * i) * 64 + r_new] = sm_v[lane + 64 * i];
+      } else {
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        for (int it = lane; it < 63 * CH; it += 64) *(u32x4*)(kt + HD + it * 8) = z;      // K rows 1..63
+        for (int it = lane; it < HD * 8; it += 64) {                                       // V^T: (d, 8-key chunk)
+          const int d = it >> 3, kc = it & 7;
+          u32x4 w = z;
+          if (kc == 0) w.x = sm_v[d];
+          *(u32x4*)(vt + d * 64 + kc * 8) = w;
+        }
+      }
+    }
+    const int mykey = t * 64 + key_of_lane;
+    const float s2 = (mykey < sq.kv_len) ? s_mine * scale_log2e : -INFINITY;
+    const float m_new = fmaxf(m_run, wave_max(s2));
+    const float alpha = fast_exp2(m_run - m_new);
+    const float p = fast_exp2(s2 - m_new);
+    l_run = l_run * alpha + wave_sum(p);
+    m_run = m_new;
+    sm_p[wave][key_of_lane] = p;
+    __builtin_amdgcn_wave_barrier();  // DS ops of one wave are in order; only stop compiler reordering
+    const f32x4 pa = *(const f32x4*)(&sm_p[wave][vchk * 8]);
+    const f32x4 pb = *(const f32x4*)(&sm_p[wave][vchk * 8 + 4]);
+    const float p_new = is_last ? sm_p[wave][r_new] : 0.f;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) {
+      float a = acc[i] * alpha;
+      a = fmaf(bf16lo_to_f32(vv[i][0]), pa[0], a);
+      a = fmaf(bf16hi_to_f32(vv[i][0]), pa[1], a);
+      a = fmaf(bf16lo_to_f32(vv[i][1]), pa[2], a);
+      a = fmaf(bf16hi_to_f32(vv[i][1]), pa[3], a);
+      a = fmaf(bf16lo_to_f32(vv[i][2]), pb[0], a);
+      a = fmaf(bf16hi_to_f32(vv[i][2]), pb[1], a);
+      a = fmaf(bf16lo_to_f32(vv[i][3]), pb[2], a);
+      a = fmaf(bf16hi_to_f32(vv[i][3]), pb[3], a);
+      acc[i] = a;
+    }
+    if (is_last && vchk == 0) {   // the stored column r_new was still zero padding when it was loaded: add the new value here
+#pragma unroll
+      for (int i = 0; i < NACC; ++i) acc[i] = fmaf(bf16_to_f32(sm_v[i * 8 + vrow]), p_new, acc[i]);
+    }
+    t += NW;
+    if (t < ntiles) toff = issue(t);
+  }
+  // reduce the 8 lanes of every V^T row, then combine the waves through LDS
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) {
+    float a = acc[i];
+    a += __shfl_xor(a, 1, 64);
+    a += __shfl_xor(a, 2, 64);
+    a += __shfl_xor(a, 4, 64);
+    if (vchk == 0) sm_o[wave][i * 8 + vrow] = a;
+  }
+  if (lane == 0) {
+    sm_m[wave] = m_run;
+    sm_l[wave] = l_run;
+  }
+  __syncthreads();
+  if (threadIdx.x < HD) {
+    float m = sm_m[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) m = fmaxf(m, sm_m[w]);
+    float l = 0.f, o = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const float wt = (sm_m[w] == -INFINITY) ? 0.f : fast_exp2(sm_m[w] - m);
+      l += sm_l[w] * wt;
+      o += sm_o[w][threadIdx.x] * wt;
+    }
+    O[(size_t)sq.q_row0 * ldo + head * HD + threadIdx.x] = f32_to_bf16(l > 0.f ? o / l : 0.f);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -680,6 +938,30 @@ int vt_attn_decode_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf16
     hipLaunchKernelGGL((attn_decode_kernel<128>), grid, block, 0, s, Q, ldq, Kt, Vt, tile_table, seqs, heads, sl2, scratch, nsplit);
     hipLaunchKernelGGL((attn_decode_combine_kernel<128>), dim3(heads, nseq), dim3(64), 0, s, scratch, seqs, O, ldo, heads, nsplit);
   }
+  VT_LAUNCH_CHECK();
+  return VT_OK;
+}
+
+int vt_attn_decode_fused_launch(const bf16_t* qkv, int ldqkv, int q_col0, int k_col0, int v_col0, bf16_t* Kt, bf16_t* Vt,
+                                const int* tile_table, const VtAttnSeq* seqs, int nseq, bf16_t* O, int ldo, int heads, int HD,
+                                float scale, const float* rope_cos, const float* rope_sin, const int* positions, hipStream_t s) {
+  VT_REQUIRE(qkv && Kt && Vt && tile_table && seqs && O, "vt_attn_decode_fused: null pointer");
+  VT_REQUIRE(HD == 64 || HD == 128, "vt_attn_decode_fused: head_dim %d unsupported", HD);
+  VT_REQUIRE(nseq > 0 && heads > 0, "vt_attn_decode_fused: empty problem");
+  VT_REQUIRE(ldqkv % 8 == 0 && q_col0 % 8 == 0 && k_col0 % 8 == 0 && v_col0 % 8 == 0, "vt_attn_decode_fused: misaligned columns");
+  if (rope_cos) VT_REQUIRE(rope_sin && positions, "vt_attn_decode_fused: rope needs sin table and positions");
+  const float sl2 = scale * 1.4426950408889634f;
+  VtProfScope prof(VT_PROF_ATTN_DECODE, 0.0, s);
+  dim3 grid(heads, nseq), block(512);
+#define VT_ADF(HDV, RV)                                                                                                          \
+  hipLaunchKernelGGL((attn_decode_fused_kernel<HDV, RV>), grid, block, 0, s, qkv, ldqkv, q_col0, k_col0, v_col0, Kt, Vt, tile_table, \
+                     seqs, heads, rope_cos, rope_sin, positions, sl2, O, ldo)
+  if (HD == 64) {
+    if (rope_cos) VT_ADF(64, true); else VT_ADF(64, false);
+  } else {
+    if (rope_cos) VT_ADF(128, true); else VT_ADF(128, false);
+  }
+#undef VT_ADF
   VT_LAUNCH_CHECK();
   return VT_OK;
 }

@@ -53,6 +53,9 @@ int vt_kv_tiles_launch(bf16_t* qkv, int ldqkv, int q_col0, int k_col0, int v_col
                        const int* tile_table, const VtAttnSeq* seqs, int nseq, int max_new_tiles, int heads, int HD,
                        const float* rope_cos, const float* rope_sin, const int* positions, hipStream_t s);
 size_t vt_attn_decode_scratch_bytes(int nseq, int heads, int HD, int max_kv_len);
+int vt_attn_decode_fused_launch(const bf16_t* qkv, int ldqkv, int q_col0, int k_col0, int v_col0, bf16_t* Kt, bf16_t* Vt,
+                                const int* tile_table, const VtAttnSeq* seqs, int nseq, bf16_t* O, int ldo, int heads, int HD,
+                                float scale, const float* rope_cos, const float* rope_sin, const int* positions, hipStream_t s);
 int vt_attn_decode_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf16_t* Vt, const int* tile_table,
                           const VtAttnSeq* seqs, int nseq, bf16_t* O, int ldo, int heads, int HD, float scale,
                           int max_kv_len, float* scratch, size_t scratch_bytes, hipStream_t s);

@@ -121,6 +121,20 @@ def attn_decode(q: torch.Tensor, k_tiles: torch.Tensor, vt_tiles: torch.Tensor, 
     return out
 
 
+def attn_decode_fused(qkv: torch.Tensor, q_col0: int, k_col0: int, v_col0: int, k_tiles: torch.Tensor, vt_tiles: torch.Tensor,
+                      tile_table: torch.Tensor, seq_desc: torch.Tensor, heads: int, head_dim: int, scale: float,
+                      rope_cos: Optional[torch.Tensor] = None, rope_sin: Optional[torch.Tensor] = None,
+                      positions: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """One decode step's attention: rotary on the new q/k rows, k/v append to the paged tiles, attention, combine."""
+    lib = _lib.load()
+    _chk(qkv, torch.bfloat16, "attn_decode_fused.qkv")
+    out = torch.empty((qkv.shape[0], heads * head_dim), device=qkv.device, dtype=torch.bfloat16)
+    _lib.check(lib.vt_attn_decode_fused(_p(qkv), qkv.stride(0), q_col0, k_col0, v_col0, _p(k_tiles), _p(vt_tiles), _p(tile_table),
+                                        _p(seq_desc), seq_desc.shape[0], _p(out), out.stride(0), heads, head_dim, float(scale),
+                                        _p(rope_cos), _p(rope_sin), _p(positions), _stream()), "vt_attn_decode_fused")
+    return out
+
+
 def attn_temporal(qkv: torch.Tensor, B: int, T: int, N: int, heads: int) -> torch.Tensor:
     lib = _lib.load()
     _chk(qkv, torch.bfloat16, "attn_temporal.qkv")
