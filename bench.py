@@ -116,6 +116,59 @@ def cpu_baseline(image_size, frames, text_len, seed):
             "est_seconds_per_step": total, "measured_seconds": time.perf_counter() - t0}
 
 
+def decode_report(model, llama, dev, steps, batch=4, ctx=609):
+    """Secondary report (outside the timed region, not part of `value`): BASELINE configs[4]-shaped decode -- `batch`
+    sequences with a `ctx`-token context (576 visual + region + prompt tokens in the real flow; synthetic embedding rows
+    here), then `steps` greedy steps: token embedding -> 32 decoder layers (weight-streaming GEMMs + fused decode attention
+    on the paged KV) -> lm_head -> argmax, through the same vt_llama_forward. HBM-bound: bytes per step = all decoder
+    weights + lm_head once + the K/V tiles of every sequence."""
+    import torch
+
+    from vitron_amd import _lib, ops, synth
+    from vitron_amd.engine import SequenceState, llama_forward
+
+    gen = synth.make_generator(777, dev)
+    H, L, I, V = llama.H, llama.L, llama.I, llama.V
+    model._ensure_kv(batch * ((ctx + steps + 8 + 63) // 64 + 1))
+    seqs = [SequenceState() for _ in range(batch)]
+    emb = (torch.randn((batch * ctx, H), generator=gen, device=dev) * 0.02).to(torch.bfloat16)
+    logits = llama_forward(llama, model.kv, seqs, emb, [ctx] * batch)
+    tok = ops.argmax(logits)
+
+    def one(tok):
+        x = model.get_model().embed_tokens(tok.long())
+        return ops.argmax(llama_forward(llama, model.kv, seqs, x, [1] * batch))
+
+    for _ in range(4):
+        tok = one(tok)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tok = one(tok)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    _lib.profile_begin()      # separate pass: per-launch events perturb the wall clock
+    for _ in range(4):
+        tok = one(tok)
+    torch.cuda.synchronize()
+    prof = _lib.profile_end()
+    for s_ in seqs:
+        model.kv.release(s_.pages)
+    wbytes = (L * (4 * H * H + 3 * H * I) + V * H) * 2
+    kv_bytes = batch * (ctx + 4 + steps // 2) * L * 2 * H * 2
+    gs = prof["gemm_skinny"]
+    return {"workload": f"batch {batch} greedy decode, context {ctx}+, Vicuna-7B-shaped decoder, paged KV (64-token pages), synthetic context rows",
+            "steps": steps, "ms_per_step": dt * 1e3, "tokens_per_s": batch / dt,
+            "roofline": {"bound": "hbm", "kernel": "gemm_skinny_dma_kernel (weight-streaming GEMM, M <= 16)",
+                         "achieved": gs["work"] / (gs["ms"] * 1e-3) / 1e9 if gs["ms"] > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (gs["work"] / (gs["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if gs["ms"] > 0 else 0.0,
+                         "avg_launch_ms": gs["ms"] / max(gs["launches"], 1), "launches_per_step": gs["launches"] / 4,
+                         "algorithmic_mbytes_per_launch": gs["work"] / max(gs["launches"], 1) / 1e6},
+            "whole_step_gbytes": (wbytes + kv_bytes) / 1e9, "whole_step_GBps": (wbytes + kv_bytes) / dt / 1e9,
+            "whole_step_frac_of_hbm_peak": (wbytes + kv_bytes) / dt / 1e9 / HBM_PEAK_GBS,
+            "kernel_ms_per_step": {k: v["ms"] / 4 for k, v in prof.items() if v["launches"]}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -125,6 +178,8 @@ def main():
     ap.add_argument("--frames", type=int, default=8)
     ap.add_argument("--text-len", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--decode-steps", type=int, default=64,
+                    help="N=1 only: after the timed prefill region, also time this many batch-4 greedy decode steps (0 = skip)")
     ap.add_argument("--seed", type=int, default=1234)
     args = ap.parse_args()
 
@@ -236,6 +291,8 @@ def main():
                          "avg_launch_ms": gt["ms"] / max(gt["launches"], 1),
                          "algorithmic_gflop_per_launch": gt["work"] / max(gt["launches"], 1) / 1e9},
         }
+        if world == 1 and args.decode_steps > 0:
+            out["decode"] = decode_report(model, llama, dev, args.decode_steps)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.image_size, args.frames, args.text_len, args.seed)
         print(json.dumps(out), flush=True)
