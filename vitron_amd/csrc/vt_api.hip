@@ -353,6 +353,7 @@ struct LlamaWs {
   float* x;
   bf16_t *y, *qkv, *att, *h, *yn;
   float* scratch;
+  float *rs_a, *rs_b;   // folded-RMSNorm partial sums of squares (decode steps)
   float* attn_scratch;
   size_t attn_scratch_bytes;
   size_t total;
@@ -368,6 +369,8 @@ LlamaWs llama_carve(const vt_llama_model* m, int rows, int n_logit, int nseq, in
   w.h = (bf16_t*)ws.take((size_t)rows * I * 2);
   w.yn = (bf16_t*)ws.take((size_t)(n_logit > 0 ? n_logit : 1) * H * 2);
   w.scratch = (float*)ws.take((size_t)16 * 2 * I * 4);
+  w.rs_a = (float*)ws.take((size_t)16 * (H / 16) * 4);
+  w.rs_b = (float*)ws.take((size_t)16 * (H / 16) * 4);
   w.attn_scratch_bytes = vt_attn_decode_scratch_bytes(nseq > 0 ? nseq : 1, m->heads, m->head_dim, max_kv_len > 0 ? max_kv_len : 64);
   w.attn_scratch = (float*)ws.take(w.attn_scratch_bytes);
   w.total = ws.off + 256;
@@ -403,10 +406,49 @@ int vt_llama_forward(const vt_llama_model* m, const vt_kv_cache* kv, const uint1
   const size_t layer_stride = (size_t)kv->num_pages * heads * 64 * HD;
 
   VT_TRY(vt_bf16_to_f32_launch(x_embeds, w.x, (size_t)rows * H, s));
+  // Decode steps (<= 16 rows, one new token per sequence): every GEMM is the weight-streaming kernel and RMSNorm is folded
+  // into them -- the residual GEMMs (o_proj, down_proj) emit bf16(x .* w_next) plus per-block sums of x^2, the GEMMs that
+  // follow (gate_up, next layer's qkv) scale their rows by rstd. Only the first norm of layer 0 and the final norm stay
+  // separate launches: 6 launches per layer -> 4.
+  const bool fold_norm = rows <= 16 && max_q_len == 1 && (H % 1024) == 0 && H <= 8192 && (I % 64) == 0;
+  VtGemmNormFuse consume_a, consume_b, none;
+  consume_a.in_partials = w.rs_a;
+  consume_b.in_partials = w.rs_b;
+  consume_a.in_n = consume_b.in_n = H / 16;
+  consume_a.inv_dim = consume_b.inv_dim = 1.0f / (float)H;
+  consume_a.eps = consume_b.eps = m->rms_eps;
   for (int l = 0; l < m->num_layers; ++l) {
     const vt_llama_layer& L = m->layers[l];
     bf16_t* kt = kv->k + l * layer_stride;
     bf16_t* vt = kv->vt + l * layer_stride;
+    if (fold_norm) {
+      if (l == 0) {
+        VT_TRY(vt_rmsnorm_launch(w.x, nullptr, L.rms1, w.y, rows, H, m->rms_eps, s));
+        VT_TRY(vt_gemm_skinny_norm_launch(w.y, H, L.wqkv, H, w.qkv, 3 * H, rows, 3 * H, H, VT_EPI_BF16, none, s));
+      } else {
+        VT_TRY(vt_gemm_skinny_norm_launch(w.y, H, L.wqkv, H, w.qkv, 3 * H, rows, 3 * H, H, VT_EPI_BF16, consume_a, s));
+      }
+      VT_TRY(vt_attn_decode_fused_launch(w.qkv, 3 * H, 0, H, 2 * H, kt, vt, tile_table, (const VtAttnSeq*)seq_desc, nseq, w.att, H,
+                                         heads, HD, scale, m->rope_cos, m->rope_sin, positions, s));
+      VtGemmNormFuse prod_b;   // x += att Wo^T ; y = bf16(x .* rms2) ; partial sums -> rs_b
+      prod_b.out_w = L.rms2;
+      prod_b.out_xw = w.y;
+      prod_b.ld_xw = H;
+      prod_b.out_partials = w.rs_b;
+      VT_TRY(vt_gemm_skinny_norm_launch(w.att, H, L.wo, H, w.x, H, rows, H, H, VT_EPI_F32_RESID, prod_b, s));
+      VT_TRY(vt_gemm_skinny_norm_launch(w.y, H, L.wgu, H, w.h, I, rows, 2 * I, H, VT_EPI_SWIGLU_BF16, consume_b, s));
+      if (l + 1 < m->num_layers) {
+        VtGemmNormFuse prod_a;   // x += h Wdown^T ; y = bf16(x .* next layer's rms1) ; partial sums -> rs_a
+        prod_a.out_w = m->layers[l + 1].rms1;
+        prod_a.out_xw = w.y;
+        prod_a.ld_xw = H;
+        prod_a.out_partials = w.rs_a;
+        VT_TRY(vt_gemm_skinny_norm_launch(w.h, I, L.wdown, I, w.x, H, rows, H, I, VT_EPI_F32_RESID, prod_a, s));
+      } else {
+        VT_TRY(vt_gemm_skinny_norm_launch(w.h, I, L.wdown, I, w.x, H, rows, H, I, VT_EPI_F32_RESID, none, s));
+      }
+      continue;
+    }
     VT_TRY(vt_rmsnorm_launch(w.x, nullptr, L.rms1, w.y, rows, H, m->rms_eps, s));
     VT_TRY(vt_gemm_launch(w.y, H, L.wqkv, H, w.qkv, 3 * H, nullptr, rows, 3 * H, H, VT_EPI_BF16, AUTO, nullptr, s));
     if (max_q_len == 1) {   // decode step: rotary + append + attention + combine in one launch

@@ -39,6 +39,7 @@ struct GemmP {
   const float* bias;
   int M, N, K;
   int lda, ldw, ldc;
+  VtGemmNormFuse nf;   // only read by the skinny LDS-DMA kernel
 };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
@@ -376,6 +377,20 @@ __global__ __launch_bounds__(64 * NWAVE) void gemm_skinny_dma_kernel(GemmP p) {
 #pragma unroll
   for (int r = 0; r < R; ++r)
     if (r < n) issue(s0 + r, r);
+  // folded RMSNorm, consumer side: thread (row m = tid>>4, part tid&15) fetches its in_n/16 (<= 32) partial sums of squares
+  // right behind the ring's first fills, so the look-up rides under the weight stream instead of sitting on the block's tail
+  f32x4 rsv[8];
+  float rs_keep[8];
+  if (p.nf.in_partials) {   // branch-free: clamped addresses, out-of-range quads get weight 0 -> all 8 loads go out back to back
+    const int cnt = p.nf.in_n >> 4;
+    const int row = min((int)(threadIdx.x >> 4) & 15, p.M - 1);
+    const float* pp = p.nf.in_partials + (size_t)row * p.nf.in_n + (threadIdx.x & 15) * cnt;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      rsv[q] = *(const f32x4*)(pp + min(4 * q, cnt - 4));
+      rs_keep[q] = (4 * q < cnt) ? 1.f : 0.f;
+    }
+  }
   for (int i = 0; i < n; ++i) {
     if (i + R <= n) vmcnt_wait<(R - 1) * PS>(); else vmcnt_wait<0>();
     const char* sb = ring + (i & (R - 1)) * SLOT;
@@ -410,11 +425,34 @@ __global__ __launch_bounds__(64 * NWAVE) void gemm_skinny_dma_kernel(GemmP p) {
 #pragma unroll
     for (int w = 0; w < NWAVE; ++w) v[t] += red[w][t][e];
   }
+  if (p.nf.in_partials) {   // folded RMSNorm, consumer side: the 16 threads of row m add up its partial sums of squares
+    float ss = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) ss += rs_keep[q] * ((rsv[q][0] + rsv[q][1]) + (rsv[q][2] + rsv[q][3]));
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) ss += __shfl_xor(ss, off, 16);
+    const float rstd = rsqrtf(ss * p.nf.inv_dim + p.nf.eps);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) v[t] *= rstd;
+  }
   if constexpr (EPI == VT_EPI_SWIGLU_BF16) {
     const int q = blockIdx.x * 16 + nn;                      // output column; gate row n_base+nn, up row n_base+16+nn
     if (n_base + 16 + nn < p.N) ((bf16_t*)p.C)[(size_t)m * p.ldc + q] = f32_to_bf16(silu(v[0]) * v[NT - 1]);
   } else {
     const int nc = n_base + nn;
+    if constexpr (EPI == VT_EPI_F32_RESID) {
+      if (p.nf.out_partials) {   // folded RMSNorm, producer side (N % 16 == 0 checked by the launcher: all 16 threads are live)
+        float* c = (float*)p.C + (size_t)m * p.ldc + nc;
+        const float x = *c + v[0];
+        *c = x;
+        p.nf.out_xw[(size_t)m * p.nf.ld_xw + nc] = f32_to_bf16(x * p.nf.out_w[nc]);
+        float ss = x * x;
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) ss += __shfl_xor(ss, off, 16);
+        if (nn == 0) p.nf.out_partials[(size_t)m * gridDim.x + blockIdx.x] = ss;
+        return;
+      }
+    }
     if (nc >= p.N) return;
     float r = v[0] + (p.bias ? p.bias[nc] : 0.f);
     if constexpr (EPI == VT_EPI_BF16_GELU) r = gelu_erf(r);
@@ -516,7 +554,7 @@ int vt_gemm_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, 
   VT_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)C % 16) == 0,
              "vt_gemm: A/W/C must be 16-byte aligned");
   VT_REQUIRE(ldc % 4 == 0, "vt_gemm: ldc must be a multiple of 4");
-  GemmP p{A, W, C, bias, M, N, K, lda, ldw, ldc};
+  GemmP p{A, W, C, bias, M, N, K, lda, ldw, ldc, VtGemmNormFuse{}};
   const bool skinny_path = (M <= 16) && (cfg == VT_GEMM_CFG_AUTO || cfg == VT_GEMM_CFG_SKINNY || cfg == VT_GEMM_CFG_SKINNY_REG);
   if (!skinny_path) {
     VT_REQUIRE((K % 64) == 0, "vt_gemm(tile): K=%d must be a multiple of 64", K);
@@ -576,5 +614,25 @@ int vt_gemm_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, 
     case VT_EPI_F32: return launch_cfg<VT_EPI_F32>(p, cfg, s);
     case VT_EPI_SWIGLU_BF16: return launch_cfg<VT_EPI_SWIGLU_BF16>(p, cfg, s);
     default: vt_set_error("vt_gemm: unknown epilogue %d", epi); return VT_ERR_ARG;
+  }
+}
+
+int vt_gemm_skinny_norm_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, int M, int N, int K, int epi,
+                               const VtGemmNormFuse& nf, hipStream_t s) {
+  VT_REQUIRE(A && W && C, "vt_gemm(norm-fused): null pointer");
+  VT_REQUIRE(M > 0 && M <= 16 && (K % 64) == 0 && (N % 32) == 0, "vt_gemm(norm-fused): needs M <= 16, K %% 64 == 0, N %% 32 == 0 (M=%d N=%d K=%d)", M, N, K);
+  VT_REQUIRE((lda % 8) == 0 && (ldw % 8) == 0 && ldc % 4 == 0, "vt_gemm(norm-fused): misaligned leading dimensions");
+  if (nf.out_partials) VT_REQUIRE(epi == VT_EPI_F32_RESID && nf.out_w && nf.out_xw, "vt_gemm(norm-fused): producer side needs the residual epilogue, weights and the xw buffer");
+  if (nf.in_partials)
+    VT_REQUIRE(nf.in_n > 0 && nf.in_n <= 512 && (nf.in_n % 64) == 0 && nf.inv_dim > 0.f,
+               "vt_gemm(norm-fused): consumer side needs in_n %% 64 == 0, in_n <= 512 (in_n=%d) and inv_dim", nf.in_n);
+  GemmP p{A, W, C, nullptr, M, N, K, lda, ldw, ldc, nf};
+  VtProfScope prof(VT_PROF_GEMM_SKINNY, 2.0 * (double)N * (double)K, s);
+  switch (epi) {
+    case VT_EPI_BF16: return launch_skinny<VT_EPI_BF16>(p, s, false);
+    case VT_EPI_F32_RESID: return launch_skinny<VT_EPI_F32_RESID>(p, s, false);
+    case VT_EPI_F32: return launch_skinny<VT_EPI_F32>(p, s, false);
+    case VT_EPI_SWIGLU_BF16: return launch_skinny<VT_EPI_SWIGLU_BF16>(p, s, false);
+    default: vt_set_error("vt_gemm(norm-fused): epilogue %d unsupported", epi); return VT_ERR_ARG;
   }
 }

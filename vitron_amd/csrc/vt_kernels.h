@@ -15,6 +15,22 @@ struct VtAttnSeq {  // device-side view of one row of seq_desc (int32 x 4)
 int vt_gemm_pick_cfg(int M, int N, int K);
 int vt_gemm_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, const float* bias,
                    int M, int N, int K, int epi, int cfg, void* skinny_scratch, hipStream_t s);
+// RMSNorm folded into the M <= 16 weight-streaming GEMMs of a decode step (no separate norm launches):
+//   producer side (VT_EPI_F32_RESID): after x += A W^T the epilogue also stores out_xw = bf16(x * out_w[n]) and, per row and
+//   16-column block, the partial sum of x^2 (out_partials[m][N/16]);
+//   consumer side: A = that xw buffer; the epilogue scales row m by rsqrt(sum(in_partials[m][0..in_n)) * inv_dim + eps) before
+//   the activation -- W (w .* x) * rstd == W (x * rstd .* w), the per-row scalar commutes with the contraction.
+struct VtGemmNormFuse {
+  const float* in_partials = nullptr;
+  int in_n = 0;
+  float inv_dim = 0.f, eps = 0.f;
+  const float* out_w = nullptr;
+  bf16_t* out_xw = nullptr;
+  int ld_xw = 0;
+  float* out_partials = nullptr;
+};
+int vt_gemm_skinny_norm_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, int M, int N, int K,
+                               int epi, const VtGemmNormFuse& nf, hipStream_t s);
 
 // ---- vt_gemm8.hip (256x256 tile, 8-phase pipeline) ---------------------------------------------------
 bool vt_gemm_p8_supported(int M, int N, int K);
