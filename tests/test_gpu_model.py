@@ -198,3 +198,84 @@ def test_decode_matches_prefill(dev, model):
     got = torch.cat([a, b, c], 0)
     assert rel_l2(got, full) <= 5e-3   # chunking changes where P is rounded to bf16 inside the attention kernels
     assert torch.equal(got.argmax(-1), full.argmax(-1)) or rel_l2(got, full) <= 5e-4
+
+
+@pytest.mark.gpu
+def test_decode_step_folded_rmsnorm_vs_oracle(dev):
+    """H = 1024 (a multiple of 1024) switches vt_llama_forward's decode steps to the 5-launch layer: weight-streaming GEMMs
+    with RMSNorm folded in (residual GEMMs emit bf16(x .* w) + partial sums of squares, consumers scale rows by rstd) and
+    the fused rotary/append/attention kernel. Three ragged sequences, prefill then 5 batched decode steps: every step's
+    logits against the fp32 oracle (same bf16-rounded weights) and against a single full prefill on the device."""
+    from vitron_amd.engine import PackedLlama, PagedKVCache, SequenceState, llama_forward
+    cfg = dict(synth.VICUNA_7B, hidden_size=1024, intermediate_size=1408, num_hidden_layers=3, num_attention_heads=8, vocab_size=640)
+    sd = synth.llama_state(cfg, synth.make_generator(11), w_std=0.05)
+    llama = PackedLlama(sd, cfg, dev)
+    sd32 = {k: v.float() for k, v in sd.items()}
+    g = torch.Generator().manual_seed(12)
+    lens0 = [70, 129, 5]
+    steps = 5
+    embs = [O.bf16_round(torch.randn((n + steps, 1024), generator=g) * 0.5) for n in lens0]
+    refs = []
+    for e in embs:   # fp32 oracle over the whole sequence: row i only sees rows <= i, so one causal pass gives every step
+        lg, _ = O.llama_forward(sd32, cfg, e.unsqueeze(0))
+        refs.append(lg[0])
+    kv = PagedKVCache(llama, 16)
+    seqs = [SequenceState() for _ in lens0]
+    flat = torch.cat([e[:n] for e, n in zip(embs, lens0)]).to(dev).bfloat16()
+    got = [llama_forward(llama, kv, seqs, flat, lens0)]
+    for t in range(steps):
+        x = torch.stack([e[n + t] for e, n in zip(embs, lens0)]).to(dev).bfloat16()
+        got.append(llama_forward(llama, kv, seqs, x, [1] * len(lens0)))
+    # the same rows through ONE prefill per sequence (tile GEMMs, separate RMSNorm, flash attention)
+    full = []
+    for e, n in zip(embs, lens0):
+        s_ = SequenceState()
+        full.append(llama_forward(llama, kv, [s_], e.to(dev).bfloat16(), [n + steps], logit_rows=list(range(n + steps))))
+        kv.release(s_.pages)
+    for t in range(steps + 1):
+        for b, n in enumerate(lens0):
+            row = n - 1 + t
+            ref, dev_full, g_ = refs[b][row], full[b][row].cpu(), got[t][b].cpu()
+            assert rel_l2(g_, ref) <= TOL_DEEP, (t, b, rel_l2(g_, ref))
+            assert rel_l2(g_, ref) <= 1.5 * rel_l2(dev_full, ref) + 2e-3, (t, b)       # folding costs no accuracy
+            assert rel_l2(g_, dev_full) <= 2e-2, (t, b, rel_l2(g_, dev_full))   # two independent bf16 paths, each <= ~1e-2 from fp32
+
+
+@pytest.mark.gpu
+def test_multi_turn_reuses_towers_and_kv_prefix(dev):
+    """Second turn of a conversation (same image + box, prompt = first prompt + reply + new text): the image is not encoded
+    again, only the rows behind the last whole common page are prefilled, and the logits match a model without reuse."""
+    from vitron_amd import synth
+    from vitron_amd.model import LlavaConfig, LlavaLlamaForCausalLM
+    cfg = dict(synth.VICUNA_7B, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4, vocab_size=512)
+    vit = dict(synth.VIT_L14, image_size=112, hidden_size=128, intermediate_size=256, num_hidden_layers=3, num_attention_heads=2)
+    models = []
+    for reuse in (True, False):
+        m = LlavaLlamaForCausalLM(LlavaConfig(**cfg, mm_hidden_size=128, mm_region_image_size=112, kv_prefix_reuse=reuse))
+        m.init_synthetic(dev, seed=7, vit_image=vit, vit_video=None)
+        models.append(m)
+    g = torch.Generator().manual_seed(5)
+    image = torch.randn((3, 112, 112), generator=g).bfloat16().to(dev)
+    box = [10.0, 20.0, 90.0, 100.0]
+    p1 = torch.tensor([[1, -200] + torch.randint(3, 500, (40,), generator=g).tolist() + [-300, 1] +
+                       torch.randint(3, 500, (30,), generator=g).tolist()], device=dev)
+    outs = []
+    for m in models:
+        o1 = m.generate(p1, images=[image], regions=[box], do_sample=False, max_new_tokens=12, eos_token_id=-1)
+        reply = o1[0, p1.shape[1]:]
+        p2 = torch.cat([p1[0], reply, torch.tensor([5, 6, 7, 8, 9], device=dev)]).unsqueeze(0)
+        o2, lg = m.generate(p2, images=[image], regions=[box], do_sample=False, max_new_tokens=4, eos_token_id=-1, return_logits=True)
+        outs.append((o1, o2, lg, dict(m.last_generate_stats)))
+    (a1, a2, la, sa), (b1, b2, lb, sb) = outs
+    assert torch.equal(a1, b1)                                  # first turn: nothing to reuse, identical work
+    rows = 64 + 1 + 30 + 1 + 40 + 1 + 12 + 5                     # spliced prompt of turn 2: 64 visual rows + region row + text
+    assert sa["prompt_rows"] == rows and sb["prompt_rows"] == rows
+    assert sa["tower_items"] == 0 and sa["reused_tokens"] == 128 and sa["prefill_rows"] == rows - 128
+    assert sb["reused_tokens"] == 0 and sb["prefill_rows"] == rows
+    for x, y in zip(la, lb):                                    # chunked prefill behind a cached prefix == full prefill
+        assert rel_l2(x.float(), y.float()) <= 5e-3
+    # a different box invalidates the region row (row 65) -> only the first whole page (visual rows) is kept
+    o3 = models[0].generate(p2, images=[image], regions=[[0.0, 0.0, 50.0, 50.0]], do_sample=False, max_new_tokens=2, eos_token_id=-1)
+    assert models[0].last_generate_stats["reused_tokens"] == 64 and models[0].last_generate_stats["tower_items"] == 1
+    models[0].reset_prefix_cache()
+    assert len(models[0].kv.free) == models[0].kv.num_pages

@@ -157,3 +157,36 @@ def test_ops_refuse_cpu_tensors():
         load_pretrained_model("synthetic", None, "x", device="cpu")
     with pytest.raises(NotImplementedError):
         load_pretrained_model("synthetic", None, "x", load_8bit=True)
+
+
+def test_prefix_cache_signatures_and_page_rounding():
+    """vitron_amd.prefix_cache: row signatures separate tokens / visual rows / region rows and depend on the image key;
+    reuse is the common prefix capped at len-1 and rounded down to whole 64-token pages; the feature cache is LRU."""
+    import numpy as np
+    import torch
+
+    from vitron_amd.prefix_cache import (VisualFeatureCache, common_prefix, key64, reusable_tokens, row_signature,
+                                         tensor_key)
+    plan = np.array([[0, 1], [1, 0], [1, 1], [1, 2], [0, 7], [2, 0], [0, 1], [3, 0]])
+    a = row_signature(plan, [(0, 3, key64(("img", 1)))], [key64(("box", 1))])
+    b = row_signature(plan, [(0, 3, key64(("img", 2)))], [key64(("box", 1))])
+    c = row_signature(plan, [(0, 3, key64(("img", 1)))], [key64(("box", 2))])
+    assert a[0] == 1 and a[4] == 7 and a[7] == -1
+    assert len(set(a[1:4].tolist())) == 3 and (a[1:4] > 32000).all()
+    assert common_prefix(a, b) == 1            # a different image changes every visual row
+    assert common_prefix(a, c) == 5            # a different box only changes the region row
+    assert common_prefix(a, a) == len(a)
+    assert reusable_tokens(np.arange(300), np.arange(300)) == 256      # last row must run -> 299 -> 4 pages
+    assert reusable_tokens(np.arange(300), np.arange(130)) == 128
+    assert reusable_tokens(np.arange(300), np.arange(64)) == 0         # 63 reusable -> not a whole page
+    x = torch.arange(24, dtype=torch.float32).reshape(2, 3, 4).to(torch.bfloat16)
+    y = x.clone()
+    y[1, 2, 3] += 1
+    assert tensor_key(x) == tensor_key(x.clone()) and tensor_key(x) != tensor_key(y)
+    assert tensor_key(x) != tensor_key(x.reshape(3, 2, 4))
+    cache = VisualFeatureCache(2)
+    cache.put("a", torch.zeros(1), None)
+    cache.put("b", torch.zeros(1), None)
+    assert cache.get("a") is not None
+    cache.put("c", torch.zeros(1), None)       # evicts "b" (least recently used)
+    assert cache.get("b") is None and cache.get("a") is not None and cache.get("c") is not None

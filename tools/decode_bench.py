@@ -22,6 +22,7 @@ def main():
     vit_image = dict(synth.VIT_L14, image_size=336)
     model = LlavaLlamaForCausalLM(LlavaConfig(**synth.VICUNA_7B, mm_hidden_size=1024, mm_region_image_size=336))
     model.init_synthetic(dev, seed=1234, vit_image=vit_image, vit_video=None)
+    model.config.kv_prefix_reuse = False     # every timed call must do the whole job: no multi-turn reuse of towers / KV pages
     gen = synth.make_generator(4321, dev)
     img = lambda: torch.randn((3, 336, 336), generator=gen, device=dev).bfloat16()  # noqa: E731
 

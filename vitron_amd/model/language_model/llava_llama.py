@@ -94,6 +94,11 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
         self._llama_sd = None
         self.kv: Optional[PagedKVCache] = None
         self.kv_pages = getattr(config, "kv_pages", None)
+        # multi-turn reuse (vitron_amd/prefix_cache.py): generate() keeps the last conversation's KV pages and the encoded
+        # images; config.kv_prefix_reuse / config.vis_cache_entries switch them off (benchmarks do)
+        self._prefix = None
+        self._vis_cache = None
+        self.last_generate_stats = {}
 
     # ---- module-like plumbing -----------------------------------------------------------------------------------
     def get_model(self):
@@ -169,9 +174,23 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
         return self.to(device)
 
     # ---- KV pool ----------------------------------------------------------------------------------------------
+    def reset_prefix_cache(self):
+        """Drop the kept conversation (KV pages go back to the pool) and the encoded-image cache."""
+        if self._prefix is not None and self.kv is not None:
+            self.kv.release(self._prefix.pages)
+        self._prefix = None
+        if self._vis_cache is not None:
+            self._vis_cache.clear()
+
     def _ensure_kv(self, pages_needed: int):
         if self.kv is not None and len(self.kv.free) >= pages_needed:
             return
+        if self._prefix is not None:            # the kept conversation is the first thing to go when pages run short
+            if self.kv is not None:
+                self.kv.release(self._prefix.pages)
+            self._prefix = None
+            if self.kv is not None and len(self.kv.free) >= pages_needed:
+                return
         if self.kv is not None and len(self.kv.free) != self.kv.num_pages:
             raise RuntimeError("KV pool exhausted while sequences are live; release past_key_values or raise config.kv_pages")
         n = max(pages_needed, int(self.kv_pages or 0))
@@ -277,8 +296,17 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
             gen = torch.Generator(device=dev)
             gen.manual_seed(sample_seed)
 
+        reuse = B == 1 and bool(getattr(self.config, "kv_prefix_reuse", True))
+        cache = None
+        if reuse and int(getattr(self.config, "vis_cache_entries", 16)) > 0:
+            if self._vis_cache is None:
+                from ...prefix_cache import VisualFeatureCache
+                self._vis_cache = VisualFeatureCache(int(getattr(self.config, "vis_cache_entries", 16)))
+            cache = self._vis_cache
+        self._last_row_sig = None
+        self.last_tower_items = None
         (_, _, _, _, embeds, _) = self.prepare_inputs_labels_for_multimodal(input_ids, None, attention_mask, None, None,
-                                                                            images, regions)
+                                                                            images, regions, feature_cache=cache)
         llama = self.model.llama
         if embeds is None:
             embeds = self.model.embed_tokens(input_ids)
@@ -291,8 +319,37 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
         flat = embeds.reshape(B * S, H)
         if len(idx) != B * S:
             flat = flat.index_select(0, torch.tensor(idx, device=dev))
-        self._ensure_kv(sum((l + max_new_tokens + 63) // 64 + 1 for l in lens))
         seqs = [SequenceState() for _ in range(B)]
+        # ---- multi-turn KV reuse (batch 1): keep the pages of the longest common whole-page prefix of the last call ------------
+        sig = None
+        kept = 0
+        if reuse:
+            import numpy as np
+
+            from ...prefix_cache import reusable_tokens
+            if self._last_row_sig is not None:
+                sig = self._last_row_sig[0][np.asarray(mask_host[0], dtype=bool)]
+            else:
+                sig = input_ids[0].cpu().numpy().astype(np.int64)[np.asarray(mask_host[0], dtype=bool)]
+            if self._prefix is not None:
+                kept = reusable_tokens(self._prefix.sig, sig) if self.kv is not None else 0
+                seqs[0].pages = self._prefix.pages[:kept // 64]
+                seqs[0].length = kept
+                self.kv.release(self._prefix.pages[kept // 64:])
+                self._prefix = None
+        elif self._prefix is not None:
+            self.reset_prefix_cache()
+        need = sum((l + max_new_tokens + 63) // 64 + 1 for l in lens) - kept // 64
+        if self.kv is None or len(self.kv.free) < need:
+            if kept:                                                          # cannot grow the pool around live pages: start over
+                self.kv.release(seqs[0].pages)
+                seqs[0].pages, seqs[0].length, kept = [], 0, 0
+                need = sum((l + max_new_tokens + 63) // 64 + 1 for l in lens)
+            self._ensure_kv(need)
+        self.last_generate_stats = {"prompt_rows": int(sum(lens)), "reused_tokens": int(kept),
+                                    "prefill_rows": int(sum(lens) - kept), "tower_items": self.last_tower_items}
+        if kept:
+            flat, lens = flat[kept:], [lens[0] - kept]
         logits = llama_forward(llama, self.kv, seqs, flat, lens)             # [B, V]: last position of every sequence
         out = input_ids
         finished = torch.zeros(B, dtype=torch.bool, device=dev)
@@ -319,8 +376,16 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
                 x = ops.embed_splice(llama.embed, None, None, plan)
                 logits = llama_forward(llama, self.kv, seqs, x, [1] * B)
         finally:
-            for s in seqs:
-                self.kv.release(s.pages)
+            if reuse and sig is not None and seqs[0].length > 0:
+                import numpy as np
+
+                from ...prefix_cache import PrefixKV
+                gen_ids = out[0, input_ids.shape[1]:].detach().cpu().numpy().astype(np.int64)
+                full = np.concatenate([sig, gen_ids])[:seqs[0].length]      # the last sampled token was never fed back
+                self._prefix = PrefixKV(full, seqs[0].pages)
+            else:
+                for s in seqs:
+                    self.kv.release(s.pages)
         if return_logits:
             return out, all_logits
         return out

@@ -149,9 +149,60 @@ class LlavaMetaForCausalLM:
         video_features = self.get_model().get_video_tower()(videos)               # [B, T, P, mm_hidden]
         return self.get_model().mm_projector(video_features)                      # [B, T, P, hidden]
 
+    def _encode_with_cache(self, images, image_idx, video_idx, regions, cache, plan, blocks):
+        """encode_images / encode_videos with a per-item content cache (prefix_cache.VisualFeatureCache): only the items whose
+        pixels (+ box) were not seen before run through the towers, as one batch. Returns the same (visual chunks, region rows)
+        the uncached branch builds and records the row signature of the spliced sequence."""
+        from ..prefix_cache import key64, row_signature, tensor_key
+        dev = self.device
+        block_keys, region_keys = [], []
+        vis_chunks: List[torch.Tensor] = []
+        region_buf = None
+        self.last_tower_items = 0
+        if image_idx:
+            keys = [(tensor_key(images[i]), None if regions is None else tuple(float(v) for v in regions[i])) for i in image_idx]
+            got = [cache.get(k) for k in keys]
+            miss = [j for j, g in enumerate(got) if g is None]
+            if miss:
+                batch = torch.stack([images[image_idx[j]] for j in miss]).to(dev)
+                rb = [regions[image_idx[j]] for j in miss] if regions is not None else None
+                feats, regs = self.encode_images(batch, rb)
+                for n, j in enumerate(miss):
+                    got[j] = (feats[n].contiguous(), regs[n].contiguous() if regions is not None else None)
+                    cache.put(keys[j], *got[j])
+                self.last_tower_items += len(miss)
+            vis_chunks.append(torch.cat([g[0] for g in got], 0))
+            if regions is not None:
+                region_buf = torch.cat([g[1].reshape(1, -1) for g in got], 0)
+            for j, k in enumerate(keys):
+                start, cnt = blocks[image_idx[j]][0]
+                block_keys.append((start, cnt, key64((k[0], 0))))
+                region_keys.append(key64(k))
+        if video_idx:
+            keys = [(tensor_key(images[i]), None) for i in video_idx]
+            got = [cache.get(k) for k in keys]
+            miss = [j for j, g in enumerate(got) if g is None]
+            if miss:
+                batch = torch.stack([images[video_idx[j]] for j in miss]).to(dev)
+                feats = self.encode_videos(batch)                                     # [b, T, P, H]
+                for n, j in enumerate(miss):
+                    got[j] = (feats[n].reshape(-1, feats.shape[-1]).contiguous(), None)
+                    cache.put(keys[j], *got[j])
+                self.last_tower_items += len(miss)
+            vis_chunks.append(torch.cat([g[0] for g in got], 0))
+            for j, k in enumerate(keys):
+                for t, (start, cnt) in enumerate(blocks[video_idx[j]]):       # one block per frame
+                    block_keys.append((start, cnt, key64((k[0], t))))
+        block_keys.sort()
+        self._last_row_sig = [row_signature(plan[b], block_keys, region_keys) for b in range(plan.shape[0])]
+        return vis_chunks, region_buf
+
     # ---- reference llava_arch.py:189-573 -----------------------------------------------------------------------
     def prepare_inputs_labels_for_multimodal(self, input_ids, position_ids, attention_mask, past_key_values, labels,
-                                             images, regions=None):
+                                             images, regions=None, feature_cache=None):
+        """`feature_cache` (vitron_amd.prefix_cache.VisualFeatureCache, only passed by generate()) lets an image / clip that
+        was already encoded in an earlier turn skip tower + region extractor + projector; it also makes this call record
+        the per-row signature generate() needs for KV prefix reuse (self._last_row_sig)."""
         image_tower, video_tower = self.get_image_tower(), self.get_video_tower()
         if (image_tower is None and video_tower is None) or images is None or input_ids.shape[1] == 1:
             # decode step (:196-205): extend the mask to past_len + 1, positions = sum(mask) - 1
@@ -206,16 +257,21 @@ class LlavaMetaForCausalLM:
         # ---- device side: towers -> region extractor -> projector -> gather/splice ------------------------------------------
         vis_chunks: List[torch.Tensor] = []
         region_buf = None
-        if image_idx:
-            batch = torch.stack([images[i] for i in image_idx]).to(dev)
-            rb = [regions[i] for i in image_idx] if use_regions else None         # :241
-            feats, region_buf = self.encode_images(batch, rb)
-            vis_chunks.append(feats.reshape(-1, feats.shape[-1]))
-            region_buf = region_buf.reshape(-1, region_buf.shape[-1]) if use_regions else None
-        if video_idx:
-            batch = torch.stack([images[i] for i in video_idx]).to(dev)
-            feats = self.encode_videos(batch)                                     # [b, T, P, H]
-            vis_chunks.append(feats.reshape(-1, feats.shape[-1]))
+        self._last_row_sig = None
+        if feature_cache is not None:
+            vis_chunks, region_buf = self._encode_with_cache(images, image_idx, video_idx, regions if use_regions else None,
+                                                             feature_cache, plan, blocks)
+        else:
+            if image_idx:
+                batch = torch.stack([images[i] for i in image_idx]).to(dev)
+                rb = [regions[i] for i in image_idx] if use_regions else None         # :241
+                feats, region_buf = self.encode_images(batch, rb)
+                vis_chunks.append(feats.reshape(-1, feats.shape[-1]))
+                region_buf = region_buf.reshape(-1, region_buf.shape[-1]) if use_regions else None
+            if video_idx:
+                batch = torch.stack([images[i] for i in video_idx]).to(dev)
+                feats = self.encode_videos(batch)                                     # [b, T, P, H]
+                vis_chunks.append(feats.reshape(-1, feats.shape[-1]))
         vis = torch.cat(vis_chunks, 0) if len(vis_chunks) > 1 else vis_chunks[0]
         if vis.shape[0] != nvis:
             raise RuntimeError(f"visual token count mismatch: planned {nvis}, encoded {vis.shape[0]}")
