@@ -305,6 +305,11 @@ def test_im2col_splice_argmax(dev):
     lg = randn((5, 32000), 55)
     lg[2, 777] = lg[2, 31999] = 50.0  # tie -> lowest index
     assert ops.argmax(lg.to(dev)).cpu().tolist() == lg.argmax(-1).tolist() and ops.argmax(lg.to(dev))[2].item() == 777
+    lg = randn((3, 32003), 56)         # odd row length: the scalar tail and, through the odd stride, the unvectorised path
+    lg[1, 32002] = lg[1, 5] = 60.0
+    assert ops.argmax(lg.to(dev)).cpu().tolist() == lg.argmax(-1).tolist() and ops.argmax(lg.to(dev))[1].item() == 5
+    lg = randn((2, 515), 57)
+    assert ops.argmax(lg.to(dev)).cpu().tolist() == lg.argmax(-1).tolist()
 
 
 def test_profile_api_counts_split_gemm(dev):
@@ -329,11 +334,13 @@ def test_sample_top_p_keep_set_and_distribution(dev):
     """Keep-set size must equal transformers' TopPLogitsWarper rule (restated on CPU); samples must come from the keep-set
     and follow the renormalised distribution; the draw is a pure function of (seed, step, row)."""
     from vitron_amd import ops
-    V, rows = 32000, 6
+    rows = 6
     g = torch.Generator().manual_seed(71)
-    logits = torch.randn((rows, V), generator=g) * 3.0
-    logits[0, 123] = 40.0                                  # one dominant token -> keep-set of size 1
-    for temperature, top_p in ((0.7, 0.9), (1.0, 0.5), (0.2, 0.95), (1.3, 1.0)):
+    # V = 32000: register-resident kernel; 32003 (+ an odd row stride): its ragged tail; 40000: the streaming kernel (V > 32768)
+    for V, temperature, top_p in ((32000, 0.7, 0.9), (32000, 1.0, 0.5), (32000, 0.2, 0.95), (32000, 1.3, 1.0), (32003, 0.7, 0.9),
+                                  (1000, 1.0, 0.5), (40000, 0.7, 0.9), (40000, 1.0, 1.0)):
+        logits = torch.randn((rows, V), generator=g) * 3.0
+        logits[0, 123] = 40.0                              # one dominant token -> keep-set of size 1
         ld = logits.to(dev)
         ids, kept = ops.sample_top_p(ld, temperature, top_p, seed=5, step=3, return_kept=True)
         probs = torch.softmax(logits.double() / temperature, -1)
