@@ -540,9 +540,12 @@ int vt_gemm_pick_cfg(int M, int N, int K) {
   const long rounds = (t256 + 255) / 256;
   const double waste = 1.0 - (double)t256 / (double)(rounds * 256);
   if (vt_gemm_p8_supported(M, N, K) && waste <= 0.15) return VT_GEMM_CFG_256x256_P8;
+  // 128x128 (two 64-KiB workgroups per CU) only pays with >= 2 full rounds of tiles and a long K loop; everything smaller
+  // -- the 1024-row remainders of the M-split, the ViT / projector shapes with K = 1024 or N = 1024 -- measured 10-20 %
+  // faster on 64x128 tiles (tools/gemm_bench.py: 1024x4096x4096 752 vs 651 TFLOP/s, 4608x1024x4096 681 vs 623)
   const long t128 = (long)cdiv(M, 128) * cdiv(N, 128);
-  if (t128 < 256 && M <= 640) return VT_GEMM_CFG_64x128;
-  return VT_GEMM_CFG_128x128;
+  if (t128 >= 1024 && K >= 2048) return VT_GEMM_CFG_128x128;
+  return VT_GEMM_CFG_64x128;
 }
 
 int vt_gemm_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, const float* bias,
