@@ -46,7 +46,7 @@ enum {
   VT_GEMM_CFG_256x256 = 4,
   VT_GEMM_CFG_64x128 = 5,
   VT_GEMM_CFG_256x256_P8 = 6, /* 256x256 tile, 8 waves, 8-phase pipelined main loop */
-  VT_GEMM_CFG_256x256_W4 = 7, /* 256x256 tile, 4 waves (one per SIMD, 128x128 register tile each) */
+  /* 7: reserved (a 4-wave 128x128-register-tile experiment, slower than the 8-phase kernel; removed) */
   VT_GEMM_CFG_256x256_RP = 8, /* 256x256 tile, 8 waves, register-pipelined 32x32x16 main loop, one barrier per K tile */
   VT_GEMM_CFG_SKINNY_REG = 9  /* M <= 16: weight rows loaded straight into MFMA operand registers; fallback when K % 64 != 0 */
 };

@@ -40,7 +40,7 @@ def _gemm_ref(a, w, bias, epi, resid=None):
     return y if epi in (ops.EPI_F32, ops.EPI_F32_RESID) else bf16r(y)
 
 
-CFGS = [2, 3, 4, 5, 6, 7, 8]  # 128x128, 256x128, 256x256, 64x128, 256x256 8-phase, 256x256 4-wave
+CFGS = [2, 3, 4, 5, 6, 8]  # 128x128, 256x128, 256x256, 64x128, 256x256 8-phase, 256x256 register-pipelined
 
 
 @pytest.mark.parametrize("cfg", CFGS)

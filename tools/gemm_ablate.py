@@ -5,7 +5,6 @@ from vitron_amd import _lib, ops
 from tools.gemm_bench import timeit
 _lib.load(); dev = torch.device("cuda:0")
 names = {6: "full", 101: "no ds_read", 102: "no DMA", 103: "no ds_read, no DMA", 104: "no MFMA", 105: "no MFMA, no ds_read", 106: "no MFMA, no DMA", 107: "barriers only"}
-names.update({7: "W4 full", 201: "W4 no ds_read", 202: "W4 no DMA", 203: "W4 no ds_read, no DMA", 204: "W4 no MFMA", 206: "W4 no MFMA, no DMA", 207: "W4 barriers only"})
 for (M, N, K) in [(4096, 4096, 4096)]:
     a = torch.randn((M, K), device=dev).bfloat16(); w = (torch.randn((N, K), device=dev) * 0.02).bfloat16()
     for cfg, nm in names.items():

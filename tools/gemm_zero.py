@@ -12,7 +12,7 @@ for (M, N, K) in [(4096, 4096, 4096), (5120, 12288, 4096), (8192, 8192, 8192)]:
         else:
             a = torch.randint(0, 3, (M, K), device=dev).bfloat16(); w = torch.randint(0, 3, (N, K), device=dev).bfloat16()
         r = {}
-        for name, cfg in (("p8", 6), ("w4", 7), ("256", 4)):
+        for name, cfg in (("p8", 6), ("rp", 8), ("256", 4)):
             ms = timeit(lambda: ops.gemm(a, w, None, ops.EPI_BF16, cfg=cfg), 10)
             r[name] = round(2.0 * M * N * K / ms / 1e9, 1)
         ms = timeit(lambda: torch.matmul(a, w.t()), 10)

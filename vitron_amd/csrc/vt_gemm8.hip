@@ -291,217 +291,6 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmP8 p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// gemm_w4_kernel: 256x256x64 tile, FOUR waves (one per SIMD, 512 registers each), 128x128 register tile per wave on
-// v_mfma_f32_32x32x16_bf16. Per K step every wave does 2 x (16 ds_read_b128 + 32 MFMA): LDS read traffic per FLOP is
-// 2/3 of the 8-wave kernel's, there is one barrier per K step, and the fragment reads / LDS-DMA of the next half step
-// are interleaved with the MFMAs of the current one inside the same instruction stream (register double buffer).
-//   iteration t:  first half : read F1 <- (t, k 32..63)            | MFMA on F0 = (t, k 0..31)
-//                 vmcnt(0) (K step t+1 landed, issued one K step ago) ; lgkmcnt(0) ; barrier
-//                 second half: DMA K step t+2 -> buffer t&1 (dead)  ; read F0 <- (t+1, k 0..31) | MFMA on F1
-// ------------------------------------------------------------------------------------------------------------------
-template <int EPI, int ABL = 0>
-__global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmP8 p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int TILE_BYTES = 256 * 64 * 2;   // 32 KiB per operand per K step
-  constexpr int STAGE = 2 * TILE_BYTES;      // 64 KiB
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
-
-  const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 255) / 256;
-  const int nwg = tiles_m * tiles_n;
-  const int sid = xcd_remap(blockIdx.x, nwg);
-  constexpr int GROUP_M = 8;
-  const int per_group = GROUP_M * tiles_n;
-  const int first_m = (sid / per_group) * GROUP_M;
-  const int gsz = min(tiles_m - first_m, GROUP_M);
-  const int tm = first_m + (sid % per_group) % gsz;
-  const int tn = (sid % per_group) / gsz;
-  const int bm0 = tm * 256, bn0 = tn * 256;
-
-  // DMA: this wave stages pieces wave*8 .. wave*8+7 (8 rows each) of the A tile and of the B tile
-  const int lrow = lane >> 3, lchk = lane & 7;
-  // 32-bit byte offsets from the (wave-uniform) base pointers: half the registers of 64-bit pointers, and the DMA
-  // takes the scalar-base + vector-offset addressing form. (The launcher checks the operands are < 4 GiB.)
-  unsigned a_src[8], b_src[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int row = (wave * 8 + i) * 8 + lrow;
-    const int coff = (lchk ^ ((row >> 1) & 7)) * 8;
-    a_src[i] = (unsigned)(((size_t)min(bm0 + row, p.M - 1) * p.lda + coff) * 2);
-    b_src[i] = (unsigned)(((size_t)min(bn0 + row, p.N - 1) * p.ldw + coff) * 2);
-  }
-  const char* a_ptr = (const char*)p.A;
-  const char* b_ptr = (const char*)p.W;
-  const int dma_off = wave * 8192;
-#define W4_STAGE(BUF)                                                        \
-  do {                                                                       \
-    if ((ABL & 2) && w4_in_loop) break;                                      \
-    char* _d = smem + (BUF) * STAGE + dma_off;                               \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                          \
-      glds16(a_ptr + a_src[i], _d + i * 1024);                               \
-      a_src[i] += 128;                                                       \
-    }                                                                        \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                          \
-      glds16(b_ptr + b_src[i], _d + TILE_BYTES + i * 1024);                  \
-      b_src[i] += 128;                                                       \
-    }                                                                        \
-  } while (0)
-
-  // fragment reads: lane -> row (lane&31), 16-B chunk 2*ks + (lane>>5), swizzled by ((row>>1)&7)
-  const int f = ((lane & 31) >> 1) & 7;
-  int fo[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) fo[ks] = (lane & 31) * 128 + ((((2 * ks) | (lane >> 5)) ^ f) << 4);
-  const int a_base = wr * 128 * 128;
-  const int b_base = TILE_BYTES + wc * 128 * 128;
-
-  f32x16 acc[4][4];
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-  bf16x8 fa0[4][2], fb0[4][2], fa1[4][2], fb1[4][2];
-
-#define W4_READ(FA, FB, BUF, HALF)                                                         \
-  do {                                                                                     \
-    if ((ABL & 1) && w4_in_loop) break;                                                    \
-    const char* _s = smem + (BUF) * STAGE;                                                 \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                          \
-      _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                   \
-        FA[i][ks] = *(const bf16x8*)(_s + a_base + i * 4096 + fo[2 * (HALF) + ks]);        \
-        FB[i][ks] = *(const bf16x8*)(_s + b_base + i * 4096 + fo[2 * (HALF) + ks]);        \
-      }                                                                                    \
-  } while (0)
-#define W4_MFMA(FA, FB)                                                                    \
-  do {                                                                                     \
-    if (ABL & 4) break;                                                                    \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                       \
-      _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                     \
-        _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                   \
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FB[ni][ks], FA[mi][ks], acc[mi][ni], 0, 0, 0); \
-  } while (0)
-
-  bool w4_in_loop = false;
-  const int nt = p.K >> 6;
-  W4_STAGE(0);
-  if (nt > 1) W4_STAGE(1);
-  if (nt > 1) VT_VMCNT(16); else VT_VMCNT(0);
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_sched_barrier(0);
-  W4_READ(fa0, fb0, 0, 0);
-
-  // one K step; STAGE_ON / READ_ON are compile-time so that the steady-state body is ONE basic block (the
-  // sched_group_barrier interleave below only works inside a basic block)
-#define W4_ITER(STAGE_ON, READ_ON)                                                        \
-  do {                                                                                    \
-    const int cur = t & 1;                                                                \
-    W4_READ(fa1, fb1, cur, 1);                                                            \
-    W4_MFMA(fa0, fb0);                                                                    \
-    /* front-load the 16 fragment reads (1 per MFMA), the last 16 MFMAs cover their latency */ \
-    _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                      \
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                  \
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                  \
-    }                                                                                     \
-    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);                                   \
-    __builtin_amdgcn_sched_barrier(0);                                                    \
-    VT_VMCNT(0);                                                                          \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                    \
-    __builtin_amdgcn_s_barrier();                                                         \
-    __builtin_amdgcn_sched_barrier(0);                                                    \
-    if (STAGE_ON) W4_STAGE(cur);                                                          \
-    if (READ_ON) W4_READ(fa0, fb0, cur ^ 1, 0);                                           \
-    W4_MFMA(fa1, fb1);                                                                    \
-    _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                      \
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                  \
-      if (READ_ON) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                     \
-      if (STAGE_ON) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);                    \
-    }                                                                                     \
-    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);                                   \
-    __builtin_amdgcn_sched_barrier(0);                                                    \
-  } while (0)
-
-  if (ABL & 1) W4_READ(fa1, fb1, 0, 1);
-  w4_in_loop = true;
-  int t = 0;
-  for (; t + 2 < nt; ++t) W4_ITER(true, true);
-  if (t + 1 < nt) {
-    W4_ITER(false, true);
-    ++t;
-  }
-  W4_ITER(false, false);
-
-  // ---- epilogue: lane (m = ..+(lane&31)) holds n = ni*32 + 8*g + 4*(lane>>5) + {0..3}, g = reg>>2 --------------------
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
-    const int m = bm0 + wr * 128 + mi * 32 + (lane & 31);
-    if (m >= p.M) continue;
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      const int nfrag = bn0 + wc * 128 + ni * 32;
-      if constexpr (EPI == VT_EPI_SWIGLU_BF16) {
-        // inside a 32-wide fragment: cols 0..15 gate, 16..31 up -> register r pairs with r+8
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-          const int nl = 8 * g + 4 * (lane >> 5);
-          if (nfrag + nl >= p.N) continue;
-          u32x2 o;
-          o.x = pack_bf16x2(silu8(acc[mi][ni][4 * g + 0]) * acc[mi][ni][4 * g + 8], silu8(acc[mi][ni][4 * g + 1]) * acc[mi][ni][4 * g + 9]);
-          o.y = pack_bf16x2(silu8(acc[mi][ni][4 * g + 2]) * acc[mi][ni][4 * g + 10], silu8(acc[mi][ni][4 * g + 3]) * acc[mi][ni][4 * g + 11]);
-          *(u32x2*)((bf16_t*)p.C + (size_t)m * p.ldc + (nfrag >> 1) + nl) = o;
-        }
-      } else {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int n = nfrag + 8 * g + 4 * (lane >> 5);
-          if (n >= p.N) continue;
-          f32x4 v = {acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
-          if (p.bias) v += *(const f32x4*)(p.bias + n);
-          if constexpr (EPI == VT_EPI_BF16_GELU) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = gelu_erf8(v[r]);
-          } else if constexpr (EPI == VT_EPI_BF16_QGELU) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = quick_gelu8(v[r]);
-          } else if constexpr (EPI == VT_EPI_BF16_RELU) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-          }
-          if constexpr (EPI == VT_EPI_F32_RESID) {
-            float* c = (float*)p.C + (size_t)m * p.ldc + n;
-            *(f32x4*)c = *(const f32x4*)c + v;
-          } else if constexpr (EPI == VT_EPI_F32) {
-            *(f32x4*)((float*)p.C + (size_t)m * p.ldc + n) = v;
-          } else {
-            u32x2 o;
-            o.x = pack_bf16x2(v[0], v[1]);
-            o.y = pack_bf16x2(v[2], v[3]);
-            *(u32x2*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
-          }
-        }
-      }
-    }
-  }
-}
-
-template <int EPI, int ABL = 0>
-int launch_w4(const GemmP8& p, hipStream_t s) {
-  constexpr int smem = 2 * 2 * 256 * 64 * 2;  // 128 KiB
-  auto kern = gemm_w4_kernel<EPI, ABL>;
-  static bool done = false;
-  if (!done) {
-    VT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    done = true;
-  }
-  const int nwg = cdiv(p.M, 256) * cdiv(p.N, 256);
-  hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), smem, s, p);
-  VT_LAUNCH_CHECK();
-  return VT_OK;
-}
-
-// ------------------------------------------------------------------------------------------------------------------
 // gemm_rp_kernel ("register-pipelined"): 256x256x64 tile, 8 waves (2 x 4, two per SIMD), 128x64 per wave as 4 x 2
 // fragments of v_mfma_f32_32x32x16_bf16. No load/compute phase split: inside every wave the fragment reads of k-step
 // j+1 (6 ds_read_b128) are in flight while the 8 MFMAs of k-step j issue (8 independent accumulators, no dependent
@@ -756,34 +545,6 @@ int vt_gemm_rp_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* 
     case VT_EPI_F32: return launch_rp<VT_EPI_F32>(p, s);
     case VT_EPI_SWIGLU_BF16: return launch_rp<VT_EPI_SWIGLU_BF16>(p, s);
     default: vt_set_error("vt_gemm(rp): unknown epilogue %d", epi); return VT_ERR_ARG;
-  }
-}
-
-int vt_gemm_w4_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, const float* bias, int M,
-                      int N, int K, int epi, hipStream_t s) {
-  VT_REQUIRE((K % 64) == 0 && N % 32 == 0, "vt_gemm(w4): needs K %% 64 == 0 and N %% 32 == 0 (K=%d N=%d)", K, N);
-  VT_REQUIRE((size_t)M * lda * 2 < (1ull << 32) && (size_t)N * ldw * 2 < (1ull << 32), "vt_gemm(w4): operands must be < 4 GiB");
-  GemmP8 p{A, W, C, bias, M, N, K, lda, ldw, ldc};
-  if (epi >= 0x100) {  // timing ablations
-    switch (epi >> 8) {
-      case 1: return launch_w4<VT_EPI_BF16, 1>(p, s);
-      case 2: return launch_w4<VT_EPI_BF16, 2>(p, s);
-      case 3: return launch_w4<VT_EPI_BF16, 3>(p, s);
-      case 4: return launch_w4<VT_EPI_BF16, 4>(p, s);
-      case 5: return launch_w4<VT_EPI_BF16, 5>(p, s);
-      case 6: return launch_w4<VT_EPI_BF16, 6>(p, s);
-      default: return launch_w4<VT_EPI_BF16, 7>(p, s);
-    }
-  }
-  switch (epi) {
-    case VT_EPI_BF16: return launch_w4<VT_EPI_BF16>(p, s);
-    case VT_EPI_BF16_GELU: return launch_w4<VT_EPI_BF16_GELU>(p, s);
-    case VT_EPI_BF16_QGELU: return launch_w4<VT_EPI_BF16_QGELU>(p, s);
-    case VT_EPI_BF16_RELU: return launch_w4<VT_EPI_BF16_RELU>(p, s);
-    case VT_EPI_F32_RESID: return launch_w4<VT_EPI_F32_RESID>(p, s);
-    case VT_EPI_F32: return launch_w4<VT_EPI_F32>(p, s);
-    case VT_EPI_SWIGLU_BF16: return launch_w4<VT_EPI_SWIGLU_BF16>(p, s);
-    default: vt_set_error("vt_gemm(w4): unknown epilogue %d", epi); return VT_ERR_ARG;
   }
 }
 

@@ -39,8 +39,6 @@ int vt_gemm_p8_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* 
 
 int vt_gemm_rp_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, const float* bias, int M,
                       int N, int K, int epi, hipStream_t s);
-int vt_gemm_w4_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, const float* bias, int M,
-                      int N, int K, int epi, hipStream_t s);
 
 // ---- vt_norm.hip ----------------------------------------------------------------------------------
 int vt_layernorm_launch(float* x, const float* temb, int T, int tokens_per_frame, const float* gamma,
