@@ -40,14 +40,14 @@ def _gemm_ref(a, w, bias, epi, resid=None):
     return y if epi in (ops.EPI_F32, ops.EPI_F32_RESID) else bf16r(y)
 
 
-CFGS = [2, 3, 4, 5, 6, 8]  # 128x128, 256x128, 256x256, 64x128, 256x256 8-phase, 256x256 register-pipelined
+CFGS = [2, 3, 4, 5, 6, 8, 10]  # 128x128, 256x128, 256x256, 64x128, 256x256 8-phase, register-pipelined, 4-phase
 
 
 @pytest.mark.parametrize("cfg", CFGS)
 @pytest.mark.parametrize("M,N,K", [(300, 384, 256), (128, 128, 64), (577, 1024, 640), (1000, 512, 1024), (700, 1056, 1408)])
 def test_gemm_tile_configs(dev, cfg, M, N, K):
     from vitron_amd import ops
-    if cfg == 6 and (K % 128 or K < 256):
+    if cfg in (6, 10) and (K % 128 or K < 256):
         pytest.skip("8-phase kernel needs an even number (>= 4) of 64-wide K steps")
     a, w, b = randn((M, K), 1), randn((N, K), 2, 0.05), randn((N,), 3)
     for epi in (ops.EPI_BF16, ops.EPI_F32, ops.EPI_BF16_GELU, ops.EPI_SWIGLU_BF16):

@@ -20,7 +20,7 @@ SHAPES = [  # (M, N, K, epi, label)
     (1024, 4096, 4096, "F32_RESID", "o_proj rows 4096.."), (4096, 4096, 11008, "F32_RESID", "down rows 0..4095"),
     (1024, 4096, 11008, "F32_RESID", "down rows 4096.."), (4608, 1024, 4096, "F32_RESID", "vit fc2 4608"), (4608, 3072, 1024, "BF16", "vit qkv 4608"), (1088, 12288, 4096, "BF16", "llm qkv C2"), (577, 3072, 1024, "BF16", "vit qkv image"),
 ]
-CFGS = {"auto": 0, "128x128": 2, "256x128": 3, "256x256": 4, "64x128": 5, "256x256_p8": 6, "256x256_rp": 8, "rp_v1": 301, "rp_v2": 302, "rp_v3": 303}
+CFGS = {"auto": 0, "128x128": 2, "256x128": 3, "256x256": 4, "64x128": 5, "256x256_p8": 6, "256x256_p4": 10, "256x256_rp": 8, "rp_v1": 301, "rp_v2": 302, "rp_v3": 303}
 
 
 def timeit(fn, iters):

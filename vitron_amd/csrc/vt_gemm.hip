@@ -530,7 +530,8 @@ int launch_skinny(const GemmP& p, hipStream_t s, bool reg_operands) {
 }  // namespace
 
 int vt_gemm_pick_cfg(int M, int N, int K) {
-  // Measured on MI355X (tools/gemm_bench.py, profiles/): the 8-phase 256x256 kernel wins whenever its grid fills
+  // Measured on MI355X (tools/gemm_bench.py, profiles/): the 256x256 ping-pong kernel (4-phase variant: 8-11 % faster
+  // than the 8-phase one on every decoder shape) wins whenever its grid fills
   // whole rounds of the 256 CUs (one 128-KiB-LDS workgroup per CU); when the last round would be mostly empty the
   // 128x128 kernel (two workgroups per CU, 4x more tiles) quantises better. The register-pipelined variant
   // (VT_GEMM_CFG_256x256_RP) is 3-8% faster than the 8-phase kernel on isolated back-to-back launches but measured
@@ -539,7 +540,7 @@ int vt_gemm_pick_cfg(int M, int N, int K) {
   const long t256 = (long)cdiv(M, 256) * cdiv(N, 256);
   const long rounds = (t256 + 255) / 256;
   const double waste = 1.0 - (double)t256 / (double)(rounds * 256);
-  if (vt_gemm_p8_supported(M, N, K) && waste <= 0.15) return VT_GEMM_CFG_256x256_P8;
+  if (vt_gemm_p8_supported(M, N, K) && waste <= 0.15) return VT_GEMM_CFG_256x256_P4;
   // 128x128 (two 64-KiB workgroups per CU) only pays with >= 2 full rounds of tiles and a long K loop; everything smaller
   // -- the 1024-row remainders of the M-split, the ViT / projector shapes with K = 1024 or N = 1024 -- measured 10-20 %
   // faster on 64x128 tiles (tools/gemm_bench.py: 1024x4096x4096 752 vs 651 TFLOP/s, 4608x1024x4096 681 vs 623)
@@ -566,7 +567,7 @@ int vt_gemm_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, 
       // Wave quantisation: when the 256x256 grid would leave most of its last round of CUs idle (e.g. M=5120, N=4096:
       // 320 tiles = 1.25 rounds), run the rows that fill WHOLE rounds on the 256x256 kernel and the remaining rows on the
       // small-tile kernel (4x more, 4x shorter tiles fill the CUs again). Both launches are plain row ranges of the same GEMM.
-      if (cfg != VT_GEMM_CFG_256x256_P8 && vt_gemm_p8_supported(M, N, K) && K >= 2048 && M > 256) {
+      if (cfg != VT_GEMM_CFG_256x256_P4 && vt_gemm_p8_supported(M, N, K) && K >= 2048 && M > 256) {
         const int tiles_n = cdiv(N, 256);
         int g = tiles_n, b = 256;
         while (b) { const int t = g % b; g = b; b = t; }   // gcd(tiles_n, 256)
@@ -574,7 +575,7 @@ int vt_gemm_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, 
         const long M1 = (M / unit) * unit;
         if (M1 >= unit && M1 < M) {
           const size_t esz = (epi == VT_EPI_F32 || epi == VT_EPI_F32_RESID) ? 4 : 2;
-          VT_TRY(vt_gemm_launch(A, lda, W, ldw, C, ldc, bias, (int)M1, N, K, epi, VT_GEMM_CFG_256x256_P8, skinny_scratch, s));
+          VT_TRY(vt_gemm_launch(A, lda, W, ldw, C, ldc, bias, (int)M1, N, K, epi, VT_GEMM_CFG_256x256_P4, skinny_scratch, s));
           return vt_gemm_launch(A + (size_t)M1 * lda, lda, W, ldw, (char*)C + (size_t)M1 * ldc * esz, ldc, bias, M - (int)M1, N, K,
                                 epi, VT_GEMM_CFG_AUTO, skinny_scratch, s);
         }
@@ -603,6 +604,7 @@ int vt_gemm_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, 
   VT_REQUIRE((K % 64) == 0, "vt_gemm(tile): K=%d must be a multiple of 64", K);
   if (epi == VT_EPI_SWIGLU_BF16) VT_REQUIRE((N % 32) == 0, "vt_gemm(swiglu): N must be a multiple of 32");
   if (cfg == VT_GEMM_CFG_256x256_P8) return vt_gemm_p8_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, epi, s);
+  if (cfg == VT_GEMM_CFG_256x256_P4) return vt_gemm_p8_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, epi | 0x1000, s);
   if (cfg >= 100 && cfg < 108) return vt_gemm_p8_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, (cfg - 100) << 8, s);
   if (cfg >= 301 && cfg <= 303) return vt_gemm_rp_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, (cfg - 300) << 8, s);
   if (cfg == VT_GEMM_CFG_256x256_RP) return vt_gemm_rp_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, epi, s);

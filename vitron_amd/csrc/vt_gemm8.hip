@@ -56,7 +56,8 @@ __device__ __forceinline__ constexpr int slot_offset(int slot) {     // LDS plac
 }
 
 // ABL (timing ablations, results are garbage): bit0 = no fragment reads, bit1 = no LDS-DMA in the loop, bit2 = no MFMA
-template <int EPI, int ABL = 0>
+// P4 = the same pipeline with the phases merged pairwise (see the loop): half as many barriers, 32 MFMAs per section.
+template <int EPI, int ABL = 0, bool P4 = false>
 __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmP8 p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -166,6 +167,12 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmP8 p) {
     if ((G) < drain_from) VT_VMCNT(6); else VT_VMCNT(0);          \
     SECTION_SPLIT();                                              \
   } while (0)
+  // 4-phase variant: COND = "the stage(s) this phase was due to issue were issued" (else nothing newer is in flight: drain)
+#define PHASE_END4(COND, N)                                       \
+  do {                                                            \
+    if (COND) VT_VMCNT(N); else VT_VMCNT(0);                      \
+    SECTION_SPLIT();                                              \
+  } while (0)
 
   bool in_loop = false;
   const int nt = p.K >> 6;                 // K steps (even, >= 4: checked by the launcher)
@@ -179,6 +186,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmP8 p) {
   STAGE(0, SLOT_A1);
   STAGE(1, SLOT_A0);
   STAGE(1, SLOT_B0);
+  if (P4) STAGE(1, SLOT_B1);
   VT_VMCNT(0);
   SECTION_SPLIT();
   if (wr == 1) __builtin_amdgcn_s_barrier();   // stagger: the second wave row runs one barrier behind
@@ -187,6 +195,58 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmP8 p) {
   // ablation builds need the fragments initialised once from valid LDS
   if (ABL & 1) { READ_B(0, SLOT_B0, b0f); READ_B(0, SLOT_B1, b1f); READ_A(0, SLOT_A0); }
   in_loop = true;
+  // ---- 4-phase loop: one K step = phase A (reads A0 B0 B1, quadrants Q00 Q01) + phase B (reads A1, quadrants Q11 Q10) -------
+  // Global phase g = 2u + {0, 1}. Stage schedule: phase 2u issues A1 of K step u+1; phase 2u+1 issues A0 B0 B1 of K step
+  // u+2 into the slots K step u read one phase earlier (its A1 slot, read in this very phase, is only re-staged at phase
+  // 2u+2). Every datum is staged THREE phases before its first read, as in the 8-phase schedule (six half-length phases).
+  //   RAW  a read in load(p) needs every wave's DMA landed before the barrier that opens it: the reader's own group waited at
+  //        M(p-1), the staggered group at M(p-2). M(even) = vmcnt(2) leaves only this phase's A1 stage in flight, M(odd) =
+  //        vmcnt(6) only this phase's A0 B0 B1: everything staged at phases <= p-3 has landed at M(p-2). OK.
+  //   WAR  a slot read in load(p) is re-staged at phase >= p+1 (A0 B0 B1: read 2u, staged 2u+1; A1: read 2u+1, staged 2u+2):
+  //        the staggered group's reads of phase p finish (lgkmcnt(0)) one barrier before any wave issues phase p+1's stages. OK.
+  if constexpr (P4) {
+    for (int it = 0; it < nt / 2; ++it) {
+      const int u = it * 2;
+      // ===== K step u (buffer 0) =====
+      if (u + 1 < nt) STAGE(1, SLOT_A1);
+      READ_B(0, SLOT_B0, b0f);
+      READ_B(0, SLOT_B1, b1f);
+      READ_A(0, SLOT_A0);
+      LOAD_SECTION_END();
+      MFMA_Q(0, 0, b0f);
+      MFMA_Q(0, 1, b1f);
+      PHASE_END4(u + 1 < nt, 2);
+      if (u + 2 < nt) {
+        STAGE(0, SLOT_A0);
+        STAGE(0, SLOT_B0);
+        STAGE(0, SLOT_B1);
+      }
+      READ_A(0, SLOT_A1);
+      LOAD_SECTION_END();
+      MFMA_Q(1, 1, b1f);
+      MFMA_Q(1, 0, b0f);
+      PHASE_END4(u + 2 < nt, 6);
+      // ===== K step u+1 (buffer 1) =====
+      if (u + 2 < nt) STAGE(0, SLOT_A1);
+      READ_B(1, SLOT_B0, b0f);
+      READ_B(1, SLOT_B1, b1f);
+      READ_A(1, SLOT_A0);
+      LOAD_SECTION_END();
+      MFMA_Q(0, 0, b0f);
+      MFMA_Q(0, 1, b1f);
+      PHASE_END4(u + 2 < nt, 2);
+      if (u + 3 < nt) {
+        STAGE(1, SLOT_A0);
+        STAGE(1, SLOT_B0);
+        STAGE(1, SLOT_B1);
+      }
+      READ_A(1, SLOT_A1);
+      LOAD_SECTION_END();
+      MFMA_Q(1, 1, b1f);
+      MFMA_Q(1, 0, b0f);
+      PHASE_END4(u + 3 < nt, 6);
+    }
+  } else
   for (int it = 0; it < nt / 2; ++it) {
     const int g0 = it * 8;                     // global phase of this iteration's first phase
     const int u = it * 2;                      // K step in buffer 0
@@ -505,10 +565,10 @@ int launch_rp(const GemmP8& p, hipStream_t s) {
   return VT_OK;
 }
 
-template <int EPI, int ABL = 0>
+template <int EPI, int ABL = 0, bool P4 = false>
 int launch_p8(const GemmP8& p, hipStream_t s) {
   constexpr int smem = 2 * BUF_BYTES;  // 128 KiB
-  auto kern = gemm_p8_kernel<EPI, ABL>;
+  auto kern = gemm_p8_kernel<EPI, ABL, P4>;
   static bool done = false;
   if (!done) {
     VT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -552,7 +612,7 @@ int vt_gemm_p8_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* 
                       int N, int K, int epi, hipStream_t s) {
   VT_REQUIRE(vt_gemm_p8_supported(M, N, K), "vt_gemm(p8): needs K %% 128 == 0, K >= 256, N %% 32 == 0 (K=%d N=%d)", K, N);
   GemmP8 p{A, W, C, bias, M, N, K, lda, ldw, ldc};
-  if (epi >= 0x100) {  // timing ablations (tools/gemm_ablate.py); not reachable through the public enums
+  if (epi >= 0x100 && !(epi & 0x1000)) {  // timing ablations (tools/gemm_ablate.py); not reachable through the public enums
     switch (epi >> 8) {
       case 1: return launch_p8<VT_EPI_BF16, 1>(p, s);
       case 2: return launch_p8<VT_EPI_BF16, 2>(p, s);
@@ -561,6 +621,18 @@ int vt_gemm_p8_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* 
       case 5: return launch_p8<VT_EPI_BF16, 5>(p, s);
       case 6: return launch_p8<VT_EPI_BF16, 6>(p, s);
       default: return launch_p8<VT_EPI_BF16, 7>(p, s);
+    }
+  }
+  if (epi & 0x1000) {   // 4-phase variant
+    switch (epi & 0xff) {
+      case VT_EPI_BF16: return launch_p8<VT_EPI_BF16, 0, true>(p, s);
+      case VT_EPI_BF16_GELU: return launch_p8<VT_EPI_BF16_GELU, 0, true>(p, s);
+      case VT_EPI_BF16_QGELU: return launch_p8<VT_EPI_BF16_QGELU, 0, true>(p, s);
+      case VT_EPI_BF16_RELU: return launch_p8<VT_EPI_BF16_RELU, 0, true>(p, s);
+      case VT_EPI_F32_RESID: return launch_p8<VT_EPI_F32_RESID, 0, true>(p, s);
+      case VT_EPI_F32: return launch_p8<VT_EPI_F32, 0, true>(p, s);
+      case VT_EPI_SWIGLU_BF16: return launch_p8<VT_EPI_SWIGLU_BF16, 0, true>(p, s);
+      default: vt_set_error("vt_gemm(p4): unknown epilogue %d", epi & 0xff); return VT_ERR_ARG;
     }
   }
   switch (epi) {
