@@ -540,7 +540,7 @@ int vt_gemm_pick_cfg(int M, int N, int K) {
   const long t256 = (long)cdiv(M, 256) * cdiv(N, 256);
   const long rounds = (t256 + 255) / 256;
   const double waste = 1.0 - (double)t256 / (double)(rounds * 256);
-  if (vt_gemm_p8_supported(M, N, K) && waste <= 0.15) return VT_GEMM_CFG_256x256_P4;
+  if (vt_gemm_p8_supported(M, N, K) && waste <= 0.20) return VT_GEMM_CFG_256x256_P4;   // 4608x3072x1024 (216 tiles): 847 vs 706 TFLOP/s
   // 128x128 (two 64-KiB workgroups per CU) only pays with >= 2 full rounds of tiles and a long K loop; everything smaller
   // -- the 1024-row remainders of the M-split, the ViT / projector shapes with K = 1024 or N = 1024 -- measured 10-20 %
   // faster on 64x128 tiles (tools/gemm_bench.py: 1024x4096x4096 752 vs 651 TFLOP/s, 4608x1024x4096 681 vs 623)
