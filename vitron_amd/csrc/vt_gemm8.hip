@@ -623,6 +623,17 @@ int vt_gemm_p8_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* 
       default: return launch_p8<VT_EPI_BF16, 7>(p, s);
     }
   }
+  if ((epi & 0x1000) && (epi & 0x700)) {   // timing ablations of the 4-phase loop
+    switch ((epi >> 8) & 7) {
+      case 1: return launch_p8<VT_EPI_BF16, 1, true>(p, s);
+      case 2: return launch_p8<VT_EPI_BF16, 2, true>(p, s);
+      case 3: return launch_p8<VT_EPI_BF16, 3, true>(p, s);
+      case 4: return launch_p8<VT_EPI_BF16, 4, true>(p, s);
+      case 5: return launch_p8<VT_EPI_BF16, 5, true>(p, s);
+      case 6: return launch_p8<VT_EPI_BF16, 6, true>(p, s);
+      default: return launch_p8<VT_EPI_BF16, 7, true>(p, s);
+    }
+  }
   if (epi & 0x1000) {   // 4-phase variant
     switch (epi & 0xff) {
       case VT_EPI_BF16: return launch_p8<VT_EPI_BF16, 0, true>(p, s);
