@@ -42,7 +42,8 @@ __device__ __forceinline__ int v_swz(int d) { return (d >> 1) & 7; }
 // NWAVES waves x 32 query rows share one K / V^T tile ring of NSTAGES 64-key tiles (LDS-DMA, counted vmcnt):
 //   <4 waves, 2 stages>  128-row blocks, 64 KiB LDS (HD=128), two blocks per CU      -- ViT (many short sequences)
 //   <8 waves, 3 stages>  256-row blocks, 96 KiB LDS, one block per CU, two tiles of DMA lead -- long causal prefill
-template <int HD, bool CAUSAL, int NWAVES, int NSTAGES>
+// ABL (timing ablations, results are garbage): bit0 = no exp / max / sum (softmax VALU), bit1 = no MFMA
+template <int HD, bool CAUSAL, int NWAVES, int NSTAGES, int ABL = 0>
 __global__ __launch_bounds__(64 * NWAVES, (NWAVES == 8) ? 2 : 2) void flash_attn_kernel(const bf16_t* __restrict__ Q, int ldq,
                                                          const bf16_t* __restrict__ Kt,
                                                          const bf16_t* __restrict__ Vt,
@@ -177,7 +178,8 @@ __global__ __launch_bounds__(64 * NWAVES, (NWAVES == 8) ? 2 : 2) void flash_attn
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub) {
         const bf16x8 kf = *(const bf16x8*)(kb + k_row_off[sub] + (chunk << 4));
-        sacc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[sub], 0, 0, 0);
+        if (!(ABL & 2)) sacc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[sub], 0, 0, 0);
+        else sacc[sub][ks] += __builtin_bit_cast(float, (uint32_t)kf[0] << 16);
       }
     }
     // lane (q,h): sacc[sub][r] = S[q][t*64 + sub*32 + 16h + r]
@@ -201,9 +203,11 @@ __global__ __launch_bounds__(64 * NWAVES, (NWAVES == 8) ? 2 : 2) void flash_attn
     // branch): P is then bounded by 2^RESCALE_THR instead of 1, which bf16's exponent range absorbs at unchanged
     // relative precision, and the O / l rescale (the expensive VALU part) is skipped on almost every tile.
     float mx = fmaxf(sacc[0][0], sacc[1][0]);
+    if (!(ABL & 1)) {
 #pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(sacc[0][r], sacc[1][r]));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(sacc[0][r], sacc[1][r]));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    }
     const float m_tile = mx * scale_log2e;
     if (__builtin_amdgcn_ballot_w64(m_tile > m_run + RESCALE_THR) != 0) {
       const float m_new = fmaxf(m_run, m_tile);
@@ -222,8 +226,10 @@ __global__ __launch_bounds__(64 * NWAVES, (NWAVES == 8) ? 2 : 2) void flash_attn
     for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        sacc[sub][r] = fast_exp2(__builtin_fmaf(sacc[sub][r], scale_log2e, -m_safe));
-        psum += sacc[sub][r];
+        if (!(ABL & 1)) {
+          sacc[sub][r] = fast_exp2(__builtin_fmaf(sacc[sub][r], scale_log2e, -m_safe));
+          psum += sacc[sub][r];
+        }
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -246,7 +252,8 @@ __global__ __launch_bounds__(64 * NWAVES, (NWAVES == 8) ? 2 : 2) void flash_attn
 #pragma unroll
         for (int db = 0; db < DB; ++db) {   // DB independent accumulators back to back
           const bf16x8 vf = *(const bf16x8*)(vb + (db * 32 + ql) * 128 + (chunk << 4));
-          oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[sub][j], oacc[db], 0, 0, 0);
+          if (!(ABL & 2)) oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[sub][j], oacc[db], 0, 0, 0);
+          else oacc[db][j] += __builtin_bit_cast(float, (uint32_t)vf[0] << 16);
         }
       }
     FA_TILE_SYNC(t);
@@ -863,9 +870,9 @@ int vt_flash_attn_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf16_
   // causal granularity wins; the 8-wave / 3-stage variant stays selectable for experiments
   static const int use_big = getenv("VT_FLASH_QBLK256") ? atoi(getenv("VT_FLASH_QBLK256")) : 0;
   const bool big = max_q_len >= 1024 && use_big;
-#define VT_FA(HDV, CV, NW, NS)                                                                                 \
+#define VT_FA(HDV, CV, NW, NS, ...)                                                                            \
   do {                                                                                                         \
-    auto kern = flash_attn_kernel<HDV, CV, NW, NS>;                                                            \
+    auto kern = flash_attn_kernel<HDV, CV, NW, NS __VA_OPT__(,) __VA_ARGS__>;                                  \
     const int smem = NS * 2 * 64 * HDV * 2;                                                                    \
     static bool done = false;                                                                                  \
     if (!done) {                                                                                               \
@@ -880,7 +887,11 @@ int vt_flash_attn_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf16_
   } else if (big) {
     if (causal) VT_FA(128, true, 8, 3); else VT_FA(128, false, 8, 3);
   } else {
-    if (causal) VT_FA(128, true, 4, 2); else VT_FA(128, false, 4, 2);
+    static const int abl = getenv("VT_FLASH_ABL") ? atoi(getenv("VT_FLASH_ABL")) : 0;   // timing ablations: VT_FLASH_ABL=1|2|3 python tools/attn_bench.py
+    if (causal && abl == 1) VT_FA(128, true, 4, 2, 1);
+    else if (causal && abl == 2) VT_FA(128, true, 4, 2, 2);
+    else if (causal && abl == 3) VT_FA(128, true, 4, 2, 3);
+    else if (causal) VT_FA(128, true, 4, 2); else VT_FA(128, false, 4, 2);
   }
 #undef VT_FA
   VT_LAUNCH_CHECK();
