@@ -194,7 +194,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # VT_BENCH_FORCE_DIST=1 (with torch.distributed.run --nproc-per-node 1) drives the N > 1 code path -- process group,
+    # all-gather of the visual tokens, barrier, max-reduce -- on a single GPU: a plumbing check, not a measurement
+    use_dist = world > 1 or os.environ.get("VT_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl", device_id=dev)
@@ -219,7 +222,7 @@ def main():
     ids = torch.cat([torch.tensor([1], device=dev), torch.full((args.frames,), -200, device=dev), text]).unsqueeze(0)
     assert ids.shape[1] == args.text_len + args.frames
 
-    if world > 1:  # clip-per-rank encode, ONE all-gather of visual tokens, then data-parallel prefill
+    if use_dist:  # clip-per-rank encode, ONE all-gather of visual tokens, then data-parallel prefill
         from vitron_amd.parallel import all_gather_visual_tokens
         orig = model.encode_videos
 
@@ -241,7 +244,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -256,7 +259,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     prof = _lib.profile_end()
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -296,7 +299,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.image_size, args.frames, args.text_len, args.seed)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

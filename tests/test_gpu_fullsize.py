@@ -187,3 +187,29 @@ def test_image_tower_full_size_batch_independence(dev, model7b):
     assert torch.equal(f2.view(torch.int16), f[perm].view(torch.int16))
     f1 = model7b.encode_images(imgs[1:2])[0]
     assert rel_l2(f1.float(), f[1:2].float()) <= 5e-3     # a different M picks different GEMM tiles: same maths, bf16 noise
+
+
+def test_bench_distributed_path_on_one_gpu(dev):
+    """bench.py's N > 1 plumbing (RCCL process group, all-gather of the visual tokens, barrier, max-reduce of the time) driven
+    on ONE GPU through `torch.distributed.run --nproc-per-node 1` + VT_BENCH_FORCE_DIST=1: must print exactly one JSON line
+    with the driver's keys. (The collective's cross-rank behaviour is covered on gloo, world size 2, in test_parallel_gloo.py.)"""
+    import json
+    import os
+    import random
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VT_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = str(random.randint(20000, 40000))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1",
+           "--no-cpu-baseline", "--decode-steps", "0"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["scaling"] == "weak" and d["roofline"]["bound"] == "mfma"
