@@ -58,7 +58,7 @@ def test_gemm_tile_configs(dev, cfg, M, N, K):
 
 
 @pytest.mark.parametrize("epi_name", ["BF16", "BF16_GELU", "BF16_QGELU", "BF16_RELU", "F32_RESID", "F32", "SWIGLU_BF16"])
-@pytest.mark.parametrize("M", [1, 4, 7, 16, 200])
+@pytest.mark.parametrize("M", [1, 4, 7, 16, 17, 40, 64, 200])
 def test_gemm_epilogues_auto(dev, epi_name, M):
     from vitron_amd import ops
     epi = getattr(ops, "EPI_" + epi_name)

@@ -25,7 +25,7 @@ def main():
             n_out = N // 2 if epi == ops.EPI_SWIGLU_BF16 else N
             out = torch.zeros((M, n_out), device=dev, dtype=torch.float32 if epi in (ops.EPI_F32, ops.EPI_F32_RESID) else torch.bfloat16)
             row = {"shape": name, "M": M, "N": N, "K": K}
-            for label, cfg in (("dma_ring", 1), ("reg_operands", 9)):
+            for label, cfg in (("auto", 0), ("dma_ring", 1), ("tile_64x128", 5)):
                 for w in ws:
                     ops.gemm(a, w, None, epi, out=out, cfg=cfg)
                 torch.cuda.synchronize()

@@ -27,6 +27,8 @@
 //
 // "skinny" kernels: M <= 16 rows (decode steps, region MLP, last-position lm_head): pure weight streaming through a
 // per-wave LDS-DMA ring into 16x16x32 MFMAs, split-K inside the block. HBM-bound.
+#include <algorithm>
+
 #include "vt_common.h"
 #include "vt_kernels.h"
 
@@ -560,6 +562,18 @@ int vt_gemm_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, 
   VT_REQUIRE(ldc % 4 == 0, "vt_gemm: ldc must be a multiple of 4");
   GemmP p{A, W, C, bias, M, N, K, lda, ldw, ldc, VtGemmNormFuse{}};
   const bool skinny_path = (M <= 16) && (cfg == VT_GEMM_CFG_AUTO || cfg == VT_GEMM_CFG_SKINNY || cfg == VT_GEMM_CFG_SKINNY_REG);
+  // 17..64 rows (short follow-up prompts, larger decode batches): a tile grid is far too small for 256 CUs at N = 4096
+  // (64x128 tiles: 32 workgroups, 0.6 TB/s of weight stream), so the rows go through the weight-streaming kernel in groups
+  // of 16 -- the weights are streamed ceil(M/16) times (the repeats mostly from the Infinity Cache), still 1.5-3x faster:
+  // o_proj M=32: 17 vs 55 us, down: 39 vs 137 us, qkv: 37 vs 56 us (tools/skinny_bench.py). For wide N (gate/up, lm_head) the
+  // tile grid fills the chip and the single pass over the weights wins.
+  if (cfg == VT_GEMM_CFG_AUTO && M > 16 && M <= 64 && (K % 64) == 0 && (N <= 8192 || (N <= 16384 && M <= 32))) {
+    const size_t esz = (epi == VT_EPI_F32 || epi == VT_EPI_F32_RESID) ? 4 : 2;
+    for (int m0 = 0; m0 < M; m0 += 16)
+      VT_TRY(vt_gemm_launch(A + (size_t)m0 * lda, lda, W, ldw, (char*)C + (size_t)m0 * ldc * esz, ldc, bias, std::min(16, M - m0), N, K,
+                            epi, VT_GEMM_CFG_SKINNY, skinny_scratch, s));
+    return VT_OK;
+  }
   if (!skinny_path) {
     VT_REQUIRE((K % 64) == 0, "vt_gemm(tile): K=%d must be a multiple of 64", K);
   if (cfg == VT_GEMM_CFG_AUTO || cfg == VT_GEMM_CFG_SKINNY || cfg == VT_GEMM_CFG_SKINNY_REG) {
