@@ -548,6 +548,12 @@ int vt_gemm_pick_cfg(int M, int N, int K) {
   // faster on 64x128 tiles (tools/gemm_bench.py: 1024x4096x4096 752 vs 651 TFLOP/s, 4608x1024x4096 681 vs 623)
   const long t128 = (long)cdiv(M, 128) * cdiv(N, 128);
   if (t128 >= 1024 && K >= 2048) return VT_GEMM_CFG_128x128;
+  // 64x128 tiles run two workgroups per CU = 512 slots: when the grid spills a little over a whole number of rounds (M = 1088,
+  // N = 4096: 544 tiles) the half-empty last round costs a full one; with a long K loop the 128x128 grid (288 tiles, all
+  // resident) wins: 1088x4096x11008 723 vs 592 TFLOP/s (at K = 4096 the small tiles still win, 675 vs 629)
+  const long t64 = (long)cdiv(M, 64) * cdiv(N, 128);
+  const long r64 = (t64 + 511) / 512;
+  if (K >= 8192 && t128 >= 256 && t128 <= 512 && (double)t64 / (double)(r64 * 512) < 0.7) return VT_GEMM_CFG_128x128;
   return VT_GEMM_CFG_64x128;
 }
 
