@@ -582,7 +582,7 @@ int vt_gemm_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, 
   }
   if (!skinny_path) {
     VT_REQUIRE((K % 64) == 0, "vt_gemm(tile): K=%d must be a multiple of 64", K);
-  if (cfg == VT_GEMM_CFG_AUTO || cfg == VT_GEMM_CFG_SKINNY || cfg == VT_GEMM_CFG_SKINNY_REG) {
+    if (cfg == VT_GEMM_CFG_AUTO || cfg == VT_GEMM_CFG_SKINNY || cfg == VT_GEMM_CFG_SKINNY_REG) {
       cfg = vt_gemm_pick_cfg(M, N, K);
       // Wave quantisation: when the 256x256 grid would leave most of its last round of CUs idle (e.g. M=5120, N=4096:
       // 320 tiles = 1.25 rounds), run the rows that fill WHOLE rounds on the 256x256 kernel and the remaining rows on the
@@ -590,8 +590,12 @@ int vt_gemm_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, 
       if (cfg != VT_GEMM_CFG_256x256_P4 && vt_gemm_p8_supported(M, N, K) && K >= 2048 && M > 256) {
         const int tiles_n = cdiv(N, 256);
         int g = tiles_n, b = 256;
-        while (b) { const int t = g % b; g = b; b = t; }   // gcd(tiles_n, 256)
-        const long unit = 256L * (256 / g);                 // rows per whole round
+        while (b) {   // gcd(tiles_n, 256)
+          const int t = g % b;
+          g = b;
+          b = t;
+        }
+        const long unit = 256L * (256 / g);   // rows per whole round
         const long M1 = (M / unit) * unit;
         if (M1 >= unit && M1 < M) {
           const size_t esz = (epi == VT_EPI_F32 || epi == VT_EPI_F32_RESID) ? 4 : 2;
