@@ -89,6 +89,13 @@ int vt_rmsnorm(const float* x, const int* idx, const float* w, uint16_t* y, int 
 int vt_flash_attn(const uint16_t* Q, int ldq, const uint16_t* k_tiles, const uint16_t* vt_tiles, const int* tile_table,
                   const int* seq_desc, int nseq, int max_q_len, uint16_t* O, int ldo, int heads, int head_dim,
                   int causal, float scale, void* stream);
+/* Residual GEMM C[M,N] (fp32) += A[M,K] W[N,K]^T + bias with an optional split-K workspace: when the 256x256 tile grid would
+ * cover at most half of the chip (M ~ 1000 rows at N = 4096, the ViT's N = 1024 projections) the K loop is split over up to 8
+ * workgroups per tile, fp32 partial products go to `partials` and a second kernel adds them in split order (deterministic).
+ * ksplit: 0 = decide (may not split), >= 2 = force; partial_bytes >= ksplit*M*N*4 when it splits. */
+int vt_gemm_bf16_resid_splitk(const uint16_t* A, int lda, const uint16_t* W, int ldw, float* C, int ldc, const float* bias,
+                              int M, int N, int K, int ksplit, float* partials, size_t partial_bytes, void* stream);
+
 /* One decode step's attention in one launch (every sequence has q_len == 1; kv_len counts the new token): rotary
  * embedding of the new q/k rows (rope tables may be NULL), append of the new k row / v column to the paged tiles (a tile
  * that starts with the new token is zero-filled around it), single-query attention over the cache. qkv is not modified.

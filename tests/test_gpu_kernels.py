@@ -88,6 +88,26 @@ def test_gemm_skinny_kernels(dev, cfg, M, N, K):
         assert rel_l2(got.float(), ref) <= TOL, (cfg, epi)
 
 
+@pytest.mark.parametrize("M,N,K,ks", [(1088, 4096, 11008, 3), (1024, 4096, 11008, 0), (577, 1024, 4096, 8), (300, 4096, 4096, 0),
+                                      (700, 512, 1024, 2), (1088, 4096, 4096, 0), (5120, 4096, 11008, 0)])
+def test_gemm_resid_two_pass_split_k(dev, M, N, K, ks):
+    """vt_gemm_bf16_resid_splitk: partial products per K range + ordered reduce == the plain residual GEMM up to fp32
+    summation order, bit-identical from run to run; ks = 0 lets the dispatcher decide (incl. the M-split remainder at M = 5120)."""
+    from vitron_amd import ops
+    a, w, b = randn((M, K), 31), randn((N, K), 32, 0.05), randn((N,), 33)
+    resid = randn((M, N), 34)
+    ad, wd, bd = a.to(dev).bfloat16(), w.to(dev).bfloat16(), b.to(dev)
+    part = torch.full((8 * 1088 * 4096,), float("nan"), device=dev)
+    o1 = ops.gemm_resid_splitk(ad, wd, resid.to(dev).clone(), bd, ks, part)
+    o2 = ops.gemm_resid_splitk(ad, wd, resid.to(dev).clone(), bd, ks, part)
+    plain = ops.gemm(ad, wd, bd, ops.EPI_F32_RESID, out=resid.to(dev).clone())
+    assert torch.equal(o1, o2)
+    ref = _gemm_ref(a, w, b, ops.EPI_F32_RESID, resid)
+    assert rel_l2(o1, ref) <= 1e-5 and rel_l2(o1, plain) <= 1e-6
+    nosplit = ops.gemm_resid_splitk(ad, wd, resid.to(dev).clone(), bd, 0, None)     # no workspace: never splits
+    assert torch.equal(nosplit, plain)
+
+
 def test_gemm_transpose_detecting(dev):
     """A = I-like selector with an ASYMMETRIC W catches row/col swaps of the MFMA C layout."""
     from vitron_amd import ops

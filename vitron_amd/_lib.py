@@ -69,6 +69,7 @@ SIGNATURES = {
     "vt_flash_attn": (_i, [vp, _i, vp, vp, vp, vp, _i, _i, vp, _i, _i, _i, _i, _f, vp]),
     "vt_attn_decode_scratch_bytes": (_sz, [_i, _i, _i, _i]),
     "vt_attn_decode": (_i, [vp, _i, vp, vp, vp, vp, _i, vp, _i, _i, _i, _f, _i, vp, _sz, vp]),
+    "vt_gemm_bf16_resid_splitk": (_i, [vp, _i, vp, _i, vp, _i, vp, _i, _i, _i, _i, vp, _sz, vp]),
     "vt_attn_decode_fused": (_i, [vp, _i, _i, _i, _i, vp, vp, vp, vp, _i, vp, _i, _i, _i, _f, vp, vp, vp, vp]),
     "vt_kv_tiles": (_i, [vp, _i, _i, _i, _i, vp, vp, vp, vp, _i, _i, _i, _i, vp, vp, vp, vp]),
     "vt_attn_temporal": (_i, [vp, vp, _i, _i, _i, _i, vp]),

@@ -152,6 +152,11 @@ int vt_attn_decode(const uint16_t* Q, int ldq, const uint16_t* k_tiles, const ui
                                head_dim, scale, max_kv_len, (float*)scratch, scratch_bytes, S(stream));
 }
 
+int vt_gemm_bf16_resid_splitk(const uint16_t* A, int lda, const uint16_t* W, int ldw, float* C, int ldc, const float* bias,
+                              int M, int N, int K, int ksplit, float* partials, size_t partial_bytes, void* stream) {
+  return vt_gemm_resid_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, ksplit, partials, partial_bytes, S(stream));
+}
+
 int vt_attn_decode_fused(const uint16_t* qkv, int ldqkv, int q_col0, int k_col0, int v_col0, uint16_t* k_tiles,
                          uint16_t* vt_tiles, const int* tile_table, const int* seq_desc, int nseq, uint16_t* O, int ldo,
                          int heads, int head_dim, float scale, const float* rope_cos, const float* rope_sin,
@@ -265,6 +270,8 @@ struct VitWs {
   float* patch_out;
   bf16_t *y, *qkv, *att, *h, *patches, *kt, *vt;
   int *seq_desc, *tile_table;
+  float* splitk;   // split-K partial products (single images: the N = 1024 projections cover a fraction of the chip)
+  size_t splitk_bytes;
   size_t total;
 };
 VitWs vit_carve(const vt_vit_model* m, int B, int T, void* p, size_t n) {
@@ -284,6 +291,8 @@ VitWs vit_carve(const vt_vit_model* m, int B, int T, void* p, size_t n) {
   w.vt = (bf16_t*)ws.take((size_t)F * ntiles * 64 * D * 2);
   w.seq_desc = (int*)ws.take((size_t)F * 4 * 4);
   w.tile_table = (int*)ws.take((size_t)F * ntiles * 4);
+  w.splitk_bytes = (size_t)8 * R * D * 4 <= ((size_t)64 << 20) ? (size_t)8 * R * D * 4 : 0;   // only worth it for a few frames
+  w.splitk = w.splitk_bytes ? (float*)ws.take(w.splitk_bytes) : nullptr;
   w.total = ws.off + 256;
   return w;
 }
@@ -340,7 +349,7 @@ int vt_vit_forward(const vt_vit_model* m, const void* pixels, int pix_dtype, int
     // MLP
     VT_TRY(vt_layernorm_launch(w.x, nullptr, 0, 0, L.ln2_g, L.ln2_b, w.y, R, D, m->ln_eps, s));
     VT_TRY(vt_gemm_launch(w.y, D, L.w1, D, w.h, I, L.b1, R, I, D, act_epi, AUTO, nullptr, s));
-    VT_TRY(vt_gemm_launch(w.h, I, L.w2, I, w.x, D, L.b2, R, D, I, VT_EPI_F32_RESID, AUTO, nullptr, s));
+    VT_TRY(vt_gemm_resid_launch(w.h, I, L.w2, I, w.x, D, L.b2, R, D, I, 0, w.splitk, w.splitk_bytes, s));
   }
   VT_TRY(vt_drop_cls_launch(w.x, out_feats, F, G2, D, s));
   if (out_hidden) VT_HIP(hipMemcpyAsync(out_hidden, w.x, (size_t)R * D * 4, hipMemcpyDeviceToDevice, s));
@@ -354,6 +363,8 @@ struct LlamaWs {
   bf16_t *y, *qkv, *att, *h, *yn;
   float* scratch;
   float *rs_a, *rs_b;   // folded-RMSNorm partial sums of squares (decode steps)
+  float* splitk;        // fp32 partial products of the split-K residual GEMMs (prefills of 65..~2000 rows)
+  size_t splitk_bytes;
   float* attn_scratch;
   size_t attn_scratch_bytes;
   size_t total;
@@ -371,6 +382,9 @@ LlamaWs llama_carve(const vt_llama_model* m, int rows, int n_logit, int nseq, in
   w.scratch = (float*)ws.take((size_t)16 * 2 * I * 4);
   w.rs_a = (float*)ws.take((size_t)16 * (H / 16) * 4);
   w.rs_b = (float*)ws.take((size_t)16 * (H / 16) * 4);
+  // tiles * ksplit <= 256 tiles of 256x256 fp32: 64 MiB covers every case the dispatcher splits
+  w.splitk_bytes = (rows > 64) ? ((size_t)256 * 256 * 256 * 4) : 0;
+  w.splitk = w.splitk_bytes ? (float*)ws.take(w.splitk_bytes) : nullptr;
   w.attn_scratch_bytes = vt_attn_decode_scratch_bytes(nseq > 0 ? nseq : 1, m->heads, m->head_dim, max_kv_len > 0 ? max_kv_len : 64);
   w.attn_scratch = (float*)ws.take(w.attn_scratch_bytes);
   w.total = ws.off + 256;
@@ -460,10 +474,10 @@ int vt_llama_forward(const vt_llama_model* m, const vt_kv_cache* kv, const uint1
       VT_TRY(vt_flash_attn_launch(w.qkv, 3 * H, kt, vt, tile_table, (const VtAttnSeq*)seq_desc, nseq, max_q_len, w.att, H,
                                   heads, HD, 1, scale, s));
     }
-    VT_TRY(vt_gemm_launch(w.att, H, L.wo, H, w.x, H, nullptr, rows, H, H, VT_EPI_F32_RESID, AUTO, nullptr, s));
+    VT_TRY(vt_gemm_resid_launch(w.att, H, L.wo, H, w.x, H, nullptr, rows, H, H, 0, w.splitk, w.splitk_bytes, s));
     VT_TRY(vt_rmsnorm_launch(w.x, nullptr, L.rms2, w.y, rows, H, m->rms_eps, s));
     VT_TRY(vt_gemm_launch(w.y, H, L.wgu, H, w.h, I, nullptr, rows, 2 * I, H, VT_EPI_SWIGLU_BF16, AUTO, w.scratch, s));
-    VT_TRY(vt_gemm_launch(w.h, I, L.wdown, I, w.x, H, nullptr, rows, H, I, VT_EPI_F32_RESID, AUTO, nullptr, s));
+    VT_TRY(vt_gemm_resid_launch(w.h, I, L.wdown, I, w.x, H, nullptr, rows, H, I, 0, w.splitk, w.splitk_bytes, s));
   }
   if (out_hidden) VT_HIP(hipMemcpyAsync(out_hidden, w.x, (size_t)rows * H * 4, hipMemcpyDeviceToDevice, s));
   if (n_logit_rows > 0) {

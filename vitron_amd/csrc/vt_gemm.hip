@@ -557,6 +557,11 @@ int vt_gemm_pick_cfg(int M, int N, int K) {
   return VT_GEMM_CFG_64x128;
 }
 
+// measured on MI355X (tools/splitk_bench.py): see the table in DESIGN.md 3.1
+// (1088x4096x11008: 149 -> 108 us at ksplit 3; 1024x4096x11008: 114 -> 91 at 4; 300x4096x11008: 96 -> 56 at 8; 577x1024x4096:
+// 39 -> 29 at 8; K = 4096 with ksplit < 8 and everything at K = 1024: no gain, the reduce pass eats it)
+bool vt_gemm_splitk_pays(int M, int N, int K, int ksplit) { return K >= 8192 || (K >= 4096 && ksplit >= 8); }
+
 int vt_gemm_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, const float* bias,
                    int M, int N, int K, int epi, int cfg, void* skinny_scratch, hipStream_t s) {
   VT_REQUIRE(A && W && C, "vt_gemm: null pointer");
@@ -663,4 +668,41 @@ int vt_gemm_skinny_norm_launch(const bf16_t* A, int lda, const bf16_t* W, int ld
     case VT_EPI_SWIGLU_BF16: return launch_skinny<VT_EPI_SWIGLU_BF16>(p, s, false);
     default: vt_set_error("vt_gemm(norm-fused): epilogue %d unsupported", epi); return VT_ERR_ARG;
   }
+}
+
+// Residual GEMM (C += A W^T + bias) with an optional split-K workspace. ksplit == 0: decide here -- split only when the 256x256
+// grid would cover at most half the chip, enough K is left per split and the workspace is large enough; otherwise the plain
+// dispatcher. ksplit >= 2 forces the two-pass path (tests, tools/splitk_bench.py).
+int vt_gemm_resid_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, float* C, int ldc, const float* bias, int M, int N,
+                         int K, int ksplit, float* partials, size_t partial_bytes, hipStream_t s) {
+  int ks = ksplit;
+  if (ks == 0 && partials && M > 64 && vt_gemm_p8_supported(M, N, K) && (N % 4) == 0) {
+    const int tiles = cdiv(M, 256) * cdiv(N, 256);
+    const int cand = std::min(std::min(256 / std::max(tiles, 1), (K >> 7) / 2), 8);
+    if (tiles <= 128 && cand >= 2 && (long)tiles * cand >= 128 && vt_gemm_splitk_pays(M, N, K, cand) &&
+        partial_bytes >= (size_t)cand * M * N * sizeof(float))
+      ks = cand;
+    if (ks == 0 && tiles > 256 && K >= 2048 && vt_gemm_pick_cfg(M, N, K) != VT_GEMM_CFG_256x256_P4) {
+      // the dispatcher's M-split (whole rounds of 256x256 tiles + remainder), done here so that the remainder can split K
+      const int tiles_n = cdiv(N, 256);
+      int g = tiles_n, b = 256;
+      while (b) {
+        const int t = g % b;
+        g = b;
+        b = t;
+      }
+      const long unit = 256L * (256 / g);
+      const long M1 = (M / unit) * unit;
+      if (M1 >= unit && M1 < M) {
+        VT_TRY(vt_gemm_launch(A, lda, W, ldw, C, ldc, bias, (int)M1, N, K, VT_EPI_F32_RESID, VT_GEMM_CFG_256x256_P4, nullptr, s));
+        return vt_gemm_resid_launch(A + (size_t)M1 * lda, lda, W, ldw, C + (size_t)M1 * ldc, ldc, bias, M - (int)M1, N, K, 0, partials,
+                                    partial_bytes, s);
+      }
+    }
+  }
+  if (ks < 2) return vt_gemm_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, VT_EPI_F32_RESID, VT_GEMM_CFG_AUTO, nullptr, s);
+  VT_REQUIRE(partials && partial_bytes >= (size_t)ks * M * N * sizeof(float), "vt_gemm(split-K): workspace too small (%zu bytes for ksplit=%d)",
+             partial_bytes, ks);
+  VtProfScope prof(VT_PROF_GEMM_TILE, 2.0 * (double)M * (double)N * (double)K, s);
+  return vt_gemm_p4_splitk_resid_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, ks, partials, s);
 }

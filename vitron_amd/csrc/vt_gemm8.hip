@@ -23,6 +23,8 @@
 //        M(p-2); both waits are vmcnt(6) = "everything but the 3 newest stages", i.e. stages <= p-5 for the laggard. OK.
 //   WAR  stage (u, j) overwrites K step u-2's slot j, whose last read was at phase 4(u-2) + {0,0,1,2}[j]; the stage is
 //        issued at 4(u-2) + j + 2 >= two phases later, after the readers' lgkmcnt wait and two barriers. OK.
+#include <algorithm>
+
 #include "vt_common.h"
 #include "vt_kernels.h"
 
@@ -35,6 +37,8 @@ struct GemmP8 {
   const float* bias;
   int M, N, K;
   int lda, ldw, ldc;
+  int ksplit;        // > 1 (fp32-out epilogue only): blocks [s*tiles, (s+1)*tiles) compute K range s of every tile into slab s of C
+  size_t slab;       // elements between consecutive slabs
 };
 
 __device__ __forceinline__ float gelu_erf8(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
@@ -67,7 +71,13 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmP8 p) {
   // ---- tile order (XCD remap + groups of 8 M tiles), as in vt_gemm.hip ---------------------------------------------
   const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 255) / 256;
   const int nwg = tiles_m * tiles_n;
-  const int sid = xcd_remap(blockIdx.x, nwg);
+  // two-pass split-K (EPI == F32 only): split s of every tile writes its partial product to slab s; a reduce kernel adds them
+  const int ksplit = (EPI == VT_EPI_F32) ? p.ksplit : 1;
+  const int split = (ksplit > 1) ? (int)blockIdx.x / nwg : 0;
+  const int sid = xcd_remap((int)blockIdx.x - split * nwg, nwg);
+  const int ku = p.K >> 7;   // K in units of 128 (two K steps), balanced over the splits
+  const int u_begin = (int)((long)ku * split / ksplit), u_end = (int)((long)ku * (split + 1) / ksplit);
+  const int k_begin = u_begin * 128;
   constexpr int GROUP_M = 8;
   const int per_group = GROUP_M * tiles_n;
   const int first_m = (sid / per_group) * GROUP_M;
@@ -83,10 +93,10 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmP8 p) {
   for (int i = 0; i < 2; ++i) {
     const int row = (wave * 2 + i) * 8 + lrow;          // row inside the half tile
     const int coff = (lchk ^ ((row >> 1) & 7)) * 8;
-    src[SLOT_A0][i] = p.A + (size_t)min(bm0 + row, p.M - 1) * p.lda + coff;
-    src[SLOT_A1][i] = p.A + (size_t)min(bm0 + 128 + row, p.M - 1) * p.lda + coff;
-    src[SLOT_B0][i] = p.W + (size_t)min(bn0 + row, p.N - 1) * p.ldw + coff;
-    src[SLOT_B1][i] = p.W + (size_t)min(bn0 + 128 + row, p.N - 1) * p.ldw + coff;
+    src[SLOT_A0][i] = p.A + (size_t)min(bm0 + row, p.M - 1) * p.lda + coff + k_begin;
+    src[SLOT_A1][i] = p.A + (size_t)min(bm0 + 128 + row, p.M - 1) * p.lda + coff + k_begin;
+    src[SLOT_B0][i] = p.W + (size_t)min(bn0 + row, p.N - 1) * p.ldw + coff + k_begin;
+    src[SLOT_B1][i] = p.W + (size_t)min(bn0 + 128 + row, p.N - 1) * p.ldw + coff + k_begin;
   }
   const int dma_off = wave * 2048;                      // this wave's two 1-KiB pieces inside a half tile
 
@@ -175,7 +185,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmP8 p) {
   } while (0)
 
   bool in_loop = false;
-  const int nt = p.K >> 6;                 // K steps (even, >= 4: checked by the launcher)
+  const int nt = (u_end - u_begin) * 2;    // K steps of this workgroup (even, >= 4: checked by the launcher)
   const int total_phases = 4 * nt;
   const int drain_from = total_phases - 6;  // phases g >= this did not all issue a stage in (g-2..g): drain instead
 
@@ -322,7 +332,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmP8 p) {
             const int n = nbase + ni * 16 + ((lane >> 4) << 2);
             if (n >= p.N) continue;
             f32x4 v = acc[qm][qn][mi][ni];
-            if (p.bias) v += *(const f32x4*)(p.bias + n);
+            if (p.bias && split == 0) v += *(const f32x4*)(p.bias + n);   // split-K: the bias goes in once
             if constexpr (EPI == VT_EPI_BF16_GELU) {
 #pragma unroll
               for (int r = 0; r < 4; ++r) v[r] = gelu_erf8(v[r]);
@@ -337,7 +347,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmP8 p) {
               float* c = (float*)p.C + (size_t)m * p.ldc + n;
               *(f32x4*)c = *(const f32x4*)c + v;
             } else if constexpr (EPI == VT_EPI_F32) {
-              *(f32x4*)((float*)p.C + (size_t)m * p.ldc + n) = v;
+              *(f32x4*)((float*)p.C + (size_t)split * p.slab + (size_t)m * p.ldc + n) = v;
             } else {
               u32x2 o;
               o.x = pack_bf16x2(v[0], v[1]);
@@ -559,7 +569,7 @@ int launch_rp(const GemmP8& p, hipStream_t s) {
     VT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     done = true;
   }
-  const int nwg = cdiv(p.M, 256) * cdiv(p.N, 256);
+  const int nwg = cdiv(p.M, 256) * cdiv(p.N, 256) * (p.ksplit > 1 ? p.ksplit : 1);
   hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), smem, s, p);
   VT_LAUNCH_CHECK();
   return VT_OK;
@@ -574,7 +584,7 @@ int launch_p8(const GemmP8& p, hipStream_t s) {
     VT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     done = true;
   }
-  const int nwg = cdiv(p.M, 256) * cdiv(p.N, 256);
+  const int nwg = cdiv(p.M, 256) * cdiv(p.N, 256) * (p.ksplit > 1 ? p.ksplit : 1);
   hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), smem, s, p);
   VT_LAUNCH_CHECK();
   return VT_OK;
@@ -588,7 +598,7 @@ int vt_gemm_rp_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* 
                       int N, int K, int epi, hipStream_t s) {
   VT_REQUIRE((K % 64) == 0 && N % 32 == 0, "vt_gemm(rp): needs K %% 64 == 0 and N %% 32 == 0 (K=%d N=%d)", K, N);
   VT_REQUIRE((size_t)M * lda * 2 < (1ull << 32) && (size_t)N * ldw * 2 < (1ull << 32), "vt_gemm(rp): operands must be < 4 GiB");
-  GemmP8 p{A, W, C, bias, M, N, K, lda, ldw, ldc};
+  GemmP8 p{A, W, C, bias, M, N, K, lda, ldw, ldc, 1, 0};
   if (epi >= 0x100) {  // A/B variants of the main loop (bf16 epilogue only)
     switch (epi >> 8) {
       case 1: return launch_rp<VT_EPI_BF16, 1>(p, s);
@@ -608,10 +618,38 @@ int vt_gemm_rp_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* 
   }
 }
 
+// Residual GEMM as a two-pass split-K: pass 1 = the 4-phase ping-pong kernel over `ksplit` K ranges, fp32 partial products to
+// `partials` ([ksplit][M][N]); pass 2 adds them (split order: deterministic) and the bias-carrying split 0 onto the residual C.
+namespace {
+__global__ __launch_bounds__(256) void splitk_reduce_resid_kernel(const float* __restrict__ part, size_t slab, int ksplit,
+                                                                  float* __restrict__ C, int ldc, int M, int N) {
+  const int n4 = N >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)M * n4; i += (long)gridDim.x * blockDim.x) {
+    const int m = (int)(i / n4), c = (int)(i % n4);
+    f32x4 acc = *(const f32x4*)(C + (size_t)m * ldc + c * 4);
+    for (int s = 0; s < ksplit; ++s) acc += *(const f32x4*)(part + (size_t)s * slab + (size_t)m * N + c * 4);
+    *(f32x4*)(C + (size_t)m * ldc + c * 4) = acc;
+  }
+}
+}  // namespace
+
+int vt_gemm_p4_splitk_resid_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, float* C, int ldc, const float* bias, int M,
+                                   int N, int K, int ksplit, float* partials, hipStream_t s) {
+  VT_REQUIRE(vt_gemm_p8_supported(M, N, K) && (N % 4) == 0, "vt_gemm(split-K): unsupported shape (N=%d K=%d)", N, K);
+  VT_REQUIRE(ksplit >= 2 && (K >> 7) / ksplit >= 2 && partials, "vt_gemm(split-K): ksplit=%d leaves < 256 of K per split, or no workspace", ksplit);
+  GemmP8 p{A, W, partials, bias, M, N, K, lda, ldw, N, ksplit, (size_t)M * N};
+  VT_TRY((launch_p8<VT_EPI_F32, 0, true>(p, s)));
+  const long total = (long)M * (N >> 2);
+  const int blocks = (int)std::min<long>((total + 255) / 256, 2048);
+  hipLaunchKernelGGL(splitk_reduce_resid_kernel, dim3(blocks), dim3(256), 0, s, partials, p.slab, ksplit, C, ldc, M, N);
+  VT_LAUNCH_CHECK();
+  return VT_OK;
+}
+
 int vt_gemm_p8_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, const float* bias, int M,
                       int N, int K, int epi, hipStream_t s) {
   VT_REQUIRE(vt_gemm_p8_supported(M, N, K), "vt_gemm(p8): needs K %% 128 == 0, K >= 256, N %% 32 == 0 (K=%d N=%d)", K, N);
-  GemmP8 p{A, W, C, bias, M, N, K, lda, ldw, ldc};
+  GemmP8 p{A, W, C, bias, M, N, K, lda, ldw, ldc, 1, 0};
   if (epi >= 0x100 && !(epi & 0x1000)) {  // timing ablations (tools/gemm_ablate.py); not reachable through the public enums
     switch (epi >> 8) {
       case 1: return launch_p8<VT_EPI_BF16, 1>(p, s);

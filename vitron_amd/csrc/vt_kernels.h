@@ -34,6 +34,11 @@ int vt_gemm_skinny_norm_launch(const bf16_t* A, int lda, const bf16_t* W, int ld
 
 // ---- vt_gemm8.hip (256x256 tile, 8-phase pipeline) ---------------------------------------------------
 bool vt_gemm_p8_supported(int M, int N, int K);
+bool vt_gemm_splitk_pays(int M, int N, int K, int ksplit);
+int vt_gemm_resid_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, float* C, int ldc, const float* bias, int M, int N,
+                         int K, int ksplit, float* partials, size_t partial_bytes, hipStream_t s);
+int vt_gemm_p4_splitk_resid_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, float* C, int ldc, const float* bias, int M,
+                                   int N, int K, int ksplit, float* partials, hipStream_t s);
 int vt_gemm_p8_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, const float* bias, int M,
                       int N, int K, int epi, hipStream_t s);
 

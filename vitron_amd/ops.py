@@ -57,6 +57,21 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     return out
 
 
+def gemm_resid_splitk(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bias: Optional[torch.Tensor] = None, ksplit: int = 0,
+                      partials: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out (fp32) += a @ w^T + bias, optionally as a two-pass split-K through the fp32 workspace `partials`."""
+    lib = _lib.load()
+    _chk(a, torch.bfloat16, "gemm_resid_splitk.a")
+    _chk(w, torch.bfloat16, "gemm_resid_splitk.w")
+    _chk(out, torch.float32, "gemm_resid_splitk.out")
+    M, K = a.shape
+    N = w.shape[0]
+    nbytes = 0 if partials is None else partials.numel() * partials.element_size()
+    _lib.check(lib.vt_gemm_bf16_resid_splitk(_p(a), a.stride(0), _p(w), w.stride(0), _p(out), out.stride(0), _p(bias), M, N, K,
+                                             int(ksplit), _p(partials), nbytes, _stream()), "vt_gemm_bf16_resid_splitk")
+    return out
+
+
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, temb: Optional[torch.Tensor] = None,
               tokens_per_frame: int = 0) -> torch.Tensor:
     """bf16 LayerNorm of the fp32 rows of x; with temb ([T,D] fp32) x[row] += temb[(row//tokens_per_frame)%T] in place."""
