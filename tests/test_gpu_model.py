@@ -279,3 +279,48 @@ def test_multi_turn_reuses_towers_and_kv_prefix(dev):
     assert models[0].last_generate_stats["reused_tokens"] == 64 and models[0].last_generate_stats["tower_items"] == 1
     models[0].reset_prefix_cache()
     assert len(models[0].kv.free) == models[0].kv.num_pages
+
+
+@pytest.mark.gpu
+def test_serving_engine_continuous_batching_matches_solo_runs(dev, model):
+    """Five requests (text-only, image, image + region, video) joining a running decode batch at different steps: every
+    request's greedy tokens equal the tokens `generate` produces for it alone; pages all return to the pool."""
+    from vitron_amd.serving import ServingEngine
+    g = torch.Generator().manual_seed(21)
+    V = cases.LLM["vocab_size"]
+    img = lambda: torch.randn((3, 56, 56), generator=g).bfloat16().to(dev)            # noqa: E731
+    clip = torch.randn((3, 4, 56, 56), generator=g).bfloat16().to(dev)                  # the golden video tower: 4 frames
+    rnd = lambda n: torch.randint(3, V, (n,), generator=g).tolist()                     # noqa: E731
+    reqs = [
+        dict(input_ids=torch.tensor([[1] + rnd(23)]), images=None, regions=None, max_new_tokens=9),
+        dict(input_ids=torch.tensor([[1, -200] + rnd(11)]), images=[img()], regions=None, max_new_tokens=14),
+        dict(input_ids=torch.tensor([[1, -200] + rnd(5) + [-300, 1] + rnd(7)]), images=[img()], regions=[[20.0, 30.0, 150.0, 200.0]], max_new_tokens=6),
+        dict(input_ids=torch.tensor([[1] + [-200] * 4 + rnd(9)]), images=[clip], regions=None, max_new_tokens=11),
+        dict(input_ids=torch.tensor([[1] + rnd(70)]), images=None, regions=None, max_new_tokens=5),
+    ]
+    model.config.kv_prefix_reuse = False
+    solo = []
+    for r in reqs:
+        o = model.generate(r["input_ids"].to(dev), images=r["images"], regions=r["regions"], do_sample=False,
+                           max_new_tokens=r["max_new_tokens"], eos_token_id=-1)
+        solo.append(o[0, r["input_ids"].shape[1]:].cpu())
+    eng = ServingEngine(model, max_batch=3, kv_pages=64)
+    ids = [eng.submit(reqs[0]["input_ids"], reqs[0]["images"], reqs[0]["regions"], reqs[0]["max_new_tokens"], eos_token_id=-1),
+           eng.submit(reqs[1]["input_ids"], reqs[1]["images"], reqs[1]["regions"], reqs[1]["max_new_tokens"], eos_token_id=-1)]
+    seen = {i: [] for i in range(5)}
+    steps = 0
+    while eng.pending():
+        if steps == 2:      # two more arrive while the first two decode; max_batch = 3 makes the fourth wait for a free slot
+            ids.append(eng.submit(reqs[2]["input_ids"], reqs[2]["images"], reqs[2]["regions"], reqs[2]["max_new_tokens"], eos_token_id=-1))
+            ids.append(eng.submit(reqs[3]["input_ids"], reqs[3]["images"], reqs[3]["regions"], reqs[3]["max_new_tokens"], eos_token_id=-1))
+        if steps == 5:
+            ids.append(eng.submit(reqs[4]["input_ids"], reqs[4]["images"], reqs[4]["regions"], reqs[4]["max_new_tokens"], eos_token_id=-1))
+        for rid, t in eng.step():
+            seen[rid].append(t)
+        steps += 1
+        assert len(eng.active) <= 3 and steps < 200
+    assert ids == [0, 1, 2, 3, 4]
+    for i in range(5):
+        assert seen[i] == solo[i].tolist(), (i, seen[i], solo[i].tolist())
+    assert len(model.kv.free) == model.kv.num_pages
+    model.config.kv_prefix_reuse = True

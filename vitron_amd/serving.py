@@ -1,0 +1,147 @@
+"""Continuous batching on the paged KV cache (the serving half).
+
+The reference serves one request at a time (`app.py:1128`: Gradio queue, concurrency 1; global `model` / `conv`). With a paged
+cache and packed sequences a second request does not have to wait for the first one's 1024 decode steps: every step of this
+engine decodes ONE token for every active sequence in a single `vt_llama_forward` call (one row per sequence, weight-streaming
+GEMMs + the fused decode attention), and requests join / leave between steps.
+
+  eng = ServingEngine(model, max_batch=16, kv_pages=512)
+  a = eng.submit(ids_a, images=[img], regions=[box], max_new_tokens=256)
+  b = eng.submit(ids_b, max_new_tokens=64)           # may be submitted while `a` is already decoding
+  for rid, token in eng.step(): ...                  # or: outputs = eng.run()   -> {rid: LongTensor of new tokens}
+
+Admission runs the request's multimodal prefill on its own (towers -> splice -> decoder prefill, exactly what `generate` does,
+including the visual-feature cache), so a request's tokens are bit-identical to running it alone with greedy decoding as long
+as the decode batch stays on one kernel path (<= 16 rows: the folded-norm path; the engine never mixes a sequence between the
+<= 16 and > 16 row paths within one request unless max_batch > 16).
+"""
+from __future__ import annotations
+
+import collections
+from dataclasses import dataclass, field
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import ops
+from .engine import PagedKVCache, SequenceState, llama_forward
+
+
+@dataclass
+class _Request:
+    rid: int
+    input_ids: torch.Tensor
+    images: Optional[list]
+    regions: Optional[list]
+    max_new_tokens: int
+    eos: frozenset
+    seq: SequenceState = field(default_factory=SequenceState)
+    tokens: List[int] = field(default_factory=list)
+    last: Optional[torch.Tensor] = None      # device int32 [1]: the token to feed next
+    done: bool = False
+
+
+class ServingEngine:
+    def __init__(self, model, max_batch: int = 16, kv_pages: Optional[int] = None, do_sample: bool = False,
+                 temperature: float = 1.0, top_p: float = 1.0, seed: int = 0):
+        self.model = model
+        self.max_batch = int(max_batch)
+        self.do_sample, self.temperature, self.top_p, self.seed = bool(do_sample), float(temperature), float(top_p), int(seed)
+        self.waiting: "collections.deque[_Request]" = collections.deque()
+        self.active: List[_Request] = []
+        self.finished: Dict[int, _Request] = {}
+        self._next_id = 0
+        self._step = 0
+        if kv_pages is not None:
+            model.reset_prefix_cache()
+            model.kv = PagedKVCache(model.get_model().llama, int(kv_pages))
+        from .prefix_cache import VisualFeatureCache
+        self._vis_cache = VisualFeatureCache(int(getattr(model.config, "vis_cache_entries", 16)))
+
+    # ---- queue ----------------------------------------------------------------------------------------------------------
+    def submit(self, input_ids: torch.Tensor, images=None, regions=None, max_new_tokens: int = 256,
+               eos_token_id=None) -> int:
+        ids = input_ids if input_ids.dim() == 2 else input_ids.unsqueeze(0)
+        if ids.shape[0] != 1:
+            raise ValueError("submit() takes one sequence per request")
+        eos = self.model.config.eos_token_id if eos_token_id is None else eos_token_id
+        eos_set = frozenset(eos) if isinstance(eos, (list, tuple, set, frozenset)) else (frozenset([eos]) if eos is not None else frozenset())
+        r = _Request(self._next_id, ids.to(self.model.device), images, regions, int(max_new_tokens), eos_set)
+        self._next_id += 1
+        self.waiting.append(r)
+        return r.rid
+
+    def pending(self) -> int:
+        return len(self.waiting) + len(self.active)
+
+    # ---- one scheduling step ---------------------------------------------------------------------------------------------
+    def _pick(self, logits: torch.Tensor) -> torch.Tensor:
+        if self.do_sample:
+            return ops.sample_top_p(logits, self.temperature, self.top_p, self.seed, self._step)
+        return ops.argmax(logits)
+
+    def _admit(self, r: _Request) -> None:
+        m = self.model
+        llama = m.get_model().llama
+        (_, _, _, _, embeds, _) = m.prepare_inputs_labels_for_multimodal(r.input_ids, None, None, None, None, r.images, r.regions,
+                                                                         feature_cache=self._vis_cache if r.images is not None else None)
+        if embeds is None:
+            flat = m.get_model().embed_tokens(r.input_ids)[0]
+        else:
+            mask = torch.tensor(m._last_splice[0][0], dtype=torch.bool, device=embeds.device)
+            flat = embeds[0][mask]
+        need = (flat.shape[0] + r.max_new_tokens + 63) // 64 + 1
+        if m.kv is None or len(m.kv.free) < need:
+            if m.kv is not None and (self.active or len(m.kv.free) != m.kv.num_pages):
+                raise RuntimeError(f"ServingEngine: KV pool exhausted ({len(m.kv.free)} free pages, request needs {need}); "
+                                   "construct the engine with a larger kv_pages")
+            m._ensure_kv(need)
+        logits = llama_forward(llama, m.kv, [r.seq], flat, [flat.shape[0]])
+        r.last = self._pick(logits)
+
+    def _retire(self, r: _Request) -> None:
+        r.done = True
+        self.model.kv.release(r.seq.pages)
+        r.seq.pages = []
+        self.finished[r.rid] = r
+
+    def step(self) -> List[Tuple[int, int]]:
+        """Admit waiting requests while there is room, emit one token for every active request. Returns [(request id, token)]."""
+        while self.waiting and len(self.active) < self.max_batch:
+            r = self.waiting.popleft()
+            self._admit(r)
+            self.active.append(r)
+        if not self.active:
+            return []
+        # tokens chosen at the end of the previous step (or by the prefill) become visible now: ONE read-back per step
+        toks = torch.cat([r.last for r in self.active]).tolist()
+        out: List[Tuple[int, int]] = []
+        still: List[_Request] = []
+        for r, t in zip(self.active, toks):
+            r.tokens.append(int(t))
+            out.append((r.rid, int(t)))
+            if int(t) in r.eos or len(r.tokens) >= r.max_new_tokens:
+                self._retire(r)
+            else:
+                still.append(r)
+        self.active = still
+        if self.active:
+            m = self.model
+            llama = m.get_model().llama
+            ids = torch.cat([r.last for r in self.active]).to(torch.int32)
+            plan = torch.stack([torch.zeros_like(ids), ids], dim=1).contiguous()
+            x = ops.embed_splice(llama.embed, None, None, plan)
+            logits = llama_forward(llama, m.kv, [r.seq for r in self.active], x, [1] * len(self.active))
+            nxt = self._pick(logits)
+            for i, r in enumerate(self.active):
+                r.last = nxt[i:i + 1]
+        self._step += 1
+        return out
+
+    def run(self, on_token=None) -> Dict[int, torch.Tensor]:
+        """Drive step() until every submitted request has finished; returns {request id: LongTensor of generated tokens}."""
+        while self.pending():
+            for rid, t in self.step():
+                if on_token is not None:
+                    on_token(rid, t)
+        return {rid: torch.tensor(r.tokens, dtype=torch.long) for rid, r in sorted(self.finished.items())}
