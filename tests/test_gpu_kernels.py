@@ -108,6 +108,22 @@ def test_gemm_resid_two_pass_split_k(dev, M, N, K, ks):
     assert torch.equal(nosplit, plain)
 
 
+@pytest.mark.parametrize("M,N,K", [(17, 96, 64), (24, 12288, 4096), (32, 4096 + 32, 11008), (20, 8192 + 32, 256), (32, 320, 1408), (40, 4096, 4096), (64, 8192, 1024)])
+def test_gemm_skinny_32_row_kernel(dev, M, N, K):
+    """17..32 rows: the weight-streaming kernel with two MFMA column groups and register-loaded activations (narrow and wide
+    variant, ragged N, all epilogues); 33..64 rows: the same kernel in groups of 32."""
+    from vitron_amd import ops
+    a, w, b = randn((M, K), 41), randn((N, K), 42, 0.05), randn((N,), 43)
+    resid = randn((M, N), 44)
+    for epi in (ops.EPI_BF16, ops.EPI_F32, ops.EPI_BF16_GELU, ops.EPI_BF16_QGELU, ops.EPI_BF16_RELU, ops.EPI_F32_RESID, ops.EPI_SWIGLU_BF16):
+        bias = None if epi == ops.EPI_SWIGLU_BF16 else b.to(dev)
+        out = resid.to(dev).clone() if epi == ops.EPI_F32_RESID else None
+        got = ops.gemm(a.to(dev).bfloat16(), w.to(dev).bfloat16(), bias, epi, out=out)
+        ref = _gemm_ref(a, w, None if bias is None else b, epi, resid)
+        assert got.shape == ref.shape
+        assert rel_l2(got.float(), ref) <= TOL, (M, epi)
+
+
 def test_gemm_transpose_detecting(dev):
     """A = I-like selector with an ASYMMETRIC W catches row/col swaps of the MFMA C layout."""
     from vitron_amd import ops

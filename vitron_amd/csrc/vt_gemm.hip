@@ -505,6 +505,154 @@ int launch_skinny_mfma(const GemmP& p, hipStream_t s) {
   return VT_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same weight stream for 17..32 activation rows (decode batches / short prompts of up to 32 rows): two 16-row MFMA column
+// groups per weight tile; the 32 activation rows of a K step (4 KiB) ride the ring next to the weights (2 KiB per tile), all
+// by LDS-DMA so that ONE counted vmcnt orders everything (mixing register loads into the same queue was tried: the counter
+// does not order LDS-DMA against ordinary loads -- sporadic stale operands). One workgroup per CU at this slot size.
+// WIDE: two weight tiles per block also for the plain epilogues (N >= 8192): halves the activation re-reads from L2.
+// ------------------------------------------------------------------------------------------------
+template <int EPI, int NWAVE, bool WIDE>
+__global__ __launch_bounds__(64 * NWAVE) void gemm_skinny_dma32_kernel(GemmP p) {
+  constexpr int NT = (EPI == VT_EPI_SWIGLU_BF16 || WIDE) ? 2 : 1;
+  constexpr int R = 4, MT = 2, XI = 4;
+  constexpr int PS = NT * 2 + XI;                            // DMA instructions per K step
+  constexpr int SLOT = PS * 1024;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ float red[NWAVE][NT][MT][256];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  char* ring = smem + wave * (R * SLOT);
+  const int n_base = blockIdx.x * 16 * NT;
+  const int steps = p.K >> 6;
+  const int s0 = (int)((long)steps * wave / NWAVE), s1 = (int)((long)steps * (wave + 1) / NWAVE);
+  const int n = s1 - s0;
+  const int lrow = lane >> 3, lchk = lane & 7;
+  const bf16_t* wsrc[NT * 2];
+#pragma unroll
+  for (int q = 0; q < NT * 2; ++q) {
+    const int row = (q & 1) * 8 + lrow;
+    const int csrc = lchk ^ ((row >> 1) & 7);
+    wsrc[q] = p.W + (size_t)min(n_base + (q >> 1) * 16 + row, p.N - 1) * p.ldw + csrc * 8;
+  }
+  const bf16_t* xsrc[XI];
+#pragma unroll
+  for (int q = 0; q < XI; ++q) {
+    const int row = q * 8 + lrow;                            // activation row 0..31 (clamped: rows >= M only feed unused columns)
+    const int csrc = lchk ^ (((row & 15) >> 1) & 7);         // swizzle by the row inside its 16-row MFMA group
+    xsrc[q] = p.A + (size_t)min(row, p.M - 1) * p.lda + csrc * 8;
+  }
+  auto issue = [&](int step, int slot) {
+    char* base = ring + slot * SLOT;
+    const size_t ko = (size_t)step * 64;
+#pragma unroll
+    for (int q = 0; q < NT * 2; ++q) glds16_nt(wsrc[q] + ko, base + q * 1024);
+#pragma unroll
+    for (int q = 0; q < XI; ++q) glds16(xsrc[q] + ko, base + (NT * 2 + q) * 1024);
+  };
+  const int f = (lane >> 1) & 7;
+  const int frag_off0 = (lane & 15) * 128 + (((lane >> 4) ^ f) << 4);
+  const int frag_off1 = (lane & 15) * 128 + ((((lane >> 4) | 4) ^ f) << 4);
+
+  f32x4 acc[NT][MT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int g = 0; g < MT; ++g) acc[t][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+    if (r < n) issue(s0 + r, r);
+  for (int i = 0; i < n; ++i) {
+    if (i + R <= n) vmcnt_wait<(R - 1) * PS>(); else vmcnt_wait<0>();
+    const char* sb = ring + (i & (R - 1)) * SLOT;
+    bf16x8 wf[NT][2], xf[MT][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      wf[t][0] = *(const bf16x8*)(sb + t * 2048 + frag_off0);
+      wf[t][1] = *(const bf16x8*)(sb + t * 2048 + frag_off1);
+    }
+#pragma unroll
+    for (int g = 0; g < MT; ++g) {
+      xf[g][0] = *(const bf16x8*)(sb + (NT + g) * 2048 + frag_off0);
+      xf[g][1] = *(const bf16x8*)(sb + (NT + g) * 2048 + frag_off1);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (i + R < n) issue(s0 + i + R, i & (R - 1));
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int g = 0; g < MT; ++g) {
+        acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][0], xf[g][0], acc[t][g], 0, 0, 0);
+        acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][1], xf[g][1], acc[t][g], 0, 0, 0);
+      }
+  }
+
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int g = 0; g < MT; ++g) *(f32x4*)&red[wave][t][g][lane * 4] = acc[t][g];
+  __syncthreads();
+  if (threadIdx.x >= 256) return;
+  const int ml = threadIdx.x >> 4, nn = threadIdx.x & 15;
+  const int e = (((nn >> 2) * 16 + ml) << 2) + (nn & 3);
+#pragma unroll
+  for (int g = 0; g < MT; ++g) {
+    const int m = g * 16 + ml;
+    if (m >= p.M) continue;
+    float v[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      v[t] = 0.f;
+#pragma unroll
+      for (int w = 0; w < NWAVE; ++w) v[t] += red[w][t][g][e];
+    }
+    if constexpr (EPI == VT_EPI_SWIGLU_BF16) {
+      const int q = blockIdx.x * 16 + nn;
+      if (n_base + 16 + nn < p.N) ((bf16_t*)p.C)[(size_t)m * p.ldc + q] = f32_to_bf16(silu(v[0]) * v[NT - 1]);
+    } else {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int nc = n_base + t * 16 + nn;
+        if (nc >= p.N) continue;
+        float r = v[t] + (p.bias ? p.bias[nc] : 0.f);
+        if constexpr (EPI == VT_EPI_BF16_GELU) r = gelu_erf(r);
+        if constexpr (EPI == VT_EPI_BF16_QGELU) r = quick_gelu(r);
+        if constexpr (EPI == VT_EPI_BF16_RELU) r = fmaxf(r, 0.f);
+        if constexpr (EPI == VT_EPI_F32_RESID) {
+          float* c = (float*)p.C + (size_t)m * p.ldc + nc;
+          *c = *c + r;
+        } else if constexpr (EPI == VT_EPI_F32) {
+          ((float*)p.C)[(size_t)m * p.ldc + nc] = r;
+        } else {
+          ((bf16_t*)p.C)[(size_t)m * p.ldc + nc] = f32_to_bf16(r);
+        }
+      }
+    }
+  }
+}
+
+template <int EPI, bool WIDE>
+int launch_skinny_dma32_w(const GemmP& p, hipStream_t s) {
+  constexpr int NT = (EPI == VT_EPI_SWIGLU_BF16 || WIDE) ? 2 : 1;
+  constexpr int NWAVE = 4;
+  constexpr int smem = NWAVE * 4 * (NT * 2 + 4) * 1024;
+  static_assert(smem + NWAVE * NT * 2 * 1024 <= 160 * 1024, "ring does not fit the 160 KiB LDS");
+  auto kern = gemm_skinny_dma32_kernel<EPI, NWAVE, WIDE>;
+  static bool done = false;
+  if (!done) {
+    VT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(cdiv(p.N, 16 * NT)), dim3(64 * NWAVE), smem, s, p);
+  VT_LAUNCH_CHECK();
+  return VT_OK;
+}
+template <int EPI>
+int launch_skinny_dma32(const GemmP& p, hipStream_t s) {
+  if (EPI != VT_EPI_SWIGLU_BF16 && p.N >= 8192) return launch_skinny_dma32_w<EPI, true>(p, s);
+  return launch_skinny_dma32_w<EPI, false>(p, s);
+}
+
 template <int EPI, int XI, int NWAVE, int R>
 int launch_skinny_dma_cfg(const GemmP& p, hipStream_t s) {
   constexpr int NT = (EPI == VT_EPI_SWIGLU_BF16) ? 2 : 1;
@@ -524,6 +672,7 @@ int launch_skinny_dma_cfg(const GemmP& p, hipStream_t s) {
 template <int EPI>
 int launch_skinny(const GemmP& p, hipStream_t s, bool reg_operands) {
   // measured on MI355X (tools/skinny_bench.py): 4 waves x 4-slot rings beat 8x4, 4x8 and 2x8 on every decode shape
+  if (p.M > 16) return launch_skinny_dma32<EPI>(p, s);   // 17..32 rows (K % 64 == 0 checked by the caller)
   if (reg_operands || (p.K % 64) != 0) return launch_skinny_mfma<EPI>(p, s);
   if (p.M <= 8) return launch_skinny_dma_cfg<EPI, 1, 4, 4>(p, s);
   return launch_skinny_dma_cfg<EPI, 2, 4, 4>(p, s);
@@ -572,16 +721,16 @@ int vt_gemm_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, 
              "vt_gemm: A/W/C must be 16-byte aligned");
   VT_REQUIRE(ldc % 4 == 0, "vt_gemm: ldc must be a multiple of 4");
   GemmP p{A, W, C, bias, M, N, K, lda, ldw, ldc, VtGemmNormFuse{}};
-  const bool skinny_path = (M <= 16) && (cfg == VT_GEMM_CFG_AUTO || cfg == VT_GEMM_CFG_SKINNY || cfg == VT_GEMM_CFG_SKINNY_REG);
-  // 17..64 rows (short follow-up prompts, larger decode batches): a tile grid is far too small for 256 CUs at N = 4096
-  // (64x128 tiles: 32 workgroups, 0.6 TB/s of weight stream), so the rows go through the weight-streaming kernel in groups
-  // of 16 -- the weights are streamed ceil(M/16) times (the repeats mostly from the Infinity Cache), still 1.5-3x faster:
-  // o_proj M=32: 17 vs 55 us, down: 39 vs 137 us, qkv: 37 vs 56 us (tools/skinny_bench.py). For wide N (gate/up, lm_head) the
-  // tile grid fills the chip and the single pass over the weights wins.
-  if (cfg == VT_GEMM_CFG_AUTO && M > 16 && M <= 64 && (K % 64) == 0 && (N <= 8192 || (N <= 16384 && M <= 32))) {
+  const bool skinny_path = (M <= 16 || (M <= 32 && (K % 64) == 0 && cfg != VT_GEMM_CFG_SKINNY_REG)) &&
+                           (cfg == VT_GEMM_CFG_AUTO || cfg == VT_GEMM_CFG_SKINNY || cfg == VT_GEMM_CFG_SKINNY_REG);
+  // 17..32 rows take the 32-row weight-streaming kernel (weights streamed once). 33..64 rows (short follow-up prompts, larger
+  // decode batches): a tile grid is far too small for 256 CUs at N = 4096 (64x128 tiles: 32 workgroups, 0.6 TB/s of weight
+  // stream), so the rows go through that kernel in two groups of 32 -- the weights are streamed twice (the repeat mostly from
+  // the Infinity Cache), still faster than the tile grid up to N = 16384 (tools/skinny_bench.py).
+  if (cfg == VT_GEMM_CFG_AUTO && M > 32 && M <= 64 && (K % 64) == 0 && N <= 16384) {
     const size_t esz = (epi == VT_EPI_F32 || epi == VT_EPI_F32_RESID) ? 4 : 2;
-    for (int m0 = 0; m0 < M; m0 += 16)
-      VT_TRY(vt_gemm_launch(A + (size_t)m0 * lda, lda, W, ldw, (char*)C + (size_t)m0 * ldc * esz, ldc, bias, std::min(16, M - m0), N, K,
+    for (int m0 = 0; m0 < M; m0 += 32)
+      VT_TRY(vt_gemm_launch(A + (size_t)m0 * lda, lda, W, ldw, (char*)C + (size_t)m0 * ldc * esz, ldc, bias, std::min(32, M - m0), N, K,
                             epi, VT_GEMM_CFG_SKINNY, skinny_scratch, s));
     return VT_OK;
   }
