@@ -311,9 +311,10 @@ def test_attn_decode_fused_matches_unfused(dev, hd):
         assert torch.equal(va.view(torch.int16), vb.view(torch.int16))
 
 
-def test_temporal_attention(dev):
+@pytest.mark.parametrize("B,T,N,heads", [(2, 8, 5, 2), (1, 8, 577, 16), (2, 4, 17, 2), (3, 1, 9, 1), (1, 7, 33, 3)])
+def test_temporal_attention(dev, B, T, N, heads):
+    """T == 8 runs the 16-byte-access kernel, other frame counts the generic one."""
     from vitron_amd import ops
-    B, T, N, heads = 2, 8, 5, 2
     D = heads * 64
     qkv = randn((B * T * N, 3 * D), 41)
     out = ops.attn_temporal(qkv.to(dev).bfloat16(), B, T, N, heads)

@@ -853,6 +853,81 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(const bf16_t* __rest
   }
 }
 
+// T == 8 (the LanguageBind video tower): one wave per (clip, position, head) with 16-byte accesses only.
+//   load  : lane (t = lane>>3, c = lane&7) fetches the 16-B chunk c of frame t's q, k and v head rows (8 lanes = one 128-B row)
+//           into a per-wave LDS image (rows padded to 144 B: conflict-free for the reads below),
+//   scores: lane (t1 = lane>>3, t2 = lane&7) owns S[t1][t2] = q[t1] . k[t2] (8 x two ds_read_b128), softmax over the 8 lanes of
+//           a row with three xor-shuffles, P stays fp32,
+//   output: lane (t1, c) owns out[t1][8c .. 8c+8) = sum_t2 P[t1][t2] v[t2][8c ..]; one 16-B store per lane.
+// The generic kernel above (one lane per head dim, 2-byte accesses, 64 wave reductions per item) took 45 us per layer on the
+// 8 x 576 x 16 items of a 336 px clip; this one is bandwidth-bound.
+__global__ __launch_bounds__(256) void attn_temporal8_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int B, int N,
+                                                             int heads) {
+  constexpr int T = 8, RS = 72;                       // row stride in bf16 elements (144 B)
+  __shared__ __attribute__((aligned(16))) bf16_t sm[4][3][T][RS];
+  __shared__ __attribute__((aligned(16))) float sp[4][T][T];
+  const int D = heads * 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long wid = (long)blockIdx.x * 4 + wave;
+  const long total = (long)B * N * heads;
+  if (wid >= total) return;
+  const int head = (int)(wid % heads);
+  const long bn = wid / heads;
+  const int n = (int)(bn % N), b = (int)(bn / N);
+  const int t = lane >> 3, c = lane & 7;
+  const size_t row = ((size_t)b * T + t) * N + n;
+  const bf16_t* src = qkv + row * (size_t)(3 * D) + head * 64 + c * 8;
+  const u32x4 qv = *(const u32x4*)src, kv = *(const u32x4*)(src + D), vv = *(const u32x4*)(src + 2 * D);
+  *(u32x4*)&sm[wave][0][t][c * 8] = qv;
+  *(u32x4*)&sm[wave][1][t][c * 8] = kv;
+  *(u32x4*)&sm[wave][2][t][c * 8] = vv;
+  __builtin_amdgcn_wave_barrier();                    // DS operations of one wave are ordered; only the compiler must not reorder
+  // ---- S[t1][t2], t1 = lane>>3, t2 = lane&7 ----
+  float sc = 0.f;
+#pragma unroll
+  for (int ch = 0; ch < 8; ++ch) {
+    const u32x4 a = *(const u32x4*)&sm[wave][0][t][ch * 8];
+    const u32x4 k8 = *(const u32x4*)&sm[wave][1][c][ch * 8];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      sc = fmaf(bf16lo_to_f32(a[w]), bf16lo_to_f32(k8[w]), sc);
+      sc = fmaf(bf16hi_to_f32(a[w]), bf16hi_to_f32(k8[w]), sc);
+    }
+  }
+  float mx = sc;
+  mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
+  const float pe = __expf(sc - mx);
+  float den = pe;
+  den += __shfl_xor(den, 1, 64);
+  den += __shfl_xor(den, 2, 64);
+  den += __shfl_xor(den, 4, 64);
+  sp[wave][t][c] = pe / den;
+  __builtin_amdgcn_wave_barrier();
+  // ---- out[t1][8c .. 8c+8) ----
+  const f32x4 p0 = *(const f32x4*)&sp[wave][t][0], p1 = *(const f32x4*)&sp[wave][t][4];
+  const float pr[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+  for (int t2 = 0; t2 < T; ++t2) {
+    const u32x4 v8 = *(const u32x4*)&sm[wave][2][t2][c * 8];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      acc[2 * w] = fmaf(pr[t2], bf16lo_to_f32(v8[w]), acc[2 * w]);
+      acc[2 * w + 1] = fmaf(pr[t2], bf16hi_to_f32(v8[w]), acc[2 * w + 1]);
+    }
+  }
+  u32x4 o;
+  o.x = pack_bf16x2(acc[0], acc[1]);
+  o.y = pack_bf16x2(acc[2], acc[3]);
+  o.z = pack_bf16x2(acc[4], acc[5]);
+  o.w = pack_bf16x2(acc[6], acc[7]);
+  *(u32x4*)(out + row * (size_t)D + head * 64 + c * 8) = o;
+}
+
 }  // namespace
 
 int vt_flash_attn_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf16_t* Vt, const int* tile_table,
@@ -982,6 +1057,11 @@ int vt_attn_temporal_launch(const bf16_t* qkv, bf16_t* out, int B, int T, int N,
   VT_REQUIRE(T >= 1 && T <= 8, "vt_attn_temporal: T=%d unsupported (1..8)", T);
   const long total = (long)B * N * heads;
   dim3 grid((unsigned)((total + 3) / 4)), block(256);
+  if (T == 8) {
+    hipLaunchKernelGGL(attn_temporal8_kernel, grid, block, 0, s, qkv, out, B, N, heads);
+    VT_LAUNCH_CHECK();
+    return VT_OK;
+  }
   switch (T) {
 #define VT_TC(TV) case TV: hipLaunchKernelGGL((attn_temporal_kernel<TV>), grid, block, 0, s, qkv, out, B, N, heads); break;
     VT_TC(1) VT_TC(2) VT_TC(3) VT_TC(4) VT_TC(5) VT_TC(6) VT_TC(7) VT_TC(8)
