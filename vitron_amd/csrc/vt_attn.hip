@@ -15,9 +15,11 @@
 //    K / V^T live in 64-key tiles (= KV-cache pages) addressed through a tile table; tiles are staged
 //    by LDS-DMA (global_load_lds_dwordx4) into a 2-stage LDS ring with XOR-swizzled chunks.
 //  * kv_tiles_kernel<HD, ROPE>: fused-QKV rows -> (rotary embedding on q,k) -> K tiles / V^T tiles.
-//  * attn_decode_kernel<HD>: single-query attention over the paged tiles (HBM-bound).
-//  * attn_temporal_kernel: the video tower's attention over T frames at one token position
-//    (reference modeling_video.py:105-127) -- T<=8, one wavefront per (position, head).
+//  * attn_decode_fused_kernel<HD, ROPE>: one decode step's attention in one launch (rotary on the new q / k, k / v append to
+//    the pages, single-query attention, in-block combine); attn_decode_kernel + _combine: the same on an existing cache as a
+//    standalone op (split over the KV tiles). HBM-bound.
+//  * attn_temporal8_kernel / attn_temporal_kernel<T>: the video tower's attention over T frames at one token position
+//    (reference modeling_video.py:105-127) -- one wavefront per (clip, position, head).
 #include <stdlib.h>
 
 #include "vt_common.h"

@@ -25,8 +25,11 @@
 //     lane-local epilogues (bias, GELU, residual, SwiGLU pairing).
 //   * 1-D grid, XCD-aware + grouped tile order so the 32 CUs of an XCD work on neighbouring tiles.
 //
-// "skinny" kernels: M <= 16 rows (decode steps, region MLP, last-position lm_head): pure weight streaming through a
-// per-wave LDS-DMA ring into 16x16x32 MFMAs, split-K inside the block. HBM-bound.
+// "skinny" kernels: M <= 16 rows (decode steps, region MLP, last-position lm_head) and 17..32 rows (larger decode batches,
+// short prompts): pure weight streaming through a per-wave LDS-DMA ring into 16x16x32 MFMAs, split-K inside the block,
+// optional folded RMSNorm. HBM-bound. The dispatcher (vt_gemm_launch / vt_gemm_pick_cfg / vt_gemm_resid_launch) at the end of
+// the file picks between them, the 256x256 ping-pong kernel of vt_gemm8.hip (whole rounds of tiles), the M-split, the two-pass
+// split-K and the small tiles -- every rule there carries the measurement it came from.
 #include <algorithm>
 
 #include "vt_common.h"

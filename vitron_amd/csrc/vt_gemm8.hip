@@ -1,4 +1,9 @@
-// vt_gemm8.hip -- the large-shape bf16 GEMM: 256x256x64 tile, 8 wavefronts, 8-phase software pipeline.
+// vt_gemm8.hip -- the large-shape bf16 GEMM: 256x256x64 tile, 8 wavefronts in two staggered rows (ping-pong).
+//
+// Three main loops share the tile, the LDS image and the epilogues: the 8-phase schedule described first (gemm_p8_kernel, P4 =
+// false), the 4-phase schedule that merges its phases pairwise (P4 = true: half the barriers, 32 MFMAs per section, +8..14 %,
+// the DEFAULT -- its stage schedule and hazard argument sit next to its loop), and a register-pipelined variant
+// (gemm_rp_kernel, opt-in). The two-pass split-K of the residual epilogue (vt_gemm_p4_splitk_resid_launch) lives here too.
 //
 // Same contract and epilogues as vt_gemm.hip's tile kernel (C = epi(A[M,K].W[N,K]^T + bias)); used for the
 // decoder's big projections where >92 % of the prefill FLOPs live.
