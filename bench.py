@@ -9,8 +9,8 @@ last-position logits -> greedy first token. Everything runs through libvitron_hi
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 N > 1: one process per GPU, one clip per rank (weak scaling). Clips are encoded on the rank that owns them, the
-visual tokens are exchanged with ONE RCCL all-gather over xGMI (BASELINE config 4), then every rank prefills its
-own sequence. value = (tokens of all ranks) / (max over ranks of the timed region).
+visual tokens are exchanged with ONE RCCL all-gather over xGMI (BASELINE config 4) that overlaps the rank's own
+prefill (started asynchronously, waited for before the step ends), and every rank prefills its own sequence. value = (tokens of all ranks) / (max over ranks of the timed region).
 
 Prints ONE JSON line (rank 0) with the driver's contract + "roofline" (dominant kernel class = the MFMA tile GEMM,
 timed live with HIP events on the kernel's stream) + "cpu_baseline" (the CPU oracle on a bounded sample).
@@ -222,13 +222,17 @@ def main():
     ids = torch.cat([torch.tensor([1], device=dev), torch.full((args.frames,), -200, device=dev), text]).unsqueeze(0)
     assert ids.shape[1] == args.text_len + args.frames
 
+    pending = []
     if use_dist:  # clip-per-rank encode, ONE all-gather of visual tokens, then data-parallel prefill
-        from vitron_amd.parallel import all_gather_visual_tokens
+        from vitron_amd.parallel import start_all_gather_visual_tokens
         orig = model.encode_videos
 
         def encode_videos_dist(videos):
             f = orig(videos)                                    # this rank's clip: [1, T, P, H]
-            return all_gather_visual_tokens(f, world)[rank:rank + 1]   # every rank receives all clips' tokens
+            # every rank receives all clips' tokens (BASELINE config 4's exchange step); the transfer overlaps this rank's own
+            # prefill, which only needs its own tokens -- the step waits for the gather before it counts as done
+            pending.append(start_all_gather_visual_tokens(f))
+            return f
         model.encode_videos = encode_videos_dist
 
     llama = model.get_model().llama
@@ -240,6 +244,10 @@ def main():
         logits = llama_forward(llama, model.kv, [seq], embeds[0], [embeds.shape[1]])
         tok = ops.argmax(logits)
         model.kv.release(seq.pages)
+        for g in pending:
+            allv = g.wait()                                     # [world, T, P, H]: the gathered tokens of all clips
+            assert allv.shape[0] == world
+        pending.clear()
         return tok, embeds.shape[1]
 
     def fence():

@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from vitron_amd.parallel import all_gather_visual_tokens, encode_clips_parallel, shard_range
+from vitron_amd.parallel import all_gather_visual_tokens, encode_clips_parallel, shard_range, start_all_gather_visual_tokens
 
 
 def _free_port():
@@ -38,6 +38,11 @@ def _worker(rank, world, port, n_clips, q):
         loc = torch.arange(s, e, dtype=torch.float32).reshape(-1, 1)
         g = all_gather_visual_tokens(loc, n_clips)
         ok = ok and torch.equal(g.flatten(), torch.arange(n_clips, dtype=torch.float32))
+        # asynchronous variant (even shards): started, other work happens, then waited for
+        h = start_all_gather_visual_tokens(torch.full((1, 2, 3), float(rank)))
+        busy = torch.ones(8).sum()
+        ga = h.wait()
+        ok = ok and busy.item() == 8 and ga.shape == (world, 2, 3) and all(bool((ga[r] == r).all()) for r in range(world))
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

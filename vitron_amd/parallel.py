@@ -44,6 +44,30 @@ def all_gather_visual_tokens(local: torch.Tensor, n_items: int, group=None) -> t
     return torch.cat([out[r * mx: r * mx + counts[r]] for r in range(world)], 0)
 
 
+class PendingGather:
+    """Handle of an all-gather started with start_all_gather_visual_tokens: `.wait()` orders the current stream behind the
+    collective (it does not block the host) and returns the [n_items, ...] tensor."""
+
+    def __init__(self, work, out: torch.Tensor):
+        self._work, self._out = work, out
+
+    def wait(self) -> torch.Tensor:
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        return self._out
+
+
+def start_all_gather_visual_tokens(local: torch.Tensor, group=None) -> PendingGather:
+    """Even shards only (one clip per rank, the benchmark layout): start the all-gather and return at once, so that work that
+    only needs THIS rank's tokens (its own prefill) overlaps the xGMI transfer. local [n, ...] -> wait() gives [world*n, ...]."""
+    world = dist.get_world_size(group)
+    send = local.contiguous()
+    out = torch.empty((world * send.shape[0], *send.shape[1:]), dtype=send.dtype, device=send.device)
+    work = dist.all_gather_into_tensor(out, send, group=group, async_op=True)
+    return PendingGather(work, out)
+
+
 def encode_clips_parallel(encode: Callable[[torch.Tensor], torch.Tensor], clips: Sequence[torch.Tensor], group=None) -> torch.Tensor:
     """clips: the GLOBAL list of clips [3,T,H,W] (every rank holds the list, or at least its own shard's entries).
     Each rank runs `encode` (tower + projector -> [n, T, P, H]) on its shard only; returns all clips' tokens."""
