@@ -323,4 +323,12 @@ def test_serving_engine_continuous_batching_matches_solo_runs(dev, model):
     for i in range(5):
         assert seen[i] == solo[i].tolist(), (i, seen[i], solo[i].tolist())
     assert len(model.kv.free) == model.kv.num_pages
+    # batch_prefill: the admitted requests share one packed decoder prefill -> same tokens up to logit near-ties
+    eng = ServingEngine(model, max_batch=5, kv_pages=64, batch_prefill=True)
+    for r in reqs:
+        eng.submit(r["input_ids"], r["images"], r["regions"], r["max_new_tokens"], eos_token_id=-1)
+    outs = eng.run()
+    agree = sum(int(outs[i].tolist() == solo[i].tolist()) for i in range(5))
+    assert agree >= 4 and all(len(outs[i]) == len(solo[i]) for i in range(5)), (agree, [outs[i].tolist() for i in range(5)])
+    assert len(model.kv.free) == model.kv.num_pages
     model.config.kv_prefix_reuse = True

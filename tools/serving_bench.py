@@ -33,10 +33,10 @@ def main():
         model.generate(ids, images=im, regions=rg, do_sample=False, max_new_tokens=N, eos_token_id=-1)
     torch.cuda.synchronize()
     t_seq = time.perf_counter() - t0
-    for mb in (4, 16, 32):
+    for mb, bp in ((4, False), (16, False), (16, True), (32, False), (32, True)):
         if mb > R and mb != 4:
             continue
-        eng = ServingEngine(model, max_batch=mb, kv_pages=R * 14 + 8)
+        eng = ServingEngine(model, max_batch=mb, kv_pages=R * 14 + 8, batch_prefill=bp)
         for ids, im, rg in reqs:
             eng.submit(ids, im, rg, N, eos_token_id=-1)
         torch.cuda.synchronize()
@@ -45,7 +45,7 @@ def main():
         torch.cuda.synchronize()
         t = time.perf_counter() - t0
         assert all(len(v) == N for v in out.values())
-        print(json.dumps({"requests": R, "new_tokens_each": N, "max_batch": mb, "seconds": round(t, 3),
+        print(json.dumps({"requests": R, "new_tokens_each": N, "max_batch": mb, "batch_prefill": bp, "seconds": round(t, 3),
                           "generated_tokens_per_s": round(R * N / t, 1), "one_at_a_time_seconds": round(t_seq, 3),
                           "one_at_a_time_tokens_per_s": round(R * N / t_seq, 1), "speedup": round(t_seq / t, 2)}), flush=True)
 

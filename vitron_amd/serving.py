@@ -43,10 +43,13 @@ class _Request:
 
 class ServingEngine:
     def __init__(self, model, max_batch: int = 16, kv_pages: Optional[int] = None, do_sample: bool = False,
-                 temperature: float = 1.0, top_p: float = 1.0, seed: int = 0):
+                 temperature: float = 1.0, top_p: float = 1.0, seed: int = 0, batch_prefill: bool = False):
         self.model = model
         self.max_batch = int(max_batch)
         self.do_sample, self.temperature, self.top_p, self.seed = bool(do_sample), float(temperature), float(top_p), int(seed)
+        # batch_prefill: requests admitted in the same step share ONE packed decoder prefill (larger GEMMs: higher throughput);
+        # their logits then differ from a solo run by bf16 noise (other GEMM tiles), so it is off where bit-identity matters
+        self.batch_prefill = bool(batch_prefill)
         self.waiting: "collections.deque[_Request]" = collections.deque()
         self.active: List[_Request] = []
         self.finished: Dict[int, _Request] = {}
@@ -80,24 +83,35 @@ class ServingEngine:
             return ops.sample_top_p(logits, self.temperature, self.top_p, self.seed, self._step)
         return ops.argmax(logits)
 
-    def _admit(self, r: _Request) -> None:
+    def _embed(self, r: _Request) -> torch.Tensor:
         m = self.model
-        llama = m.get_model().llama
         (_, _, _, _, embeds, _) = m.prepare_inputs_labels_for_multimodal(r.input_ids, None, None, None, None, r.images, r.regions,
                                                                          feature_cache=self._vis_cache if r.images is not None else None)
         if embeds is None:
-            flat = m.get_model().embed_tokens(r.input_ids)[0]
-        else:
-            mask = torch.tensor(m._last_splice[0][0], dtype=torch.bool, device=embeds.device)
-            flat = embeds[0][mask]
-        need = (flat.shape[0] + r.max_new_tokens + 63) // 64 + 1
+            return m.get_model().embed_tokens(r.input_ids)[0]
+        mask = torch.tensor(m._last_splice[0][0], dtype=torch.bool, device=embeds.device)
+        return embeds[0][mask]
+
+    def _admit(self, reqs: List[_Request]) -> None:
+        """Multimodal prefill of the admitted requests: towers + splice per request, decoder prefill per request (default) or
+        one packed pass for all of them (batch_prefill)."""
+        m = self.model
+        llama = m.get_model().llama
+        flats = [self._embed(r) for r in reqs]
+        need = sum((f.shape[0] + r.max_new_tokens + 63) // 64 + 1 for f, r in zip(flats, reqs))
         if m.kv is None or len(m.kv.free) < need:
             if m.kv is not None and (self.active or len(m.kv.free) != m.kv.num_pages):
-                raise RuntimeError(f"ServingEngine: KV pool exhausted ({len(m.kv.free)} free pages, request needs {need}); "
+                raise RuntimeError(f"ServingEngine: KV pool exhausted ({len(m.kv.free)} free pages, admission needs {need}); "
                                    "construct the engine with a larger kv_pages")
             m._ensure_kv(need)
-        logits = llama_forward(llama, m.kv, [r.seq], flat, [flat.shape[0]])
-        r.last = self._pick(logits)
+        if self.batch_prefill and len(reqs) > 1:
+            logits = llama_forward(llama, m.kv, [r.seq for r in reqs], torch.cat(flats, 0), [f.shape[0] for f in flats])
+            nxt = self._pick(logits)
+            for i, r in enumerate(reqs):
+                r.last = nxt[i:i + 1]
+        else:
+            for r, f in zip(reqs, flats):
+                r.last = self._pick(llama_forward(llama, m.kv, [r.seq], f, [f.shape[0]]))
 
     def _retire(self, r: _Request) -> None:
         r.done = True
@@ -107,10 +121,12 @@ class ServingEngine:
 
     def step(self) -> List[Tuple[int, int]]:
         """Admit waiting requests while there is room, emit one token for every active request. Returns [(request id, token)]."""
-        while self.waiting and len(self.active) < self.max_batch:
-            r = self.waiting.popleft()
-            self._admit(r)
-            self.active.append(r)
+        admitted: List[_Request] = []
+        while self.waiting and len(self.active) + len(admitted) < self.max_batch:
+            admitted.append(self.waiting.popleft())
+        if admitted:
+            self._admit(admitted)
+            self.active += admitted
         if not self.active:
             return []
         # tokens chosen at the end of the previous step (or by the prefill) become visible now: ONE read-back per step
