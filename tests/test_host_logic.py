@@ -31,6 +31,32 @@ def test_mm_utils_match_reference_goldens():
     assert mm_utils.get_model_name_from_path("/a/b/checkpoint-12/") == "b_checkpoint-12"
 
 
+def test_keywords_stopping_criteria_semantics():
+    """reference mm_utils.py:146-177: stop on an id-tail match or on the keyword appearing in the decoded tail."""
+    from vitron_amd.mm_utils import KeywordsStoppingCriteria
+
+    class Tok(StubTok):
+        def batch_decode(self, ids, skip_special_tokens=True):
+            return ["".join(chr(int(t) - 100) for t in row if int(t) != 1) for row in ids]
+
+    tok = Tok()
+    prompt = torch.tensor([tok("hello").input_ids])
+    crit = KeywordsStoppingCriteria(["</s>", "##"], tok, prompt)
+    assert [k.tolist() for k in crit.keyword_ids] == [tok("</s>").input_ids[1:], tok("##").input_ids[1:]]   # BOS stripped
+    assert crit.max_keyword_len == 4 and crit.start_len == prompt.shape[1]
+    grow = lambda text: torch.cat([prompt, torch.tensor([tok(text).input_ids[1:]])], 1)
+    assert not crit(prompt, None)                      # nothing generated yet
+    assert not crit(grow("abc"), None)
+    assert crit(grow("abc##"), None)                   # id-tail match
+    assert crit(grow("ab##c"), None)                   # only in the decoded window (4 new tokens)
+    assert not crit(grow("##abcd"), None)              # keyword scrolled out of the window
+    assert crit(grow("x</s>"), None)
+    both = torch.cat([grow("ab##"), grow("abcd")], 0)  # batch: every row must be finished
+    assert not crit(both, None)
+    assert crit(torch.cat([grow("ab##"), grow("a##b")], 0), None)
+    assert crit.call_for_batch(both, None) is True     # first row only
+
+
 def test_constants_match_reference_values():
     from vitron_amd import constants as c
     assert (c.IGNORE_INDEX, c.IMAGE_TOKEN_INDEX, c.OBJS_TOKEN_INDEX) == (-100, -200, -300)

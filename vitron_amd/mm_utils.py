@@ -61,32 +61,39 @@ def get_model_name_from_path(model_path):
 
 
 class KeywordsStoppingCriteria:
-    """reference mm_utils.py:146-177 -- stop when the tail of the output matches a keyword's ids, or the decoded
-    tail contains the keyword. Called as criteria(output_ids, scores) -> bool."""
+    """Stop test with the reference's semantics (mm_utils.py:146-177): a row is finished when its generated tail
+    equals the ids of one stop keyword, or when the decoded tail (as many new tokens as the longest keyword has)
+    contains a keyword as text; a batch is finished when every row is. Called as criteria(output_ids, scores)."""
 
     def __init__(self, keywords, tokenizer, input_ids):
-        self.keywords = keywords
-        self.keyword_ids = []
-        self.max_keyword_len = 0
-        for kw in keywords:
-            ids = tokenizer(kw).input_ids
-            if len(ids) > 1 and ids[0] == tokenizer.bos_token_id:
-                ids = ids[1:]
-            self.max_keyword_len = max(self.max_keyword_len, len(ids))
-            self.keyword_ids.append(torch.tensor(ids))
+        self.keywords = list(keywords)
         self.tokenizer = tokenizer
-        self.start_len = input_ids.shape[1]
+        self.start_len = int(input_ids.shape[1])
+        bos = tokenizer.bos_token_id
+        self.keyword_ids = [self._strip_bos(tokenizer(kw).input_ids, bos) for kw in self.keywords]
+        self.max_keyword_len = max((int(k.numel()) for k in self.keyword_ids), default=0)
+
+    @staticmethod
+    def _strip_bos(ids, bos):
+        drop = 1 if len(ids) > 1 and ids[0] == bos else 0
+        return torch.tensor(ids[drop:])
+
+    def _row_done(self, row):  # row: [1, L]
+        length = row.shape[1]
+        for n, kid in enumerate(self.keyword_ids):
+            if kid.device != row.device:
+                kid = self.keyword_ids[n] = kid.to(row.device)
+            k = int(kid.numel())
+            if 0 < k <= length and torch.equal(row[0, length - k:], kid):
+                return True
+        window = min(length - self.start_len, self.max_keyword_len)
+        if window <= 0:
+            return False
+        tail = self.tokenizer.batch_decode(row[:, length - window:], skip_special_tokens=True)[0]
+        return any(kw in tail for kw in self.keywords)
 
     def call_for_batch(self, output_ids, scores, **kwargs):
-        offset = min(output_ids.shape[1] - self.start_len, self.max_keyword_len)
-        self.keyword_ids = [k.to(output_ids.device) for k in self.keyword_ids]
-        for k in self.keyword_ids:
-            if output_ids.shape[1] >= k.shape[0] and bool((output_ids[0, -k.shape[0]:] == k).all()):
-                return True
-        if offset <= 0:
-            return False
-        text = self.tokenizer.batch_decode(output_ids[:, -offset:], skip_special_tokens=True)[0]
-        return any(kw in text for kw in self.keywords)
+        return self._row_done(output_ids[:1])
 
     def __call__(self, output_ids, scores, **kwargs):
-        return all(self.call_for_batch(output_ids[i].unsqueeze(0), scores) for i in range(output_ids.shape[0]))
+        return all(self._row_done(output_ids[r:r + 1]) for r in range(output_ids.shape[0]))
