@@ -125,7 +125,7 @@ def decode_report(model, llama, dev, steps, batch=4, ctx=609):
     import torch
 
     from vitron_amd import _lib, ops, synth
-    from vitron_amd.engine import SequenceState, llama_forward
+    from vitron_amd.engine import DecodeState, SequenceState, llama_forward
 
     gen = synth.make_generator(777, dev)
     H, L, I, V = llama.H, llama.L, llama.I, llama.V
@@ -133,11 +133,12 @@ def decode_report(model, llama, dev, steps, batch=4, ctx=609):
     seqs = [SequenceState() for _ in range(batch)]
     emb = (torch.randn((batch * ctx, H), generator=gen, device=dev) * 0.02).to(torch.bfloat16)
     logits = llama_forward(llama, model.kv, seqs, emb, [ctx] * batch)
+    state = DecodeState(llama, model.kv, seqs, steps + 8)   # device-resident step state: what generate() runs
     tok = ops.argmax(logits)
 
     def one(tok):
-        x = model.get_model().embed_tokens(tok.long())
-        return ops.argmax(llama_forward(llama, model.kv, seqs, x, [1] * batch))
+        state.feed(tok)
+        return ops.argmax(state.forward())
 
     for _ in range(4):
         tok = one(tok)

@@ -142,6 +142,17 @@ int vt_embed_splice(const uint16_t* tok_table, const uint16_t* vis, const uint16
 
 /* greedy next token: first index of the row maximum (GenerationMixin greedy search). */
 int vt_argmax(const float* logits, int rows, int V, int ldl, int* out_ids, void* stream);
+
+/* Decode-loop feedback, one launch per generated token (the body of GenerationMixin's sampling loop that
+ * model.generate runs between two forward passes, reference app.py:562-571 / inference_image.py:60-70 via
+ * transformers; here without the host round trip). For every sequence i < nseq:
+ *   t = finished[i] ? pad_id : next_ids[i];  finished[i] |= (t in eos_ids[0..n_eos));
+ *   tokens_out[i] = t;  tokens_out[nseq + i] = finished[i];          (int32 [2][nseq], for the asynchronous read-back)
+ *   x[i][0..H) = tok_table[t][0..H)                                  (input row of the next vt_llama_forward)
+ *   seq_desc[i].kv_len += 1;  positions[i] += 1                      (device-side step metadata of that pass)
+ * so the next decoder pass can be enqueued before the host has seen the token. */
+int vt_decode_feed(const uint16_t* tok_table, int H, int vocab, const int* next_ids, int* finished, const int* eos_ids, int n_eos,
+                   int pad_id, int* tokens_out, uint16_t* x, int* seq_desc, int* positions, int nseq, void* stream);
 /* one sampled token per row: softmax(logits / temperature), transformers' TopPLogitsWarper keep-set (top_p >= 1 keeps all),
  * inverse-CDF draw with a counter-based uniform of (seed, step, row). kept_count (optional) = size of the keep-set per row.
  * Replaces GenerationMixin.sample's temperature / top-p / multinomial step (reference app.py:562-571, do_sample=True). */

@@ -332,3 +332,128 @@ def test_serving_engine_continuous_batching_matches_solo_runs(dev, model):
     assert agree >= 4 and all(len(outs[i]) == len(solo[i]) for i in range(5)), (agree, [outs[i].tolist() for i in range(5)])
     assert len(model.kv.free) == model.kv.num_pages
     model.config.kv_prefix_reuse = True
+
+
+@pytest.mark.gpu
+def test_decode_feed_kernel(dev):
+    """vt_decode_feed against its definition: pad once finished, EOS flags, embedding rows, metadata advance."""
+    from vitron_amd import ops
+    g = torch.Generator().manual_seed(11)
+    V, H, B = 97, 256, 5
+    table = torch.randn((V, H), generator=g).bfloat16().to(dev)
+    nxt = torch.tensor([3, 96, 50, 7, 7], dtype=torch.int32, device=dev)
+    fin = torch.tensor([0, 0, 1, 0, 0], dtype=torch.int32, device=dev)
+    eos = torch.tensor([7, 96], dtype=torch.int32, device=dev)
+    desc = torch.tensor([[i, 1, 10 * i + 5, 3 * i] for i in range(B)], dtype=torch.int32, device=dev)
+    pos = torch.tensor([10 * i + 4 for i in range(B)], dtype=torch.int32, device=dev)
+    tok = torch.full((2, B), -1, dtype=torch.int32, device=dev)
+    x = torch.zeros((B, H), dtype=torch.bfloat16, device=dev)
+    d0, p0 = desc.clone(), pos.clone()
+    ops.decode_feed(table, nxt, fin, eos, 2, tok, x, desc, pos)
+    want = [3, 96, 2, 7, 7]                                     # sequence 2 was finished already: pad
+    assert tok[0].tolist() == want and tok[1].tolist() == [0, 1, 1, 1, 1] and fin.tolist() == [0, 1, 1, 1, 1]
+    assert torch.equal(x, table[torch.tensor(want, device=dev)])
+    assert torch.equal(desc[:, 2], d0[:, 2] + 1) and torch.equal(desc[:, [0, 1, 3]], d0[:, [0, 1, 3]]) and torch.equal(pos, p0 + 1)
+    ops.decode_feed(table, nxt, fin, None, 2, tok, x, desc, pos)   # no EOS set: flags only carry over
+    assert tok[0].tolist() == [3, 2, 2, 2, 2] and fin.tolist() == [0, 1, 1, 1, 1] and torch.equal(pos, p0 + 2)
+    with pytest.raises(Exception):
+        ops.decode_feed(table, nxt[:3], fin, eos, 2, tok, x, desc, pos)
+
+
+@pytest.mark.gpu
+def test_decode_state_matches_host_driven_steps(dev, model):
+    """The device-resident decode state runs the same launches as llama_forward with host-built metadata: logits are
+    bit-identical step by step (ragged batch, page boundaries crossed), and rollback() leaves the cache consistent."""
+    from vitron_amd import ops
+    from vitron_amd.engine import DecodeState, PagedKVCache, SequenceState, llama_forward
+    llama = model.get_model().llama
+    g = torch.Generator().manual_seed(21)
+    lens = [61, 130, 7]
+    ids = torch.randint(3, cases.LLM["vocab_size"], (sum(lens),), generator=g).to(dev)
+    emb = model.get_model().embed_tokens(ids)
+    steps = 9
+    runs = []
+    for use_state in (False, True):
+        kv = PagedKVCache(llama, 16)
+        seqs = [SequenceState() for _ in lens]
+        logits = llama_forward(llama, kv, seqs, emb, lens)
+        trace = [logits.clone()]
+        state = DecodeState(llama, kv, seqs, steps + 1) if use_state else None
+        for _ in range(steps):
+            tok = ops.argmax(logits)
+            if use_state:
+                state.feed(tok)
+                logits = state.forward()
+            else:
+                logits = llama_forward(llama, kv, seqs, model.get_model().embed_tokens(tok.long()), [1] * len(lens))
+            trace.append(logits.clone())
+        runs.append((trace, [s.length for s in seqs], state, kv, seqs))
+    (ta, la, _, _, _), (tb, lb, state, kv, seqs) = runs
+    assert la == lb == [l + steps for l in lens]
+    for a, b in zip(ta, tb):
+        assert torch.equal(a, b)
+    # speculative pass + rollback, then the same token again: same logits as the first time
+    tok = ops.argmax(tb[-1])
+    slot = state.feed(tok)
+    l1 = state.forward().clone()
+    toks, fin = state.read(slot)
+    assert toks == tok.tolist() and fin == [False] * len(lens)
+    state.rollback()
+    assert [s.length for s in seqs] == lb
+    l2 = llama_forward(llama, kv, seqs, model.get_model().embed_tokens(tok.long()), [1] * len(lens))
+    assert torch.equal(l1, l2)
+    with pytest.raises(Exception):
+        DecodeState(llama, kv, [SequenceState()], 4)             # no context
+
+
+@pytest.mark.gpu
+def test_generate_stops_on_eos_with_speculative_step_rolled_back(dev):
+    """generate() enqueues pass t+1 before it reads token t: when token t is EOS (or a stop keyword fires) the extra pass
+    must not leak into the output, the pad/finished rule of a batch, or the KV prefix kept for the next turn."""
+    from vitron_amd import synth
+    from vitron_amd.mm_utils import KeywordsStoppingCriteria
+    from vitron_amd.model import LlavaConfig, LlavaLlamaForCausalLM
+    cfg = dict(synth.VICUNA_7B, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4, vocab_size=512)
+    m = LlavaLlamaForCausalLM(LlavaConfig(**cfg, mm_hidden_size=128, mm_region_image_size=112))
+    m.init_synthetic(dev, seed=9, vit_image=None, vit_video=None)
+    g = torch.Generator().manual_seed(2)
+    p = torch.tensor([[1] + torch.randint(3, 500, (90,), generator=g).tolist(),
+                      [1] + torch.randint(3, 500, (90,), generator=g).tolist()], device=dev)
+    m.config.kv_prefix_reuse = False
+    free = None
+    full = m.generate(p, do_sample=False, max_new_tokens=10, eos_token_id=-1)
+    free = len(m.kv.free)
+    assert free == m.kv.num_pages
+    new = full[:, p.shape[1]:].tolist()
+    # stop row 0 at its 4th token, row 1 at its 7th: row 0 pads from then on, the run ends at step 7
+    e0, e1 = new[0][3], new[1][6]
+    if e0 in new[1][:6] or e1 in new[0][:3] or e0 in new[0][:3] or e1 in new[1][:6]:
+        pytest.skip("synthetic tokens collide with the chosen EOS ids")
+    out = m.generate(p, do_sample=False, max_new_tokens=10, eos_token_id=[e0, e1], pad_token_id=0)
+    got = out[:, p.shape[1]:].tolist()
+    assert got[1] == new[1][:7] and got[0] == new[0][:4] + [0, 0, 0]
+    assert len(m.kv.free) == free
+    # keyword stop on a single row, with the multi-turn prefix kept: the follow-up turn must see a consistent cache
+    class Tok:
+        bos_token_id = 1
+        def __call__(self, text):
+            r = type("R", (), {})()
+            r.input_ids = [1] + [int(t) for t in text.split()]
+            return r
+        def batch_decode(self, ids, skip_special_tokens=True):
+            return [" ".join(str(int(t)) for t in row) for row in ids]
+    m.config.kv_prefix_reuse = True
+    p1 = p[:1]
+    kw = f"{new[0][4]} {new[0][5]}"
+    crit = KeywordsStoppingCriteria([kw], Tok(), p1)
+    o1 = m.generate(p1, do_sample=False, max_new_tokens=10, eos_token_id=-1, stopping_criteria=[crit])
+    assert o1[0, p1.shape[1]:].tolist() == new[0][:6]
+    p2 = torch.cat([o1[0], torch.tensor([11, 12, 13], device=dev)]).unsqueeze(0)
+    o2, lg2 = m.generate(p2, do_sample=False, max_new_tokens=3, eos_token_id=-1, return_logits=True)
+    assert m.last_generate_stats["reused_tokens"] == 64
+    m.reset_prefix_cache()
+    m.config.kv_prefix_reuse = False
+    o3, lg3 = m.generate(p2, do_sample=False, max_new_tokens=3, eos_token_id=-1, return_logits=True)
+    for a, b in zip(lg2, lg3):
+        assert rel_l2(a.float(), b.float()) <= 5e-3
+    assert torch.equal(o2, o3) or rel_l2(lg2[-1].float(), lg3[-1].float()) <= 5e-4

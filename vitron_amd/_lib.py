@@ -78,6 +78,7 @@ SIGNATURES = {
                            C.c_long, vp]),
     "vt_embed_splice": (_i, [vp, vp, vp, vp, _i, _i, vp, vp]),
     "vt_argmax": (_i, [vp, _i, _i, _i, vp, vp]),
+    "vt_decode_feed": (_i, [vp, _i, _i, vp, vp, vp, _i, _i, vp, vp, vp, vp, _i, vp]),
     "vt_sample_top_p": (_i, [vp, _i, _i, _i, _f, _f, C.c_uint64, C.c_uint64, vp, vp, vp]),
     "vt_projector_workspace_bytes": (_sz, [_i, _i]),
     "vt_projector_forward": (_i, [vp, _i, _i, vp, vp, _i, vp, vp, _i, vp, vp, _sz, vp]),

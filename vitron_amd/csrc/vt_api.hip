@@ -192,6 +192,12 @@ int vt_argmax(const float* logits, int rows, int V, int ldl, int* out_ids, void*
   return vt_argmax_launch(logits, rows, V, ldl, out_ids, S(stream));
 }
 
+int vt_decode_feed(const uint16_t* tok_table, int H, int vocab, const int* next_ids, int* finished, const int* eos_ids, int n_eos,
+                   int pad_id, int* tokens_out, uint16_t* x, int* seq_desc, int* positions, int nseq, void* stream) {
+  return vt_decode_feed_launch(tok_table, H, vocab, next_ids, finished, eos_ids, n_eos, pad_id, tokens_out, x, seq_desc, positions,
+                               nseq, S(stream));
+}
+
 int vt_preprocess(const void* src, int src_u8, int hwc, int F, int H, int W, int bicubic, int S, const float* mean,
                   const float* std, int flip, void* dst, int dst_dtype, long dst_stride_c, long dst_stride_f, void* stream) {
   return vt_preprocess_launch(src, src_u8, hwc, F, H, W, bicubic, S, mean, std, flip, dst, dst_dtype, dst_stride_c, dst_stride_f,

@@ -88,6 +88,9 @@ int vt_region_pool_launch(const bf16_t* feats, const int* slices, int B, int G, 
 int vt_embed_splice_launch(const bf16_t* tok_table, const bf16_t* vis, const bf16_t* reg, const int* plan,
                            int rows, int H, bf16_t* out, hipStream_t s);
 int vt_argmax_launch(const float* logits, int rows, int V, int ldl, int* out_ids, hipStream_t s);
+int vt_decode_feed_launch(const bf16_t* tok_table, int H, int vocab, const int* next_ids, int* finished, const int* eos_ids,
+                          int n_eos, int pad_id, int* tokens_out, bf16_t* x, int* seq_desc, int* positions, int nseq,
+                          hipStream_t s);
 int vt_sample_top_p_launch(const float* logits, int rows, int V, int ldl, float temperature, float top_p, uint64_t seed,
                            uint64_t step, int* out_ids, int* kept_count, hipStream_t s);
 

@@ -30,6 +30,34 @@ __global__ __launch_bounds__(256) void embed_splice_kernel(const bf16_t* __restr
   }
 }
 
+// decode-loop feedback, one block per sequence: thread 0 resolves the token this sequence emits (pad once finished), updates
+// the finished flag against the EOS set and advances the sequence's device-side step metadata (kv_len, position); the block
+// then copies the token's embedding row into the next step's input. Everything the next decoder pass needs is on the device
+// after this launch, so the host can enqueue that pass before it has seen the token.
+__global__ __launch_bounds__(256) void decode_feed_kernel(const bf16_t* __restrict__ tok_table, int H, int vocab,
+                                                          const int* __restrict__ next_ids, int* __restrict__ finished,
+                                                          const int* __restrict__ eos_ids, int n_eos, int pad_id,
+                                                          int* __restrict__ tokens_out, bf16_t* __restrict__ x,
+                                                          int* __restrict__ seq_desc, int* __restrict__ positions, int nseq) {
+  __shared__ int tok_s;
+  const int i = blockIdx.x;
+  if (threadIdx.x == 0) {
+    int fin = finished[i];
+    const int t = fin ? pad_id : next_ids[i];
+    for (int e = 0; e < n_eos; ++e) fin |= (t == eos_ids[e]);
+    finished[i] = fin;
+    tokens_out[i] = t;
+    tokens_out[nseq + i] = fin;
+    seq_desc[4 * i + 2] += 1;   // VtAttnSeq::kv_len
+    positions[i] += 1;
+    tok_s = min(max(t, 0), vocab - 1);
+  }
+  __syncthreads();
+  const bf16_t* src = tok_table + (size_t)tok_s * H;
+  bf16_t* dst = x + (size_t)i * H;
+  for (int c = threadIdx.x; c < (H >> 3); c += 256) *(u32x4*)(dst + c * 8) = *(const u32x4*)(src + c * 8);
+}
+
 // first index of the maximum of each row (torch.argmax tie rule on CPU: lowest index). 1024 threads per row, 16-B loads,
 // every request of the row in flight at once (a 32000-float row is 8 loads per thread).
 __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ logits, int V, int ldl,
@@ -344,6 +372,19 @@ int vt_embed_splice_launch(const bf16_t* tok_table, const bf16_t* vis, const bf1
   const long total = (long)rows * (H / 8);
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   hipLaunchKernelGGL(embed_splice_kernel, dim3(blocks), dim3(256), 0, s, tok_table, vis, reg, plan, rows, H, out);
+  VT_LAUNCH_CHECK();
+  return VT_OK;
+}
+
+int vt_decode_feed_launch(const bf16_t* tok_table, int H, int vocab, const int* next_ids, int* finished, const int* eos_ids,
+                          int n_eos, int pad_id, int* tokens_out, bf16_t* x, int* seq_desc, int* positions, int nseq,
+                          hipStream_t s) {
+  VT_REQUIRE(tok_table && next_ids && finished && tokens_out && x && seq_desc && positions, "vt_decode_feed: null pointer");
+  VT_REQUIRE(nseq > 0 && vocab > 0 && H > 0 && H % 8 == 0, "vt_decode_feed: nseq=%d vocab=%d H=%d (H must be a multiple of 8)",
+             nseq, vocab, H);
+  VT_REQUIRE(n_eos == 0 || eos_ids, "vt_decode_feed: n_eos=%d without eos_ids", n_eos);
+  hipLaunchKernelGGL(decode_feed_kernel, dim3(nseq), dim3(256), 0, s, tok_table, H, vocab, next_ids, finished, eos_ids,
+                     n_eos < 0 ? 0 : n_eos, pad_id, tokens_out, x, seq_desc, positions, nseq);
   VT_LAUNCH_CHECK();
   return VT_OK;
 }

@@ -438,3 +438,92 @@ def llama_forward(llama: PackedLlama, kv: PagedKVCache, seqs: Sequence[SequenceS
     if return_hidden:
         return logits, hidden
     return logits
+
+
+class DecodeState:
+    """Device-resident state of a run of single-token decode steps over a fixed set of sequences.
+
+    `llama_forward` rebuilds the step metadata (sequence descriptors, page table, positions) on the host and uploads it for
+    every call, and the sampling loop around it needs each token on the host before it can enqueue the next pass: the GPU
+    idles for that round trip once per token. Here the metadata lives on the device for the whole run -- pages for
+    `max_steps` more tokens are reserved up front, one `vt_decode_feed` launch per token resolves pad / EOS, writes the next
+    input rows and advances kv_len / positions -- so `forward()` needs nothing from the host and the caller can enqueue
+    pass t+1 before it has read token t (read-back through pinned memory and an event, double-buffered).
+    The caller owns the speculation: `rollback()` forgets the last pass when the token before it turned out to end the run."""
+
+    def __init__(self, llama: PackedLlama, kv: PagedKVCache, seqs: Sequence[SequenceState], max_steps: int,
+                 eos_ids: Sequence[int] = (), pad_id: int = 0):
+        from . import ops
+        self._ops = ops
+        self.llama, self.kv, self.seqs = llama, kv, list(seqs)
+        dev = llama.device
+        B = self.B = len(self.seqs)
+        desc, table = [], []
+        for i, s in enumerate(self.seqs):
+            if s.length <= 0:
+                raise _lib.VitronHipError("DecodeState: every sequence needs a prefilled context")
+            need = (s.length + max_steps + PAGE_TOKENS - 1) // PAGE_TOKENS
+            if need > len(s.pages):
+                s.pages += kv.alloc(need - len(s.pages))
+            desc.append([i, 1, s.length, len(table)])        # kv_len / position are advanced by feed() BEFORE each pass
+            table += s.pages
+        self.max_len = max(s.length for s in self.seqs) + max_steps
+        self.desc = torch.tensor(desc, dtype=torch.int32, device=dev)
+        self.table = torch.tensor(table, dtype=torch.int32, device=dev)
+        self.pos = torch.tensor([s.length - 1 for s in self.seqs], dtype=torch.int32, device=dev)
+        self.rows = torch.arange(B, dtype=torch.int32, device=dev)
+        self.eos = torch.tensor(sorted(int(e) for e in eos_ids), dtype=torch.int32, device=dev) if len(eos_ids) else None
+        self.pad_id = int(pad_id)
+        self.finished = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.x = torch.empty((B, llama.H), dtype=torch.bfloat16, device=dev)
+        self.tok_dev = [torch.empty((2, B), dtype=torch.int32, device=dev) for _ in range(2)]
+        self.tok_pin = [torch.empty((2, B), dtype=torch.int32).pin_memory() for _ in range(2)]
+        self.events = [torch.cuda.Event() for _ in range(2)]
+        self.fed = 0        # tokens handed to feed()
+        self.passes = 0     # decoder passes enqueued
+
+    def feed(self, next_ids: torch.Tensor) -> int:
+        """Consume one sampled token id per sequence (device int32 [B]); returns the read-back slot for `read()`."""
+        slot = self.fed & 1
+        self._ops.decode_feed(self.llama.embed, next_ids.contiguous(), self.finished, self.eos, self.pad_id, self.tok_dev[slot],
+                              self.x, self.desc, self.pos)
+        self.tok_pin[slot].copy_(self.tok_dev[slot], non_blocking=True)
+        self.events[slot].record(torch.cuda.current_stream(self.llama.device))
+        self.fed += 1
+        return slot
+
+    def read(self, slot: int):
+        """(tokens, finished flags) of the feed() that returned `slot`, as host lists; waits for that launch only."""
+        self.events[slot].synchronize()
+        t = self.tok_pin[slot].tolist()
+        return t[0], [bool(f) for f in t[1]]
+
+    def forward(self) -> torch.Tensor:
+        """One decoder pass over the rows feed() just wrote; fp32 logits [B, V]. No host -> device traffic."""
+        if self.passes >= self.fed:
+            raise _lib.VitronHipError("DecodeState.forward: feed() the sampled tokens first")
+        lib = _lib.load()
+        llama, B = self.llama, self.B
+        for s in self.seqs:
+            if s.length >= llama.rope_len:
+                raise _lib.VitronHipError(f"llama_forward: position {s.length} beyond rope table ({llama.rope_len})")
+            if s.length + 1 > len(s.pages) * PAGE_TOKENS:
+                raise _lib.VitronHipError("DecodeState.forward: more steps than pages were reserved for")
+        logits = torch.empty((B, llama.V), dtype=torch.float32, device=llama.device)
+        ws = llama.ws.get(lib.vt_llama_workspace_bytes(C.byref(llama.model), B, B, B, self.max_len))
+        _lib.check(lib.vt_llama_forward(C.byref(llama.model), C.byref(self.kv.struct), self.x.data_ptr(), B, self.pos.data_ptr(),
+                                        self.desc.data_ptr(), B, 1, 1, int(self.max_len), self.table.data_ptr(),
+                                        self.rows.data_ptr(), B, logits.data_ptr(), None, ws.data_ptr(), ws.numel(), _stream()),
+                   "vt_llama_forward")
+        for s in self.seqs:
+            s.length += 1
+        self.passes += 1
+        return logits
+
+    def rollback(self) -> None:
+        """Forget the last pass (its token should not have been fed): the cache slot is simply overwritten later."""
+        if self.passes <= 0:
+            return
+        for s in self.seqs:
+            s.length -= 1
+        self.passes -= 1

@@ -14,8 +14,8 @@ from typing import List, Optional, Sequence
 import torch
 
 from ... import ops, synth
-from ...engine import PackedLlama, PagedKVCache, SequenceState, llama_forward
-from ..llava_arch import KIND_TOKEN, LlavaMetaForCausalLM, LlavaMetaModel
+from ...engine import DecodeState, PackedLlama, PagedKVCache, SequenceState, llama_forward
+from ..llava_arch import LlavaMetaForCausalLM, LlavaMetaModel
 from ..multimodal_encoder.builder import build_image_tower, build_video_tower
 from ..multimodal_projector.builder import build_vision_projector
 from ..region_extractor.builder import build_region_extractor
@@ -351,41 +351,56 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
         if kept:
             flat, lens = flat[kept:], [lens[0] - kept]
         logits = llama_forward(llama, self.kv, seqs, flat, lens)             # [B, V]: last position of every sequence
-        out = input_ids
-        finished = torch.zeros(B, dtype=torch.bool, device=dev)
+        # ---- decode loop: device-resident step state, the next pass is enqueued before the host has seen the token it consumes
+        L0 = input_ids.shape[1]
+        out_host = torch.empty((B, L0 + max_new_tokens), dtype=torch.long)
+        out_host[:, :L0] = input_ids.cpu()
+        n_out = L0
         all_logits = []
+        state = None
         try:
             for step in range(max_new_tokens):
                 if return_logits:
                     all_logits.append(logits.clone())
                 if do_sample and not top_k:   # device-side temperature + top-p sampler (no host sync, counter-based RNG)
-                    nxt = ops.sample_top_p(logits, temperature, top_p if top_p else 1.0, sample_seed, step).to(torch.long)
+                    nxt = ops.sample_top_p(logits, temperature, top_p if top_p else 1.0, sample_seed, step)
+                elif do_sample:
+                    nxt = self._sample(logits, do_sample, temperature, top_p, top_k, gen).to(torch.int32)
                 else:
-                    nxt = self._sample(logits, do_sample, temperature, top_p, top_k, gen)
-                nxt = torch.where(finished, torch.full_like(nxt, pad), nxt)
-                out = torch.cat([out, nxt.unsqueeze(1)], dim=1)
-                for e in eos_set:
-                    finished |= nxt == e
-                if bool(finished.all()):
+                    nxt = ops.argmax(logits)
+                last = step + 1 == max_new_tokens
+                scores = logits
+                if state is None and last:    # single-token call (prefill benchmarks, scoring): no decode state to set up
+                    toks = nxt.tolist()
+                    fin = [t in eos_set for t in toks]
+                else:
+                    if state is None:
+                        state = DecodeState(llama, self.kv, seqs, max_new_tokens, sorted(eos_set), pad)
+                    slot = state.feed(nxt)
+                    if not last:
+                        logits = state.forward()          # speculative: rolled back below if this token ends the run
+                    toks, fin = state.read(slot)
+                out_host[:, n_out] = torch.tensor(toks, dtype=torch.long)
+                n_out += 1
+                stop = all(fin)
+                if not stop and stopping_criteria is not None:
+                    stop = all(c(out_host[:, :n_out], scores) for c in stopping_criteria)
+                if stop:
+                    if state is not None and not last:
+                        state.rollback()
                     break
-                if stopping_criteria is not None and all(c(out, logits) for c in stopping_criteria):
-                    break
-                if step + 1 == max_new_tokens:
-                    break
-                plan = torch.stack([torch.full_like(nxt, KIND_TOKEN), nxt], dim=1).to(torch.int32).contiguous()
-                x = ops.embed_splice(llama.embed, None, None, plan)
-                logits = llama_forward(llama, self.kv, seqs, x, [1] * B)
         finally:
             if reuse and sig is not None and seqs[0].length > 0:
                 import numpy as np
 
                 from ...prefix_cache import PrefixKV
-                gen_ids = out[0, input_ids.shape[1]:].detach().cpu().numpy().astype(np.int64)
+                gen_ids = out_host[0, L0:n_out].numpy().astype(np.int64)
                 full = np.concatenate([sig, gen_ids])[:seqs[0].length]      # the last sampled token was never fed back
                 self._prefix = PrefixKV(full, seqs[0].pages)
             else:
                 for s in seqs:
                     self.kv.release(s.pages)
+        out = out_host[:, :n_out].to(dev)
         if return_logits:
             return out, all_logits
         return out

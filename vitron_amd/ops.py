@@ -190,6 +190,27 @@ def argmax(logits: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def decode_feed(tok_table: torch.Tensor, next_ids: torch.Tensor, finished: torch.Tensor, eos_ids: Optional[torch.Tensor],
+                pad_id: int, tokens_out: torch.Tensor, x: torch.Tensor, seq_desc: torch.Tensor, positions: torch.Tensor) -> None:
+    """In-place decode-loop feedback (vt_decode_feed): token resolution, EOS flags, next input rows, metadata advance."""
+    lib = _lib.load()
+    _chk(tok_table, torch.bfloat16, "decode_feed.tok_table")
+    _chk(x, torch.bfloat16, "decode_feed.x")
+    for name, t in (("next_ids", next_ids), ("finished", finished), ("tokens_out", tokens_out), ("seq_desc", seq_desc),
+                    ("positions", positions)):
+        _chk(t, torch.int32, f"decode_feed.{name}")
+    nseq = next_ids.shape[0]
+    if finished.numel() != nseq or tokens_out.numel() != 2 * nseq or seq_desc.numel() != 4 * nseq or positions.numel() != nseq \
+            or tuple(x.shape) != (nseq, tok_table.shape[1]):
+        raise _lib.VitronHipError("decode_feed: buffer sizes do not match the number of sequences")
+    n_eos = 0 if eos_ids is None else int(eos_ids.numel())
+    if n_eos:
+        _chk(eos_ids, torch.int32, "decode_feed.eos_ids")
+    _lib.check(lib.vt_decode_feed(_p(tok_table), tok_table.shape[1], tok_table.shape[0], _p(next_ids), _p(finished),
+                                  _p(eos_ids) if n_eos else None, n_eos, int(pad_id), _p(tokens_out), _p(x), _p(seq_desc),
+                                  _p(positions), nseq, _stream()), "vt_decode_feed")
+
+
 def sample_top_p(logits: torch.Tensor, temperature: float, top_p: float, seed: int, step: int, return_kept: bool = False):
     """One sampled token id per row (int32), on device; see vt_sample_top_p in include/vitron_hip.h."""
     lib = _lib.load()
