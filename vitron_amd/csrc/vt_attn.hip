@@ -769,9 +769,18 @@ __global__ __launch_bounds__(512) void attn_decode_fused_kernel(
     m_run = m_new;
     sm_p[wave][key_of_lane] = p;
     __builtin_amdgcn_wave_barrier();  // DS ops of one wave are in order; only stop compiler reordering
+    float p_new = 0.f;
+    if (is_last) {
+      // the new token's value comes from sm_v below, never from the loaded tile: its weight is taken out of the tile's row of
+      // probabilities, so a column r_new that already holds a value (a step that was rolled back and is run again) is not
+      // counted twice and the kernel is idempotent
+      p_new = sm_p[wave][r_new];
+      __builtin_amdgcn_wave_barrier();
+      if (key_of_lane == r_new) sm_p[wave][r_new] = 0.f;
+      __builtin_amdgcn_wave_barrier();
+    }
     const f32x4 pa = *(const f32x4*)(&sm_p[wave][vchk * 8]);
     const f32x4 pb = *(const f32x4*)(&sm_p[wave][vchk * 8 + 4]);
-    const float p_new = is_last ? sm_p[wave][r_new] : 0.f;
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int i = 0; i < NACC; ++i) {
@@ -786,7 +795,7 @@ __global__ __launch_bounds__(512) void attn_decode_fused_kernel(
       a = fmaf(bf16hi_to_f32(vv[i][3]), pb[3], a);
       acc[i] = a;
     }
-    if (is_last && vchk == 0) {   // the stored column r_new was still zero padding when it was loaded: add the new value here
+    if (is_last && vchk == 0) {   // column r_new of the loaded tile carries no weight (see above): add the new value here
 #pragma unroll
       for (int i = 0; i < NACC; ++i) acc[i] = fmaf(bf16_to_f32(sm_v[i * 8 + vrow]), p_new, acc[i]);
     }
