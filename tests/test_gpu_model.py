@@ -420,8 +420,9 @@ def test_generate_stops_on_eos_with_speculative_step_rolled_back(dev):
     p = torch.tensor([[1] + torch.randint(3, 500, (90,), generator=g).tolist(),
                       [1] + torch.randint(3, 500, (90,), generator=g).tolist()], device=dev)
     m.config.kv_prefix_reuse = False
-    free = None
-    full = m.generate(p, do_sample=False, max_new_tokens=10, eos_token_id=-1)
+    # sampled (counter-based device RNG: same seed, same tokens) so that the tiny random model emits distinct tokens
+    kw_args = dict(do_sample=True, temperature=1.0, top_p=1.0, seed=123)
+    full = m.generate(p, max_new_tokens=10, eos_token_id=-1, **kw_args)
     free = len(m.kv.free)
     assert free == m.kv.num_pages
     new = full[:, p.shape[1]:].tolist()
@@ -429,7 +430,7 @@ def test_generate_stops_on_eos_with_speculative_step_rolled_back(dev):
     e0, e1 = new[0][3], new[1][6]
     if e0 in new[1][:6] or e1 in new[0][:3] or e0 in new[0][:3] or e1 in new[1][:6]:
         pytest.skip("synthetic tokens collide with the chosen EOS ids")
-    out = m.generate(p, do_sample=False, max_new_tokens=10, eos_token_id=[e0, e1], pad_token_id=0)
+    out = m.generate(p, max_new_tokens=10, eos_token_id=[e0, e1], pad_token_id=0, **kw_args)
     got = out[:, p.shape[1]:].tolist()
     assert got[1] == new[1][:7] and got[0] == new[0][:4] + [0, 0, 0]
     assert len(m.kv.free) == free
@@ -442,12 +443,13 @@ def test_generate_stops_on_eos_with_speculative_step_rolled_back(dev):
             return r
         def batch_decode(self, ids, skip_special_tokens=True):
             return [" ".join(str(int(t)) for t in row) for row in ids]
-    m.config.kv_prefix_reuse = True
     p1 = p[:1]
-    kw = f"{new[0][4]} {new[0][5]}"
+    new1 = m.generate(p1, max_new_tokens=10, eos_token_id=-1, **kw_args)[0, p1.shape[1]:].tolist()
+    m.config.kv_prefix_reuse = True
+    kw = f"{new1[4]} {new1[5]}"
     crit = KeywordsStoppingCriteria([kw], Tok(), p1)
-    o1 = m.generate(p1, do_sample=False, max_new_tokens=10, eos_token_id=-1, stopping_criteria=[crit])
-    assert o1[0, p1.shape[1]:].tolist() == new[0][:6]
+    o1 = m.generate(p1, max_new_tokens=10, eos_token_id=-1, stopping_criteria=[crit], **kw_args)
+    assert o1[0, p1.shape[1]:].tolist() == new1[:6]
     p2 = torch.cat([o1[0], torch.tensor([11, 12, 13], device=dev)]).unsqueeze(0)
     o2, lg2 = m.generate(p2, do_sample=False, max_new_tokens=3, eos_token_id=-1, return_logits=True)
     assert m.last_generate_stats["reused_tokens"] == 64
