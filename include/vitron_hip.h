@@ -65,11 +65,14 @@ int vt_last_error(char* buf, size_t buf_len);
  * ---------------------------------------------------------------------------------------------------------- */
 
 /* nn.Linear: C = epi(A[M,K] . W[N,K]^T + bias[N]).  bias may be NULL. C is bf16 or fp32 per `epi`.
- * `scratch` is reserved (no kernel needs it any more); pass NULL.
+ * `row_scale` (optional, fp32 [M], device): the accumulator of row m is multiplied by row_scale[m] before bias and activation
+ * -- a per-row scalar commutes with the contraction, so a GEMM on x .* w followed by this factor is Linear(RMSNorm(x)) with the
+ * normalisation folded in (what vt_llama_forward does for rows > 64). Rows with a scale run on the MFMA tile kernels whatever M
+ * is. NULL = no scaling.
  * Replaces every torch.nn.Linear on the path (transformers-4.31 CLIPAttention/CLIPMLP/LlamaAttention/LlamaMLP,
  * reference call sites modeling_video.py:69,71,81; llava_llama.py:49,91-102; multimodal_projector/builder.py:33-51). */
 int vt_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, void* C, int ldc, const float* bias, int M,
-                 int N, int K, int epi, int cfg, void* scratch, void* stream);
+                 int N, int K, int epi, int cfg, const float* row_scale, void* stream);
 
 /* y_bf16[rows][D] = LayerNorm(x_f32) * gamma + beta. If temb != NULL first x[row] += temb[(row / tokens_per_frame) % T]
  * (written back): the video tower's temporal_embedding add (reference modeling_video.py:110-114) fused with

@@ -175,6 +175,47 @@ def test_decoder_7b_chunking_and_batch_invariance(dev, model7b):
     assert rel_l2(both[1:2], full[-1:]) <= 2e-2 and rel_l2(both[0:1], alone_b) <= 2e-2
 
 
+def test_prefill_folded_rmsnorm_matches_separate_norms(dev, model7b):
+    """rows > 64: RMSNorm folded into the MFMA tile GEMMs (producers: 4-phase kernel, small-tile remainder, split-K reduce pass;
+    consumers: qkv / gate_up) against the same pass with separate norm launches (VT_PREFILL_NORM_FOLD=0). The only difference is
+    where bf16 rounding happens (x*w before the row factor instead of after): two independently rounded bf16 paths: ~6e-3 apart after two layers at the 7B width (each equally far from fp32:
+    tests/test_gpu_model.py::test_prefill_folded_rmsnorm_vs_oracle), the
+    deep-chain noise floor after 32."""
+    import os
+    import time
+    from vitron_amd.engine import PagedKVCache, SequenceState, llama_forward
+    from vitron_amd.model import LlavaConfig, LlavaLlamaForCausalLM
+    shallow = LlavaLlamaForCausalLM(LlavaConfig(**dict(synth.VICUNA_7B, num_hidden_layers=2), mm_hidden_size=1024, kv_prefix_reuse=False))
+    shallow.init_synthetic(dev, seed=77, vit_image=None, vit_video=None)
+    g = torch.Generator(device=dev).manual_seed(15)
+    for name, model, tol_logits, tol_hidden in (("2 layers", shallow, 1e-2, 1e-2), ("32 layers", model7b, 4e-2, 4e-2)):
+        llama = model.get_model().llama
+        kv = PagedKVCache(llama, 96)
+        for S in (5120, 1088, 300):       # M-split + split-K remainder / one round of 256x256 tiles / small tiles + split-K
+            emb = (torch.randn((S, 4096), generator=g, device=dev) * 0.02).bfloat16()
+            res = {}
+            for fold in ("1", "0"):
+                os.environ["VT_PREFILL_NORM_FOLD"] = fold
+                try:
+                    times = []
+                    for _ in range(2):
+                        s_ = SequenceState()
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        lg, hid = llama_forward(llama, kv, [s_], emb, [S], logit_rows=[0, S // 2, S - 1], return_hidden=True)
+                        torch.cuda.synchronize()
+                        times.append(time.perf_counter() - t0)
+                        kv.release(s_.pages)
+                    res[fold] = (lg, hid, min(times))
+                finally:
+                    os.environ.pop("VT_PREFILL_NORM_FOLD", None)
+            (la, ha, ta), (lb, hb, tb) = res["1"], res["0"]
+            assert torch.isfinite(la).all() and torch.isfinite(ha).all()
+            print(f"prefill {name} S={S}: folded {ta * 1e3:.2f} ms, separate norms {tb * 1e3:.2f} ms, "
+                  f"rel_l2 logits {rel_l2(la, lb):.2e} hidden {rel_l2(ha, hb):.2e}")
+            assert rel_l2(la, lb) <= tol_logits and rel_l2(ha, hb) <= tol_hidden, (name, S, rel_l2(la, lb), rel_l2(ha, hb))
+
+
 def test_image_tower_full_size_batch_independence(dev, model7b):
     """LanguageBind image tower at 336 px (ViT-L/14, 23 layers, 577 tokens): permuting the batch permutes the projected
     features bit-exactly, and a batch item equals the same image encoded alone."""

@@ -404,3 +404,34 @@ def test_sample_top_p_keep_set_and_distribution(dev):
     assert (freq - torch.tensor([0.5, 0.25, 0.15, 0.10], dtype=torch.float64)).abs().max() < 0.04 and int((ids >= 4).sum()) == 0
     ids = ops.sample_top_p(ld, 1.0, 0.7, seed=11, step=0).cpu().long()   # keep-set {0,1}: mass .75 >= .7
     assert int((ids >= 2).sum()) == 0 and abs(float((ids == 0).double().mean()) - 2 / 3) < 0.04
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K,epi_name,cfg", [(700, 512, 256, "BF16", 0), (700, 512, 256, "BF16", 10), (300, 1024, 192, "SWIGLU_BF16", 0),
+                                                 (9, 256, 128, "BF16", 0), (530, 768, 512, "BF16_GELU", 5), (513, 512, 512, "F32", 2),
+                                                 (1100, 2048, 1024, "SWIGLU_BF16", 10), (260, 512, 256, "BF16", 6)])
+def test_gemm_row_scale(dev, M, N, K, epi_name, cfg):
+    """vt_gemm_bf16's optional per-row factor (the consumer side of the folded RMSNorm): epi(rs[m] * (a w^T) + bias) on every
+    MFMA tile path, ragged M included, against fp32 torch."""
+    from vitron_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn((M, K), generator=g).bfloat16()
+    w = (torch.randn((N, K), generator=g) * 0.1).bfloat16()
+    rs = torch.rand((M,), generator=g) * 1.5 + 0.25
+    bias = None if epi_name == "SWIGLU_BF16" else torch.randn((N,), generator=g)
+    epi = getattr(ops, "EPI_" + epi_name)
+    out = ops.gemm(a.to(dev), w.to(dev), None if bias is None else bias.to(dev), epi, cfg=cfg, row_scale=rs.to(dev)).float().cpu()
+    acc = (a.float() @ w.float().t()) * rs[:, None]
+    if epi_name == "SWIGLU_BF16":   # weight rows interleaved in blocks of 16: [gate 16 | up 16 | ...]
+        v = acc.view(M, N // 32, 2, 16)
+        ref = (torch.nn.functional.silu(v[:, :, 0]) * v[:, :, 1]).reshape(M, N // 2)
+    else:
+        acc = acc + bias
+        ref = torch.nn.functional.gelu(acc) if epi_name == "BF16_GELU" else acc
+    assert rel_l2(out, ref) <= (1e-5 if epi_name == "F32" else 3e-3), rel_l2(out, ref)
+    plain = ops.gemm(a.to(dev), w.to(dev), None if bias is None else bias.to(dev), epi, cfg=cfg,
+                     row_scale=torch.ones(M, device=dev)).float().cpu()
+    base = ops.gemm(a.to(dev), w.to(dev), None if bias is None else bias.to(dev), epi, cfg=(cfg if M > 64 else 5)).float().cpu()
+    assert torch.equal(plain, base)                      # a factor of 1.0 changes nothing, bit for bit
+    with pytest.raises(Exception):
+        ops.gemm(a.to(dev), w.to(dev), None, epi, row_scale=rs[:-1].to(dev))

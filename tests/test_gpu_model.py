@@ -459,3 +459,38 @@ def test_generate_stops_on_eos_with_speculative_step_rolled_back(dev):
     for a, b in zip(lg2, lg3):
         assert rel_l2(a.float(), b.float()) <= 5e-3
     assert torch.equal(o2, o3) or rel_l2(lg2[-1].float(), lg3[-1].float()) <= 5e-4
+
+
+@pytest.mark.gpu
+def test_prefill_folded_rmsnorm_vs_oracle(dev):
+    """rows > 64: RMSNorm folded into the MFMA tile GEMMs (residual GEMMs emit bf16(x .* w_next) + per-row partial sums of x^2,
+    vt_rowscale_finalize turns them into rstd, the consumer GEMMs scale their accumulator rows). Every row's logits against the
+    fp32 oracle, with the fold and with separate norm launches (VT_PREFILL_NORM_FOLD=0): folding costs no accuracy. Shapes chosen
+    to hit the 4-phase kernel (K % 128 == 0), the small tiles (K = 192 gate / down) and ragged row counts."""
+    import os
+    from vitron_amd.engine import PackedLlama, PagedKVCache, SequenceState, llama_forward
+    for H, I, heads, rows in ((1024, 1408, 8, 333), (256, 192, 2, 97)):
+        cfg = dict(synth.VICUNA_7B, hidden_size=H, intermediate_size=I, num_hidden_layers=3, num_attention_heads=heads, vocab_size=640)
+        sd = synth.llama_state(cfg, synth.make_generator(31), w_std=0.05)
+        llama = PackedLlama(sd, cfg, dev)
+        sd32 = {k: v.float() for k, v in sd.items()}
+        g = torch.Generator().manual_seed(32)
+        e = O.bf16_round(torch.randn((rows, H), generator=g) * 0.5)
+        ref, _ = O.llama_forward(sd32, cfg, e.unsqueeze(0))
+        ref = ref[0]
+        kv = PagedKVCache(llama, 16)
+        got = {}
+        for fold in ("1", "0"):
+            os.environ["VT_PREFILL_NORM_FOLD"] = fold
+            try:
+                s_ = SequenceState()
+                got[fold] = llama_forward(llama, kv, [s_], e.to(dev).bfloat16(), [rows], logit_rows=list(range(rows))).cpu()
+                kv.release(s_.pages)
+            finally:
+                os.environ.pop("VT_PREFILL_NORM_FOLD", None)
+        ef, es = rel_l2(got["1"], ref), rel_l2(got["0"], ref)
+        assert not torch.equal(got["1"], got["0"])                    # the switch really selects two different paths
+        assert ef <= TOL_DEEP and es <= TOL_DEEP, (H, ef, es)
+        assert ef <= 1.25 * es + 1e-3, (H, ef, es)                    # no farther from fp32 than the separate-norm path
+        worst = max(rel_l2(got["1"][r], ref[r]) for r in range(rows))
+        assert worst <= 2 * TOL_DEEP, (H, worst)                      # no single row off (a wrong row factor would be O(1))

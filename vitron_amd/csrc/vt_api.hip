@@ -124,8 +124,11 @@ int vt_profile_end(int* launches, double* total_ms, double* total_work) {
 
 // ---- primitives -----------------------------------------------------------------------------------------------------
 int vt_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, void* C, int ldc, const float* bias, int M,
-                 int N, int K, int epi, int cfg, void* scratch, void* stream) {
-  return vt_gemm_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, epi, cfg, scratch, S(stream));
+                 int N, int K, int epi, int cfg, const float* row_scale, void* stream) {
+  if (!row_scale) return vt_gemm_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, epi, cfg, nullptr, S(stream));
+  VtGemmNormFuse nf;
+  nf.row_scale = row_scale;
+  return vt_gemm_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, epi, cfg, nullptr, S(stream), &nf);
 }
 
 int vt_layernorm(float* x, const float* temb, int T, int tokens_per_frame, const float* gamma, const float* beta,
@@ -368,7 +371,8 @@ struct LlamaWs {
   float* x;
   bf16_t *y, *qkv, *att, *h, *yn;
   float* scratch;
-  float *rs_a, *rs_b;   // folded-RMSNorm partial sums of squares (decode steps)
+  float *rs_a, *rs_b;   // folded-RMSNorm partial sums of squares (decode steps: [16][H/16]; rows > 64: rs_a = [rows][H/32])
+  float* rstd;          // rows > 64: per-row factor of the folded RMSNorm (vt_rowscale_finalize_launch)
   float* splitk;        // fp32 partial products of the split-K residual GEMMs (prefills of 65..~2000 rows)
   size_t splitk_bytes;
   float* attn_scratch;
@@ -386,8 +390,9 @@ LlamaWs llama_carve(const vt_llama_model* m, int rows, int n_logit, int nseq, in
   w.h = (bf16_t*)ws.take((size_t)rows * I * 2);
   w.yn = (bf16_t*)ws.take((size_t)(n_logit > 0 ? n_logit : 1) * H * 2);
   w.scratch = (float*)ws.take((size_t)16 * 2 * I * 4);
-  w.rs_a = (float*)ws.take((size_t)16 * (H / 16) * 4);
+  w.rs_a = (float*)ws.take(std::max((size_t)16 * (H / 16), rows > 64 ? (size_t)rows * (H / 32) : (size_t)0) * 4);
   w.rs_b = (float*)ws.take((size_t)16 * (H / 16) * 4);
+  w.rstd = (float*)ws.take((size_t)(rows > 64 ? rows : 1) * 4);
   // tiles * ksplit <= 256 tiles of 256x256 fp32: 64 MiB covers every case the dispatcher splits
   w.splitk_bytes = (rows > 64) ? ((size_t)256 * 256 * 256 * 4) : 0;
   w.splitk = w.splitk_bytes ? (float*)ws.take(w.splitk_bytes) : nullptr;
@@ -431,6 +436,12 @@ int vt_llama_forward(const vt_llama_model* m, const vt_kv_cache* kv, const uint1
   // follow (gate_up, next layer's qkv) scale their rows by rstd. Only the first norm of layer 0 and the final norm stay
   // separate launches: 6 launches per layer -> 4.
   const bool fold_norm = rows <= 16 && max_q_len == 1 && (H % 1024) == 0 && H <= 8192 && (I % 64) == 0;
+  // Opt-in (VT_PREFILL_NORM_FOLD=1): measured neutral to slightly slower on the C3 step -- the 1.9 ms of RMSNorm
+  // launches it removes come back as longer residual epilogues (+12 us each: the y store), the finalize launches and ~1.5 %
+  // slower consumer GEMMs (same code, un-normalised operands: the MFMA clock is data dependent on this power-limited part).
+  const char* fold_env = getenv("VT_PREFILL_NORM_FOLD");
+  const bool fold_tile_enabled = fold_env && fold_env[0] == '1';
+  const bool fold_tile = fold_tile_enabled && !fold_norm && vt_gemm_norm_fold_supported(rows, H, H) && (I % 64) == 0;
   VtGemmNormFuse consume_a, consume_b, none;
   consume_a.in_partials = w.rs_a;
   consume_b.in_partials = w.rs_b;
@@ -469,8 +480,18 @@ int vt_llama_forward(const vt_llama_model* m, const vt_kv_cache* kv, const uint1
       }
       continue;
     }
-    VT_TRY(vt_rmsnorm_launch(w.x, nullptr, L.rms1, w.y, rows, H, m->rms_eps, s));
-    VT_TRY(vt_gemm_launch(w.y, H, L.wqkv, H, w.qkv, 3 * H, nullptr, rows, 3 * H, H, VT_EPI_BF16, AUTO, nullptr, s));
+    // Prefill (rows > 64): the same fold on the MFMA tile kernels -- the residual GEMMs (o_proj, down_proj) also store
+    // y = bf16(x .* w_next) and per-row sums of x^2 per 32-column group, one small launch turns those into rstd[row], and the GEMM
+    // that consumes y (gate_up, the next layer's qkv) scales its accumulator rows by rstd. Saves the 84 MB read of x per norm
+    // (opt-in, see above).
+    VtGemmNormFuse cons_t;
+    cons_t.row_scale = w.rstd;
+    if (fold_tile && l > 0) {
+      VT_TRY(vt_gemm_launch(w.y, H, L.wqkv, H, w.qkv, 3 * H, nullptr, rows, 3 * H, H, VT_EPI_BF16, AUTO, nullptr, s, &cons_t));
+    } else {
+      VT_TRY(vt_rmsnorm_launch(w.x, nullptr, L.rms1, w.y, rows, H, m->rms_eps, s));
+      VT_TRY(vt_gemm_launch(w.y, H, L.wqkv, H, w.qkv, 3 * H, nullptr, rows, 3 * H, H, VT_EPI_BF16, AUTO, nullptr, s));
+    }
     if (max_q_len == 1) {   // decode step: rotary + append + attention + combine in one launch
       VT_TRY(vt_attn_decode_fused_launch(w.qkv, 3 * H, 0, H, 2 * H, kt, vt, tile_table, (const VtAttnSeq*)seq_desc, nseq, w.att, H,
                                          heads, HD, scale, m->rope_cos, m->rope_sin, positions, s));
@@ -479,6 +500,26 @@ int vt_llama_forward(const vt_llama_model* m, const vt_kv_cache* kv, const uint1
                                 max_new_tiles, heads, HD, m->rope_cos, m->rope_sin, positions, s));
       VT_TRY(vt_flash_attn_launch(w.qkv, 3 * H, kt, vt, tile_table, (const VtAttnSeq*)seq_desc, nseq, max_q_len, w.att, H,
                                   heads, HD, 1, scale, s));
+    }
+    if (fold_tile) {
+      VtGemmNormFuse prod;
+      prod.out_xw = w.y;
+      prod.ld_xw = H;
+      prod.out_partials = w.rs_a;
+      prod.out_np = H / 32;
+      prod.out_ldp = rows;
+      prod.out_w = L.rms2;
+      VT_TRY(vt_gemm_resid_launch(w.att, H, L.wo, H, w.x, H, nullptr, rows, H, H, 0, w.splitk, w.splitk_bytes, s, &prod));
+      VT_TRY(vt_rowscale_finalize_launch(w.rs_a, H / 32, rows, rows, 1.0f / (float)H, m->rms_eps, w.rstd, s));
+      VT_TRY(vt_gemm_launch(w.y, H, L.wgu, H, w.h, I, nullptr, rows, 2 * I, H, VT_EPI_SWIGLU_BF16, AUTO, w.scratch, s, &cons_t));
+      if (l + 1 < m->num_layers) {
+        prod.out_w = m->layers[l + 1].rms1;
+        VT_TRY(vt_gemm_resid_launch(w.h, I, L.wdown, I, w.x, H, nullptr, rows, H, I, 0, w.splitk, w.splitk_bytes, s, &prod));
+        VT_TRY(vt_rowscale_finalize_launch(w.rs_a, H / 32, rows, rows, 1.0f / (float)H, m->rms_eps, w.rstd, s));
+      } else {
+        VT_TRY(vt_gemm_resid_launch(w.h, I, L.wdown, I, w.x, H, nullptr, rows, H, I, 0, w.splitk, w.splitk_bytes, s));
+      }
+      continue;
     }
     VT_TRY(vt_gemm_resid_launch(w.att, H, L.wo, H, w.x, H, nullptr, rows, H, H, 0, w.splitk, w.splitk_bytes, s));
     VT_TRY(vt_rmsnorm_launch(w.x, nullptr, L.rms2, w.y, rows, H, m->rms_eps, s));

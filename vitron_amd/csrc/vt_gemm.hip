@@ -160,12 +160,20 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bt_kernel(GemmP p
   }
 
   // ---- epilogue: lane holds C[m][n0..n0+3], m = ..+(lane&15), n0 = ..+(lane>>4)*4 ----------------
+  // folded RMSNorm (VtGemmNormFuse, rows > 64): consumer = scale the row's accumulators by row_scale[m] first; producer
+  // (residual epilogue) = also store bf16(x_new * out_w[n]) and the row's sum of x_new^2 over each 32-column group
+  const float* const row_scale = p.nf.row_scale;
+  float* const out_partials = (EPI == VT_EPI_F32_RESID) ? p.nf.out_partials : nullptr;
   const int m_lane = bm0 + wm * WTM + (lane & 15);
   const int n_lane = bn0 + wn * WTN + ((lane >> 4) << 2);
+  float rsv[MI];   // fetched before the first store: a load inside the row loop would queue behind the previous row's stores
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) rsv[mi] = row_scale ? row_scale[min(m_lane + mi * 16, p.M - 1)] : 1.f;
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int m = m_lane + mi * 16;
     if (m >= p.M) continue;
+    const float rs = rsv[mi];
     if constexpr (EPI == VT_EPI_SWIGLU_BF16) {
       // W rows are interleaved in blocks of 16: [gate 16 | up 16 | gate 16 | up 16 ...]
       bf16_t* crow = (bf16_t*)p.C + (size_t)m * p.ldc;
@@ -174,43 +182,62 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bt_kernel(GemmP p
         const int n = n_lane + ni * 16;  // column of the gate fragment in the interleaved space
         if (n >= p.N) continue;
         const int no = ((bn0 + wn * WTN + ni * 16) >> 1) + ((lane >> 4) << 2);
-        const f32x4 g = acc[mi][ni], u = acc[mi][ni + 1];
+        const f32x4 g = acc[mi][ni] * rs, u = acc[mi][ni + 1] * rs;
         u32x2 o;
         o.x = pack_bf16x2(silu(g[0]) * u[0], silu(g[1]) * u[1]);
         o.y = pack_bf16x2(silu(g[2]) * u[2], silu(g[3]) * u[3]);
         *(u32x2*)(crow + no) = o;
       }
     } else {
+      float ss = 0.f;   // producer: sum of x_new^2 over the current 32-column group (two fragments)
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
         const int n = n_lane + ni * 16;
-        if (n >= p.N) continue;
-        f32x4 v = acc[mi][ni];
-        if (p.bias) {
-          const f32x4 b = *(const f32x4*)(p.bias + n);
-          v += b;
-        }
-        if constexpr (EPI == VT_EPI_BF16_GELU) {
+        if (n < p.N) {
+          f32x4 v = acc[mi][ni] * rs;
+          if (p.bias) {
+            const f32x4 b = *(const f32x4*)(p.bias + n);
+            v += b;
+          }
+          if constexpr (EPI == VT_EPI_BF16_GELU) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
-        } else if constexpr (EPI == VT_EPI_BF16_QGELU) {
+            for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+          } else if constexpr (EPI == VT_EPI_BF16_QGELU) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = quick_gelu(v[r]);
-        } else if constexpr (EPI == VT_EPI_BF16_RELU) {
+            for (int r = 0; r < 4; ++r) v[r] = quick_gelu(v[r]);
+          } else if constexpr (EPI == VT_EPI_BF16_RELU) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+          }
+          if constexpr (EPI == VT_EPI_F32_RESID) {
+            float* c = (float*)p.C + (size_t)m * p.ldc + n;
+            const f32x4 nv = *(const f32x4*)c + v;
+            *(f32x4*)c = nv;
+            if (out_partials) {
+              const f32x4 w4 = *(const f32x4*)(p.nf.out_w + n);
+              u32x2 o;
+              o.x = pack_bf16x2(nv[0] * w4[0], nv[1] * w4[1]);
+              o.y = pack_bf16x2(nv[2] * w4[2], nv[3] * w4[3]);
+              *(u32x2*)(p.nf.out_xw + (size_t)m * p.nf.ld_xw + n) = o;
+              ss += (nv[0] * nv[0] + nv[1] * nv[1]) + (nv[2] * nv[2] + nv[3] * nv[3]);
+            }
+          } else if constexpr (EPI == VT_EPI_F32) {
+            *(f32x4*)((float*)p.C + (size_t)m * p.ldc + n) = v;
+          } else {
+            u32x2 o;
+            o.x = pack_bf16x2(v[0], v[1]);
+            o.y = pack_bf16x2(v[2], v[3]);
+            *(u32x2*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
+          }
         }
         if constexpr (EPI == VT_EPI_F32_RESID) {
-          float* c = (float*)p.C + (size_t)m * p.ldc + n;
-          f32x4 old = *(const f32x4*)c;
-          *(f32x4*)c = old + v;
-        } else if constexpr (EPI == VT_EPI_F32) {
-          *(f32x4*)((float*)p.C + (size_t)m * p.ldc + n) = v;
-        } else {
-          u32x2 o;
-          o.x = pack_bf16x2(v[0], v[1]);
-          o.y = pack_bf16x2(v[2], v[3]);
-          *(u32x2*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
+          if ((ni & 1) && out_partials) {   // the 4 lanes (lane>>4) of a row hold the group's 32 columns; N % 32 == 0
+            ss += __shfl_xor(ss, 16, 64);
+            ss += __shfl_xor(ss, 32, 64);
+            const int grp = (bn0 + wn * WTN + (ni - 1) * 16) >> 5;
+            if ((lane >> 4) == 0 && grp < p.nf.out_np) out_partials[(size_t)grp * p.nf.out_ldp + m] = ss;
+            ss = 0.f;
+          }
         }
       }
     }
@@ -714,8 +741,10 @@ int vt_gemm_pick_cfg(int M, int N, int K) {
 // 39 -> 29 at 8; K = 4096 with ksplit < 8 and everything at K = 1024: no gain, the reduce pass eats it)
 bool vt_gemm_splitk_pays(int M, int N, int K, int ksplit) { return K >= 8192 || (K >= 4096 && ksplit >= 8); }
 
+bool vt_gemm_norm_fold_supported(int M, int N, int K) { return M > 64 && (N % 32) == 0 && (K % 64) == 0; }
+
 int vt_gemm_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, const float* bias,
-                   int M, int N, int K, int epi, int cfg, void* skinny_scratch, hipStream_t s) {
+                   int M, int N, int K, int epi, int cfg, void* skinny_scratch, hipStream_t s, const VtGemmNormFuse* nf) {
   VT_REQUIRE(A && W && C, "vt_gemm: null pointer");
   VT_REQUIRE(M > 0 && N > 0 && K > 0, "vt_gemm: empty problem M=%d N=%d K=%d", M, N, K);
   VT_REQUIRE((N % 4) == 0, "vt_gemm: N=%d must be a multiple of 4", N);
@@ -723,14 +752,25 @@ int vt_gemm_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, 
   VT_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)C % 16) == 0,
              "vt_gemm: A/W/C must be 16-byte aligned");
   VT_REQUIRE(ldc % 4 == 0, "vt_gemm: ldc must be a multiple of 4");
-  GemmP p{A, W, C, bias, M, N, K, lda, ldw, ldc, VtGemmNormFuse{}};
-  const bool skinny_path = (M <= 16 || (M <= 32 && (K % 64) == 0 && cfg != VT_GEMM_CFG_SKINNY_REG)) &&
+  if (nf && !nf->row_scale && !nf->out_partials) nf = nullptr;
+  if (nf) {   // folded RMSNorm on the MFMA tile kernels (vt_kernels.h)
+    const bool tile_cfg = cfg == VT_GEMM_CFG_AUTO || cfg == VT_GEMM_CFG_256x256_P4 || cfg == VT_GEMM_CFG_256x256_P8 ||
+                          cfg == VT_GEMM_CFG_128x128 || cfg == VT_GEMM_CFG_256x128 || cfg == VT_GEMM_CFG_256x256 || cfg == VT_GEMM_CFG_64x128;
+    VT_REQUIRE((N % 32) == 0 && (K % 64) == 0 && tile_cfg,
+               "vt_gemm: row scale / norm fold needs N %% 32 == 0, K %% 64 == 0 and an MFMA tile configuration (N=%d K=%d cfg=%d)", N, K, cfg);
+    if (nf->out_partials)
+      VT_REQUIRE(epi == VT_EPI_F32_RESID && nf->out_w && nf->out_xw && nf->out_np >= N / 32 && nf->out_ldp >= M && (nf->ld_xw % 4) == 0,
+                 "vt_gemm: norm-fold producer needs the residual epilogue, out_w, out_xw and out_np >= N/32");
+  }
+  GemmP p{A, W, C, bias, M, N, K, lda, ldw, ldc, nf ? *nf : VtGemmNormFuse{}};
+  // (a row range that carries the tile kernels' norm fold stays on the tile kernels whatever its height: remainders of an M-split)
+  const bool skinny_path = !nf && (M <= 16 || (M <= 32 && (K % 64) == 0 && cfg != VT_GEMM_CFG_SKINNY_REG)) &&
                            (cfg == VT_GEMM_CFG_AUTO || cfg == VT_GEMM_CFG_SKINNY || cfg == VT_GEMM_CFG_SKINNY_REG);
   // 17..32 rows take the 32-row weight-streaming kernel (weights streamed once). 33..64 rows (short follow-up prompts, larger
   // decode batches): a tile grid is far too small for 256 CUs at N = 4096 (64x128 tiles: 32 workgroups, 0.6 TB/s of weight
   // stream), so the rows go through that kernel in two groups of 32 -- the weights are streamed twice (the repeat mostly from
   // the Infinity Cache), still faster than the tile grid up to N = 16384 (tools/skinny_bench.py).
-  if (cfg == VT_GEMM_CFG_AUTO && M > 32 && M <= 64 && (K % 64) == 0 && N <= 16384) {
+  if (!nf && cfg == VT_GEMM_CFG_AUTO && M > 32 && M <= 64 && (K % 64) == 0 && N <= 16384) {
     const size_t esz = (epi == VT_EPI_F32 || epi == VT_EPI_F32_RESID) ? 4 : 2;
     for (int m0 = 0; m0 < M; m0 += 32)
       VT_TRY(vt_gemm_launch(A + (size_t)m0 * lda, lda, W, ldw, (char*)C + (size_t)m0 * ldc * esz, ldc, bias, std::min(32, M - m0), N, K,
@@ -756,9 +796,10 @@ int vt_gemm_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, 
         const long M1 = (M / unit) * unit;
         if (M1 >= unit && M1 < M) {
           const size_t esz = (epi == VT_EPI_F32 || epi == VT_EPI_F32_RESID) ? 4 : 2;
-          VT_TRY(vt_gemm_launch(A, lda, W, ldw, C, ldc, bias, (int)M1, N, K, epi, VT_GEMM_CFG_256x256_P4, skinny_scratch, s));
+          VT_TRY(vt_gemm_launch(A, lda, W, ldw, C, ldc, bias, (int)M1, N, K, epi, VT_GEMM_CFG_256x256_P4, skinny_scratch, s, nf));
+          const VtGemmNormFuse rest = nf ? vt_nf_rows(*nf, M1) : VtGemmNormFuse{};
           return vt_gemm_launch(A + (size_t)M1 * lda, lda, W, ldw, (char*)C + (size_t)M1 * ldc * esz, ldc, bias, M - (int)M1, N, K,
-                                epi, VT_GEMM_CFG_AUTO, skinny_scratch, s);
+                                epi, VT_GEMM_CFG_AUTO, skinny_scratch, s, nf ? &rest : nullptr);
         }
       }
     }
@@ -784,9 +825,9 @@ int vt_gemm_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, 
   }
   VT_REQUIRE((K % 64) == 0, "vt_gemm(tile): K=%d must be a multiple of 64", K);
   if (epi == VT_EPI_SWIGLU_BF16) VT_REQUIRE((N % 32) == 0, "vt_gemm(swiglu): N must be a multiple of 32");
-  if (cfg == VT_GEMM_CFG_256x256_P8) return vt_gemm_p8_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, epi, s);
+  if (cfg == VT_GEMM_CFG_256x256_P8) return vt_gemm_p8_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, epi, s, nf);
   if (cfg >= 111 && cfg < 118) return vt_gemm_p8_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, ((cfg - 110) << 8) | 0x1000, s);
-  if (cfg == VT_GEMM_CFG_256x256_P4) return vt_gemm_p8_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, epi | 0x1000, s);
+  if (cfg == VT_GEMM_CFG_256x256_P4) return vt_gemm_p8_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, epi | 0x1000, s, nf);
   if (cfg >= 100 && cfg < 108) return vt_gemm_p8_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, (cfg - 100) << 8, s);
   if (cfg >= 301 && cfg <= 303) return vt_gemm_rp_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, (cfg - 300) << 8, s);
   if (cfg == VT_GEMM_CFG_256x256_RP) return vt_gemm_rp_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, epi, s);
@@ -826,7 +867,7 @@ int vt_gemm_skinny_norm_launch(const bf16_t* A, int lda, const bf16_t* W, int ld
 // grid would cover at most half the chip, enough K is left per split and the workspace is large enough; otherwise the plain
 // dispatcher. ksplit >= 2 forces the two-pass path (tests, tools/splitk_bench.py).
 int vt_gemm_resid_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, float* C, int ldc, const float* bias, int M, int N,
-                         int K, int ksplit, float* partials, size_t partial_bytes, hipStream_t s) {
+                         int K, int ksplit, float* partials, size_t partial_bytes, hipStream_t s, const VtGemmNormFuse* nf) {
   int ks = ksplit;
   if (ks == 0 && partials && M > 64 && vt_gemm_p8_supported(M, N, K) && (N % 4) == 0) {
     const int tiles = cdiv(M, 256) * cdiv(N, 256);
@@ -846,15 +887,16 @@ int vt_gemm_resid_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, flo
       const long unit = 256L * (256 / g);
       const long M1 = (M / unit) * unit;
       if (M1 >= unit && M1 < M) {
-        VT_TRY(vt_gemm_launch(A, lda, W, ldw, C, ldc, bias, (int)M1, N, K, VT_EPI_F32_RESID, VT_GEMM_CFG_256x256_P4, nullptr, s));
+        VT_TRY(vt_gemm_launch(A, lda, W, ldw, C, ldc, bias, (int)M1, N, K, VT_EPI_F32_RESID, VT_GEMM_CFG_256x256_P4, nullptr, s, nf));
+        const VtGemmNormFuse rest = nf ? vt_nf_rows(*nf, M1) : VtGemmNormFuse{};
         return vt_gemm_resid_launch(A + (size_t)M1 * lda, lda, W, ldw, C + (size_t)M1 * ldc, ldc, bias, M - (int)M1, N, K, 0, partials,
-                                    partial_bytes, s);
+                                    partial_bytes, s, nf ? &rest : nullptr);
       }
     }
   }
-  if (ks < 2) return vt_gemm_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, VT_EPI_F32_RESID, VT_GEMM_CFG_AUTO, nullptr, s);
+  if (ks < 2) return vt_gemm_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, VT_EPI_F32_RESID, VT_GEMM_CFG_AUTO, nullptr, s, nf);
   VT_REQUIRE(partials && partial_bytes >= (size_t)ks * M * N * sizeof(float), "vt_gemm(split-K): workspace too small (%zu bytes for ksplit=%d)",
              partial_bytes, ks);
   VtProfScope prof(VT_PROF_GEMM_TILE, 2.0 * (double)M * (double)N * (double)K, s);
-  return vt_gemm_p4_splitk_resid_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, ks, partials, s);
+  return vt_gemm_p4_splitk_resid_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, ks, partials, s, nf);
 }

@@ -44,6 +44,7 @@ struct GemmP8 {
   int lda, ldw, ldc;
   int ksplit;        // > 1 (fp32-out epilogue only): blocks [s*tiles, (s+1)*tiles) compute K range s of every tile into slab s of C
   size_t slab;       // elements between consecutive slabs
+  VtGemmNormFuse nf; // folded RMSNorm (tile flavour, vt_kernels.h): row_scale on the consumer side, out_* on the producer side
 };
 
 __device__ __forceinline__ float gelu_erf8(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
@@ -194,6 +195,17 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmP8 p) {
   const int total_phases = 4 * nt;
   const int drain_from = total_phases - 6;  // phases g >= this did not all issue a stage in (g-2..g): drain instead
 
+  // consumer side of the norm fold: this lane's 8 row factors are requested ahead of the first stage and pinned in registers
+  // behind the prologue's vmcnt(0) -- fetched at the top of the epilogue they cost every tile an exposed L2/HBM round trip
+  // (+1.3 us per tile measured), and inside the row loop one per row
+  float rsv[2][4];
+  if constexpr (EPI != VT_EPI_F32_RESID && EPI != VT_EPI_F32) {
+#pragma unroll
+    for (int qm = 0; qm < 2; ++qm)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+        rsv[qm][mi] = p.nf.row_scale ? p.nf.row_scale[min(bm0 + qm * 128 + wr * 64 + mi * 16 + (lane & 15), p.M - 1)] : 1.f;
+  }
   // ---- prologue: stages of global phases -6..-1 = K step 0 (A0 B0 B1 A1) + K step 1 (A0 B0) -----------------------------
   STAGE(0, SLOT_A0);
   STAGE(0, SLOT_B0);
@@ -203,6 +215,12 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmP8 p) {
   STAGE(1, SLOT_B0);
   if (P4) STAGE(1, SLOT_B1);
   VT_VMCNT(0);
+  if constexpr (EPI != VT_EPI_F32_RESID && EPI != VT_EPI_F32) {
+#pragma unroll
+    for (int qm = 0; qm < 2; ++qm)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) asm volatile("" : "+v"(rsv[qm][mi]));   // the loads stay up here
+  }
   SECTION_SPLIT();
   if (wr == 1) __builtin_amdgcn_s_barrier();   // stagger: the second wave row runs one barrier behind
   __builtin_amdgcn_sched_barrier(0);
@@ -315,54 +333,127 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmP8 p) {
   if (wr == 0) __builtin_amdgcn_s_barrier();   // pairs with the stagger barrier of the second wave row
 
   // ---- epilogue ------------------------------------------------------------------------------------------------------------
+  // folded RMSNorm: consumer = accumulators of row m scaled by row_scale[m]; producer (residual epilogue) = also bf16(x_new *
+  // out_w[n]) and the sum of x_new^2 per row and 32-column group (the 4 lanes lane>>4 of a row hold one group: 2 x 16 columns)
+  const float* const row_scale = p.nf.row_scale;
+  if constexpr (EPI == VT_EPI_F32_RESID) {
+    // residual epilogue: C += acc (+ bias). The 4 x 16-byte reads of a row are issued together and one row ahead of the
+    // stores (the compiler cannot move a load across the stores of the previous row: it cannot prove they do not alias), so
+    // a wave has 8 read requests in flight instead of 1-4. With the norm fold the row's y values and partial sums follow.
+    float* const __restrict__ Cf = (float*)p.C;
+    float* const __restrict__ out_partials = p.nf.out_partials;
+    bf16_t* const __restrict__ out_xw = p.nf.out_xw;
+    const int lq = (lane >> 4) << 2;
+    f32x4 w4[2][2], b4[2][2];
 #pragma unroll
-  for (int qm = 0; qm < 2; ++qm)
+    for (int qn = 0; qn < 2; ++qn)
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-      const int m = bm0 + qm * 128 + wr * 64 + mi * 16 + (lane & 15);
-      if (m >= p.M) continue;
+      for (int ni = 0; ni < 2; ++ni) {
+        const int n = min(bn0 + qn * 128 + wc * 32 + ni * 16 + lq, p.N - 4);
+        w4[qn][ni] = out_partials ? *(const f32x4*)(p.nf.out_w + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        b4[qn][ni] = p.bias ? *(const f32x4*)(p.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    auto row_of = [&](int r) { return bm0 + (r >> 2) * 128 + wr * 64 + (r & 3) * 16 + (lane & 15); };
+    auto load_row = [&](int r, f32x4 (&dst)[2][2]) {
+      const int m = min(row_of(r), p.M - 1);
 #pragma unroll
-      for (int qn = 0; qn < 2; ++qn) {
-        const int nbase = bn0 + qn * 128 + wc * 32;     // multiple of 32
-        if constexpr (EPI == VT_EPI_SWIGLU_BF16) {
-          if (nbase + ((lane >> 4) << 2) >= p.N) continue;
-          const f32x4 g = acc[qm][qn][mi][0], u2 = acc[qm][qn][mi][1];
-          u32x2 o;
-          o.x = pack_bf16x2(silu8(g[0]) * u2[0], silu8(g[1]) * u2[1]);
-          o.y = pack_bf16x2(silu8(g[2]) * u2[2], silu8(g[3]) * u2[3]);
-          *(u32x2*)((bf16_t*)p.C + (size_t)m * p.ldc + (nbase >> 1) + ((lane >> 4) << 2)) = o;
-        } else {
+      for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const int n = min(bn0 + qn * 128 + wc * 32 + ni * 16 + lq, p.N - 4);
+          dst[qn][ni] = *(const f32x4*)(Cf + (size_t)m * p.ldc + n);
+        }
+    };
+    float rs8[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) rs8[r] = row_scale ? row_scale[min(row_of(r), p.M - 1)] : 1.f;
+    f32x4 cur[2][2], nxt[2][2];
+    load_row(0, cur);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      if (r + 1 < 8) load_row(r + 1, nxt);
+      const int m = row_of(r);
+      const int qm = r >> 2, mi = r & 3;
+      if (m < p.M) {
+        const float rs = rs8[r];
+#pragma unroll
+        for (int qn = 0; qn < 2; ++qn) {
+          const int nbase = bn0 + qn * 128 + wc * 32;
+          float ss = 0.f;
 #pragma unroll
           for (int ni = 0; ni < 2; ++ni) {
-            const int n = nbase + ni * 16 + ((lane >> 4) << 2);
+            const int n = nbase + ni * 16 + lq;
             if (n >= p.N) continue;
-            f32x4 v = acc[qm][qn][mi][ni];
-            if (p.bias && split == 0) v += *(const f32x4*)(p.bias + n);   // split-K: the bias goes in once
-            if constexpr (EPI == VT_EPI_BF16_GELU) {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] = gelu_erf8(v[r]);
-            } else if constexpr (EPI == VT_EPI_BF16_QGELU) {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] = quick_gelu8(v[r]);
-            } else if constexpr (EPI == VT_EPI_BF16_RELU) {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-            }
-            if constexpr (EPI == VT_EPI_F32_RESID) {
-              float* c = (float*)p.C + (size_t)m * p.ldc + n;
-              *(f32x4*)c = *(const f32x4*)c + v;
-            } else if constexpr (EPI == VT_EPI_F32) {
-              *(f32x4*)((float*)p.C + (size_t)split * p.slab + (size_t)m * p.ldc + n) = v;
-            } else {
+            const f32x4 nv = cur[qn][ni] + (acc[qm][qn][mi][ni] * rs + b4[qn][ni]);
+            *(f32x4*)(Cf + (size_t)m * p.ldc + n) = nv;
+            if (out_partials) {
               u32x2 o;
-              o.x = pack_bf16x2(v[0], v[1]);
-              o.y = pack_bf16x2(v[2], v[3]);
-              *(u32x2*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
+              o.x = pack_bf16x2(nv[0] * w4[qn][ni][0], nv[1] * w4[qn][ni][1]);
+              o.y = pack_bf16x2(nv[2] * w4[qn][ni][2], nv[3] * w4[qn][ni][3]);
+              *(u32x2*)(out_xw + (size_t)m * p.nf.ld_xw + n) = o;
+              ss += (nv[0] * nv[0] + nv[1] * nv[1]) + (nv[2] * nv[2] + nv[3] * nv[3]);
+            }
+          }
+          if (out_partials && nbase < p.N) {   // N % 32 == 0: the group is whole or absent, uniform over the row's 4 lanes
+            ss += __shfl_xor(ss, 16, 64);
+            ss += __shfl_xor(ss, 32, 64);
+            if ((lane >> 4) == 0) out_partials[(size_t)(nbase >> 5) * p.nf.out_ldp + m] = ss;
+          }
+        }
+      }
+#pragma unroll
+      for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) cur[qn][ni] = nxt[qn][ni];
+    }
+  } else {
+#pragma unroll
+    for (int qm = 0; qm < 2; ++qm)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        const int m = bm0 + qm * 128 + wr * 64 + mi * 16 + (lane & 15);
+        if (m >= p.M) continue;
+        const float rs = (EPI == VT_EPI_F32) ? 1.f : rsv[qm][mi];
+#pragma unroll
+        for (int qn = 0; qn < 2; ++qn) {
+          const int nbase = bn0 + qn * 128 + wc * 32;     // multiple of 32
+          if constexpr (EPI == VT_EPI_SWIGLU_BF16) {
+            if (nbase + ((lane >> 4) << 2) >= p.N) continue;
+            const f32x4 g = acc[qm][qn][mi][0] * rs, u2 = acc[qm][qn][mi][1] * rs;
+            u32x2 o;
+            o.x = pack_bf16x2(silu8(g[0]) * u2[0], silu8(g[1]) * u2[1]);
+            o.y = pack_bf16x2(silu8(g[2]) * u2[2], silu8(g[3]) * u2[3]);
+            *(u32x2*)((bf16_t*)p.C + (size_t)m * p.ldc + (nbase >> 1) + ((lane >> 4) << 2)) = o;
+          } else {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+              const int n = nbase + ni * 16 + ((lane >> 4) << 2);
+              if (n >= p.N) continue;
+              f32x4 v = acc[qm][qn][mi][ni] * rs;
+              if (p.bias && split == 0) v += *(const f32x4*)(p.bias + n);   // split-K: the bias goes in once
+              if constexpr (EPI == VT_EPI_BF16_GELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_erf8(v[r]);
+              } else if constexpr (EPI == VT_EPI_BF16_QGELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = quick_gelu8(v[r]);
+              } else if constexpr (EPI == VT_EPI_BF16_RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+              }
+              if constexpr (EPI == VT_EPI_F32) {
+                *(f32x4*)((float*)p.C + (size_t)split * p.slab + (size_t)m * p.ldc + n) = v;
+              } else {
+                u32x2 o;
+                o.x = pack_bf16x2(v[0], v[1]);
+                o.y = pack_bf16x2(v[2], v[3]);
+                *(u32x2*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
+              }
             }
           }
         }
       }
-    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -603,7 +694,7 @@ int vt_gemm_rp_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* 
                       int N, int K, int epi, hipStream_t s) {
   VT_REQUIRE((K % 64) == 0 && N % 32 == 0, "vt_gemm(rp): needs K %% 64 == 0 and N %% 32 == 0 (K=%d N=%d)", K, N);
   VT_REQUIRE((size_t)M * lda * 2 < (1ull << 32) && (size_t)N * ldw * 2 < (1ull << 32), "vt_gemm(rp): operands must be < 4 GiB");
-  GemmP8 p{A, W, C, bias, M, N, K, lda, ldw, ldc, 1, 0};
+  GemmP8 p{A, W, C, bias, M, N, K, lda, ldw, ldc, 1, 0, VtGemmNormFuse{}};
   if (epi >= 0x100) {  // A/B variants of the main loop (bf16 epilogue only)
     switch (epi >> 8) {
       case 1: return launch_rp<VT_EPI_BF16, 1>(p, s);
@@ -627,34 +718,63 @@ int vt_gemm_rp_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* 
 // `partials` ([ksplit][M][N]); pass 2 adds them (split order: deterministic) and the bias-carrying split 0 onto the residual C.
 namespace {
 __global__ __launch_bounds__(256) void splitk_reduce_resid_kernel(const float* __restrict__ part, size_t slab, int ksplit,
-                                                                  float* __restrict__ C, int ldc, int M, int N) {
+                                                                  float* __restrict__ C, int ldc, int M, int N, VtGemmNormFuse nf) {
   const int n4 = N >> 2;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)M * n4; i += (long)gridDim.x * blockDim.x) {
-    const int m = (int)(i / n4), c = (int)(i % n4);
-    f32x4 acc = *(const f32x4*)(C + (size_t)m * ldc + c * 4);
-    for (int s = 0; s < ksplit; ++s) acc += *(const f32x4*)(part + (size_t)s * slab + (size_t)m * N + c * 4);
-    *(f32x4*)(C + (size_t)m * ldc + c * 4) = acc;
+  // folded RMSNorm producer (N % 256 == 0 there): 8 consecutive lanes own one 32-column group of one row
+  const long total = (long)M * n4;
+  const long total_r = nf.out_partials ? ((total + 63) & ~63L) : total;   // whole waves enter the shuffles
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total_r; i += (long)gridDim.x * blockDim.x) {
+    const bool live = i < total;
+    const int m = live ? (int)(i / n4) : 0, c = live ? (int)(i % n4) : 0;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (live) {
+      acc = *(const f32x4*)(C + (size_t)m * ldc + c * 4);
+      for (int s = 0; s < ksplit; ++s) acc += *(const f32x4*)(part + (size_t)s * slab + (size_t)m * N + c * 4);
+      *(f32x4*)(C + (size_t)m * ldc + c * 4) = acc;
+    }
+    if (nf.out_partials) {
+      float ss = (acc[0] * acc[0] + acc[1] * acc[1]) + (acc[2] * acc[2] + acc[3] * acc[3]);
+      ss += __shfl_xor(ss, 1, 64);
+      ss += __shfl_xor(ss, 2, 64);
+      ss += __shfl_xor(ss, 4, 64);
+      if (live) {
+        const f32x4 w4 = *(const f32x4*)(nf.out_w + c * 4);
+        u32x2 o;
+        o.x = pack_bf16x2(acc[0] * w4[0], acc[1] * w4[1]);
+        o.y = pack_bf16x2(acc[2] * w4[2], acc[3] * w4[3]);
+        *(u32x2*)(nf.out_xw + (size_t)m * nf.ld_xw + c * 4) = o;
+        if ((c & 7) == 0) nf.out_partials[(size_t)(c >> 3) * nf.out_ldp + m] = ss;
+      }
+    }
   }
 }
 }  // namespace
 
 int vt_gemm_p4_splitk_resid_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, float* C, int ldc, const float* bias, int M,
-                                   int N, int K, int ksplit, float* partials, hipStream_t s) {
+                                   int N, int K, int ksplit, float* partials, hipStream_t s, const VtGemmNormFuse* nf) {
   VT_REQUIRE(vt_gemm_p8_supported(M, N, K) && (N % 4) == 0, "vt_gemm(split-K): unsupported shape (N=%d K=%d)", N, K);
   VT_REQUIRE(ksplit >= 2 && (K >> 7) / ksplit >= 2 && partials, "vt_gemm(split-K): ksplit=%d leaves < 256 of K per split, or no workspace", ksplit);
-  GemmP8 p{A, W, partials, bias, M, N, K, lda, ldw, N, ksplit, (size_t)M * N};
+  GemmP8 p{A, W, partials, bias, M, N, K, lda, ldw, N, ksplit, (size_t)M * N, VtGemmNormFuse{}};   // the fold happens in the reduce pass
   VT_TRY((launch_p8<VT_EPI_F32, 0, true>(p, s)));
   const long total = (long)M * (N >> 2);
   const int blocks = (int)std::min<long>((total + 255) / 256, 2048);
-  hipLaunchKernelGGL(splitk_reduce_resid_kernel, dim3(blocks), dim3(256), 0, s, partials, p.slab, ksplit, C, ldc, M, N);
+  VtGemmNormFuse rnf;
+  if (nf && nf->out_partials) {
+    VT_REQUIRE((N % 32) == 0 && nf->out_np >= N / 32 && nf->out_ldp >= M && nf->out_w && nf->out_xw, "vt_gemm(split-K): norm fold needs N %% 32 == 0 and its buffers");
+    rnf = *nf;
+  }
+  hipLaunchKernelGGL(splitk_reduce_resid_kernel, dim3(blocks), dim3(256), 0, s, partials, p.slab, ksplit, C, ldc, M, N, rnf);
   VT_LAUNCH_CHECK();
   return VT_OK;
 }
 
 int vt_gemm_p8_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, const float* bias, int M,
-                      int N, int K, int epi, hipStream_t s) {
+                      int N, int K, int epi, hipStream_t s, const VtGemmNormFuse* nf) {
   VT_REQUIRE(vt_gemm_p8_supported(M, N, K), "vt_gemm(p8): needs K %% 128 == 0, K >= 256, N %% 32 == 0 (K=%d N=%d)", K, N);
-  GemmP8 p{A, W, C, bias, M, N, K, lda, ldw, ldc, 1, 0};
+  GemmP8 p{A, W, C, bias, M, N, K, lda, ldw, ldc, 1, 0, nf ? *nf : VtGemmNormFuse{}};
+  if (p.nf.out_partials)
+    VT_REQUIRE((epi & 0xff) == VT_EPI_F32_RESID && p.nf.out_w && p.nf.out_xw && p.nf.out_np >= N / 32 && p.nf.out_ldp >= M,
+               "vt_gemm(p8): norm-fold producer needs the residual epilogue and its buffers");
   if (epi >= 0x100 && !(epi & 0x1000)) {  // timing ablations (tools/gemm_ablate.py); not reachable through the public enums
     switch (epi >> 8) {
       case 1: return launch_p8<VT_EPI_BF16, 1>(p, s);

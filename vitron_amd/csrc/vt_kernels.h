@@ -13,13 +13,18 @@ struct VtAttnSeq {  // device-side view of one row of seq_desc (int32 x 4)
 
 // ---- vt_gemm.hip ----------------------------------------------------------------------------------
 int vt_gemm_pick_cfg(int M, int N, int K);
+struct VtGemmNormFuse;
 int vt_gemm_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, const float* bias,
-                   int M, int N, int K, int epi, int cfg, void* skinny_scratch, hipStream_t s);
+                   int M, int N, int K, int epi, int cfg, void* skinny_scratch, hipStream_t s,
+                   const VtGemmNormFuse* nf = nullptr);
 // RMSNorm folded into the M <= 16 weight-streaming GEMMs of a decode step (no separate norm launches):
 //   producer side (VT_EPI_F32_RESID): after x += A W^T the epilogue also stores out_xw = bf16(x * out_w[n]) and, per row and
 //   16-column block, the partial sum of x^2 (out_partials[m][N/16]);
 //   consumer side: A = that xw buffer; the epilogue scales row m by rsqrt(sum(in_partials[m][0..in_n)) * inv_dim + eps) before
 //   the activation -- W (w .* x) * rstd == W (x * rstd .* w), the per-row scalar commutes with the contraction.
+// The MFMA tile kernels (rows > 64: prefill) use the same fold with two differences: the partial sums are per 32-column
+//   group (out_partials[group][m], out_np = N/32 groups of out_ldp rows), and the consumer takes the finished per-row factor (row_scale[m] =
+//   rstd, produced from the partials by vt_rowscale_finalize_launch) instead of summing partials in its epilogue.
 struct VtGemmNormFuse {
   const float* in_partials = nullptr;
   int in_n = 0;
@@ -28,7 +33,20 @@ struct VtGemmNormFuse {
   bf16_t* out_xw = nullptr;
   int ld_xw = 0;
   float* out_partials = nullptr;
+  int out_np = 0;                      // tile kernels: 32-column groups per row; out_partials is [out_np][out_ldp] (group-major:
+                                       // the 16 rows a store instruction covers are 64 contiguous bytes)
+  int out_ldp = 0;                     // tile kernels: row capacity of one group's array
+  const float* row_scale = nullptr;    // tile kernels, consumer side: accumulator of row m is scaled by row_scale[m]
 };
+// the same descriptor for the row range [m0, ...) of the problem (M-split, remainders)
+inline VtGemmNormFuse vt_nf_rows(const VtGemmNormFuse& nf, long m0) {
+  VtGemmNormFuse r = nf;
+  if (r.in_partials) r.in_partials += m0 * r.in_n;
+  if (r.out_xw) r.out_xw += m0 * r.ld_xw;
+  if (r.out_partials) r.out_partials += (r.out_ldp ? m0 : m0 * r.out_np);
+  if (r.row_scale) r.row_scale += m0;
+  return r;
+}
 int vt_gemm_skinny_norm_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, int M, int N, int K,
                                int epi, const VtGemmNormFuse& nf, hipStream_t s);
 
@@ -36,11 +54,14 @@ int vt_gemm_skinny_norm_launch(const bf16_t* A, int lda, const bf16_t* W, int ld
 bool vt_gemm_p8_supported(int M, int N, int K);
 bool vt_gemm_splitk_pays(int M, int N, int K, int ksplit);
 int vt_gemm_resid_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, float* C, int ldc, const float* bias, int M, int N,
-                         int K, int ksplit, float* partials, size_t partial_bytes, hipStream_t s);
+                         int K, int ksplit, float* partials, size_t partial_bytes, hipStream_t s,
+                         const VtGemmNormFuse* nf = nullptr);
 int vt_gemm_p4_splitk_resid_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, float* C, int ldc, const float* bias, int M,
-                                   int N, int K, int ksplit, float* partials, hipStream_t s);
+                                   int N, int K, int ksplit, float* partials, hipStream_t s, const VtGemmNormFuse* nf = nullptr);
 int vt_gemm_p8_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, const float* bias, int M,
-                      int N, int K, int epi, hipStream_t s);
+                      int N, int K, int epi, hipStream_t s, const VtGemmNormFuse* nf = nullptr);
+// tile-kernel norm fold: is (M, N, K) a shape whose residual GEMM can produce / whose GEMM can consume the folded norm?
+bool vt_gemm_norm_fold_supported(int M, int N, int K);
 
 int vt_gemm_rp_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, const float* bias, int M,
                       int N, int K, int epi, hipStream_t s);
@@ -50,6 +71,7 @@ int vt_layernorm_launch(float* x, const float* temb, int T, int tokens_per_frame
                         const float* beta, bf16_t* y, int rows, int D, float eps, hipStream_t s);
 int vt_rmsnorm_launch(const float* x, const int* idx, const float* w, bf16_t* y, int rows, int D, float eps,
                       hipStream_t s);
+int vt_rowscale_finalize_launch(const float* partials, int np, int ldp, int rows, float inv_dim, float eps, float* out, hipStream_t s);
 int vt_gather_f32_to_bf16_launch(const float* in, const int* idx, bf16_t* out, int rows, int D, hipStream_t s);
 int vt_bf16_to_f32_launch(const bf16_t* in, float* out, size_t n, hipStream_t s);
 int vt_add_f32_launch(float* dst, const float* a, size_t n, hipStream_t s);

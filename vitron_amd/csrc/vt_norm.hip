@@ -105,6 +105,29 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
   }
 }
 
+// folded RMSNorm, tile-GEMM flavour: the residual GEMMs leave per-row partial sums of x^2, one per 32-column group, group-major
+// ([np][ldp]); this turns them into the per-row factor the consumer GEMM's epilogue multiplies its accumulators with. One
+// thread per (row, 1/16 of the groups): 16 rows per block (64-byte row segments per load), every thread's loads independent.
+__global__ __launch_bounds__(256) void rowscale_finalize_kernel(const float* __restrict__ partials, int np, int ldp, int rows,
+                                                                float inv_dim, float eps, float* __restrict__ out) {
+  __shared__ float red[16][17];
+  const int r = threadIdx.x & 15, q = threadIdx.x >> 4;
+  const int row = blockIdx.x * 16 + r;
+  float s = 0.f;
+  if (row < rows) {
+#pragma unroll 8
+    for (int g = q; g < np; g += 16) s += partials[(size_t)g * ldp + row];
+  }
+  red[q][r] = s;
+  __syncthreads();
+  if (q == 0 && row < rows) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += red[i][r];
+    out[row] = rsqrtf(t * inv_dim + eps);
+  }
+}
+
 // few rows (decode steps): one 256-thread block per row so the row's 16 KiB are fetched by 4 waves at once
 __global__ __launch_bounds__(256) void rmsnorm_row_block_kernel(const float* __restrict__ x, const int* __restrict__ idx,
                                                                 const float* __restrict__ w, bf16_t* __restrict__ y,
@@ -215,6 +238,14 @@ int vt_rmsnorm_launch(const float* x, const int* idx, const float* w, bf16_t* y,
   }
   dim3 grid(cdiv(rows, 4));
   VT_NORM_DISPATCH(rmsnorm_kernel, D, x, idx, w, y, rows, D, eps);
+  VT_LAUNCH_CHECK();
+  return VT_OK;
+}
+
+int vt_rowscale_finalize_launch(const float* partials, int np, int ldp, int rows, float inv_dim, float eps, float* out,
+                                hipStream_t s) {
+  VT_REQUIRE(partials && out && rows > 0 && np > 0 && ldp >= rows, "vt_rowscale_finalize: bad arguments (rows=%d np=%d ldp=%d)", rows, np, ldp);
+  hipLaunchKernelGGL(rowscale_finalize_kernel, dim3(cdiv(rows, 16)), dim3(256), 0, s, partials, np, ldp, rows, inv_dim, eps, out);
   VT_LAUNCH_CHECK();
   return VT_OK;
 }

@@ -34,8 +34,8 @@ def _chk(t: torch.Tensor, dtype, name: str):
 
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, epi: int = EPI_BF16,
-         out: Optional[torch.Tensor] = None, cfg: int = CFG_AUTO) -> torch.Tensor:
-    """out = epi(a[M,K] @ w[N,K]^T + bias). EPI_F32_RESID accumulates into `out` (fp32, required)."""
+         out: Optional[torch.Tensor] = None, cfg: int = CFG_AUTO, row_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = epi(row_scale[:, None] * (a[M,K] @ w[N,K]^T) + bias). EPI_F32_RESID accumulates into `out` (fp32, required)."""
     lib = _lib.load()
     _chk(a, torch.bfloat16, "gemm.a")
     _chk(w, torch.bfloat16, "gemm.w")
@@ -52,8 +52,12 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
             raise _lib.VitronHipError("gemm: EPI_F32_RESID needs `out` (the fp32 residual stream)")
         out = torch.empty((M, n_out), device=a.device, dtype=odt)
     _chk(out, odt, "gemm.out")
+    if row_scale is not None:
+        _chk(row_scale, torch.float32, "gemm.row_scale")
+        if row_scale.numel() != M:
+            raise _lib.VitronHipError(f"gemm: row_scale has {row_scale.numel()} elements for M={M}")
     _lib.check(lib.vt_gemm_bf16(_p(a), a.stride(0), _p(w), w.stride(0), _p(out), out.stride(0), _p(bias), M, N, K, epi,
-                                cfg, None, _stream()), "vt_gemm_bf16")
+                                cfg, _p(row_scale), _stream()), "vt_gemm_bf16")
     return out
 
 
