@@ -174,6 +174,57 @@ def test_cabi_library_loads_and_exports_header_symbols():
     assert lib.vt_projector_workspace_bytes(100, 4096) >= 100 * 4096 * 2
 
 
+def test_cabi_argument_validation_without_a_gpu():
+    """The error convention of include/vitron_hip.h on every family of entry points: invalid arguments come back as a negative
+    status with a message in vt_last_error BEFORE anything is launched (so this runs on a box without a GPU), and the size
+    queries are pure functions."""
+    import ctypes as C
+    from vitron_amd import _lib
+    lib = _lib.load()
+    P = 0x10000                      # an aligned non-null address; never dereferenced because validation fails first
+
+    def bad(status, *needles):
+        msg = _lib.last_error()
+        assert status < 0, (status, msg)
+        assert all(n in msg for n in needles), msg
+
+    bad(lib.vt_gemm_bf16(P, 8, P, 8, P, 8, None, 0, 4, 8, 0, 0, None, None), "empty")
+    bad(lib.vt_gemm_bf16(P, 8, P, 8, P, 8, None, 4, 6, 8, 0, 0, None, None), "multiple of 4")
+    bad(lib.vt_gemm_bf16(P, 12, P, 8, P, 8, None, 4, 8, 8, 0, 0, None, None), "lda")
+    bad(lib.vt_gemm_bf16(P + 2, 8, P, 8, P, 8, None, 4, 8, 8, 0, 0, None, None), "aligned")
+    bad(lib.vt_gemm_bf16(P, 64, P, 64, P, 64, None, 128, 64, 40, 0, 2, None, None), "K=40")            # tile kernels: K % 64
+    bad(lib.vt_gemm_bf16(P, 64, P, 64, P, 48, None, 128, 48, 64, 0, 0, P, None), "row scale")          # row factor: N % 32
+    bad(lib.vt_gemm_bf16(P, 64, P, 64, P, 64, None, 128, 64, 64, 99, 2, None, None), "epilogue")
+    bad(lib.vt_gemm_bf16_resid_splitk(P, 256, P, 256, P, 256, None, 128, 256, 256, 4, None, 0, None), "workspace")
+    bad(lib.vt_rmsnorm(None, None, P, P, 4, 64, 1e-5, None))
+    bad(lib.vt_layernorm(P, None, 0, 0, None, None, P, 4, 64, 1e-5, None))
+    bad(lib.vt_argmax(P, 0, 10, 10, P, None), "argmax")
+    bad(lib.vt_embed_splice(P, None, None, P, 4, 12, P, None), "multiple of 8")
+    bad(lib.vt_decode_feed(P, 12, 100, P, P, None, 0, 0, P, P, P, P, 2, None), "multiple of 8")
+    bad(lib.vt_decode_feed(P, 64, 100, P, P, None, 2, 0, P, P, P, P, 2, None), "eos")
+    bad(lib.vt_decode_feed(P, 64, 100, None, P, None, 0, 0, P, P, P, P, 2, None), "null")
+    bad(lib.vt_flash_attn(P, 384, P, P, P, P, 1, 16, P, 128, 2, 48, 0, 1.0, None))                     # head_dim 48
+    bad(lib.vt_attn_temporal(P, P, 1, 8, 16, 0, None))
+    bad(lib.vt_sample_top_p(P, 2, 100, 100, 0.0, 0.9, 0, 0, P, None, None))                            # temperature 0
+    m = _lib.VtLlamaModel()
+    m.hidden, m.heads, m.head_dim, m.intermediate, m.num_layers, m.vocab = 256, 4, 48, 512, 1, 100
+    kv = _lib.VtKvCache()
+    bad(lib.vt_llama_forward(C.byref(m), C.byref(kv), P, 4, P, P, 1, 4, 1, 4, P, None, 0, None, None, P, 1 << 20, None), "head_dim")
+    m.head_dim = 64
+    m.rope_cos = m.rope_sin = P
+    ws = lib.vt_llama_workspace_bytes(C.byref(m), 100, 1, 1, 100)
+    assert ws > 100 * 256 * 4 and lib.vt_llama_workspace_bytes(C.byref(m), 200, 1, 1, 200) > ws
+    bad(lib.vt_llama_forward(C.byref(m), C.byref(kv), P, 100, P, P, 1, 100, 2, 100, P, None, 0, None, None, P, 16, None), "workspace")
+    bad(lib.vt_llama_forward(C.byref(m), C.byref(kv), P, 0, P, P, 1, 1, 1, 1, P, None, 0, None, None, P, 1 << 20, None), "empty")
+    assert lib.vt_llama_workspace_bytes(None, 1, 1, 1, 1) == 0
+    assert lib.vt_attn_decode_scratch_bytes(4, 32, 128, 2048) > lib.vt_attn_decode_scratch_bytes(4, 32, 128, 64) > 0
+    assert lib.vt_region_workspace_bytes(4, 1024, 4096) > 0
+    buf = C.create_string_buffer(8)                     # message longer than the buffer: truncated, NUL-terminated
+    lib.vt_gemm_bf16(None, 8, None, 8, None, 8, None, 4, 4, 8, 0, 0, None, None)
+    lib.vt_last_error(buf, 8)
+    assert len(buf.value) <= 7
+
+
 def test_ops_refuse_cpu_tensors():
     from vitron_amd import _lib, ops
     with pytest.raises(_lib.VitronHipError):
