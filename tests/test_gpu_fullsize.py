@@ -216,6 +216,36 @@ def test_prefill_folded_rmsnorm_matches_separate_norms(dev, model7b):
             assert rel_l2(la, lb) <= tol_logits and rel_l2(ha, hb) <= tol_hidden, (name, S, rel_l2(la, lb), rel_l2(ha, hb))
 
 
+def test_decoder_packed_batch_of_eight_clip_prompts(dev):
+    """BASELINE configs[3]'s per-node load on one GPU: eight 5120-row prompts (8-frame clip + 512 tokens each) packed into ONE
+    decoder pass of 40960 rows (activation buffers of 1 GB: element offsets up to 5e8, byte offsets beyond 2^31) through a
+    7B-wide two-layer decoder. Every sequence must get the logits it gets alone (same kernels, other tile rows), and two
+    sequences with identical rows identical logits."""
+    from vitron_amd.engine import PagedKVCache, SequenceState, llama_forward
+    from vitron_amd.model import LlavaConfig, LlavaLlamaForCausalLM
+    m = LlavaLlamaForCausalLM(LlavaConfig(**dict(synth.VICUNA_7B, num_hidden_layers=2), mm_hidden_size=1024, kv_prefix_reuse=False))
+    m.init_synthetic(dev, seed=78, vit_image=None, vit_video=None)
+    llama = m.get_model().llama
+    g = torch.Generator(device=dev).manual_seed(25)
+    S, B = 5120, 8
+    emb = (torch.randn((B * S, 4096), generator=g, device=dev) * 0.02).bfloat16()
+    emb[7 * S:] = emb[2 * S:3 * S]                                  # sequence 7 repeats sequence 2
+    kv = PagedKVCache(llama, B * (S // 64) + 8)
+    seqs = [SequenceState() for _ in range(B)]
+    rows = [b * S + r for b in range(B) for r in (0, S // 2, S - 1)]
+    packed = llama_forward(llama, kv, seqs, emb, [S] * B, logit_rows=rows).view(B, 3, -1)
+    assert torch.isfinite(packed).all()
+    assert rel_l2(packed[7], packed[2]) <= 2e-3                      # same rows at another offset: other tiles, same values
+    for s_ in seqs:
+        kv.release(s_.pages)
+    for b in (0, 5, 7):
+        s1 = SequenceState()
+        alone = llama_forward(llama, kv, [s1], emb[b * S:(b + 1) * S], [S], logit_rows=[0, S // 2, S - 1])
+        kv.release(s1.pages)
+        assert rel_l2(packed[b], alone) <= 5e-3, (b, rel_l2(packed[b], alone))
+    assert len(kv.free) == kv.num_pages
+
+
 def test_image_tower_full_size_batch_independence(dev, model7b):
     """LanguageBind image tower at 336 px (ViT-L/14, 23 layers, 577 tokens): permuting the batch permutes the projected
     features bit-exactly, and a batch item equals the same image encoded alone."""
