@@ -28,6 +28,16 @@ BOXES = [[0, 0, 224, 224], [0, 58.94736842105263, 117.89473684210526, 117.894736
 REGION_CASES = {"g16": (128, 256, 16), "g4": (128, 256, 4)}
 
 PROMPTS = ["ab<image>cd", "<image><image>\nq", "a<image>\n<objs> b", "x<objs>y<objs>", "plain text", ""]
+MODEL_OUTPUTS = [
+    "Sure, here it is. <module>A</module><instruction>prompt: a red fox in the snow</instruction>",
+    "I segmented it.<module>B</module> <instruction>track: the dog: left one </instruction><region>[10, 20, 110, 220]</region> done",
+    "<module>C</module><instruction>a</instruction><instruction>edit: make it night</instruction><instruction>x:y: z</instruction>",
+    "no tags at all", "", "<module></module><instruction></instruction><region></region>",
+    "dangling <module>D and <instruction>never closed", "<SP>hidden</SP>visible<module>E</module> tail <b>bold</b>!",
+    "line one <module>F\n</module> spans a newline <region>r1</region><region>r2</region>",
+    "a < b and c > d <module>G</module>", "<instruction>only: colon:</instruction>", "x<module>H</module>y<module>I</module>z",
+    "<instruction> spaced : arg with spaces  </instruction>\n<instruction>second line: two</instruction>",
+]
 REGION_RESCALE = [([0, 100, 300, 200], [570, 380], [224, 224]), ([12.5, 3, 99, 640], [640, 480], [336, 336])]
 
 

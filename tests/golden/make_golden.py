@@ -24,6 +24,7 @@ from vitron_amd import synth  # noqa: E402
 from tests.golden import cases  # noqa: E402
 
 OUT = os.path.dirname(os.path.abspath(__file__))
+REF = getattr(ref_shim, "REF", "/root/reference")
 
 
 def f32(sd):
@@ -113,6 +114,25 @@ def gen_mm_utils(ns):
     print("mm_utils.npz", {k: v.tolist() for k, v in out.items()})
 
 
+def gen_output_parser():
+    """The reference's reply parser lives in app.py next to the Gradio UI; importing app.py would start loading models, so its
+    five small functions are compiled straight from the source text (ast), nothing else of the file runs."""
+    import ast
+    import json
+    import re
+    src = open(os.path.join(REF, "app.py")).read()
+    want = {"find_module_content", "find_instruction_content", "find_region_instrction_content", "remove_special_tags", "parse_model_output"}
+    tree = ast.parse(src)
+    fns = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in want]
+    assert {f.name for f in fns} == want
+    scope = {"re": re}
+    exec(compile(ast.Module(body=fns, type_ignores=[]), "app.py", "exec"), scope)
+    out = [{"text": t, "parsed": list(scope["parse_model_output"](t))} for t in cases.MODEL_OUTPUTS]
+    with open(os.path.join(OUT, "output_parser.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("output_parser.json", out)
+
+
 def build_ref_llava(ns):
     """The reference's LlavaLlamaForCausalLM with tiny towers attached."""
     ll, lb = ns.llava_llama, sys.modules["vitron.model.multimodal_encoder.languagebind"]
@@ -177,6 +197,7 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     ns = ref_shim.install()
     gen_mm_utils(ns)
+    gen_output_parser()
     gen_vit(ns)
     gen_region_projector(ns)
     gen_glue(ns)

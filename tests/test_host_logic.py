@@ -57,6 +57,20 @@ def test_keywords_stopping_criteria_semantics():
     assert crit.call_for_batch(both, None) is True     # first row only
 
 
+def test_output_parser_matches_reference_goldens():
+    """vitron_amd.output_parser.parse_model_output against what the reference's own functions (app.py:345-395) returned for the
+    same strings (tests/golden/output_parser.json, made by make_golden.gen_output_parser), plus the tuple protocol callers use."""
+    import json
+    from vitron_amd.output_parser import parse_model_output
+    gold = json.load(open(os.path.join(G, "output_parser.json")))
+    assert [g["text"] for g in gold] == cases.MODEL_OUTPUTS
+    for g in gold:
+        got = parse_model_output(g["text"])
+        assert list(got) == g["parsed"], (g["text"], list(got), g["parsed"])
+    output, module, instruction, region = parse_model_output(cases.MODEL_OUTPUTS[1])      # app.py:572 unpacks four values
+    assert (module, instruction, region) == ("B", ["left one"], "[10, 20, 110, 220]") and output == "I segmented it.  done"
+
+
 def test_constants_match_reference_values():
     from vitron_amd import constants as c
     assert (c.IGNORE_INDEX, c.IMAGE_TOKEN_INDEX, c.OBJS_TOKEN_INDEX) == (-100, -200, -300)
