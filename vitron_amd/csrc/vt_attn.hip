@@ -190,6 +190,9 @@ __global__ __launch_bounds__(64 * NWAVES, (NWAVES == 8) ? 2 : 2) void flash_attn
     const int key0 = t * 64;
     const bool need_mask = (key0 + 64 > sq.kv_len) || (CAUSAL && (key0 + 63 > past + q0 + wave * 32));
     if (need_mask) {
+      // a REAL branch: without the empty asm the compiler if-converts this block into 3 VALU instructions per score on EVERY
+      // tile (92 of the loop's 240 VALU instructions, ISA dump) although only the diagonal / last tiles need them
+      asm volatile("" ::: "memory");
       const int lim = CAUSAL ? min(sq.kv_len - 1, past + qrow) : (sq.kv_len - 1);  // last visible key
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub)
