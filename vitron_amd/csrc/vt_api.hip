@@ -47,12 +47,12 @@ void vt_prof_start(int cls, double work, hipStream_t s) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   ProfRec r{prof_event(), prof_event(), cls, work};
   if (!r.a || !r.b) return;
-  hipEventRecord(r.a, s);
+  if (hipEventRecord(r.a, s) != hipSuccess) return;   // profiling is best effort: an unrecorded pair is simply not counted
   g_prof_recs.push_back(r);
 }
 void vt_prof_stop(hipStream_t s) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  if (!g_prof_recs.empty()) hipEventRecord(g_prof_recs.back().b, s);
+  if (!g_prof_recs.empty() && hipEventRecord(g_prof_recs.back().b, s) != hipSuccess) g_prof_recs.pop_back();
 }
 
 namespace {
@@ -125,10 +125,10 @@ int vt_profile_end(int* launches, double* total_ms, double* total_work) {
 // ---- primitives -----------------------------------------------------------------------------------------------------
 int vt_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, void* C, int ldc, const float* bias, int M,
                  int N, int K, int epi, int cfg, const float* row_scale, void* stream) {
-  if (!row_scale) return vt_gemm_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, epi, cfg, nullptr, S(stream));
+  if (!row_scale) return vt_gemm_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, epi, cfg, S(stream));
   VtGemmNormFuse nf;
   nf.row_scale = row_scale;
-  return vt_gemm_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, epi, cfg, nullptr, S(stream), &nf);
+  return vt_gemm_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, epi, cfg, S(stream), &nf);
 }
 
 int vt_layernorm(float* x, const float* temb, int T, int tokens_per_frame, const float* gamma, const float* beta,
@@ -221,7 +221,7 @@ int vt_projector_forward(const uint16_t* x, int M, int Din, const uint16_t* w1, 
   VT_REQUIRE(x && w1 && out && M > 0, "vt_projector_forward: null pointer / empty input");
   hipStream_t s = S(stream);
   if (!w2) {  // 'linear' projector
-    return vt_gemm_launch(x, Din, w1, Din, out, Dh, b1, M, Dh, Din, VT_EPI_BF16, VT_GEMM_CFG_AUTO, nullptr, s);
+    return vt_gemm_launch(x, Din, w1, Din, out, Dh, b1, M, Dh, Din, VT_EPI_BF16, VT_GEMM_CFG_AUTO, s);
   }
   Carver ws(workspace, workspace_bytes);
   bf16_t* h = (bf16_t*)ws.take((size_t)M * Dh * 2);
@@ -229,8 +229,8 @@ int vt_projector_forward(const uint16_t* x, int M, int Din, const uint16_t* w1, 
     vt_set_error("vt_projector_forward: workspace too small (%zu < %zu)", workspace_bytes, ws.off);
     return VT_ERR_WORKSPACE;
   }
-  VT_TRY(vt_gemm_launch(x, Din, w1, Din, h, Dh, b1, M, Dh, Din, VT_EPI_BF16_GELU, VT_GEMM_CFG_AUTO, nullptr, s));
-  VT_TRY(vt_gemm_launch(h, Dh, w2, Dh, out, Dout, b2, M, Dout, Dh, VT_EPI_BF16, VT_GEMM_CFG_AUTO, nullptr, s));
+  VT_TRY(vt_gemm_launch(x, Din, w1, Din, h, Dh, b1, M, Dh, Din, VT_EPI_BF16_GELU, VT_GEMM_CFG_AUTO, s));
+  VT_TRY(vt_gemm_launch(h, Dh, w2, Dh, out, Dout, b2, M, Dout, Dh, VT_EPI_BF16, VT_GEMM_CFG_AUTO, s));
   return VT_OK;
 }
 
@@ -263,11 +263,11 @@ int vt_region_forward(const vt_region_weights* w, const uint16_t* feats, const i
   }
   VT_TRY(vt_region_pool_launch(feats, slices, B, G, image_size, D, pooled, cell_mask, cell_count, s));
   const int SK = VT_GEMM_CFG_SKINNY;
-  VT_TRY(vt_gemm_launch(pooled, D, w->mlp_w[0], D, h1, H, w->mlp_b[0], B, H, D, VT_EPI_BF16_RELU, SK, nullptr, s));
-  VT_TRY(vt_gemm_launch(h1, H, w->mlp_w[1], H, h2, H, w->mlp_b[1], B, H, H, VT_EPI_BF16_RELU, SK, nullptr, s));
-  VT_TRY(vt_gemm_launch(h2, H, w->mlp_w[2], H, acc, H, w->mlp_b[2], B, H, H, VT_EPI_F32, SK, nullptr, s));
-  VT_TRY(vt_gemm_launch(coords, 8, w->loc_w[0], 8, l1, H / 2, w->loc_b[0], B, H / 2, 8, VT_EPI_BF16_RELU, SK, nullptr, s));
-  VT_TRY(vt_gemm_launch(l1, H / 2, w->loc_w[1], H / 2, acc, H, w->loc_b[1], B, H, H / 2, VT_EPI_F32_RESID, SK, nullptr, s));
+  VT_TRY(vt_gemm_launch(pooled, D, w->mlp_w[0], D, h1, H, w->mlp_b[0], B, H, D, VT_EPI_BF16_RELU, SK, s));
+  VT_TRY(vt_gemm_launch(h1, H, w->mlp_w[1], H, h2, H, w->mlp_b[1], B, H, H, VT_EPI_BF16_RELU, SK, s));
+  VT_TRY(vt_gemm_launch(h2, H, w->mlp_w[2], H, acc, H, w->mlp_b[2], B, H, H, VT_EPI_F32, SK, s));
+  VT_TRY(vt_gemm_launch(coords, 8, w->loc_w[0], 8, l1, H / 2, w->loc_b[0], B, H / 2, 8, VT_EPI_BF16_RELU, SK, s));
+  VT_TRY(vt_gemm_launch(l1, H / 2, w->loc_w[1], H / 2, acc, H, w->loc_b[1], B, H, H / 2, VT_EPI_F32_RESID, SK, s));
   VT_TRY(vt_gather_f32_to_bf16_launch(acc, nullptr, out, B, H, s));
   return VT_OK;
 }
@@ -334,7 +334,7 @@ int vt_vit_forward(const vt_vit_model* m, const void* pixels, int pix_dtype, int
 
   // embeddings: patch GEMM (fp32 out) -> + CLS / position -> pre-LayerNorm -> fp32 residual stream x
   VT_TRY(vt_im2col_launch(pixels, pix_dtype, w.patches, B, T, m->image_size, m->image_size, m->patch, m->k_pad, video_layout, s));
-  VT_TRY(vt_gemm_launch(w.patches, m->k_pad, m->w_patch, m->k_pad, w.patch_out, D, nullptr, F * G2, D, m->k_pad, VT_EPI_F32, AUTO, nullptr, s));
+  VT_TRY(vt_gemm_launch(w.patches, m->k_pad, m->w_patch, m->k_pad, w.patch_out, D, nullptr, F * G2, D, m->k_pad, VT_EPI_F32, AUTO, s));
   VT_TRY(vt_vit_embed_launch(w.patch_out, m->cls, m->pos, m->pre_ln_g, m->pre_ln_b, w.x, F, G2, D, m->ln_eps, s));
   VT_TRY(vt_vit_attn_meta_launch(w.seq_desc, w.tile_table, F, N, s));
 
@@ -343,21 +343,21 @@ int vt_vit_forward(const vt_vit_model* m, const void* pixels, int pix_dtype, int
     if (m->add_time_attn) {
       // x += temporal_embedding[t]; y = temporal_layer_norm1(x); temporal attention over T; x += out_proj
       VT_TRY(vt_layernorm_launch(w.x, (T != 1) ? L.t_embed : nullptr, T, N, L.t_ln_g, L.t_ln_b, w.y, R, D, m->ln_eps, s));
-      VT_TRY(vt_gemm_launch(w.y, D, L.t_wqkv, D, w.qkv, 3 * D, L.t_bqkv, R, 3 * D, D, VT_EPI_BF16, AUTO, nullptr, s));
+      VT_TRY(vt_gemm_launch(w.y, D, L.t_wqkv, D, w.qkv, 3 * D, L.t_bqkv, R, 3 * D, D, VT_EPI_BF16, AUTO, s));
       VT_TRY(vt_attn_temporal_launch(w.qkv, w.att, B, T, N, heads, s));
-      VT_TRY(vt_gemm_launch(w.att, D, L.t_wo, D, w.x, D, L.t_bo, R, D, D, VT_EPI_F32_RESID, AUTO, nullptr, s));
+      VT_TRY(vt_gemm_launch(w.att, D, L.t_wo, D, w.x, D, L.t_bo, R, D, D, VT_EPI_F32_RESID, AUTO, s));
     }
     // spatial attention
     VT_TRY(vt_layernorm_launch(w.x, nullptr, 0, 0, L.ln1_g, L.ln1_b, w.y, R, D, m->ln_eps, s));
-    VT_TRY(vt_gemm_launch(w.y, D, L.wqkv, D, w.qkv, 3 * D, L.bqkv, R, 3 * D, D, VT_EPI_BF16, AUTO, nullptr, s));
+    VT_TRY(vt_gemm_launch(w.y, D, L.wqkv, D, w.qkv, 3 * D, L.bqkv, R, 3 * D, D, VT_EPI_BF16, AUTO, s));
     VT_TRY(vt_kv_tiles_launch(w.qkv, 3 * D, 0, D, 2 * D, w.kt, w.vt, w.tile_table, (const VtAttnSeq*)w.seq_desc, F,
                               cdiv(N, 64), heads, 64, nullptr, nullptr, nullptr, s));
     VT_TRY(vt_flash_attn_launch(w.qkv, 3 * D, w.kt, w.vt, w.tile_table, (const VtAttnSeq*)w.seq_desc, F, N, w.att, D,
                                 heads, 64, 0, 1.0f, s));
-    VT_TRY(vt_gemm_launch(w.att, D, L.wo, D, w.x, D, L.bo, R, D, D, VT_EPI_F32_RESID, AUTO, nullptr, s));
+    VT_TRY(vt_gemm_launch(w.att, D, L.wo, D, w.x, D, L.bo, R, D, D, VT_EPI_F32_RESID, AUTO, s));
     // MLP
     VT_TRY(vt_layernorm_launch(w.x, nullptr, 0, 0, L.ln2_g, L.ln2_b, w.y, R, D, m->ln_eps, s));
-    VT_TRY(vt_gemm_launch(w.y, D, L.w1, D, w.h, I, L.b1, R, I, D, act_epi, AUTO, nullptr, s));
+    VT_TRY(vt_gemm_launch(w.y, D, L.w1, D, w.h, I, L.b1, R, I, D, act_epi, AUTO, s));
     VT_TRY(vt_gemm_resid_launch(w.h, I, L.w2, I, w.x, D, L.b2, R, D, I, 0, w.splitk, w.splitk_bytes, s));
   }
   VT_TRY(vt_drop_cls_launch(w.x, out_feats, F, G2, D, s));
@@ -370,7 +370,6 @@ namespace {
 struct LlamaWs {
   float* x;
   bf16_t *y, *qkv, *att, *h, *yn;
-  float* scratch;
   float *rs_a, *rs_b;   // folded-RMSNorm partial sums of squares (decode steps: [16][H/16]; rows > 64: rs_a = [rows][H/32])
   float* rstd;          // rows > 64: per-row factor of the folded RMSNorm (vt_rowscale_finalize_launch)
   float* splitk;        // fp32 partial products of the split-K residual GEMMs (prefills of 65..~2000 rows)
@@ -389,7 +388,6 @@ LlamaWs llama_carve(const vt_llama_model* m, int rows, int n_logit, int nseq, in
   w.att = (bf16_t*)ws.take((size_t)rows * H * 2);
   w.h = (bf16_t*)ws.take((size_t)rows * I * 2);
   w.yn = (bf16_t*)ws.take((size_t)(n_logit > 0 ? n_logit : 1) * H * 2);
-  w.scratch = (float*)ws.take((size_t)16 * 2 * I * 4);
   w.rs_a = (float*)ws.take(std::max((size_t)16 * (H / 16), rows > 64 ? (size_t)rows * (H / 32) : (size_t)0) * 4);
   w.rs_b = (float*)ws.take((size_t)16 * (H / 16) * 4);
   w.rstd = (float*)ws.take((size_t)(rows > 64 ? rows : 1) * 4);
@@ -487,10 +485,10 @@ int vt_llama_forward(const vt_llama_model* m, const vt_kv_cache* kv, const uint1
     VtGemmNormFuse cons_t;
     cons_t.row_scale = w.rstd;
     if (fold_tile && l > 0) {
-      VT_TRY(vt_gemm_launch(w.y, H, L.wqkv, H, w.qkv, 3 * H, nullptr, rows, 3 * H, H, VT_EPI_BF16, AUTO, nullptr, s, &cons_t));
+      VT_TRY(vt_gemm_launch(w.y, H, L.wqkv, H, w.qkv, 3 * H, nullptr, rows, 3 * H, H, VT_EPI_BF16, AUTO, s, &cons_t));
     } else {
       VT_TRY(vt_rmsnorm_launch(w.x, nullptr, L.rms1, w.y, rows, H, m->rms_eps, s));
-      VT_TRY(vt_gemm_launch(w.y, H, L.wqkv, H, w.qkv, 3 * H, nullptr, rows, 3 * H, H, VT_EPI_BF16, AUTO, nullptr, s));
+      VT_TRY(vt_gemm_launch(w.y, H, L.wqkv, H, w.qkv, 3 * H, nullptr, rows, 3 * H, H, VT_EPI_BF16, AUTO, s));
     }
     if (max_q_len == 1) {   // decode step: rotary + append + attention + combine in one launch
       VT_TRY(vt_attn_decode_fused_launch(w.qkv, 3 * H, 0, H, 2 * H, kt, vt, tile_table, (const VtAttnSeq*)seq_desc, nseq, w.att, H,
@@ -511,7 +509,7 @@ int vt_llama_forward(const vt_llama_model* m, const vt_kv_cache* kv, const uint1
       prod.out_w = L.rms2;
       VT_TRY(vt_gemm_resid_launch(w.att, H, L.wo, H, w.x, H, nullptr, rows, H, H, 0, w.splitk, w.splitk_bytes, s, &prod));
       VT_TRY(vt_rowscale_finalize_launch(w.rs_a, H / 32, rows, rows, 1.0f / (float)H, m->rms_eps, w.rstd, s));
-      VT_TRY(vt_gemm_launch(w.y, H, L.wgu, H, w.h, I, nullptr, rows, 2 * I, H, VT_EPI_SWIGLU_BF16, AUTO, w.scratch, s, &cons_t));
+      VT_TRY(vt_gemm_launch(w.y, H, L.wgu, H, w.h, I, nullptr, rows, 2 * I, H, VT_EPI_SWIGLU_BF16, AUTO, s, &cons_t));
       if (l + 1 < m->num_layers) {
         prod.out_w = m->layers[l + 1].rms1;
         VT_TRY(vt_gemm_resid_launch(w.h, I, L.wdown, I, w.x, H, nullptr, rows, H, I, 0, w.splitk, w.splitk_bytes, s, &prod));
@@ -523,13 +521,13 @@ int vt_llama_forward(const vt_llama_model* m, const vt_kv_cache* kv, const uint1
     }
     VT_TRY(vt_gemm_resid_launch(w.att, H, L.wo, H, w.x, H, nullptr, rows, H, H, 0, w.splitk, w.splitk_bytes, s));
     VT_TRY(vt_rmsnorm_launch(w.x, nullptr, L.rms2, w.y, rows, H, m->rms_eps, s));
-    VT_TRY(vt_gemm_launch(w.y, H, L.wgu, H, w.h, I, nullptr, rows, 2 * I, H, VT_EPI_SWIGLU_BF16, AUTO, w.scratch, s));
+    VT_TRY(vt_gemm_launch(w.y, H, L.wgu, H, w.h, I, nullptr, rows, 2 * I, H, VT_EPI_SWIGLU_BF16, AUTO, s));
     VT_TRY(vt_gemm_resid_launch(w.h, I, L.wdown, I, w.x, H, nullptr, rows, H, I, 0, w.splitk, w.splitk_bytes, s));
   }
   if (out_hidden) VT_HIP(hipMemcpyAsync(out_hidden, w.x, (size_t)rows * H * 4, hipMemcpyDeviceToDevice, s));
   if (n_logit_rows > 0) {
     VT_TRY(vt_rmsnorm_launch(w.x, logit_rows, m->final_norm, w.yn, n_logit_rows, H, m->rms_eps, s));
-    VT_TRY(vt_gemm_launch(w.yn, H, m->lm_head, H, logits, m->vocab, nullptr, n_logit_rows, m->vocab, H, VT_EPI_F32, AUTO, nullptr, s));
+    VT_TRY(vt_gemm_launch(w.yn, H, m->lm_head, H, logits, m->vocab, nullptr, n_logit_rows, m->vocab, H, VT_EPI_F32, AUTO, s));
   }
   return VT_OK;
 }

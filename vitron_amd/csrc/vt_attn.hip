@@ -55,7 +55,6 @@ __global__ __launch_bounds__(64 * NWAVES, (NWAVES == 8) ? 2 : 2) void flash_attn
   constexpr int KS = HD / 16;          // k-steps of the QK^T MFMA
   constexpr int DB = HD / 32;          // 32-wide d blocks of the output
   constexpr int KROW = HD * 2;         // bytes per K row
-  constexpr int KCH = HD / 8;          // 16-B chunks per K row
   constexpr int TILE_BYTES = 64 * HD * 2;  // K tile == V^T tile == 64*HD bf16
   constexpr int STAGE_BYTES = 2 * TILE_BYTES;
   constexpr int PIECES = TILE_BYTES / 1024;  // 1-KiB DMA pieces per tile

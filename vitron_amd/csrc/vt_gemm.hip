@@ -44,7 +44,7 @@ struct GemmP {
   const float* bias;
   int M, N, K;
   int lda, ldw, ldc;
-  VtGemmNormFuse nf;   // only read by the skinny LDS-DMA kernel
+  VtGemmNormFuse nf;   // folded RMSNorm / row scale (vt_kernels.h): skinny LDS-DMA kernel (decode flavour), tile kernel (row_scale, out_*)
 };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
@@ -739,12 +739,12 @@ int vt_gemm_pick_cfg(int M, int N, int K) {
 // measured on MI355X (tools/splitk_bench.py): see the table in DESIGN.md 3.1
 // (1088x4096x11008: 149 -> 108 us at ksplit 3; 1024x4096x11008: 114 -> 91 at 4; 300x4096x11008: 96 -> 56 at 8; 577x1024x4096:
 // 39 -> 29 at 8; K = 4096 with ksplit < 8 and everything at K = 1024: no gain, the reduce pass eats it)
-bool vt_gemm_splitk_pays(int M, int N, int K, int ksplit) { return K >= 8192 || (K >= 4096 && ksplit >= 8); }
+bool vt_gemm_splitk_pays(int /*M*/, int /*N*/, int K, int ksplit) { return K >= 8192 || (K >= 4096 && ksplit >= 8); }
 
 bool vt_gemm_norm_fold_supported(int M, int N, int K) { return M > 64 && (N % 32) == 0 && (K % 64) == 0; }
 
 int vt_gemm_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, const float* bias,
-                   int M, int N, int K, int epi, int cfg, void* skinny_scratch, hipStream_t s, const VtGemmNormFuse* nf) {
+                   int M, int N, int K, int epi, int cfg, hipStream_t s, const VtGemmNormFuse* nf) {
   VT_REQUIRE(A && W && C, "vt_gemm: null pointer");
   VT_REQUIRE(M > 0 && N > 0 && K > 0, "vt_gemm: empty problem M=%d N=%d K=%d", M, N, K);
   VT_REQUIRE((N % 4) == 0, "vt_gemm: N=%d must be a multiple of 4", N);
@@ -774,7 +774,7 @@ int vt_gemm_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, 
     const size_t esz = (epi == VT_EPI_F32 || epi == VT_EPI_F32_RESID) ? 4 : 2;
     for (int m0 = 0; m0 < M; m0 += 32)
       VT_TRY(vt_gemm_launch(A + (size_t)m0 * lda, lda, W, ldw, (char*)C + (size_t)m0 * ldc * esz, ldc, bias, std::min(32, M - m0), N, K,
-                            epi, VT_GEMM_CFG_SKINNY, skinny_scratch, s));
+                            epi, VT_GEMM_CFG_SKINNY, s));
     return VT_OK;
   }
   if (!skinny_path) {
@@ -796,10 +796,10 @@ int vt_gemm_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, 
         const long M1 = (M / unit) * unit;
         if (M1 >= unit && M1 < M) {
           const size_t esz = (epi == VT_EPI_F32 || epi == VT_EPI_F32_RESID) ? 4 : 2;
-          VT_TRY(vt_gemm_launch(A, lda, W, ldw, C, ldc, bias, (int)M1, N, K, epi, VT_GEMM_CFG_256x256_P4, skinny_scratch, s, nf));
+          VT_TRY(vt_gemm_launch(A, lda, W, ldw, C, ldc, bias, (int)M1, N, K, epi, VT_GEMM_CFG_256x256_P4, s, nf));
           const VtGemmNormFuse rest = nf ? vt_nf_rows(*nf, M1) : VtGemmNormFuse{};
           return vt_gemm_launch(A + (size_t)M1 * lda, lda, W, ldw, (char*)C + (size_t)M1 * ldc * esz, ldc, bias, M - (int)M1, N, K,
-                                epi, VT_GEMM_CFG_AUTO, skinny_scratch, s, nf ? &rest : nullptr);
+                                epi, VT_GEMM_CFG_AUTO, s, nf ? &rest : nullptr);
         }
       }
     }
@@ -887,14 +887,14 @@ int vt_gemm_resid_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, flo
       const long unit = 256L * (256 / g);
       const long M1 = (M / unit) * unit;
       if (M1 >= unit && M1 < M) {
-        VT_TRY(vt_gemm_launch(A, lda, W, ldw, C, ldc, bias, (int)M1, N, K, VT_EPI_F32_RESID, VT_GEMM_CFG_256x256_P4, nullptr, s, nf));
+        VT_TRY(vt_gemm_launch(A, lda, W, ldw, C, ldc, bias, (int)M1, N, K, VT_EPI_F32_RESID, VT_GEMM_CFG_256x256_P4, s, nf));
         const VtGemmNormFuse rest = nf ? vt_nf_rows(*nf, M1) : VtGemmNormFuse{};
         return vt_gemm_resid_launch(A + (size_t)M1 * lda, lda, W, ldw, C + (size_t)M1 * ldc, ldc, bias, M - (int)M1, N, K, 0, partials,
                                     partial_bytes, s, nf ? &rest : nullptr);
       }
     }
   }
-  if (ks < 2) return vt_gemm_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, VT_EPI_F32_RESID, VT_GEMM_CFG_AUTO, nullptr, s, nf);
+  if (ks < 2) return vt_gemm_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, VT_EPI_F32_RESID, VT_GEMM_CFG_AUTO, s, nf);
   VT_REQUIRE(partials && partial_bytes >= (size_t)ks * M * N * sizeof(float), "vt_gemm(split-K): workspace too small (%zu bytes for ksplit=%d)",
              partial_bytes, ks);
   VtProfScope prof(VT_PROF_GEMM_TILE, 2.0 * (double)M * (double)N * (double)K, s);

@@ -688,7 +688,7 @@ int launch_p8(const GemmP8& p, hipStream_t s) {
 
 }  // namespace
 
-bool vt_gemm_p8_supported(int M, int N, int K) { return (K % 128) == 0 && K >= 256 && N % 32 == 0; }
+bool vt_gemm_p8_supported(int /*M*/, int N, int K) { return (K % 128) == 0 && K >= 256 && N % 32 == 0; }
 
 int vt_gemm_rp_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, const float* bias, int M,
                       int N, int K, int epi, hipStream_t s) {

@@ -15,7 +15,7 @@ struct VtAttnSeq {  // device-side view of one row of seq_desc (int32 x 4)
 int vt_gemm_pick_cfg(int M, int N, int K);
 struct VtGemmNormFuse;
 int vt_gemm_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, const float* bias,
-                   int M, int N, int K, int epi, int cfg, void* skinny_scratch, hipStream_t s,
+                   int M, int N, int K, int epi, int cfg, hipStream_t s,
                    const VtGemmNormFuse* nf = nullptr);
 // RMSNorm folded into the M <= 16 weight-streaming GEMMs of a decode step (no separate norm launches):
 //   producer side (VT_EPI_F32_RESID): after x += A W^T the epilogue also stores out_xw = bf16(x * out_w[n]) and, per row and
