@@ -6,6 +6,8 @@ ROCm toolchain is installed. Objects are cached under vitron_amd/csrc/build/ key
 """
 from __future__ import annotations
 
+import contextlib
+import fcntl
 import os
 import shutil
 import subprocess
@@ -36,20 +38,41 @@ def _deps_mtime() -> float:
 
 
 def _compile_one(src: Path, obj: Path, verbose: bool) -> None:
-    cmd = [_hipcc(), *FLAGS, "-c", str(src), "-o", str(obj)]
+    tmp = obj.with_suffix(f".tmp{os.getpid()}.o")
+    cmd = [_hipcc(), *FLAGS, "-c", str(src), "-o", str(tmp)]
     if verbose:
         print("[vitron_amd.build]", " ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
+        with contextlib.suppress(OSError):
+            tmp.unlink()
         raise RuntimeError(f"hipcc failed for {src.name}:\n{r.stdout}\n{r.stderr}")
+    os.replace(tmp, obj)          # a reader never sees a half-written object
     if verbose and r.stderr.strip():
         print(r.stderr, file=sys.stderr)
+
+
+@contextlib.contextmanager
+def _build_lock(bdir: Path):
+    """One builder at a time across processes (torchrun starts one rank per GPU, each of which may find a stale library):
+    the others wait here, then see up-to-date objects and return without compiling."""
+    with open(bdir / ".lock", "w") as f:
+        fcntl.flock(f, fcntl.LOCK_EX)
+        try:
+            yield
+        finally:
+            fcntl.flock(f, fcntl.LOCK_UN)
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:
     """Compile every HIP source for gfx950 and link libvitron_hip.so. Returns the library path."""
     bdir = CSRC / "build"
     bdir.mkdir(exist_ok=True)
+    with _build_lock(bdir):
+        return _build_locked(bdir, force, verbose)
+
+
+def _build_locked(bdir: Path, force: bool, verbose: bool) -> Path:
     hdr_m = _deps_mtime()
     todo = []
     objs = []
@@ -65,12 +88,16 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         with ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 4)) as ex:
             list(ex.map(lambda so: _compile_one(so[0], so[1], verbose), todo))
     if todo or not LIB_PATH.exists() or any(o.stat().st_mtime > LIB_PATH.stat().st_mtime for o in objs):
-        cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *map(str, objs), "-o", str(LIB_PATH)]
+        tmp = LIB_PATH.with_suffix(f".tmp{os.getpid()}.so")
+        cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *map(str, objs), "-o", str(tmp)]
         if verbose:
             print("[vitron_amd.build]", " ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
+            with contextlib.suppress(OSError):
+                tmp.unlink()
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        os.replace(tmp, LIB_PATH)   # processes that already mapped the old file keep it; new loads see a complete library
     return LIB_PATH
 
 
