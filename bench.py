@@ -295,7 +295,7 @@ def main():
                 "end_to_end_frac_of_mfma_peak": fl["total"] / 1e12 / (ms_per_step * 1e-3) / MFMA_BF16_PEAK_TFLOPS,
                 "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items() if v["launches"]},
             },
-            "roofline": {"bound": "mfma", "kernel": "gemm_bt_kernel (bf16 MFMA tile GEMM, all tile configs/epilogues)",
+            "roofline": {"bound": "mfma", "kernel": "bf16 MFMA tile GEMM class: gemm_p8_kernel<*,0,true> (256x256 4-phase ping-pong, ~85 % of the class time) + gemm_bt_kernel<*> (small tiles) + splitk_reduce_resid_kernel, all epilogues",
                          "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": pmc_traffic_per_launch(),
                          "traffic_note": "mean bytes per launch, FETCH_SIZE x2 + WRITE_SIZE (KiB) from profiles/r1_pmc_traffic.json; includes Infinity-Cache hits",
