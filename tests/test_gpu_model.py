@@ -494,3 +494,30 @@ def test_prefill_folded_rmsnorm_vs_oracle(dev):
         assert ef <= 1.25 * es + 1e-3, (H, ef, es)                    # no farther from fp32 than the separate-norm path
         worst = max(rel_l2(got["1"][r], ref[r]) for r in range(rows))
         assert worst <= 2 * TOL_DEEP, (H, worst)                      # no single row off (a wrong row factor would be O(1))
+
+
+@pytest.mark.gpu
+def test_generate_edge_cases_empty_and_ragged(dev):
+    """Degenerate calls the chat loop can produce: nothing to generate, a one-token prompt, a very ragged text batch (1 and 200
+    tokens, right-padded with a mask) -- same tokens as running each sequence alone, pages all returned."""
+    from vitron_amd import synth
+    from vitron_amd.model import LlavaConfig, LlavaLlamaForCausalLM
+    cfg = dict(synth.VICUNA_7B, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4, vocab_size=512)
+    m = LlavaLlamaForCausalLM(LlavaConfig(**cfg, mm_hidden_size=128, mm_region_image_size=112, kv_prefix_reuse=False))
+    m.init_synthetic(dev, seed=19, vit_image=None, vit_video=None)
+    g = torch.Generator().manual_seed(4)
+    long = torch.tensor([[1] + torch.randint(3, 500, (199,), generator=g).tolist()], device=dev)
+    one = torch.tensor([[7]], device=dev)
+    out0 = m.generate(long, do_sample=False, max_new_tokens=0, eos_token_id=-1)
+    assert torch.equal(out0, long)                                                  # nothing generated, nothing lost
+    a = m.generate(one, do_sample=False, max_new_tokens=5, eos_token_id=-1)
+    b = m.generate(long, do_sample=False, max_new_tokens=5, eos_token_id=-1)
+    assert a.shape == (1, 6) and b.shape == (1, 205)
+    ids = torch.zeros((2, 200), dtype=torch.long, device=dev)
+    mask = torch.zeros((2, 200), dtype=torch.long, device=dev)
+    ids[0, :1], mask[0, :1] = one[0], 1
+    ids[1], mask[1] = long[0], 1
+    both = m.generate(ids, attention_mask=mask, do_sample=False, max_new_tokens=5, eos_token_id=-1)
+    assert both[0, 200:].tolist() == a[0, 1:].tolist()
+    assert both[1, 200:].tolist() == b[0, 200:].tolist()
+    assert len(m.kv.free) == m.kv.num_pages
