@@ -105,6 +105,54 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
   }
 }
 
+// many rows (prefill): persistent waves, each walking rows w, w + stride, ...; the NEXT row's 16-byte loads are issued before the
+// current row is reduced and stored, so on the whole chip the read stream of one row overlaps the write stream of the previous
+// one (the one-row-per-wave kernel above runs as two chip-wide phases: every wave reads, then every wave writes).
+template <int NCH>
+__global__ __launch_bounds__(256) void rmsnorm_stream_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             bf16_t* __restrict__ y, int rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int stride = gridDim.x * 4;
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  f32x4 g[NCH], cur[NCH], nxt[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (lane + i * 64) * 4;
+    g[i] = (c < D) ? *(const f32x4*)(w + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    cur[i] = (c < D) ? *(const f32x4*)(x + (size_t)row * D + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  const float inv_d = 1.0f / (float)D;
+  for (; row < rows; row += stride) {
+    const int nrow = row + stride;
+    if (nrow < rows) {
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int c = (lane + i * 64) * 4;
+        nxt[i] = (c < D) ? *(const f32x4*)(x + (size_t)nrow * D + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);   // keep the next row's loads ahead of this row's arithmetic and stores
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) sq += cur[i][0] * cur[i][0] + cur[i][1] * cur[i][1] + cur[i][2] * cur[i][2] + cur[i][3] * cur[i][3];
+    const float rstd = rsqrtf(wave_sum(sq) * inv_d + eps);
+    bf16_t* yr = y + (size_t)row * D;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = (lane + i * 64) * 4;
+      if (c < D) {
+        u32x2 o;
+        o.x = pack_bf16x2(cur[i][0] * rstd * g[i][0], cur[i][1] * rstd * g[i][1]);
+        o.y = pack_bf16x2(cur[i][2] * rstd * g[i][2], cur[i][3] * rstd * g[i][3]);
+        *(u32x2*)(yr + c) = o;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) cur[i] = nxt[i];
+  }
+}
+
 // folded RMSNorm, tile-GEMM flavour: the residual GEMMs leave per-row partial sums of x^2, one per 32-column group, group-major
 // ([np][ldp]); this turns them into the per-row factor the consumer GEMM's epilogue multiplies its accumulators with. One
 // thread per (row, 1/16 of the groups): 16 rows per block (64-byte row segments per load), every thread's loads independent.
@@ -233,6 +281,12 @@ int vt_rmsnorm_launch(const float* x, const int* idx, const float* w, bf16_t* y,
   VT_REQUIRE(rows > 0 && D > 0 && D % 4 == 0 && D <= 4096, "vt_rmsnorm: D=%d must be a multiple of 4, <= 4096", D);
   if (rows <= 64) {
     hipLaunchKernelGGL(rmsnorm_row_block_kernel, dim3(rows), dim3(256), 0, s, x, idx, w, y, D, eps);
+    VT_LAUNCH_CHECK();
+    return VT_OK;
+  }
+  if (!idx && rows >= 2048) {   // prefill-sized: persistent waves with the next row prefetched (two waves per SIMD, 256 CUs)
+    dim3 grid(512);
+    VT_NORM_DISPATCH(rmsnorm_stream_kernel, D, x, w, y, rows, D, eps);
     VT_LAUNCH_CHECK();
     return VT_OK;
   }
