@@ -124,6 +124,77 @@ def test_splice_plan_matches_reference_layout(name):
     assert lengths == [int(r.sum()) for r in ref_m]
 
 
+def test_splice_plan_randomised_against_the_oracle():
+    """200 random batches (sentinels at random places, images / video frames of mixed block sizes, optional regions, optional
+    masks with holes, truncation, left / right padding): the integer plan must move exactly the rows the oracle's restatement of
+    the reference's list surgery moves -- embeddings, masks and position ids bit for bit."""
+    import random
+    from vitron_amd.model.llava_arch import build_splice_plan
+    rnd = random.Random(1234)
+    H, V = 4, 64
+    tok = torch.arange(V * H, dtype=torch.float32).reshape(V, H)
+    for trial in range(200):
+        B = rnd.randint(1, 4)
+        L = rnd.randint(1, 24)
+        use_regions = rnd.random() < 0.5
+        ids, masks = [], []
+        blocks, regs, flat_f, flat_r = [], [], [], []
+        vis_rows, reg_rows = 0, 0
+        for b in range(B):
+            n_img = rnd.choice([0, 0, 1, 1, 2, 3])
+            row = [rnd.randint(0, V - 1) for _ in range(L)]
+            slots = rnd.sample(range(L), min(L, n_img + (rnd.randint(0, 2) if (use_regions and n_img) else 0)))
+            slots.sort()
+            img_slots = slots[:n_img]
+            for s_ in img_slots:
+                row[s_] = -200
+            for s_ in slots[n_img:]:
+                if s_ > min(img_slots):          # an <objs> before any <image> would index feature -1 in the reference
+                    row[s_] = -300
+            m = [1] * L
+            if rnd.random() < 0.4:               # a mask with holes, but never over a sentinel (keeps the feature count in sync)
+                for j in range(L):
+                    if row[j] >= 0 and rnd.random() < 0.3:
+                        m[j] = 0
+            ids.append(row)
+            masks.append(m)
+            kept_imgs = sum(1 for j in range(L) if row[j] == -200 and m[j])
+            for _ in range(max(kept_imgs, 1)):   # a sample without <image> still consumes one feature slot
+                n = rnd.choice([1, 3, 5])
+                blocks.append((vis_rows, n))
+                has_reg = rnd.random() < 0.7
+                regs.append(reg_rows if has_reg else -1)
+                vis_rows += n
+                reg_rows += 1 if has_reg else 0
+        vis = -1.0 - torch.arange(max(vis_rows, 1) * H, dtype=torch.float32).reshape(-1, H)
+        reg = 1e6 + torch.arange(max(reg_rows, 1) * H, dtype=torch.float32).reshape(-1, H)
+        for (first, n), r in zip(blocks, regs):
+            flat_f.append(vis[first:first + n])
+            flat_r.append(reg[r:r + 1] if r >= 0 else torch.zeros((1, H)))
+        if use_regions and any(r < 0 for r in regs):   # a region-less feature: give it a real row so both sides index the same thing
+            regs2, reg2 = [], [reg]
+            extra = reg.shape[0]
+            for i, r in enumerate(regs):
+                if r < 0:
+                    regs2.append(extra)
+                    extra += 1
+                else:
+                    regs2.append(r)
+            reg = torch.cat([reg, torch.zeros((extra - reg.shape[0], H))])
+            regs = regs2
+        max_length = rnd.choice([None, None, rnd.randint(1, 30)])
+        side = rnd.choice(["right", "left"])
+        am = None if all(all(m) for m in masks) and rnd.random() < 0.5 else masks
+        t_ids = torch.tensor(ids)
+        t_am = None if am is None else torch.tensor(am)
+        plan, mask, pos, lengths = build_splice_plan(ids, am, blocks, regs if use_regions else None, max_length, side)
+        e, m2, p2 = O.splice_embeddings(t_ids, t_am, tok, flat_f, flat_r if use_regions else None, max_length, side)
+        got = torch.stack([_materialise(p_, tok, vis, reg) for p_ in plan])
+        assert torch.equal(got, e), (trial, ids, am, blocks, regs)
+        assert torch.equal(torch.tensor(mask).bool(), m2) and torch.equal(torch.tensor(pos), p2), trial
+        assert lengths == [int(r.sum()) for r in m2], trial
+
+
 def test_splice_plan_errors_and_quirks():
     from vitron_amd.model.llava_arch import build_splice_plan
     # a sample without <image> still consumes a feature slot (llava_arch.py:317-324)
@@ -152,6 +223,16 @@ def test_region_slice_resolution_is_python_exact():
         exp = torch.zeros(224, 224)
         exp[r0:r1, c0:c1] = 1
         assert torch.equal(m, exp), (x1, y1, x2, y2)
+    # 500 random boxes (negative, inverted, fractional, far outside, both image sizes) against the oracle's mask
+    import random
+    rnd = random.Random(7)
+    for size in (224, 336):
+        boxes = [[rnd.uniform(-1.5, 1.5) * size * rnd.choice([0.01, 0.5, 1, 3]) for _ in range(4)] for _ in range(250)]
+        ref = O.region_mask(boxes, size)
+        for b, (r0, r1, c0, c1), m in zip(boxes, resolve_region_slices(boxes, size), ref):
+            exp = torch.zeros(size, size)
+            exp[r0:r1, c0:c1] = 1
+            assert torch.equal(m, exp), (size, b)
 
 
 def test_weight_packing_layouts():
