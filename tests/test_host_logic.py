@@ -31,6 +31,23 @@ def test_mm_utils_match_reference_goldens():
     assert mm_utils.get_model_name_from_path("/a/b/checkpoint-12/") == "b_checkpoint-12"
 
 
+def test_prompt_tokenisation_randomised_against_the_oracle():
+    """Random prompts built from text pieces, '<image>' and '<objs>' (adjacent, leading, trailing, none): the product's
+    tokenizer_image_token / tokenizer_image_region_token return the ids the oracle's restatement of mm_utils.py:80-117 returns."""
+    import random
+    from vitron_amd import mm_utils
+    rnd = random.Random(99)
+    tok = StubTok()
+    pieces = ["<image>", "<objs>", "a", "bc", " ", "\n", "x y", ""]
+    for _ in range(300):
+        prompt = "".join(rnd.choice(pieces) for _ in range(rnd.randint(0, 8)))
+        assert mm_utils.tokenizer_image_token(prompt.replace("<objs>", "o"), tok) == O.tokenizer_image_token(prompt.replace("<objs>", "o"), tok)
+        assert mm_utils.tokenizer_image_region_token(prompt, tok) == O.tokenizer_image_region_token(prompt, tok), prompt
+        for first in (True, False):
+            assert mm_utils.tokenizer_image_token(prompt.replace("<objs>", ""), tok, is_first=first) == \
+                O.tokenizer_image_token(prompt.replace("<objs>", ""), tok, is_first=first), (prompt, first)
+
+
 def test_keywords_stopping_criteria_semantics():
     """reference mm_utils.py:146-177: stop on an id-tail match or on the keyword appearing in the decoded tail."""
     from vitron_amd.mm_utils import KeywordsStoppingCriteria
