@@ -97,3 +97,60 @@ def glue_cases():
     c["batch_left"] = dict(input_ids=ids, attention_mask=am, images=[img(4), img(5)], regions=[BOXES[1], BOXES[2]],
                            padding_side="left")
     return c
+
+
+def random_glue_cases(n=24, seed=20260924):
+    """Seeded random layouts for the glue (more of what glue_cases() does by hand): batches of 1-3 samples, each with 0-2 images
+    and / or one clip, optional <objs> after an image, optional regions (one box per entry of `images`, as app.py passes them),
+    ragged lengths with right-padded masks, optional truncation, either padding side. The reference's
+    prepare_inputs_labels_for_multimodal is run on these by make_golden.gen_glue_random; stored: the masks and a fixed random
+    projection of the spliced embeddings (every row of the layout is pinned, the fixture stays small)."""
+    import random
+    rnd = random.Random(seed)
+    T = VIT_VIDEO["num_frames"]
+    out = {}
+    for i in range(n):
+        B = rnd.randint(1, 3)
+        use_regions = rnd.random() < 0.6
+        rows, images, regions = [], [], []
+        for b in range(B):
+            ids = [1] + _ids(rnd.randint(0, 3), SEED_IDS + 100 * i + b)
+            entries = []
+            if rnd.random() < 0.35:
+                entries.append("vid")                                  # videos come first in `images` (app.py:559)
+            entries += ["img"] * rnd.choice([0, 1, 1, 2])
+            if not entries and rnd.random() < 0.5:
+                entries = ["img"]
+            for k, e in enumerate(entries):
+                if e == "vid":
+                    ids += [-200] * T
+                    images.append(pixels((3, T, 56, 56), SEED_PIX + 1000 + 10 * i + 3 * b + k))
+                else:
+                    ids += [-200]
+                    images.append(pixels((3, 56, 56), SEED_PIX + 2000 + 10 * i + 3 * b + k))
+                    if use_regions and rnd.random() < 0.7:
+                        ids += _ids(rnd.randint(0, 2), SEED_IDS + 7 * i + k) + [-300]
+                regions.append([rnd.uniform(0, 100), rnd.uniform(0, 100), rnd.uniform(100, 224), rnd.uniform(100, 224)])
+                ids += _ids(rnd.randint(0, 4), SEED_IDS + 13 * i + 5 * b + k)
+            if not entries:                                            # text-only sample still consumes one (zeros) image
+                images.append(torch.zeros(3, 56, 56))
+                regions.append([0, 0, 224, 224])
+                ids += _ids(rnd.randint(1, 5), SEED_IDS + 17 * i + b)
+            rows.append(ids)
+        L = max(len(r) for r in rows)
+        ragged = any(len(r) != L for r in rows)
+        ids_t = torch.tensor([r + [0] * (L - len(r)) for r in rows])
+        am = torch.tensor([[1] * len(r) + [0] * (L - len(r)) for r in rows]) if (ragged or rnd.random() < 0.3) else None
+        case = dict(input_ids=ids_t, attention_mask=am, images=images, regions=regions if use_regions else None)
+        if rnd.random() < 0.3:
+            case["max_length"] = rnd.randint(8, 90)
+        if rnd.random() < 0.4:
+            case["padding_side"] = "left"
+        out[f"rand{i:02d}"] = case
+    return out
+
+
+def glue_projection(hidden):
+    """The fixed direction the random-case goldens are projected on (float64)."""
+    g = torch.Generator().manual_seed(424242)
+    return torch.randn((hidden,), generator=g, dtype=torch.float64)

@@ -193,6 +193,26 @@ def gen_glue(ns):
     print("glue_llm.npz", {k: v.shape for k, v in out.items()})
 
 
+def gen_glue_random(ns):
+    import contextlib
+    import io
+    model = build_ref_llava(ns)
+    proj = cases.glue_projection(cases.LLM["hidden_size"])
+    out = {}
+    for name, case in cases.random_glue_cases().items():
+        model.config.tokenizer_model_max_length = case.get("max_length")
+        model.config.tokenizer_padding_side = case.get("padding_side", "right")
+        with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+            (_, pos, mask, _, embeds, _) = model.prepare_inputs_labels_for_multimodal(
+                case["input_ids"], None, case["attention_mask"], None, None, case["images"], case["regions"])
+        out[f"{name}_proj"] = (embeds.double() @ proj).numpy()
+        out[f"{name}_mask"] = (mask if mask is not None else torch.ones(embeds.shape[:2])).numpy().astype(np.int32)
+        if pos is not None:
+            out[f"{name}_pos"] = pos.numpy().astype(np.int64)
+    np.savez_compressed(os.path.join(OUT, "glue_random.npz"), **out)
+    print("glue_random.npz", {k: v.shape for k, v in out.items() if k.endswith("_mask")})
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     ns = ref_shim.install()
@@ -201,3 +221,4 @@ if __name__ == "__main__":
     gen_vit(ns)
     gen_region_projector(ns)
     gen_glue(ns)
+    gen_glue_random(ns)

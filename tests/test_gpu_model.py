@@ -521,3 +521,31 @@ def test_generate_edge_cases_empty_and_ragged(dev):
     assert both[0, 200:].tolist() == a[0, 1:].tolist()
     assert both[1, 200:].tolist() == b[0, 200:].tolist()
     assert len(m.kv.free) == m.kv.num_pages
+
+
+@pytest.mark.gpu
+def test_multimodal_glue_random_layouts_vs_reference(dev, model):
+    """The 24 seeded random batches the REFERENCE's prepare_inputs_labels_for_multimodal was run on (tests/golden/
+    glue_random.npz): through the product (towers, region extractor, projector, splice kernel) the padded shape and the mask are
+    exact and every row of the spliced embeddings lands where the reference put it (stored: a fixed random projection of the
+    reference's fp32 embeddings; visual rows carry bf16 storage noise, text rows are exact)."""
+    g = np.load(os.path.join(G, "glue_random.npz"))
+    proj = cases.glue_projection(cases.LLM["hidden_size"])
+    try:
+        for name, case in cases.random_glue_cases().items():
+            model.config.tokenizer_model_max_length = case.get("max_length")
+            model.config.tokenizer_padding_side = case.get("padding_side", "right")
+            ids = case["input_ids"].to(dev)
+            am = None if case["attention_mask"] is None else case["attention_mask"].to(dev)
+            images = [im.to(dev).bfloat16() for im in case["images"]]
+            (_, pos, mask, _, embeds, _) = model.prepare_inputs_labels_for_multimodal(ids, None, am, None, None, images, case["regions"])
+            ref_m, ref_p = g[f"{name}_mask"], torch.as_tensor(g[f"{name}_proj"])
+            assert np.array_equal(np.array(model._last_splice[0], dtype=np.int32), ref_m), name
+            got = embeds.double().cpu() @ proj
+            assert got.shape == ref_p.shape, name
+            assert rel_l2(got.float(), ref_p.float()) <= 1e-2, (name, rel_l2(got.float(), ref_p.float()))
+            # a misplaced row would show as an O(1) error in that row: bound the worst row against the scale of the case
+            assert float((got - ref_p).abs().max()) <= 0.05 * float(ref_p.abs().max()), name
+    finally:
+        model.config.tokenizer_model_max_length = None
+        model.config.tokenizer_padding_side = "right"

@@ -212,6 +212,37 @@ def test_splice_plan_randomised_against_the_oracle():
         assert lengths == [int(r.sum()) for r in m2], trial
 
 
+def test_splice_plan_random_layouts_match_the_reference_masks():
+    """The product's integer plan on the 24 random batches the REFERENCE was run on (tests/golden/glue_random.npz): same padded
+    shape, same attention mask, same position ids as the reference's prepare_inputs_labels_for_multimodal returned."""
+    from vitron_amd.model.llava_arch import build_splice_plan
+    g = np.load(os.path.join(G, "glue_random.npz"))
+    P, T = 16, cases.VIT_VIDEO["num_frames"]
+    for name, case in cases.random_glue_cases().items():
+        use_regions = case["regions"] is not None and len(case["regions"]) > 0
+        blocks, regs, rows, nimg = [], [], 0, 0
+        for im in case["images"]:                       # flat feature list in `images` order: one block per image, T per clip
+            if im.dim() == 3:
+                blocks.append((rows, P))
+                regs.append(nimg)
+                nimg += 1
+                rows += P
+            else:
+                for _ in range(T):
+                    blocks.append((rows, P))
+                    regs.append(-1)
+                    rows += P
+        am = None if case["attention_mask"] is None else case["attention_mask"].tolist()
+        plan, mask, pos, lengths = build_splice_plan(case["input_ids"].tolist(), am, blocks, regs if use_regions else None,
+                                                     case.get("max_length"), case.get("padding_side", "right"))
+        ref_m = g[f"{name}_mask"]
+        assert np.array_equal(np.array(mask, dtype=np.int32), ref_m), name
+        assert lengths == [int(r.sum()) for r in ref_m], name
+        if f"{name}_pos" in g:
+            valid = ref_m.astype(bool)
+            assert np.array_equal(np.array(pos)[valid], g[f"{name}_pos"][valid]), name
+
+
 def test_splice_plan_errors_and_quirks():
     from vitron_amd.model.llava_arch import build_splice_plan
     # a sample without <image> still consumes a feature slot (llava_arch.py:317-324)

@@ -109,3 +109,26 @@ def test_glue_and_prefill_logits(name):
     valid = torch.as_tensor(ref_m).bool()
     assert rel(logits[valid], torch.as_tensor(ref_l)[valid]) <= 1e-4
     assert torch.equal(logits[valid].argmax(-1), torch.as_tensor(ref_l)[valid].argmax(-1))
+
+
+def test_glue_random_layouts_against_the_reference():
+    """24 seeded random batches (cases.random_glue_cases) through the REFERENCE's prepare_inputs_labels_for_multimodal
+    (tests/golden/glue_random.npz, make_golden.gen_glue_random): the oracle must produce the same spliced layout -- masks and
+    position ids exact, every row of the embeddings (a fixed random projection of them is stored) to fp32 accuracy."""
+    g = np.load(os.path.join(G, "glue_random.npz"))
+    w, cfgs = oracle_weights()
+    proj = cases.glue_projection(cases.LLM["hidden_size"])
+    n = 0
+    for name, case in cases.random_glue_cases().items():
+        embeds, mask, pos = O.multimodal_prepare(w, cfgs, case["input_ids"], case["attention_mask"], case["images"], case["regions"],
+                                                 case.get("max_length"), case.get("padding_side", "right"))
+        ref_m, ref_p = g[f"{name}_mask"], g[f"{name}_proj"]
+        assert np.array_equal(mask.numpy().astype(np.int32), ref_m), name
+        got = (embeds.double() @ proj).numpy()
+        assert got.shape == ref_p.shape, name
+        assert np.abs(got - ref_p).max() <= 1e-4 * max(np.abs(ref_p).max(), 1e-6), (name, np.abs(got - ref_p).max())
+        if f"{name}_pos" in g:
+            valid = ref_m.astype(bool)
+            assert np.array_equal(pos.numpy()[valid], g[f"{name}_pos"][valid]), name
+        n += 1
+    assert n == 24
