@@ -13,6 +13,11 @@ SEED_VIT, SEED_PIX, SEED_REGION, SEED_FEATS, SEED_PROJ, SEED_LLM, SEED_IDS = 123
 VIT_VIDEO = dict(hidden_size=128, intermediate_size=256, num_hidden_layers=3, num_attention_heads=2, patch_size=14,
                  image_size=56, hidden_act="gelu", layer_norm_eps=1e-5, add_time_attn=True, num_frames=4)
 VIT_IMAGE = dict(VIT_VIDEO, add_time_attn=False, num_frames=1)
+# second pinned tower shape: the class-default activation, the 8-frame temporal path (the T = 8 kernel), an odd patch grid (5 x 5)
+VIT_VIDEO_B = dict(hidden_size=128, intermediate_size=192, num_hidden_layers=2, num_attention_heads=2, patch_size=14,
+                   image_size=70, hidden_act="quick_gelu", layer_norm_eps=1e-5, add_time_attn=True, num_frames=8)
+VIT_IMAGE_B = dict(VIT_VIDEO_B, add_time_attn=False, num_frames=1)
+VIT_B_CASES = {"video_b": (VIT_VIDEO_B, (1, 3, 8, 70, 70)), "image_b": (VIT_IMAGE_B, (2, 3, 70, 70))}
 MM_HIDDEN = 128
 LLM = dict(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2, vocab_size=512,
            rms_norm_eps=1e-5, rope_theta=10000.0, max_position_embeddings=512)

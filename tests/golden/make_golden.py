@@ -66,6 +66,21 @@ def gen_vit(ns):
     print("vit.npz", {k: getattr(v, "shape", v) for k, v in out.items()})
 
 
+def gen_vit_b(ns):
+    out = {}
+    for name, (cfg, shape) in cases.VIT_B_CASES.items():
+        sd = synth.vit_state(cfg, synth.make_generator(cases.SEED_VIT + 1), **cases.VIT_INIT)
+        m = build_ref_vit(ns, cfg, sd)
+        x = cases.pixels(shape, cases.SEED_PIX + 9)
+        with torch.no_grad():
+            hs = m(x, output_hidden_states=True).hidden_states
+        out[f"{name}_checksum"] = np.float64(synth.checksum(sd))
+        for i, h in enumerate(hs):
+            out[f"{name}_hidden_{i}"] = h.reshape(-1, h.shape[-2], h.shape[-1]).numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "vit_b.npz"), **out)
+    print("vit_b.npz", {k: getattr(v, "shape", v) for k, v in out.items()})
+
+
 def gen_region_projector(ns):
     out = {}
     # region extractor at the reference-native geometry (224 canvas, 16x16 grid) and on a 4x4 grid
@@ -219,6 +234,7 @@ if __name__ == "__main__":
     gen_mm_utils(ns)
     gen_output_parser()
     gen_vit(ns)
+    gen_vit_b(ns)
     gen_region_projector(ns)
     gen_glue(ns)
     gen_glue_random(ns)

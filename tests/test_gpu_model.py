@@ -89,6 +89,26 @@ def test_vit_tower(dev, name, cfg, shape):
     assert rel_l2(vit.forward(x.to(dev)).float(), feats.float()) == 0.0   # fp32 pixels take the same path
 
 
+@pytest.mark.parametrize("name", list(cases.VIT_B_CASES))
+def test_vit_tower_second_shape(dev, name):
+    """The second pinned tower shape (quick_gelu, 8 frames -> the T = 8 temporal kernel, 70 px -> 5 x 5 patches, 26 tokens):
+    all layers on the device against the reference's hidden states and the bf16-emulating oracle."""
+    from vitron_amd.engine import PackedVit
+    g = np.load(os.path.join(G, "vit_b.npz"))
+    cfg, shape = cases.VIT_B_CASES[name]
+    sd = synth.vit_state(cfg, synth.make_generator(cases.SEED_VIT + 1), **cases.VIT_INIT)
+    x = cases.pixels(shape, cases.SEED_PIX + 9)
+    for sel in (-1, -2):
+        vit = PackedVit(sd, cfg, dev, select_layer=sel)
+        feats, hidden = vit.forward(x.to(dev).bfloat16(), return_hidden=True)
+        nl = vit.run_layers
+        emu = O.vit_forward(f32(sd), cfg, x, nl, emulate_bf16=True)
+        ref = torch.as_tensor(g[f"{name}_hidden_{nl}"])
+        assert rel_l2(hidden, emu) <= (TOL if nl <= 1 else 5e-3), (sel, "vs emulating oracle")
+        assert rel_l2(hidden, ref) <= TOL_FP32 and no_worse_than_emulation(hidden, emu, ref), (sel, "vs reference fp32")
+        assert feats.shape == ((1, 8, 25, 128) if name == "video_b" else (2, 25, 128))
+
+
 def test_projector_and_region(dev, model):
     g = np.load(os.path.join(G, "region_projector.npz"))
     st = _states()

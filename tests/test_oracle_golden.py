@@ -61,6 +61,19 @@ def test_vit_hidden_states(name, cfg, shape):
     assert rel(f.reshape(ref.shape), ref) <= 1e-5
 
 
+@pytest.mark.parametrize("name", list(cases.VIT_B_CASES))
+def test_vit_hidden_states_second_shape(name):
+    """quick_gelu, 8 frames, a 5 x 5 patch grid: every hidden state of the reference's towers (tests/golden/vit_b.npz)."""
+    g = np.load(os.path.join(G, "vit_b.npz"))
+    cfg, shape = cases.VIT_B_CASES[name]
+    sd = synth.vit_state(cfg, synth.make_generator(cases.SEED_VIT + 1), **cases.VIT_INIT)
+    assert synth.checksum(sd) == pytest.approx(float(g[f"{name}_checksum"]), rel=1e-12)
+    x = cases.pixels(shape, cases.SEED_PIX + 9)
+    for nl in range(cfg["num_hidden_layers"] + 1):
+        h = O.vit_forward(f32(sd), cfg, x, num_layers=nl)
+        assert rel(h, g[f"{name}_hidden_{nl}"]) <= 1e-5, nl
+
+
 @pytest.mark.parametrize("tag", list(cases.REGION_CASES))
 def test_region_extractor(tag):
     g = np.load(os.path.join(G, "region_projector.npz"))
