@@ -350,7 +350,6 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
                                     "prefill_rows": int(sum(lens) - kept), "tower_items": self.last_tower_items}
         if kept:
             flat, lens = flat[kept:], [lens[0] - kept]
-        logits = llama_forward(llama, self.kv, seqs, flat, lens)             # [B, V]: last position of every sequence
         # ---- decode loop: device-resident step state, the next pass is enqueued before the host has seen the token it consumes
         L0 = input_ids.shape[1]
         out_host = torch.empty((B, L0 + max_new_tokens), dtype=torch.long)
@@ -358,7 +357,8 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
         n_out = L0
         all_logits = []
         state = None
-        try:
+        try:   # (the prefill is inside: pages it took before a failure go back to the pool / the kept prefix below)
+            logits = llama_forward(llama, self.kv, seqs, flat, lens)         # [B, V]: last position of every sequence
             for step in range(max_new_tokens):
                 if return_logits:
                     all_logits.append(logits.clone())
