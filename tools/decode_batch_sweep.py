@@ -1,4 +1,4 @@
-import os, sys, json, torch
+import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from vitron_amd import _lib, synth

@@ -16,7 +16,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Dict, List, Optional, Sequence
 
 import torch
 

@@ -15,12 +15,10 @@ from __future__ import annotations
 import glob
 import json
 import os
-from types import SimpleNamespace
 
 import torch
 
 from .language_model.llava_llama import LlavaConfig, LlavaLlamaForCausalLM
-from .multimodal_encoder.languagebind import VisionConfig
 
 DEFAULT_IMAGE_PATCH_TOKEN = "<im_patch>"
 DEFAULT_IM_START_TOKEN = "<im_start>"

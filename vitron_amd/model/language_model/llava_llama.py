@@ -9,7 +9,7 @@ top of it (the reference gets its loop from GenerationMixin).
 from __future__ import annotations
 
 from types import SimpleNamespace
-from typing import List, Optional, Sequence
+from typing import List, Optional
 
 import torch
 

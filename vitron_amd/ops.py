@@ -6,7 +6,6 @@ torch-op fallback: without the shared library, or on a CPU tensor, these raise.
 """
 from __future__ import annotations
 
-import ctypes as C
 from typing import Optional, Sequence
 
 import torch

@@ -10,7 +10,7 @@ Works with any torch.distributed backend: the tests run it under gloo on CPU ten
 """
 from __future__ import annotations
 
-from typing import Callable, List, Sequence, Tuple
+from typing import Callable, Sequence, Tuple
 
 import torch
 import torch.distributed as dist

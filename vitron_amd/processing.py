@@ -9,7 +9,6 @@ The reference's RandomHorizontalFlipVideo(p=0.5) -- applied at inference, proces
 from __future__ import annotations
 
 import ctypes as C
-from typing import List, Sequence, Union
 
 import numpy as np
 import torch
