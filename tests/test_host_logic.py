@@ -88,6 +88,17 @@ def test_output_parser_matches_reference_goldens():
     assert (module, instruction, region) == ("B", ["left one"], "[10, 20, 110, 220]") and output == "I segmented it.  done"
 
 
+def test_bench_algorithmic_work_matches_survey_accounting():
+    """bench.py's roofline numerator follows SURVEY.md 8(d): C3 (8 x 336 px frames + 512 tokens, S = 5120) is 77.20 TFLOP
+    (ViT 3.82, projector 0.19, decoder linears 66.31, attention 6.87); C3 at 224 px 36.60."""
+    import bench
+    fl = bench.algorithmic_flops(5120, 4608, 8, 577, 576)
+    assert fl["total"] / 1e12 == pytest.approx(77.20, abs=0.01)
+    assert fl["vit"] / 1e12 == pytest.approx(3.82, abs=0.01) and fl["projector"] / 1e12 == pytest.approx(0.19, abs=0.005)
+    assert fl["llm_linear"] / 1e12 == pytest.approx(66.31, abs=0.01) and fl["llm_attention"] / 1e12 == pytest.approx(6.87, abs=0.01)
+    assert bench.algorithmic_flops(2560, 2048, 8, 257, 256)["total"] / 1e12 == pytest.approx(36.60, abs=0.01)
+
+
 def test_constants_match_reference_values():
     from vitron_amd import constants as c
     assert (c.IGNORE_INDEX, c.IMAGE_TOKEN_INDEX, c.OBJS_TOKEN_INDEX) == (-100, -200, -300)
