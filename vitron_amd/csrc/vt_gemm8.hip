@@ -457,6 +457,278 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmP8 p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// gemm_p4x_kernel: the 4-phase ping-pong schedule above on v_mfma_f32_32x32x16_bf16.
+//
+// Same tile (256x256x64), same 8 waves as two staggered rows, same LDS image / DMA schedule / vmcnt counts / hazard argument as
+// gemm_p8_kernel<.., P4 = true>; only the matrix instruction and therefore the fragment shapes differ. A wave's 64x32 quadrant
+// is two 32x32 blocks (mi = 0, 1) and a K step is four k-slices of 16: one section (two quadrants that share the A half tile)
+// is 16 MFMAs of 32 cycles instead of 32 of ~17 (the 16x16x32 instruction issues at ~17 cycles per MFMA on one SIMD,
+// MI355X_MICROARCH.md constants table: 5 % more matrix-pipe cycles for the same FLOPs), with half the operand-register reads
+// per FLOP. The four accumulators of a section are visited round-robin, so two MFMAs on the same accumulator are four issue
+// slots (128 cycles) apart -- the 8-phase attempt with this instruction had two accumulators per phase and
+// stalled on the dependent chain.
+// Fragment reads: lane l supplies row (l & 31), k-chunk (2*ks + (l >> 5)) of the 8 16-byte chunks of a 64-element row; with the
+// source-side XOR swizzle chunk ^ ((row >> 1) & 7) the 16 lanes of every ds_read_b128 service group hit 16 distinct 16-byte
+// slots of the 256-byte bank row (rows {0-3,12-15,20-27}: ((row>>1)&7, row&1) are all different).
+// Epilogue layout (W fragment is the MFMA "A" operand): lane holds m = lane & 31 and n = 8*g + 4*(lane>>5) + {0..3}, g = reg>>2.
+// ------------------------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_p4x_kernel(GemmP8 p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 255) / 256;
+  const int nwg = tiles_m * tiles_n;
+  const int ksplit = (EPI == VT_EPI_F32) ? p.ksplit : 1;
+  const int split = (ksplit > 1) ? (int)blockIdx.x / nwg : 0;
+  const int sid = xcd_remap((int)blockIdx.x - split * nwg, nwg);
+  const int ku = p.K >> 7;
+  const int u_begin = (int)((long)ku * split / ksplit), u_end = (int)((long)ku * (split + 1) / ksplit);
+  const int k_begin = u_begin * 128;
+  constexpr int GROUP_M = 8;
+  const int per_group = GROUP_M * tiles_n;
+  const int first_m = (sid / per_group) * GROUP_M;
+  const int gsz = min(tiles_m - first_m, GROUP_M);
+  const int tm = first_m + (sid % per_group) % gsz;
+  const int tn = (sid % per_group) / gsz;
+  const int bm0 = tm * 256, bn0 = tn * 256;
+
+  const int lrow = lane >> 3, lchk = lane & 7;
+  const bf16_t* src[4][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (wave * 2 + i) * 8 + lrow;
+    const int coff = (lchk ^ ((row >> 1) & 7)) * 8;
+    src[SLOT_A0][i] = p.A + (size_t)min(bm0 + row, p.M - 1) * p.lda + coff + k_begin;
+    src[SLOT_A1][i] = p.A + (size_t)min(bm0 + 128 + row, p.M - 1) * p.lda + coff + k_begin;
+    src[SLOT_B0][i] = p.W + (size_t)min(bn0 + row, p.N - 1) * p.ldw + coff + k_begin;
+    src[SLOT_B1][i] = p.W + (size_t)min(bn0 + 128 + row, p.N - 1) * p.ldw + coff + k_begin;
+  }
+  const int dma_off = wave * 2048;
+#define XSTAGE(BUF, SLOT)                                                                       \
+  do {                                                                                          \
+    char* _d = smem + (BUF) * BUF_BYTES + slot_offset(SLOT) + dma_off;                          \
+    glds16(src[SLOT][0], _d);                                                                   \
+    glds16(src[SLOT][1], _d + 1024);                                                            \
+    src[SLOT][0] += 64;                                                                         \
+    src[SLOT][1] += 64;                                                                         \
+  } while (0)
+
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int f = (l31 >> 1) & 7;
+  int fo[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) fo[ks] = l31 * 128 + ((((2 * ks) | hi) ^ f) << 4);
+  const int a_row_off = wr * 64 * 128;
+  const int b_row_off = wc * 32 * 128;
+
+  f32x16 acc[2][2][2];   // [qm][qn][mi]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][mi][r] = 0.f;
+  bf16x8 af[2][4], b0f[4], b1f[4];
+
+#define XREAD_A(BUF, SLOT)                                                                     \
+  do {                                                                                         \
+    const char* _s = smem + (BUF) * BUF_BYTES + slot_offset(SLOT) + a_row_off;                 \
+    _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                           \
+      _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) af[mi][ks] = *(const bf16x8*)(_s + mi * 4096 + fo[ks]); \
+  } while (0)
+#define XREAD_B(BUF, SLOT, DST)                                                                \
+  do {                                                                                         \
+    const char* _s = smem + (BUF) * BUF_BYTES + slot_offset(SLOT) + b_row_off;                 \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) DST[ks] = *(const bf16x8*)(_s + fo[ks]);  \
+  } while (0)
+  // one section: the two quadrants (QM, QNA) and (QM, QNB) share the A fragments; accumulators visited round-robin
+#define XMFMA_2Q(QM, QNA, BFA, QNB, BFB)                                                       \
+  do {                                                                                         \
+    __builtin_amdgcn_s_setprio(1);                                                             \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                         \
+      _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                         \
+        acc[QM][QNA][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BFA[ks], af[mi][ks], acc[QM][QNA][mi], 0, 0, 0); \
+      _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                         \
+        acc[QM][QNB][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BFB[ks], af[mi][ks], acc[QM][QNB][mi], 0, 0, 0); \
+    }                                                                                          \
+    __builtin_amdgcn_s_setprio(0);                                                             \
+  } while (0)
+
+  const int nt = (u_end - u_begin) * 2;
+
+  float rsv[2][2];
+  if constexpr (EPI != VT_EPI_F32_RESID && EPI != VT_EPI_F32) {
+#pragma unroll
+    for (int qm = 0; qm < 2; ++qm)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+        rsv[qm][mi] = p.nf.row_scale ? p.nf.row_scale[min(bm0 + qm * 128 + wr * 64 + mi * 32 + l31, p.M - 1)] : 1.f;
+  }
+  XSTAGE(0, SLOT_A0);
+  XSTAGE(0, SLOT_B0);
+  XSTAGE(0, SLOT_B1);
+  XSTAGE(0, SLOT_A1);
+  XSTAGE(1, SLOT_A0);
+  XSTAGE(1, SLOT_B0);
+  XSTAGE(1, SLOT_B1);
+  VT_VMCNT(0);
+  if constexpr (EPI != VT_EPI_F32_RESID && EPI != VT_EPI_F32) {
+#pragma unroll
+    for (int qm = 0; qm < 2; ++qm)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) asm volatile("" : "+v"(rsv[qm][mi]));
+  }
+  SECTION_SPLIT();
+  if (wr == 1) __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+
+  // stage schedule, waits and hazards: exactly the 4-phase loop of gemm_p8_kernel (see there)
+  for (int it = 0; it < nt / 2; ++it) {
+    const int u = it * 2;
+    if (u + 1 < nt) XSTAGE(1, SLOT_A1);
+    XREAD_B(0, SLOT_B0, b0f);
+    XREAD_B(0, SLOT_B1, b1f);
+    XREAD_A(0, SLOT_A0);
+    LOAD_SECTION_END();
+    XMFMA_2Q(0, 0, b0f, 1, b1f);
+    PHASE_END4(u + 1 < nt, 2);
+    if (u + 2 < nt) {
+      XSTAGE(0, SLOT_A0);
+      XSTAGE(0, SLOT_B0);
+      XSTAGE(0, SLOT_B1);
+    }
+    XREAD_A(0, SLOT_A1);
+    LOAD_SECTION_END();
+    XMFMA_2Q(1, 1, b1f, 0, b0f);
+    PHASE_END4(u + 2 < nt, 6);
+    if (u + 2 < nt) XSTAGE(0, SLOT_A1);
+    XREAD_B(1, SLOT_B0, b0f);
+    XREAD_B(1, SLOT_B1, b1f);
+    XREAD_A(1, SLOT_A0);
+    LOAD_SECTION_END();
+    XMFMA_2Q(0, 0, b0f, 1, b1f);
+    PHASE_END4(u + 2 < nt, 2);
+    if (u + 3 < nt) {
+      XSTAGE(1, SLOT_A0);
+      XSTAGE(1, SLOT_B0);
+      XSTAGE(1, SLOT_B1);
+    }
+    XREAD_A(1, SLOT_A1);
+    LOAD_SECTION_END();
+    XMFMA_2Q(1, 1, b1f, 0, b0f);
+    PHASE_END4(u + 3 < nt, 6);
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();
+#undef XSTAGE
+#undef XREAD_A
+#undef XREAD_B
+#undef XMFMA_2Q
+
+  // ---- epilogue ------------------------------------------------------------------------------------------------------------
+  if constexpr (EPI == VT_EPI_F32_RESID) {
+    // C += acc (+ bias): the 8 x 16-byte reads of a row slot are issued together and one slot ahead of the stores
+    float* const __restrict__ Cf = (float*)p.C;
+    auto row_of = [&](int r) { return bm0 + (r >> 1) * 128 + wr * 64 + (r & 1) * 32 + l31; };
+    auto col_of = [&](int qn, int g) { return bn0 + qn * 128 + wc * 32 + 8 * g + 4 * hi; };
+    auto load_row = [&](int r, f32x4 (&dst)[2][4]) {
+      const int m = min(row_of(r), p.M - 1);
+#pragma unroll
+      for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dst[qn][g] = *(const f32x4*)(Cf + (size_t)m * p.ldc + min(col_of(qn, g), p.N - 4));
+    };
+    f32x4 b4[2][4];
+#pragma unroll
+    for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) b4[qn][g] = p.bias ? *(const f32x4*)(p.bias + min(col_of(qn, g), p.N - 4)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    float rs4[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rs4[r] = p.nf.row_scale ? p.nf.row_scale[min(row_of(r), p.M - 1)] : 1.f;
+    f32x4 cur[2][4], nxt[2][4];
+    load_row(0, cur);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (r + 1 < 4) load_row(r + 1, nxt);
+      const int m = row_of(r);
+      if (m < p.M) {
+#pragma unroll
+        for (int qn = 0; qn < 2; ++qn) {
+          const f32x16 a = acc[r >> 1][qn][r & 1];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int n = col_of(qn, g);
+            if (n >= p.N) continue;
+            const f32x4 v = {a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]};
+            *(f32x4*)(Cf + (size_t)m * p.ldc + n) = cur[qn][g] + (v * rs4[r] + b4[qn][g]);
+          }
+        }
+      }
+#pragma unroll
+      for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) cur[qn][g] = nxt[qn][g];
+    }
+  } else {
+#pragma unroll
+    for (int qm = 0; qm < 2; ++qm)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const int m = bm0 + qm * 128 + wr * 64 + mi * 32 + l31;
+        if (m >= p.M) continue;
+        const float rs = (EPI == VT_EPI_F32) ? 1.f : rsv[qm][mi];
+#pragma unroll
+        for (int qn = 0; qn < 2; ++qn) {
+          const int nfrag = bn0 + qn * 128 + wc * 32;     // multiple of 32; N % 32 == 0: the fragment is whole or absent
+          if (nfrag >= p.N) continue;
+          const f32x16 a = acc[qm][qn][mi];
+          if constexpr (EPI == VT_EPI_SWIGLU_BF16) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+              const int nl = 8 * g + 4 * hi;
+              u32x2 o;
+              o.x = pack_bf16x2(silu8(a[4 * g + 0] * rs) * (a[4 * g + 8] * rs), silu8(a[4 * g + 1] * rs) * (a[4 * g + 9] * rs));
+              o.y = pack_bf16x2(silu8(a[4 * g + 2] * rs) * (a[4 * g + 10] * rs), silu8(a[4 * g + 3] * rs) * (a[4 * g + 11] * rs));
+              *(u32x2*)((bf16_t*)p.C + (size_t)m * p.ldc + (nfrag >> 1) + nl) = o;
+            }
+          } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int n = nfrag + 8 * g + 4 * hi;
+              f32x4 v = {a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]};
+              v = v * rs;
+              if (p.bias && split == 0) v += *(const f32x4*)(p.bias + n);
+              if constexpr (EPI == VT_EPI_BF16_GELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_erf8(v[r]);
+              } else if constexpr (EPI == VT_EPI_BF16_QGELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = quick_gelu8(v[r]);
+              } else if constexpr (EPI == VT_EPI_BF16_RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+              }
+              if constexpr (EPI == VT_EPI_F32) {
+                *(f32x4*)((float*)p.C + (size_t)split * p.slab + (size_t)m * p.ldc + n) = v;
+              } else {
+                u32x2 o;
+                o.x = pack_bf16x2(v[0], v[1]);
+                o.y = pack_bf16x2(v[2], v[3]);
+                *(u32x2*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
+              }
+            }
+          }
+        }
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // gemm_rp_kernel ("register-pipelined"): 256x256x64 tile, 8 waves (2 x 4, two per SIMD), 128x64 per wave as 4 x 2
 // fragments of v_mfma_f32_32x32x16_bf16. No load/compute phase split: inside every wave the fragment reads of k-step
 // j+1 (6 ds_read_b128) are in flight while the 8 MFMAs of k-step j issue (8 independent accumulators, no dependent
@@ -671,6 +943,21 @@ int launch_rp(const GemmP8& p, hipStream_t s) {
   return VT_OK;
 }
 
+template <int EPI>
+int launch_p4x(const GemmP8& p, hipStream_t s) {
+  constexpr int smem = 2 * BUF_BYTES;  // 128 KiB
+  auto kern = gemm_p4x_kernel<EPI>;
+  static bool done = false;
+  if (!done) {
+    VT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    done = true;
+  }
+  const int nwg = cdiv(p.M, 256) * cdiv(p.N, 256) * (p.ksplit > 1 ? p.ksplit : 1);
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), smem, s, p);
+  VT_LAUNCH_CHECK();
+  return VT_OK;
+}
+
 template <int EPI, int ABL = 0, bool P4 = false>
 int launch_p8(const GemmP8& p, hipStream_t s) {
   constexpr int smem = 2 * BUF_BYTES;  // 128 KiB
@@ -795,6 +1082,19 @@ int vt_gemm_p8_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* 
       case 5: return launch_p8<VT_EPI_BF16, 5, true>(p, s);
       case 6: return launch_p8<VT_EPI_BF16, 6, true>(p, s);
       default: return launch_p8<VT_EPI_BF16, 7, true>(p, s);
+    }
+  }
+  if (epi & 0x2000) {   // 4-phase schedule on the 32x32x16 instruction (no norm-fold producer side)
+    VT_REQUIRE(!p.nf.out_partials, "vt_gemm(p4x): the norm-fold producer epilogue lives in the 16x16x32 kernel");
+    switch (epi & 0xff) {
+      case VT_EPI_BF16: return launch_p4x<VT_EPI_BF16>(p, s);
+      case VT_EPI_BF16_GELU: return launch_p4x<VT_EPI_BF16_GELU>(p, s);
+      case VT_EPI_BF16_QGELU: return launch_p4x<VT_EPI_BF16_QGELU>(p, s);
+      case VT_EPI_BF16_RELU: return launch_p4x<VT_EPI_BF16_RELU>(p, s);
+      case VT_EPI_F32_RESID: return launch_p4x<VT_EPI_F32_RESID>(p, s);
+      case VT_EPI_F32: return launch_p4x<VT_EPI_F32>(p, s);
+      case VT_EPI_SWIGLU_BF16: return launch_p4x<VT_EPI_SWIGLU_BF16>(p, s);
+      default: vt_set_error("vt_gemm(p4x): unknown epilogue %d", epi & 0xff); return VT_ERR_ARG;
     }
   }
   if (epi & 0x1000) {   // 4-phase variant
