@@ -140,9 +140,11 @@ int vt_preprocess(const void* src, int src_u8, int hwc, int F, int H, int W, int
                   const float* std, int flip, void* dst, int dst_dtype, long dst_stride_c, long dst_stride_f, void* stream);
 
 /* embed_tokens gather + visual / region splice (reference llava_arch.py:306-398, 479-558).
- * plan: device int32 [rows][2] = {kind, index}; kind 0 = token id, 1 = row of vis, 2 = row of reg, 3 = zero row. */
-int vt_embed_splice(const uint16_t* tok_table, const uint16_t* vis, const uint16_t* reg, const int* plan, int rows,
-                    int H, uint16_t* out, void* stream);
+ * plan: device int32 [rows][2] = {kind, index}; kind 0 = token id, 1 = row of vis, 2 = row of reg, 3 = zero row.
+ * tok_table has `vocab` rows, vis `vis_rows`, reg `reg_rows` (0 with a NULL table): an index outside its table gives a
+ * zero row instead of an out-of-bounds read (the host mirror raises before it gets that far). */
+int vt_embed_splice(const uint16_t* tok_table, int vocab, const uint16_t* vis, int vis_rows, const uint16_t* reg, int reg_rows,
+                    const int* plan, int rows, int H, uint16_t* out, void* stream);
 
 /* greedy next token: first index of the row maximum (GenerationMixin greedy search). */
 int vt_argmax(const float* logits, int rows, int V, int ldl, int* out_ids, void* stream);
@@ -157,10 +159,12 @@ int vt_argmax(const float* logits, int rows, int V, int ldl, int* out_ids, void*
  * so the next decoder pass can be enqueued before the host has seen the token. */
 int vt_decode_feed(const uint16_t* tok_table, int H, int vocab, const int* next_ids, int* finished, const int* eos_ids, int n_eos,
                    int pad_id, int* tokens_out, uint16_t* x, int* seq_desc, int* positions, int nseq, void* stream);
-/* one sampled token per row: softmax(logits / temperature), transformers' TopPLogitsWarper keep-set (top_p >= 1 keeps all),
- * inverse-CDF draw with a counter-based uniform of (seed, step, row). kept_count (optional) = size of the keep-set per row.
- * Replaces GenerationMixin.sample's temperature / top-p / multinomial step (reference app.py:562-571, do_sample=True). */
-int vt_sample_top_p(const float* logits, int rows, int V, int ldl, float temperature, float top_p, uint64_t seed,
+/* one sampled token per row, the warper chain of GenerationMixin.sample in transformers' order: logits / temperature,
+ * TopKLogitsWarper (top_k > 0: everything below the k-th largest value is removed, ties stay; 0 = off), softmax,
+ * TopPLogitsWarper keep-set (top_p >= 1 keeps all), inverse-CDF draw with a counter-based uniform of (seed, step, row).
+ * kept_count (optional) = size of the final keep-set per row.
+ * Replaces GenerationMixin.sample's temperature / top-k / top-p / multinomial step (reference app.py:562-571, do_sample=True). */
+int vt_sample_top_p(const float* logits, int rows, int V, int ldl, float temperature, int top_k, float top_p, uint64_t seed,
                     uint64_t step, int* out_ids, int* kept_count, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
@@ -178,17 +182,22 @@ int vt_projector_forward(const uint16_t* x, int M, int Din, const uint16_t* w1, 
  *   slices  int32 [B][4]          {row_start,row_stop,col_start,col_stop} = Python slice(int(x1),int(x2)) /
  *                                  slice(int(y1),int(y2)) resolved against image_size on the host (x -> rows, :83)
  *   coords  bf16 [B][8]           raw box {x1,y1,x2,y2,0,0,0,0} (LocationEncoder input, :126)
- *   mlp_w[3]/mlp_b[3]             region_linear (D->H->H->H, ReLU between); loc_w[0] is [H/2][8] (zero padded
- *                                  from [H/2][4]), loc_w[1] is [H][H/2]
+ *   mlp_w[2]/mlp_b[2]             first two layers of region_linear (D->H, H->H, ReLU after each; layer.py:17-20)
+ *   loc_w0 / loc_b0               LocationEncoder layer 0, bf16 [H/2][8] (zero padded from [H/2][4]) / fp32 [H/2]
+ *   final_w / final_b             [H][H + H/2] = [ region_linear.layers.2.weight | loc_encoder.2.weight ] and the SUM of their
+ *                                  biases: MLP output + location embedding (layer.py:129) is one contraction over the
+ *                                  concatenated K, accumulated in fp32 and rounded to bf16 once
  *   out     bf16 [B][H]; cell_mask int32 [B][G*G] and cell_count int32 [B] are optional outputs (may be NULL)
- *   B <= 16 per call.
+ *   B <= 16 per call, G <= 64. Four launches: pool (+ mask, count, LocationEncoder layer 0) and three weight-streaming GEMMs.
  * ---------------------------------------------------------------------------------------------------------- */
 typedef struct vt_region_weights {
   int in_dim, out_dim;
-  const uint16_t* mlp_w[3];
-  const float* mlp_b[3];
-  const uint16_t* loc_w[2];
-  const float* loc_b[2];
+  const uint16_t* mlp_w[2];
+  const float* mlp_b[2];
+  const uint16_t* loc_w0;
+  const float* loc_b0;
+  const uint16_t* final_w;
+  const float* final_b;
 } vt_region_weights;
 size_t vt_region_workspace_bytes(int B, int in_dim, int out_dim);
 int vt_region_forward(const vt_region_weights* w, const uint16_t* feats, const int* slices, const uint16_t* coords,
@@ -269,6 +278,9 @@ typedef struct vt_llama_model {
   const float* rope_sin;
   int rope_len;
   const vt_llama_layer* layers; /* host array [num_layers] */
+  int prefill_norm_fold;        /* 1: prefills (rows > 64) fold RMSNorm into the MFMA tile GEMMs (residual epilogues emit bf16(x .* w)
+                                   and partial sums of x^2, the consumer GEMMs scale their rows); same accuracy, measured no faster:
+                                   default 0. Decode steps (<= 16 rows) always fold. */
 } vt_llama_model;
 
 /* KV pool: k  [num_layers][num_pages][heads][64][head_dim]   (K rows, rotary applied)

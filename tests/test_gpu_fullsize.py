@@ -177,7 +177,7 @@ def test_decoder_7b_chunking_and_batch_invariance(dev, model7b):
 
 def test_prefill_folded_rmsnorm_matches_separate_norms(dev, model7b):
     """rows > 64: RMSNorm folded into the MFMA tile GEMMs (producers: 4-phase kernel, small-tile remainder, split-K reduce pass;
-    consumers: qkv / gate_up) against the same pass with separate norm launches (VT_PREFILL_NORM_FOLD=0). The only difference is
+    consumers: qkv / gate_up) against the same pass with separate norm launches (vt_llama_model.prefill_norm_fold = 0). The only difference is
     where bf16 rounding happens (x*w before the row factor instead of after): two independently rounded bf16 paths: ~6e-3 apart after two layers at the 7B width (each equally far from fp32:
     tests/test_gpu_model.py::test_prefill_folded_rmsnorm_vs_oracle), the
     deep-chain noise floor after 32."""
@@ -195,7 +195,7 @@ def test_prefill_folded_rmsnorm_matches_separate_norms(dev, model7b):
             emb = (torch.randn((S, 4096), generator=g, device=dev) * 0.02).bfloat16()
             res = {}
             for fold in ("1", "0"):
-                os.environ["VT_PREFILL_NORM_FOLD"] = fold
+                llama.set_prefill_norm_fold(fold == "1")
                 try:
                     times = []
                     for _ in range(2):
@@ -208,7 +208,7 @@ def test_prefill_folded_rmsnorm_matches_separate_norms(dev, model7b):
                         kv.release(s_.pages)
                     res[fold] = (lg, hid, min(times))
                 finally:
-                    os.environ.pop("VT_PREFILL_NORM_FOLD", None)
+                    llama.set_prefill_norm_fold(False)
             (la, ha, ta), (lb, hb, tb) = res["1"], res["0"]
             assert torch.isfinite(la).all() and torch.isfinite(ha).all()
             print(f"prefill {name} S={S}: folded {ta * 1e3:.2f} ms, separate norms {tb * 1e3:.2f} ms, "

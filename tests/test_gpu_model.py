@@ -485,7 +485,7 @@ def test_generate_stops_on_eos_with_speculative_step_rolled_back(dev):
 def test_prefill_folded_rmsnorm_vs_oracle(dev):
     """rows > 64: RMSNorm folded into the MFMA tile GEMMs (residual GEMMs emit bf16(x .* w_next) + per-row partial sums of x^2,
     vt_rowscale_finalize turns them into rstd, the consumer GEMMs scale their accumulator rows). Every row's logits against the
-    fp32 oracle, with the fold and with separate norm launches (VT_PREFILL_NORM_FOLD=0): folding costs no accuracy. Shapes chosen
+    fp32 oracle, with the fold and with separate norm launches (vt_llama_model.prefill_norm_fold = 0): folding costs no accuracy. Shapes chosen
     to hit the 4-phase kernel (K % 128 == 0), the small tiles (K = 192 gate / down) and ragged row counts."""
     import os
     from vitron_amd.engine import PackedLlama, PagedKVCache, SequenceState, llama_forward
@@ -501,13 +501,13 @@ def test_prefill_folded_rmsnorm_vs_oracle(dev):
         kv = PagedKVCache(llama, 16)
         got = {}
         for fold in ("1", "0"):
-            os.environ["VT_PREFILL_NORM_FOLD"] = fold
+            llama.set_prefill_norm_fold(fold == "1")
             try:
                 s_ = SequenceState()
                 got[fold] = llama_forward(llama, kv, [s_], e.to(dev).bfloat16(), [rows], logit_rows=list(range(rows))).cpu()
                 kv.release(s_.pages)
             finally:
-                os.environ.pop("VT_PREFILL_NORM_FOLD", None)
+                llama.set_prefill_norm_fold(False)
         ef, es = rel_l2(got["1"], ref), rel_l2(got["0"], ref)
         assert not torch.equal(got["1"], got["0"])                    # the switch really selects two different paths
         assert ef <= TOL_DEEP and es <= TOL_DEEP, (H, ef, es)

@@ -353,13 +353,19 @@ def test_cabi_argument_validation_without_a_gpu():
     bad(lib.vt_rmsnorm(None, None, P, P, 4, 64, 1e-5, None))
     bad(lib.vt_layernorm(P, None, 0, 0, None, None, P, 4, 64, 1e-5, None))
     bad(lib.vt_argmax(P, 0, 10, 10, P, None), "argmax")
-    bad(lib.vt_embed_splice(P, None, None, P, 4, 12, P, None), "multiple of 8")
+    bad(lib.vt_embed_splice(P, 100, None, 0, None, 0, P, 4, 12, P, None), "multiple of 8")
+    bad(lib.vt_embed_splice(P, 100, None, 7, None, 0, P, 4, 16, P, None), "table sizes")                # rows without a table
     bad(lib.vt_decode_feed(P, 12, 100, P, P, None, 0, 0, P, P, P, P, 2, None), "multiple of 8")
     bad(lib.vt_decode_feed(P, 64, 100, P, P, None, 2, 0, P, P, P, P, 2, None), "eos")
     bad(lib.vt_decode_feed(P, 64, 100, None, P, None, 0, 0, P, P, P, P, 2, None), "null")
     bad(lib.vt_flash_attn(P, 384, P, P, P, P, 1, 16, P, 128, 2, 48, 0, 1.0, None))                     # head_dim 48
     bad(lib.vt_attn_temporal(P, P, 1, 8, 16, 0, None))
-    bad(lib.vt_sample_top_p(P, 2, 100, 100, 0.0, 0.9, 0, 0, P, None, None))                            # temperature 0
+    bad(lib.vt_sample_top_p(P, 2, 100, 100, 0.0, 0, 0.9, 0, 0, P, None, None))                         # temperature 0
+    bad(lib.vt_sample_top_p(P, 2, 100, 100, 1.0, -3, 0.9, 0, 0, P, None, None), "top_k")
+    rw = _lib.VtRegionWeights()
+    rw.in_dim, rw.out_dim = 1024, 4096
+    bad(lib.vt_region_forward(C.byref(rw), P, P, P, 17, 24, 224, P, None, None, P, 1 << 24, None), "B=17")
+    bad(lib.vt_region_forward(C.byref(rw), P, P, P, 4, 24, 224, P, None, None, P, 1 << 24, None), "weight pointer")
     m = _lib.VtLlamaModel()
     m.hidden, m.heads, m.head_dim, m.intermediate, m.num_layers, m.vocab = 256, 4, 48, 512, 1, 100
     kv = _lib.VtKvCache()

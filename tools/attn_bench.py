@@ -46,7 +46,7 @@ def run(S, heads, hd, nseq, causal):
 
 
 if __name__ == "__main__":
-    _lib.load()
+    _lib.load(ablations=bool(os.environ.get("VT_FLASH_ABL") or os.environ.get("VT_FLASH_QBLK256")))   # the switches exist only in the test library
     run(5120, 32, 128, 1, True)
     run(1088, 32, 128, 1, True)
     run(577, 16, 64, 8, False)

@@ -25,8 +25,8 @@ vp = C.c_void_p
 
 
 class VtRegionWeights(C.Structure):
-    _fields_ = [("in_dim", C.c_int), ("out_dim", C.c_int), ("mlp_w", vp * 3), ("mlp_b", vp * 3),
-                ("loc_w", vp * 2), ("loc_b", vp * 2)]
+    _fields_ = [("in_dim", C.c_int), ("out_dim", C.c_int), ("mlp_w", vp * 2), ("mlp_b", vp * 2),
+                ("loc_w0", vp), ("loc_b0", vp), ("final_w", vp), ("final_b", vp)]
 
 
 class VtVitLayer(C.Structure):
@@ -51,7 +51,7 @@ class VtLlamaModel(C.Structure):
     _fields_ = [("hidden", C.c_int), ("heads", C.c_int), ("head_dim", C.c_int), ("intermediate", C.c_int),
                 ("num_layers", C.c_int), ("vocab", C.c_int), ("rms_eps", C.c_float), ("final_norm", vp),
                 ("lm_head", vp), ("rope_cos", vp), ("rope_sin", vp), ("rope_len", C.c_int),
-                ("layers", C.POINTER(VtLlamaLayer))]
+                ("layers", C.POINTER(VtLlamaLayer)), ("prefill_norm_fold", C.c_int)]
 
 
 class VtKvCache(C.Structure):
@@ -76,10 +76,10 @@ SIGNATURES = {
     "vt_im2col": (_i, [vp, _i, vp, _i, _i, _i, _i, _i, _i, _i, vp]),
     "vt_preprocess": (_i, [vp, _i, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _i, vp, _i, C.c_long,
                            C.c_long, vp]),
-    "vt_embed_splice": (_i, [vp, vp, vp, vp, _i, _i, vp, vp]),
+    "vt_embed_splice": (_i, [vp, _i, vp, _i, vp, _i, vp, _i, _i, vp, vp]),
     "vt_argmax": (_i, [vp, _i, _i, _i, vp, vp]),
     "vt_decode_feed": (_i, [vp, _i, _i, vp, vp, vp, _i, _i, vp, vp, vp, vp, _i, vp]),
-    "vt_sample_top_p": (_i, [vp, _i, _i, _i, _f, _f, C.c_uint64, C.c_uint64, vp, vp, vp]),
+    "vt_sample_top_p": (_i, [vp, _i, _i, _i, _f, _i, _f, C.c_uint64, C.c_uint64, vp, vp, vp]),
     "vt_projector_workspace_bytes": (_sz, [_i, _i]),
     "vt_projector_forward": (_i, [vp, _i, _i, vp, vp, _i, vp, vp, _i, vp, vp, _sz, vp]),
     "vt_region_workspace_bytes": (_sz, [_i, _i, _i]),
@@ -111,11 +111,23 @@ def _needs_build() -> bool:
     return max(p.stat().st_mtime for p in srcs) > LIB_PATH.stat().st_mtime
 
 
-def load(build_if_needed: bool = True):
-    """Load (building first when stale and hipcc is present) libvitron_hip.so. Raises if unavailable."""
+def load(build_if_needed: bool = True, ablations: bool = False):
+    """Load (building first when stale and hipcc is present) libvitron_hip.so. Raises if unavailable.
+    ablations=True (tools/ only, must be the FIRST load of the process): the -DVT_ABLATIONS build of the same sources,
+    libvitron_hip_abl.so, which also carries the timing-ablation kernels and their switches (vitron_amd/build.py)."""
     global _lib
     if _lib is not None:
         return _lib
+    if ablations:
+        from . import build as _build
+        import torch  # noqa: F401  (same runtime-ordering reason as below)
+        lib = C.CDLL(str(_build.build(ablations=True)))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
     if build_if_needed and _needs_build() and os.environ.get("VITRON_AMD_NO_BUILD") != "1":
         from . import build as _build
         try:

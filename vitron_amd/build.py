@@ -19,6 +19,10 @@ PKG_DIR = Path(__file__).resolve().parent
 CSRC = PKG_DIR / "csrc"
 INCLUDE = PKG_DIR.parent / "include"
 LIB_PATH = PKG_DIR / "libvitron_hip.so"
+# the SAME sources compiled with -DVT_ABLATIONS: timing-ablation / A-B variants of the GEMM and attention main loops (garbage
+# results by construction) and their environment switches. Only tools/ load it (vitron_amd._lib.load(ablations=True)); the
+# product library above contains none of that code.
+ABL_LIB_PATH = PKG_DIR / "libvitron_hip_abl.so"
 SOURCES = ["vt_api.hip", "vt_gemm.hip", "vt_gemm8.hip", "vt_norm.hip", "vt_attn.hip", "vt_vit.hip", "vt_region.hip", "vt_llama.hip", "vt_preproc.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
@@ -37,9 +41,9 @@ def _deps_mtime() -> float:
     return max(p.stat().st_mtime for p in hdrs)
 
 
-def _compile_one(src: Path, obj: Path, verbose: bool) -> None:
+def _compile_one(src: Path, obj: Path, verbose: bool, extra=()) -> None:
     tmp = obj.with_suffix(f".tmp{os.getpid()}.o")
-    cmd = [_hipcc(), *FLAGS, "-c", str(src), "-o", str(tmp)]
+    cmd = [_hipcc(), *FLAGS, *extra, "-c", str(src), "-o", str(tmp)]
     if verbose:
         print("[vitron_amd.build]", " ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -64,15 +68,18 @@ def _build_lock(bdir: Path):
             fcntl.flock(f, fcntl.LOCK_UN)
 
 
-def build(force: bool = False, verbose: bool = False) -> Path:
-    """Compile every HIP source for gfx950 and link libvitron_hip.so. Returns the library path."""
-    bdir = CSRC / "build"
+def build(force: bool = False, verbose: bool = False, ablations: bool = False) -> Path:
+    """Compile every HIP source for gfx950 and link libvitron_hip.so (ablations=True: the -DVT_ABLATIONS test library
+    libvitron_hip_abl.so instead). Returns the library path."""
+    bdir = CSRC / ("build_abl" if ablations else "build")
     bdir.mkdir(exist_ok=True)
     with _build_lock(bdir):
-        return _build_locked(bdir, force, verbose)
+        return _build_locked(bdir, force, verbose, ablations)
 
 
-def _build_locked(bdir: Path, force: bool, verbose: bool) -> Path:
+def _build_locked(bdir: Path, force: bool, verbose: bool, ablations: bool = False) -> Path:
+    LIB_PATH = ABL_LIB_PATH if ablations else globals()["LIB_PATH"]
+    extra = ("-DVT_ABLATIONS",) if ablations else ()
     hdr_m = _deps_mtime()
     todo = []
     objs = []
@@ -86,7 +93,7 @@ def _build_locked(bdir: Path, force: bool, verbose: bool) -> Path:
             todo.append((src, obj))
     if todo:
         with ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 4)) as ex:
-            list(ex.map(lambda so: _compile_one(so[0], so[1], verbose), todo))
+            list(ex.map(lambda so: _compile_one(so[0], so[1], verbose, extra), todo))
     if todo or not LIB_PATH.exists() or any(o.stat().st_mtime > LIB_PATH.stat().st_mtime for o in objs):
         tmp = LIB_PATH.with_suffix(f".tmp{os.getpid()}.so")
         cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *map(str, objs), "-o", str(tmp)]
@@ -102,5 +109,5 @@ def _build_locked(bdir: Path, force: bool, verbose: bool) -> Path:
 
 
 if __name__ == "__main__":
-    p = build(force="--force" in sys.argv, verbose=True)
+    p = build(force="--force" in sys.argv, verbose=True, ablations="--ablations" in sys.argv)
     print(p)

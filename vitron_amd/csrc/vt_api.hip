@@ -186,9 +186,9 @@ int vt_im2col(const void* pixels, int pix_dtype, uint16_t* patches, int B, int T
   return vt_im2col_launch(pixels, pix_dtype, patches, B, T, H, W, P, k_pad, video_layout, S(stream));
 }
 
-int vt_embed_splice(const uint16_t* tok_table, const uint16_t* vis, const uint16_t* reg, const int* plan, int rows,
-                    int H, uint16_t* out, void* stream) {
-  return vt_embed_splice_launch(tok_table, vis, reg, plan, rows, H, out, S(stream));
+int vt_embed_splice(const uint16_t* tok_table, int vocab, const uint16_t* vis, int vis_rows, const uint16_t* reg, int reg_rows,
+                    const int* plan, int rows, int H, uint16_t* out, void* stream) {
+  return vt_embed_splice_launch(tok_table, vocab, vis, vis_rows, reg, reg_rows, plan, rows, H, out, S(stream));
 }
 
 int vt_argmax(const float* logits, int rows, int V, int ldl, int* out_ids, void* stream) {
@@ -207,9 +207,9 @@ int vt_preprocess(const void* src, int src_u8, int hwc, int F, int H, int W, int
                               S_(stream));
 }
 
-int vt_sample_top_p(const float* logits, int rows, int V, int ldl, float temperature, float top_p, uint64_t seed,
+int vt_sample_top_p(const float* logits, int rows, int V, int ldl, float temperature, int top_k, float top_p, uint64_t seed,
                     uint64_t step, int* out_ids, int* kept_count, void* stream) {
-  return vt_sample_top_p_launch(logits, rows, V, ldl, temperature, top_p, seed, step, out_ids, kept_count, S(stream));
+  return vt_sample_top_p_launch(logits, rows, V, ldl, temperature, top_k, top_p, seed, step, out_ids, kept_count, S(stream));
 }
 
 // ---- mm_projector ---------------------------------------------------------------------------------------------------
@@ -237,10 +237,9 @@ int vt_projector_forward(const uint16_t* x, int M, int Din, const uint16_t* w1, 
 // ---- region_extractor ------------------------------------------------------------------------------------------------
 size_t vt_region_workspace_bytes(int B, int in_dim, int out_dim) {
   size_t n = 0;
-  n += align_up((size_t)B * in_dim * 2, 256);       // pooled
-  n += 2 * align_up((size_t)B * out_dim * 2, 256);  // h1, h2
-  n += align_up((size_t)B * (out_dim / 2) * 2, 256);  // loc hidden
-  n += align_up((size_t)B * out_dim * 4, 256);      // fp32 sum
+  n += align_up((size_t)B * in_dim * 2, 256);                       // pooled
+  n += align_up((size_t)B * out_dim * 2, 256);                      // h1
+  n += align_up((size_t)B * (out_dim + out_dim / 2) * 2, 256);      // [ h2 | location hidden ]
   return n + 1024;
 }
 
@@ -251,24 +250,25 @@ int vt_region_forward(const vt_region_weights* w, const uint16_t* feats, const i
   VT_REQUIRE(B > 0 && B <= 16, "vt_region_forward: B=%d (1..16 boxes per call)", B);
   hipStream_t s = S(stream);
   const int D = w->in_dim, H = w->out_dim;
+  VT_REQUIRE(D % 64 == 0 && H % 128 == 0, "vt_region_forward: in_dim %% 64 and out_dim %% 128 must be 0 (in=%d out=%d)", D, H);
+  VT_REQUIRE(w->mlp_w[0] && w->mlp_w[1] && w->loc_w0 && w->loc_b0 && w->final_w, "vt_region_forward: weight pointer missing");
+  const int KC = H + H / 2;
   Carver ws(workspace, workspace_bytes);
   bf16_t* pooled = (bf16_t*)ws.take((size_t)B * D * 2);
   bf16_t* h1 = (bf16_t*)ws.take((size_t)B * H * 2);
-  bf16_t* h2 = (bf16_t*)ws.take((size_t)B * H * 2);
-  bf16_t* l1 = (bf16_t*)ws.take((size_t)B * (H / 2) * 2);
-  float* acc = (float*)ws.take((size_t)B * H * 4);
+  bf16_t* cat = (bf16_t*)ws.take((size_t)B * KC * 2);
   if (!workspace || !ws.ok()) {
     vt_set_error("vt_region_forward: workspace too small (%zu < %zu)", workspace_bytes, ws.off);
     return VT_ERR_WORKSPACE;
   }
-  VT_TRY(vt_region_pool_launch(feats, slices, B, G, image_size, D, pooled, cell_mask, cell_count, s));
+  // 1: cell mask + count + masked mean + LocationEncoder layer 0 (into the right part of `cat`)
+  VT_TRY(vt_region_pool_launch(feats, slices, B, G, image_size, D, pooled, cell_mask, cell_count, coords, w->loc_w0, w->loc_b0,
+                               H / 2, cat + H, KC, s));
+  // 2-4: weight-streaming GEMMs; the last contracts [h2 | loc hidden] with [W2 | Wloc1]: MLP output + location embedding
   const int SK = VT_GEMM_CFG_SKINNY;
   VT_TRY(vt_gemm_launch(pooled, D, w->mlp_w[0], D, h1, H, w->mlp_b[0], B, H, D, VT_EPI_BF16_RELU, SK, s));
-  VT_TRY(vt_gemm_launch(h1, H, w->mlp_w[1], H, h2, H, w->mlp_b[1], B, H, H, VT_EPI_BF16_RELU, SK, s));
-  VT_TRY(vt_gemm_launch(h2, H, w->mlp_w[2], H, acc, H, w->mlp_b[2], B, H, H, VT_EPI_F32, SK, s));
-  VT_TRY(vt_gemm_launch(coords, 8, w->loc_w[0], 8, l1, H / 2, w->loc_b[0], B, H / 2, 8, VT_EPI_BF16_RELU, SK, s));
-  VT_TRY(vt_gemm_launch(l1, H / 2, w->loc_w[1], H / 2, acc, H, w->loc_b[1], B, H, H / 2, VT_EPI_F32_RESID, SK, s));
-  VT_TRY(vt_gather_f32_to_bf16_launch(acc, nullptr, out, B, H, s));
+  VT_TRY(vt_gemm_launch(h1, H, w->mlp_w[1], H, cat, KC, w->mlp_b[1], B, H, H, VT_EPI_BF16_RELU, SK, s));
+  VT_TRY(vt_gemm_launch(cat, KC, w->final_w, KC, out, H, w->final_b, B, H, KC, VT_EPI_BF16, SK, s));
   return VT_OK;
 }
 
@@ -434,12 +434,10 @@ int vt_llama_forward(const vt_llama_model* m, const vt_kv_cache* kv, const uint1
   // follow (gate_up, next layer's qkv) scale their rows by rstd. Only the first norm of layer 0 and the final norm stay
   // separate launches: 6 launches per layer -> 4.
   const bool fold_norm = rows <= 16 && max_q_len == 1 && (H % 1024) == 0 && H <= 8192 && (I % 64) == 0;
-  // Opt-in (VT_PREFILL_NORM_FOLD=1): measured neutral to slightly slower on the C3 step -- the 1.9 ms of RMSNorm
+  // Opt-in (vt_llama_model.prefill_norm_fold = 1): measured neutral to slightly slower on the C3 step -- the 1.9 ms of RMSNorm
   // launches it removes come back as longer residual epilogues (+12 us each: the y store), the finalize launches and ~1.5 %
   // slower consumer GEMMs (same code, un-normalised operands: the MFMA clock is data dependent on this power-limited part).
-  const char* fold_env = getenv("VT_PREFILL_NORM_FOLD");
-  const bool fold_tile_enabled = fold_env && fold_env[0] == '1';
-  const bool fold_tile = fold_tile_enabled && !fold_norm && vt_gemm_norm_fold_supported(rows, H, H) && (I % 64) == 0;
+  const bool fold_tile = m->prefill_norm_fold == 1 && !fold_norm && vt_gemm_norm_fold_supported(rows, H, H) && (I % 64) == 0;
   VtGemmNormFuse consume_a, consume_b, none;
   consume_a.in_partials = w.rs_a;
   consume_b.in_partials = w.rs_b;

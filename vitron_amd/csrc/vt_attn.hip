@@ -968,8 +968,12 @@ int vt_flash_attn_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf16_
   // long sequences: 256-row blocks, 3-stage ring; short ones (ViT frames, small prefills): 128-row blocks
   // measured (tools/attn_bench.py, S=5120 causal): 128-row blocks (2 per CU) 272 us vs 256-row blocks 288 us -- the finer
   // causal granularity wins; the 8-wave / 3-stage variant stays selectable for experiments
+#ifdef VT_ABLATIONS   // experiment switches exist only in the test library (python -m vitron_amd.build --ablations)
   static const int use_big = getenv("VT_FLASH_QBLK256") ? atoi(getenv("VT_FLASH_QBLK256")) : 0;
   const bool big = max_q_len >= 1024 && use_big;
+#else
+  (void)0;
+#endif
 #define VT_FA(HDV, CV, NW, NS, ...)                                                                            \
   do {                                                                                                         \
     auto kern = flash_attn_kernel<HDV, CV, NW, NS __VA_OPT__(,) __VA_ARGS__>;                                  \
@@ -984,14 +988,19 @@ int vt_flash_attn_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf16_
   } while (0)
   if (HD == 64) {
     if (causal) VT_FA(64, true, 4, 2); else VT_FA(64, false, 4, 2);
+#ifdef VT_ABLATIONS
   } else if (big) {
     if (causal) VT_FA(128, true, 8, 3); else VT_FA(128, false, 8, 3);
+#endif
   } else {
+#ifdef VT_ABLATIONS
     static const int abl = getenv("VT_FLASH_ABL") ? atoi(getenv("VT_FLASH_ABL")) : 0;   // timing ablations: VT_FLASH_ABL=1|2|3 python tools/attn_bench.py
     if (causal && abl == 1) VT_FA(128, true, 4, 2, 1);
     else if (causal && abl == 2) VT_FA(128, true, 4, 2, 2);
     else if (causal && abl == 3) VT_FA(128, true, 4, 2, 3);
-    else if (causal) VT_FA(128, true, 4, 2); else VT_FA(128, false, 4, 2);
+    else
+#endif
+    if (causal) VT_FA(128, true, 4, 2); else VT_FA(128, false, 4, 2);
   }
 #undef VT_FA
   VT_LAUNCH_CHECK();

@@ -826,11 +826,13 @@ int vt_gemm_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, 
   VT_REQUIRE((K % 64) == 0, "vt_gemm(tile): K=%d must be a multiple of 64", K);
   if (epi == VT_EPI_SWIGLU_BF16) VT_REQUIRE((N % 32) == 0, "vt_gemm(swiglu): N must be a multiple of 32");
   if (cfg == VT_GEMM_CFG_256x256_P8) return vt_gemm_p8_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, epi, s, nf);
+#ifdef VT_ABLATIONS   // timing ablations / main-loop A/B variants (results are garbage for 100..117): test library only
   if (cfg >= 111 && cfg < 118) return vt_gemm_p8_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, ((cfg - 110) << 8) | 0x1000, s);
-  if (cfg == VT_GEMM_CFG_256x256_P4) return vt_gemm_p8_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, epi | 0x1000, s, nf);
-  if (cfg == VT_GEMM_CFG_256x256_P4X) return vt_gemm_p8_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, epi | 0x2000, s, nf);
   if (cfg >= 100 && cfg < 108) return vt_gemm_p8_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, (cfg - 100) << 8, s);
   if (cfg >= 301 && cfg <= 303) return vt_gemm_rp_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, (cfg - 300) << 8, s);
+#endif
+  if (cfg == VT_GEMM_CFG_256x256_P4) return vt_gemm_p8_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, epi | 0x1000, s, nf);
+  if (cfg == VT_GEMM_CFG_256x256_P4X) return vt_gemm_p8_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, epi | 0x2000, s, nf);
   if (cfg == VT_GEMM_CFG_256x256_RP) return vt_gemm_rp_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, epi, s);
   switch (epi) {
     case VT_EPI_BF16: return launch_cfg<VT_EPI_BF16>(p, cfg, s);

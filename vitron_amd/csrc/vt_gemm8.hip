@@ -982,13 +982,15 @@ int vt_gemm_rp_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* 
   VT_REQUIRE((K % 64) == 0 && N % 32 == 0, "vt_gemm(rp): needs K %% 64 == 0 and N %% 32 == 0 (K=%d N=%d)", K, N);
   VT_REQUIRE((size_t)M * lda * 2 < (1ull << 32) && (size_t)N * ldw * 2 < (1ull << 32), "vt_gemm(rp): operands must be < 4 GiB");
   GemmP8 p{A, W, C, bias, M, N, K, lda, ldw, ldc, 1, 0, VtGemmNormFuse{}};
-  if (epi >= 0x100) {  // A/B variants of the main loop (bf16 epilogue only)
+#ifdef VT_ABLATIONS
+  if (epi >= 0x100) {  // A/B variants of the main loop (bf16 epilogue only); test library only
     switch (epi >> 8) {
       case 1: return launch_rp<VT_EPI_BF16, 1>(p, s);
       case 2: return launch_rp<VT_EPI_BF16, 2>(p, s);
       default: return launch_rp<VT_EPI_BF16, 3>(p, s);
     }
   }
+#endif
   switch (epi) {
     case VT_EPI_BF16: return launch_rp<VT_EPI_BF16>(p, s);
     case VT_EPI_BF16_GELU: return launch_rp<VT_EPI_BF16_GELU>(p, s);
@@ -1062,7 +1064,8 @@ int vt_gemm_p8_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* 
   if (p.nf.out_partials)
     VT_REQUIRE((epi & 0xff) == VT_EPI_F32_RESID && p.nf.out_w && p.nf.out_xw && p.nf.out_np >= N / 32 && p.nf.out_ldp >= M,
                "vt_gemm(p8): norm-fold producer needs the residual epilogue and its buffers");
-  if (epi >= 0x100 && !(epi & 0x1000)) {  // timing ablations (tools/gemm_ablate.py); not reachable through the public enums
+#ifdef VT_ABLATIONS
+  if (epi >= 0x100 && !(epi & 0x3000)) {  // timing ablations (tools/gemm_ablate.py); test library only
     switch (epi >> 8) {
       case 1: return launch_p8<VT_EPI_BF16, 1>(p, s);
       case 2: return launch_p8<VT_EPI_BF16, 2>(p, s);
@@ -1084,6 +1087,7 @@ int vt_gemm_p8_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* 
       default: return launch_p8<VT_EPI_BF16, 7, true>(p, s);
     }
   }
+#endif
   if (epi & 0x2000) {   // 4-phase schedule on the 32x32x16 instruction (no norm-fold producer side)
     VT_REQUIRE(!p.nf.out_partials, "vt_gemm(p4x): the norm-fold producer epilogue lives in the 16x16x32 kernel");
     switch (epi & 0xff) {

@@ -103,17 +103,20 @@ int vt_attn_decode_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf16
 int vt_attn_temporal_launch(const bf16_t* qkv, bf16_t* out, int B, int T, int N, int heads, hipStream_t s);
 
 // ---- vt_region.hip --------------------------------------------------------------------------------
+// cell mask / count / masked mean per (box, 64-channel slab); optionally also LocationEncoder layer 0:
+// loc_out[b][n] = bf16(relu(coords[b][0..4) . loc_w0[n][0..4) + loc_b0[n])), n < loc_n
 int vt_region_pool_launch(const bf16_t* feats, const int* slices, int B, int G, int image_size, int D,
-                          bf16_t* pooled, int* cell_mask, int* cell_count, hipStream_t s);
+                          bf16_t* pooled, int* cell_mask, int* cell_count, const bf16_t* coords, const bf16_t* loc_w0,
+                          const float* loc_b0, int loc_n, bf16_t* loc_out, int ld_loc, hipStream_t s);
 
 // ---- vt_llama.hip ---------------------------------------------------------------------------------
-int vt_embed_splice_launch(const bf16_t* tok_table, const bf16_t* vis, const bf16_t* reg, const int* plan,
-                           int rows, int H, bf16_t* out, hipStream_t s);
+int vt_embed_splice_launch(const bf16_t* tok_table, int vocab, const bf16_t* vis, int vis_rows, const bf16_t* reg, int reg_rows,
+                           const int* plan, int rows, int H, bf16_t* out, hipStream_t s);
 int vt_argmax_launch(const float* logits, int rows, int V, int ldl, int* out_ids, hipStream_t s);
 int vt_decode_feed_launch(const bf16_t* tok_table, int H, int vocab, const int* next_ids, int* finished, const int* eos_ids,
                           int n_eos, int pad_id, int* tokens_out, bf16_t* x, int* seq_desc, int* positions, int nseq,
                           hipStream_t s);
-int vt_sample_top_p_launch(const float* logits, int rows, int V, int ldl, float temperature, float top_p, uint64_t seed,
+int vt_sample_top_p_launch(const float* logits, int rows, int V, int ldl, float temperature, int top_k, float top_p, uint64_t seed,
                            uint64_t step, int* out_ids, int* kept_count, hipStream_t s);
 
 // ---- vt_preproc.hip -------------------------------------------------------------------------------

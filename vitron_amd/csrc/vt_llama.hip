@@ -16,16 +16,18 @@ __global__ __launch_bounds__(256) void embed_splice_kernel(const bf16_t* __restr
                                                            const bf16_t* __restrict__ vis,
                                                            const bf16_t* __restrict__ reg,
                                                            const int* __restrict__ plan, int rows, int H,
-                                                           bf16_t* __restrict__ out) {
+                                                           bf16_t* __restrict__ out, int vocab, int vis_rows, int reg_rows) {
   const int chunks = H >> 3;  // 16-B chunks per row
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)rows * chunks;
        i += (long)gridDim.x * blockDim.x) {
     const int r = (int)(i / chunks), c = (int)(i % chunks);
     const int kind = plan[2 * r], idx = plan[2 * r + 1];
     u32x4 v = {0u, 0u, 0u, 0u};
-    if (kind == 0) v = *(const u32x4*)(tok_table + (size_t)idx * H + c * 8);
-    else if (kind == 1) v = *(const u32x4*)(vis + (size_t)idx * H + c * 8);
-    else if (kind == 2) v = *(const u32x4*)(reg + (size_t)idx * H + c * 8);
+    // an index outside its table (a stray sentinel, an id >= the embedding rows) yields a zero row, never an out-of-bounds read;
+    // the host mirror range-checks ids and raises like the reference's nn.Embedding would (vitron_amd/model/llava_arch.py)
+    if (kind == 0 && (unsigned)idx < (unsigned)vocab) v = *(const u32x4*)(tok_table + (size_t)idx * H + c * 8);
+    else if (kind == 1 && (unsigned)idx < (unsigned)vis_rows) v = *(const u32x4*)(vis + (size_t)idx * H + c * 8);
+    else if (kind == 2 && (unsigned)idx < (unsigned)reg_rows) v = *(const u32x4*)(reg + (size_t)idx * H + c * 8);
     *(u32x4*)(out + (size_t)r * H + c * 8) = v;
   }
 }
@@ -133,8 +135,16 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
   return x ^ (x >> 31);
 }
 
+// monotone map float -> uint32 (a < b  <=>  key(a) < key(b)); -inf maps below every finite value
+__device__ __forceinline__ uint32_t order_key(float x) {
+  const uint32_t u = __float_as_uint(x);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// TopKLogitsWarper (transformers 4.31: scores < topk(scores, k)[..., -1] are removed, ties with the k-th value stay): the
+// k-th largest scaled logit is found exactly by bisection on the ordered bit pattern (32 counting passes), no sort.
 __global__ __launch_bounds__(1024) void sample_top_p_kernel(const float* __restrict__ logits, int V, int ldl,
-                                                            float inv_temp, float top_p, uint64_t seed, uint64_t step,
+                                                            float inv_temp, int top_k, float top_p, uint64_t seed, uint64_t step,
                                                             int* __restrict__ out_ids, int* __restrict__ kept_count) {
   __shared__ float sh[16];
   __shared__ float sh_scan[16];
@@ -143,8 +153,22 @@ __global__ __launch_bounds__(1024) void sample_top_p_kernel(const float* __restr
   float mx = -INFINITY;
   for (int i = tid; i < V; i += 1024) mx = fmaxf(mx, row[i] * inv_temp);
   mx = block_max_1024(mx, sh);
+  float floor_logit = -INFINITY;   // scaled logits below this are outside the top-k set
+  if (top_k > 0 && top_k < V) {
+    uint64_t lo = 0, hi = 0x100000000ull;   // invariant: count(key >= lo) >= k, count(key >= hi) < k
+    for (int it = 0; it < 32; ++it) {
+      const uint64_t mid = lo + ((hi - lo) >> 1);
+      float c = 0.f;
+      for (int i = tid; i < V; i += 1024) c += ((uint64_t)order_key(row[i] * inv_temp) >= mid) ? 1.f : 0.f;
+      c = block_sum_1024(c, sh);
+      if (c >= (float)top_k) lo = mid; else hi = mid;
+    }
+    const uint32_t k32 = (uint32_t)lo;
+    floor_logit = __uint_as_float((k32 & 0x80000000u) ? (k32 & 0x7fffffffu) : ~k32);
+  }
+#define VT_P_OF(i) ((row[i] * inv_temp >= floor_logit) ? __expf(row[i] * inv_temp - mx) : 0.f)
   float z = 0.f;
-  for (int i = tid; i < V; i += 1024) z += __expf(row[i] * inv_temp - mx);
+  for (int i = tid; i < V; i += 1024) z += VT_P_OF(i);
   z = block_sum_1024(z, sh);
   const float inv_z = 1.f / z;
   // bisection on the threshold t in (0, 1]: mass(t) = sum of p_i with p_i >= t is non-increasing in t.
@@ -154,7 +178,7 @@ __global__ __launch_bounds__(1024) void sample_top_p_kernel(const float* __restr
     const float mid = 0.5f * (lo + hi);
     float m = 0.f;
     for (int i = tid; i < V; i += 1024) {
-      const float p = __expf(row[i] * inv_temp - mx) * inv_z;
+      const float p = VT_P_OF(i) * inv_z;
       if (p >= mid) m += p;
     }
     m = block_sum_1024(m, sh);
@@ -163,7 +187,7 @@ __global__ __launch_bounds__(1024) void sample_top_p_kernel(const float* __restr
   const float thr = (top_p >= 1.f) ? 0.f : fminf(lo, inv_z);   // inv_z = probability of the arg-max token: always kept
   float kept = 0.f, cnt = 0.f;
   for (int i = tid; i < V; i += 1024) {
-    const float p = __expf(row[i] * inv_temp - mx) * inv_z;
+    const float p = VT_P_OF(i) * inv_z;
     if (p >= thr) {
       kept += p;
       cnt += 1.f;
@@ -179,7 +203,7 @@ __global__ __launch_bounds__(1024) void sample_top_p_kernel(const float* __restr
   const int i0 = tid * chunk, i1 = min(V, i0 + chunk);
   float mine = 0.f;
   for (int i = i0; i < i1; ++i) {
-    const float p = __expf(row[i] * inv_temp - mx) * inv_z;
+    const float p = VT_P_OF(i) * inv_z;
     if (p >= thr) mine += p;
   }
   // exclusive prefix over threads: wave scan + scan of the 16 wave totals
@@ -203,7 +227,7 @@ __global__ __launch_bounds__(1024) void sample_top_p_kernel(const float* __restr
     float c = excl;
     int pick = -1;
     for (int i = i0; i < i1; ++i) {
-      const float p = __expf(row[i] * inv_temp - mx) * inv_z;
+      const float p = VT_P_OF(i) * inv_z;
       if (p >= thr) {
         pick = i;
         c += p;
@@ -216,18 +240,19 @@ __global__ __launch_bounds__(1024) void sample_top_p_kernel(const float* __restr
   if (chosen < 0 && mine > 0.f) {  // u landed on a rounding seam: take the last kept token of the highest owning range
     int last = -1;
     for (int i = i0; i < i1; ++i)
-      if (__expf(row[i] * inv_temp - mx) * inv_z >= thr) last = i;
+      if (VT_P_OF(i) * inv_z >= thr) last = i;
     atomicMax(&chosen, last);
   }
   __syncthreads();
   if (tid == 0) out_ids[blockIdx.x] = chosen;
 }
+#undef VT_P_OF
 
 // Same rule with the row held in registers (V <= 32 * 1024): every thread owns 32 consecutive logits, computes their
 // exponentials ONCE, and the 30 bisection passes, the kept-mass pass and the inverse-CDF walk never touch memory again.
 // 165 us -> ~20 us per call at V = 32000 (tools/sampler_bench.py).
 __global__ __launch_bounds__(1024) void sample_top_p_reg_kernel(const float* __restrict__ logits, int V, int ldl,
-                                                                float inv_temp, float top_p, uint64_t seed, uint64_t step,
+                                                                float inv_temp, int top_k, float top_p, uint64_t seed, uint64_t step,
                                                                 int* __restrict__ out_ids, int* __restrict__ kept_count) {
   constexpr int NPT = 32;
   __shared__ float sh[2][16];
@@ -275,10 +300,23 @@ __global__ __launch_bounds__(1024) void sample_top_p_reg_kernel(const float* __r
     mx = t;
     buf ^= 1;
   }
+  if (top_k > 0 && top_k < V) {   // TopKLogitsWarper: everything below the k-th largest scaled logit leaves the distribution
+    uint64_t lo = 0, hi = 0x100000000ull;
+    for (int it = 0; it < 32; ++it) {
+      const uint64_t mid = lo + ((hi - lo) >> 1);
+      float c = 0.f;
+#pragma unroll
+      for (int j = 0; j < NPT; ++j) c += ((uint64_t)order_key(p[j]) >= mid) ? 1.f : 0.f;
+      c = block_sum(c);
+      if (c >= (float)top_k) lo = mid; else hi = mid;
+    }
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) p[j] = ((uint64_t)order_key(p[j]) >= lo) ? p[j] : -INFINITY;
+  }
   float zl = 0.f;
 #pragma unroll
   for (int j = 0; j < NPT; ++j) {
-    p[j] = __expf(p[j] - mx);     // exp(-inf) = 0 for the slots past V
+    p[j] = __expf(p[j] - mx);     // exp(-inf) = 0 for the slots past V and outside the top-k set
     zl += p[j];
   }
   const float z = block_sum(zl);
@@ -351,27 +389,29 @@ __global__ __launch_bounds__(1024) void sample_top_p_reg_kernel(const float* __r
 
 }  // namespace
 
-int vt_sample_top_p_launch(const float* logits, int rows, int V, int ldl, float temperature, float top_p, uint64_t seed,
+int vt_sample_top_p_launch(const float* logits, int rows, int V, int ldl, float temperature, int top_k, float top_p, uint64_t seed,
                            uint64_t step, int* out_ids, int* kept_count, hipStream_t s) {
   VT_REQUIRE(logits && out_ids && rows > 0 && V > 0, "vt_sample_top_p: bad arguments");
-  VT_REQUIRE(temperature > 0.f && top_p > 0.f, "vt_sample_top_p: temperature and top_p must be > 0");
+  VT_REQUIRE(temperature > 0.f && top_p > 0.f && top_k >= 0, "vt_sample_top_p: temperature and top_p must be > 0, top_k >= 0");
   if (V <= 32 * 1024 && (ldl % 4) == 0 && ((uintptr_t)logits % 16) == 0)
-    hipLaunchKernelGGL(sample_top_p_reg_kernel, dim3(rows), dim3(1024), 0, s, logits, V, ldl, 1.0f / temperature, top_p, seed, step,
-                       out_ids, kept_count);
+    hipLaunchKernelGGL(sample_top_p_reg_kernel, dim3(rows), dim3(1024), 0, s, logits, V, ldl, 1.0f / temperature, top_k, top_p, seed,
+                       step, out_ids, kept_count);
   else
-    hipLaunchKernelGGL(sample_top_p_kernel, dim3(rows), dim3(1024), 0, s, logits, V, ldl, 1.0f / temperature, top_p, seed, step,
-                       out_ids, kept_count);
+    hipLaunchKernelGGL(sample_top_p_kernel, dim3(rows), dim3(1024), 0, s, logits, V, ldl, 1.0f / temperature, top_k, top_p, seed,
+                       step, out_ids, kept_count);
   VT_LAUNCH_CHECK();
   return VT_OK;
 }
 
-int vt_embed_splice_launch(const bf16_t* tok_table, const bf16_t* vis, const bf16_t* reg, const int* plan, int rows,
-                           int H, bf16_t* out, hipStream_t s) {
+int vt_embed_splice_launch(const bf16_t* tok_table, int vocab, const bf16_t* vis, int vis_rows, const bf16_t* reg, int reg_rows,
+                           const int* plan, int rows, int H, bf16_t* out, hipStream_t s) {
   VT_REQUIRE(tok_table && plan && out, "vt_embed_splice: null pointer");
+  VT_REQUIRE(vocab > 0 && vis_rows >= 0 && reg_rows >= 0 && (vis || vis_rows == 0) && (reg || reg_rows == 0),
+             "vt_embed_splice: table sizes (vocab=%d vis_rows=%d reg_rows=%d)", vocab, vis_rows, reg_rows);
   VT_REQUIRE(rows > 0 && H % 8 == 0, "vt_embed_splice: rows=%d H=%d (H must be a multiple of 8)", rows, H);
   const long total = (long)rows * (H / 8);
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-  hipLaunchKernelGGL(embed_splice_kernel, dim3(blocks), dim3(256), 0, s, tok_table, vis, reg, plan, rows, H, out);
+  hipLaunchKernelGGL(embed_splice_kernel, dim3(blocks), dim3(256), 0, s, tok_table, vis, reg, plan, rows, H, out, vocab, vis_rows, reg_rows);
   VT_LAUNCH_CHECK();
   return VT_OK;
 }

@@ -249,16 +249,18 @@ class PackedRegion:
         self.in_dim = sd["region_linear.layers.0.weight"].shape[1]
         self.out_dim = sd["region_linear.layers.2.weight"].shape[0]
         w.in_dim, w.out_dim = self.in_dim, self.out_dim
-        for i in range(3):
+        for i in range(2):
             wt, bt = _bf(sd[f"region_linear.layers.{i}.weight"], device), _f32(sd[f"region_linear.layers.{i}.bias"], device)
             self._keep += [wt, bt]
             w.mlp_w[i], w.mlp_b[i] = wt.data_ptr(), bt.data_ptr()
         l0 = torch.zeros((self.out_dim // 2, 8), dtype=torch.bfloat16, device=device)  # K padded 4 -> 8
         l0[:, :4] = _bf(sd["loc_encoder.loc_encoder.0.weight"], device)
         l0b = _f32(sd["loc_encoder.loc_encoder.0.bias"], device)
-        l1, l1b = _bf(sd["loc_encoder.loc_encoder.2.weight"], device), _f32(sd["loc_encoder.loc_encoder.2.bias"], device)
-        self._keep += [l0, l0b, l1, l1b]
-        w.loc_w[0], w.loc_b[0], w.loc_w[1], w.loc_b[1] = l0.data_ptr(), l0b.data_ptr(), l1.data_ptr(), l1b.data_ptr()
+        # region_linear's last layer and LocationEncoder's last layer are added (layer.py:129): one GEMM over [h2 | loc hidden]
+        fw = torch.cat([_bf(sd["region_linear.layers.2.weight"], device), _bf(sd["loc_encoder.loc_encoder.2.weight"], device)], 1).contiguous()
+        fb = (_f32(sd["region_linear.layers.2.bias"], device) + _f32(sd["loc_encoder.loc_encoder.2.bias"], device)).contiguous()
+        self._keep += [l0, l0b, fw, fb]
+        w.loc_w0, w.loc_b0, w.final_w, w.final_b = l0.data_ptr(), l0b.data_ptr(), fw.data_ptr(), fb.data_ptr()
         self.weights = w
         self.ws = Workspace(device)
 
@@ -313,7 +315,15 @@ class PackedLlama:
         self.device = torch.device(device)
         H, heads = cfg["hidden_size"], cfg["num_attention_heads"]
         self.H, self.heads, self.hd = H, heads, H // heads
-        self.I, self.V, self.L = cfg["intermediate_size"], cfg["vocab_size"], cfg["num_hidden_layers"]
+        self.I, self.L = cfg["intermediate_size"], cfg["num_hidden_layers"]
+        # the vocabulary is what the TENSORS say (a LoRA adapter's config can name more rows than a 32 000-row base has,
+        # reference builder.py:57-61; resize_token_embeddings adds rows after loading, :146): never index past them
+        emb_w, head_w = sd["model.embed_tokens.weight"], sd["lm_head.weight"]
+        if emb_w.dim() != 2 or head_w.dim() != 2 or emb_w.shape[1] != H or head_w.shape[1] != H:
+            raise _lib.VitronHipError(f"PackedLlama: embed_tokens {tuple(emb_w.shape)} / lm_head {tuple(head_w.shape)} do not match hidden_size {H}")
+        self.V = int(head_w.shape[0])
+        self.embed_rows = int(emb_w.shape[0])
+        self.V_pad = (self.V + 3) // 4 * 4     # the logits GEMM wants N % 4 == 0: zero rows behind the vocabulary, never returned
         if self.hd not in (64, 128):
             raise _lib.VitronHipError("PackedLlama: head_dim must be 64 or 128")
         if self.I % 16:
@@ -327,13 +337,22 @@ class PackedLlama:
 
         self.embed = keep(_bf(sd["model.embed_tokens.weight"], dev))
         self.final_norm = keep(_f32(sd["model.norm.weight"], dev))
-        self.lm_head = keep(_bf(sd["lm_head.weight"], dev))
+        head = _bf(sd["lm_head.weight"], dev)
+        if self.V_pad != self.V:
+            head = torch.cat([head, torch.zeros((self.V_pad - self.V, H), dtype=torch.bfloat16, device=dev)], 0).contiguous()
+        self.lm_head = keep(head)
         self.rope_len = int(rope_len or max(cfg.get("max_position_embeddings", 4096), 8192))
         self.rope_cos, self.rope_sin = rope_tables(self.hd, self.rope_len, float(cfg.get("rope_theta", 10000.0)), dev)
         self.layers = (_lib.VtLlamaLayer * self.L)()
         for l in range(self.L):
             p = f"model.layers.{l}."
             Ly = self.layers[l]
+            want = {"self_attn.q_proj": (H, H), "self_attn.k_proj": (H, H), "self_attn.v_proj": (H, H), "self_attn.o_proj": (H, H),
+                    "mlp.gate_proj": (self.I, H), "mlp.up_proj": (self.I, H), "mlp.down_proj": (H, self.I),
+                    "input_layernorm": (H,), "post_attention_layernorm": (H,)}
+            for name, shp in want.items():
+                if tuple(sd[p + name + ".weight"].shape) != shp:
+                    raise _lib.VitronHipError(f"PackedLlama: {p}{name}.weight is {tuple(sd[p + name + '.weight'].shape)}, config says {shp}")
             Ly.rms1 = keep(_f32(sd[p + "input_layernorm.weight"], dev)).data_ptr()
             Ly.rms2 = keep(_f32(sd[p + "post_attention_layernorm.weight"], dev)).data_ptr()
             wqkv = torch.cat([_bf(sd[p + "self_attn.q_proj.weight"], dev), _bf(sd[p + "self_attn.k_proj.weight"], dev),
@@ -343,13 +362,18 @@ class PackedLlama:
             Ly.wgu = keep(interleave_gate_up(_bf(sd[p + "mlp.gate_proj.weight"], dev), _bf(sd[p + "mlp.up_proj.weight"], dev)).contiguous()).data_ptr()
             Ly.wdown = keep(_bf(sd[p + "mlp.down_proj.weight"], dev)).data_ptr()
         m = _lib.VtLlamaModel()
-        m.hidden, m.heads, m.head_dim, m.intermediate, m.num_layers, m.vocab = H, heads, self.hd, self.I, self.L, self.V
+        m.hidden, m.heads, m.head_dim, m.intermediate, m.num_layers, m.vocab = H, heads, self.hd, self.I, self.L, self.V_pad
         m.rms_eps = float(cfg.get("rms_norm_eps", 1e-5))
         m.final_norm, m.lm_head = self.final_norm.data_ptr(), self.lm_head.data_ptr()
         m.rope_cos, m.rope_sin, m.rope_len = self.rope_cos.data_ptr(), self.rope_sin.data_ptr(), self.rope_len
         m.layers = C.cast(self.layers, C.POINTER(_lib.VtLlamaLayer))
+        m.prefill_norm_fold = int(bool(cfg.get("prefill_norm_fold", False)))
         self.model = m
         self.ws = Workspace(dev)
+
+    def set_prefill_norm_fold(self, on: bool) -> None:
+        """RMSNorm folded into the prefill tile GEMMs (vt_llama_model.prefill_norm_fold; measured neutral, default off)."""
+        self.model.prefill_norm_fold = int(bool(on))
 
 
 class PagedKVCache:
@@ -423,7 +447,7 @@ def llama_forward(llama: PackedLlama, kv: PagedKVCache, seqs: Sequence[SequenceS
         logit_rows = [d[0] + d[1] - 1 for d in desc]
     n_logit = len(logit_rows)
     lr_t = torch.tensor(list(logit_rows), dtype=torch.int32, device=dev) if n_logit else None
-    logits = torch.empty((n_logit, llama.V), dtype=torch.float32, device=dev) if n_logit else None
+    logits = torch.empty((n_logit, llama.V_pad), dtype=torch.float32, device=dev) if n_logit else None
     hidden = torch.empty((rows, llama.H), dtype=torch.float32, device=dev) if return_hidden else None
     max_kv = max(d[2] for d in desc)
     ws = llama.ws.get(lib.vt_llama_workspace_bytes(C.byref(llama.model), rows, n_logit, len(desc), max_kv))
@@ -435,6 +459,8 @@ def llama_forward(llama: PackedLlama, kv: PagedKVCache, seqs: Sequence[SequenceS
                "vt_llama_forward")
     for s, q in zip(seqs, q_lens):
         s.length += q
+    if logits is not None and llama.V_pad != llama.V:
+        logits = logits[:, :llama.V]               # rows keep the padded stride; the kernels take (V, row stride)
     if return_hidden:
         return logits, hidden
     return logits
@@ -509,7 +535,7 @@ class DecodeState:
                 raise _lib.VitronHipError(f"llama_forward: position {s.length} beyond rope table ({llama.rope_len})")
             if s.length + 1 > len(s.pages) * PAGE_TOKENS:
                 raise _lib.VitronHipError("DecodeState.forward: more steps than pages were reserved for")
-        logits = torch.empty((B, llama.V), dtype=torch.float32, device=llama.device)
+        logits = torch.empty((B, llama.V_pad), dtype=torch.float32, device=llama.device)
         ws = llama.ws.get(lib.vt_llama_workspace_bytes(C.byref(llama.model), B, B, B, self.max_len))
         _lib.check(lib.vt_llama_forward(C.byref(llama.model), C.byref(self.kv.struct), self.x.data_ptr(), B, self.pos.data_ptr(),
                                         self.desc.data_ptr(), B, 1, 1, int(self.max_len), self.table.data_ptr(),
@@ -518,7 +544,7 @@ class DecodeState:
         for s in self.seqs:
             s.length += 1
         self.passes += 1
-        return logits
+        return logits if llama.V_pad == llama.V else logits[:, :llama.V]
 
     def rollback(self) -> None:
         """Forget the last pass (its token should not have been fed): the cache slot is simply overwritten later."""

@@ -20,9 +20,8 @@ import torch
 
 from .language_model.llava_llama import LlavaConfig, LlavaLlamaForCausalLM
 
-DEFAULT_IMAGE_PATCH_TOKEN = "<im_patch>"
-DEFAULT_IM_START_TOKEN = "<im_start>"
-DEFAULT_IM_END_TOKEN = "<im_end>"
+from ..constants import (DEFAULT_IM_END_TOKEN, DEFAULT_IM_START_TOKEN, DEFAULT_IMAGE_PATCH_TOKEN, DEFAULT_VID_END_TOKEN,
+                         DEFAULT_VID_START_TOKEN, DEFAULT_VIDEO_PATCH_TOKEN)
 
 
 def _load_weight_files(path):
@@ -123,7 +122,22 @@ def load_pretrained_model(model_path, model_base, model_name, load_8bit=False, l
         sd = _merge_llm_lora(sd, ad, float(acfg.get("lora_alpha", 16)), acfg.get("r"))
     else:
         sd = _load_weight_files(model_path)
+    # a LoRA adapter's config may name more vocabulary rows than the base checkpoint holds: the reference re-creates lm_head /
+    # embed_tokens at config size (builder.py:57-61, uninitialised rows that non_lora_trainables.bin may fill) -- zero rows here
+    for key in ("model.embed_tokens.weight", "lm_head.weight"):
+        if key in sd and sd[key].shape[0] < cfg.vocab_size:
+            w = sd[key]
+            sd[key] = torch.cat([w, torch.zeros((cfg.vocab_size - w.shape[0], w.shape[1]), dtype=w.dtype)], 0)
     model.load_state_dict(sd, strict=False)
+    # special tokens + embedding resize, reference builder.py:136-146
+    if tokenizer is not None and hasattr(tokenizer, "add_tokens"):
+        if getattr(cfg, "mm_use_im_patch_token", True):
+            tokenizer.add_tokens([DEFAULT_IMAGE_PATCH_TOKEN], special_tokens=True)
+            tokenizer.add_tokens([DEFAULT_VIDEO_PATCH_TOKEN], special_tokens=True)
+        if getattr(cfg, "mm_use_im_start_end", False):
+            tokenizer.add_tokens([DEFAULT_IM_START_TOKEN, DEFAULT_IM_END_TOKEN], special_tokens=True)
+            tokenizer.add_tokens([DEFAULT_VID_START_TOKEN, DEFAULT_VID_END_TOKEN], special_tokens=True)
+        model.resize_token_embeddings(len(tokenizer))
     # towers (reference builder.py:149-163): LanguageBind checkpoint directories named by the config
     for get in (model.get_image_tower, model.get_video_tower):
         t = get()

@@ -78,6 +78,12 @@ class LlavaLlamaModel(LlavaMetaModel):
         return self.llama.embed
 
     def embed_tokens(self, ids: torch.Tensor) -> torch.Tensor:
+        """nn.Embedding forward. Like the reference's, an id outside the table is an error (IndexError), checked on a host
+        copy of the ids (prompts only: the decode loop feeds tokens through vt_decode_feed, which cannot leave the table)."""
+        host = ids.detach().reshape(-1).cpu()
+        if host.numel() and (int(host.min()) < 0 or int(host.max()) >= self.llama.embed_rows):
+            bad = int(host.min()) if int(host.min()) < 0 else int(host.max())
+            raise IndexError(f"embed_tokens: token id {bad} outside the embedding table ({self.llama.embed_rows} rows)")
         flat = ids.reshape(-1).to(device=self.llama.device, dtype=torch.int32)
         plan = torch.stack([torch.zeros_like(flat), flat], dim=1).contiguous()
         return ops.embed_splice(self.llama.embed, None, None, plan).view(*ids.shape, -1)
@@ -133,7 +139,33 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
         if llm:
             self._llama_sd = llm
             self.model.llama = None
+        self.reset_prefix_cache()        # cached visual tokens / KV pages belong to the previous weights
         return [], []
+
+    def resize_token_embeddings(self, new_num_tokens: Optional[int] = None):
+        """PreTrainedModel.resize_token_embeddings as reference builder.py:146 calls it after tokenizer.add_tokens: embed_tokens
+        and lm_head get `new_num_tokens` rows (old rows kept, new rows ZERO -- transformers draws them from N(0, 0.02^2); they are
+        the untrained <im_patch> / <vi_patch> placeholders that never reach the model, a zero row gives them logit 0), and
+        config.vocab_size follows."""
+        if new_num_tokens is None:
+            return self
+        n = int(new_num_tokens)
+        sd = self._llama_sd
+        if sd is None:
+            if self.model.llama is None:
+                raise RuntimeError("resize_token_embeddings: load weights first")
+            raise RuntimeError("resize_token_embeddings: call it before .to(device) packs the weights (load_pretrained_model does)")
+        for key in ("model.embed_tokens.weight", "lm_head.weight"):
+            w = sd[key]
+            if w.shape[0] == n:
+                continue
+            out = torch.zeros((n, w.shape[1]), dtype=w.dtype, device=w.device)
+            keep = min(n, w.shape[0])
+            out[:keep] = w[:keep]
+            sd[key] = out
+        self.config.vocab_size = n
+        self.vocab_size = n
+        return self
 
     def to(self, device=None, dtype=None):
         if device is None:
@@ -242,9 +274,9 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
         logits_p, hidden = llama_forward(llama, past.kv, seqs, flat, lens, logit_rows=list(range(rows)), return_hidden=True)
         if len(idx) != B * S:
             logits = torch.zeros((B * S, llama.V), dtype=torch.float32, device=flat.device)
-            logits.index_copy_(0, torch.tensor(idx, device=flat.device), logits_p)
+            logits.index_copy_(0, torch.tensor(idx, device=flat.device), logits_p.contiguous())
         else:
-            logits = logits_p
+            logits = logits_p.contiguous()
         logits = logits.view(B, S, llama.V)
         loss = None
         if labels is not None:  # shifted cross entropy, ignore_index -100 (LlamaForCausalLM.forward)
@@ -290,11 +322,11 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
         pad = pad_token_id if pad_token_id is not None else (self.config.pad_token_id if self.config.pad_token_id is not None else 0)
         if max_new_tokens is None:
             max_new_tokens = (max_length - input_ids.shape[1]) if max_length else 20
-        gen = None
-        sample_seed = int(seed) if seed is not None else int(torch.seed() % (2 ** 31))
+        # seed of the counter-based sampler: drawn from torch's global CPU generator (so torch.manual_seed makes sampling
+        # reproducible, as with GenerationMixin.sample) and only when sampling -- greedy calls leave the RNG state alone
+        sample_seed = 0
         if do_sample:
-            gen = torch.Generator(device=dev)
-            gen.manual_seed(sample_seed)
+            sample_seed = int(seed) if seed is not None else int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
 
         reuse = B == 1 and bool(getattr(self.config, "kv_prefix_reuse", True))
         cache = None
@@ -308,6 +340,7 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
         (_, _, _, _, embeds, _) = self.prepare_inputs_labels_for_multimodal(input_ids, None, attention_mask, None, None,
                                                                             images, regions, feature_cache=cache)
         llama = self.model.llama
+        embeds_spliced = embeds is not None
         if embeds is None:
             embeds = self.model.embed_tokens(input_ids)
             mask_host = attention_mask.to(torch.int32).tolist() if attention_mask is not None else [[1] * input_ids.shape[1]] * B
@@ -329,9 +362,15 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
             from ...prefix_cache import reusable_tokens
             if self._last_row_sig is not None:
                 sig = self._last_row_sig[0][np.asarray(mask_host[0], dtype=bool)]
+            elif embeds_spliced:
+                # visual rows were spliced in without the feature cache (config.vis_cache_entries = 0): there is no per-row
+                # signature of the spliced sequence, so this call neither reuses nor leaves a KV prefix
+                reuse = False
+                if self._prefix is not None:
+                    self.reset_prefix_cache()
             else:
                 sig = input_ids[0].cpu().numpy().astype(np.int64)[np.asarray(mask_host[0], dtype=bool)]
-            if self._prefix is not None:
+            if reuse and self._prefix is not None:
                 kept = reusable_tokens(self._prefix.sig, sig) if self.kv is not None else 0
                 seqs[0].pages = self._prefix.pages[:kept // 64]
                 seqs[0].length = kept
@@ -362,10 +401,8 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
             for step in range(max_new_tokens):
                 if return_logits:
                     all_logits.append(logits.clone())
-                if do_sample and not top_k:   # device-side temperature + top-p sampler (no host sync, counter-based RNG)
-                    nxt = ops.sample_top_p(logits, temperature, top_p if top_p else 1.0, sample_seed, step)
-                elif do_sample:
-                    nxt = self._sample(logits, do_sample, temperature, top_p, top_k, gen).to(torch.int32)
+                if do_sample:   # device-side temperature / top-k / top-p sampler (no host sync, counter-based RNG)
+                    nxt = ops.sample_top_p(logits, temperature, top_p if top_p else 1.0, sample_seed, step, top_k=int(top_k or 0))
                 else:
                     nxt = ops.argmax(logits)
                 last = step + 1 == max_new_tokens
@@ -384,7 +421,7 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
                 n_out += 1
                 stop = all(fin)
                 if not stop and stopping_criteria is not None:
-                    stop = all(c(out_host[:, :n_out], scores) for c in stopping_criteria)
+                    stop = any(c(out_host[:, :n_out], scores) for c in stopping_criteria)    # StoppingCriteriaList: any()
                 if stop:
                     if state is not None and not last:
                         state.rollback()
@@ -404,23 +441,6 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
         if return_logits:
             return out, all_logits
         return out
-
-    @staticmethod
-    def _sample(logits, do_sample, temperature, top_p, top_k, gen):
-        if not do_sample:
-            return ops.argmax(logits).to(torch.long)
-        lg = logits / max(float(temperature), 1e-5)
-        if top_k and top_k > 0:
-            kth = torch.topk(lg, min(top_k, lg.shape[-1]), dim=-1).values[..., -1, None]
-            lg = lg.masked_fill(lg < kth, float("-inf"))
-        if top_p is not None and top_p < 1.0:  # TopPLogitsWarper: drop the lowest-probability tail whose mass <= 1 - top_p
-            sl, si = torch.sort(lg, descending=False, dim=-1)
-            cp = sl.softmax(dim=-1).cumsum(dim=-1)
-            rm = cp <= (1.0 - top_p)
-            rm[..., -1:] = False
-            lg = lg.masked_fill(rm.scatter(1, si, rm), float("-inf"))
-        probs = torch.softmax(lg, dim=-1)
-        return torch.multinomial(probs, 1, generator=gen).squeeze(1)
 
 
 VitronLlamaForCausalLM = LlavaLlamaForCausalLM  # name used by BASELINE.json's north_star; the reference class is LlavaLlamaForCausalLM

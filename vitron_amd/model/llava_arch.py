@@ -199,10 +199,14 @@ class LlavaMetaForCausalLM:
 
     # ---- reference llava_arch.py:189-573 -----------------------------------------------------------------------
     def prepare_inputs_labels_for_multimodal(self, input_ids, position_ids, attention_mask, past_key_values, labels,
-                                             images, regions=None, feature_cache=None):
+                                             images, regions=None, feature_cache=None, input_ids_host=None):
         """`feature_cache` (vitron_amd.prefix_cache.VisualFeatureCache, only passed by generate()) lets an image / clip that
         was already encoded in an earlier turn skip tower + region extractor + projector; it also makes this call record
-        the per-row signature generate() needs for KV prefix reuse (self._last_row_sig)."""
+        the per-row signature generate() needs for KV prefix reuse (self._last_row_sig).
+        `input_ids_host` (optional, a CPU copy of `input_ids` -- what the tokenizer returned before `.cuda()`): the splice plan is
+        integer work on the host, and reading the ids back from the device costs a stream synchronisation right where a
+        serving loop wants the next request's launches queued behind the previous one's; with the host copy at hand the call
+        never waits for the device."""
         image_tower, video_tower = self.get_image_tower(), self.get_video_tower()
         if (image_tower is None and video_tower is None) or images is None or input_ids.shape[1] == 1:
             # decode step (:196-205): extend the mask to past_len + 1, positions = sum(mask) - 1
@@ -246,12 +250,22 @@ class LlavaMetaForCausalLM:
             nvis = nvis_end
         flat_blocks = [blk for bl in blocks for blk in bl]
         flat_regs = [r for rl in reg_rows for r in rl] if use_regions else None
-        ids_host = input_ids.cpu().numpy()
+        if input_ids_host is not None:
+            if tuple(input_ids_host.shape) != tuple(input_ids.shape):
+                raise ValueError("input_ids_host must be a host copy of input_ids (same shape)")
+            ids_host = input_ids_host.cpu().numpy()
+        else:
+            ids_host = input_ids.cpu().numpy()
         am_host = None if attention_mask is None else attention_mask.cpu().numpy()
         plan, mask, pos, lengths = build_splice_plan_np(
             ids_host, am_host, flat_blocks, flat_regs, getattr(self.config, "tokenizer_model_max_length", None),
             getattr(self.config, "tokenizer_padding_side", "right"))
         B, S = plan.shape[0], plan.shape[1]
+        tok_rows = plan[..., 1][plan[..., 0] == KIND_TOKEN]
+        n_embed = self.get_model().llama.embed_rows
+        if tok_rows.size and (int(tok_rows.min()) < 0 or int(tok_rows.max()) >= n_embed):   # nn.Embedding would raise
+            bad = int(tok_rows.min()) if int(tok_rows.min()) < 0 else int(tok_rows.max())
+            raise IndexError(f"token id {bad} outside the embedding table ({n_embed} rows)")
         plan_t = torch.from_numpy(plan.reshape(B * S, 2)).to(dev, non_blocking=True)
 
         # ---- device side: towers -> region extractor -> projector -> gather/splice ------------------------------------------

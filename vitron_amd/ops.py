@@ -175,18 +175,27 @@ def im2col(pixels: torch.Tensor, patch: int, k_pad: int) -> torch.Tensor:
     return out
 
 
+def _chk_rows(t: torch.Tensor, dtype, name: str):
+    """2-D tensor whose rows are contiguous (row stride free): logits narrowed to the true vocabulary of a padded lm_head."""
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.VitronHipError(f"{name}: expected a CUDA/HIP tensor (vitron_amd has no CPU path)")
+    if t.dtype != dtype or t.dim() != 2 or t.stride(1) != 1:
+        raise _lib.VitronHipError(f"{name}: expected a 2-D {dtype} tensor with contiguous rows")
+
+
 def embed_splice(tok_table: torch.Tensor, vis: Optional[torch.Tensor], reg: Optional[torch.Tensor], plan: torch.Tensor) -> torch.Tensor:
     lib = _lib.load()
     _chk(tok_table, torch.bfloat16, "embed_splice.tok_table")
     rows, H = plan.shape[0], tok_table.shape[1]
     out = torch.empty((rows, H), device=tok_table.device, dtype=torch.bfloat16)
-    _lib.check(lib.vt_embed_splice(_p(tok_table), _p(vis), _p(reg), _p(plan), rows, H, _p(out), _stream()), "vt_embed_splice")
+    _lib.check(lib.vt_embed_splice(_p(tok_table), tok_table.shape[0], _p(vis), 0 if vis is None else vis.shape[0], _p(reg),
+                                   0 if reg is None else reg.shape[0], _p(plan), rows, H, _p(out), _stream()), "vt_embed_splice")
     return out
 
 
 def argmax(logits: torch.Tensor) -> torch.Tensor:
     lib = _lib.load()
-    _chk(logits, torch.float32, "argmax.logits")
+    _chk_rows(logits, torch.float32, "argmax.logits")
     rows, V = logits.shape
     out = torch.empty((rows,), device=logits.device, dtype=torch.int32)
     _lib.check(lib.vt_argmax(_p(logits), rows, V, logits.stride(0), _p(out), _stream()), "vt_argmax")
@@ -214,13 +223,15 @@ def decode_feed(tok_table: torch.Tensor, next_ids: torch.Tensor, finished: torch
                                   _p(positions), nseq, _stream()), "vt_decode_feed")
 
 
-def sample_top_p(logits: torch.Tensor, temperature: float, top_p: float, seed: int, step: int, return_kept: bool = False):
+def sample_top_p(logits: torch.Tensor, temperature: float, top_p: float, seed: int, step: int, return_kept: bool = False,
+                 top_k: int = 0):
     """One sampled token id per row (int32), on device; see vt_sample_top_p in include/vitron_hip.h."""
     lib = _lib.load()
-    _chk(logits, torch.float32, "sample_top_p.logits")
+    _chk_rows(logits, torch.float32, "sample_top_p.logits")
     rows, V = logits.shape
     out = torch.empty((rows,), device=logits.device, dtype=torch.int32)
     kept = torch.empty((rows,), device=logits.device, dtype=torch.int32) if return_kept else None
-    _lib.check(lib.vt_sample_top_p(_p(logits), rows, V, logits.stride(0), float(temperature), float(top_p if top_p else 1.0),
-                                   int(seed) & (2 ** 64 - 1), int(step), _p(out), _p(kept), _stream()), "vt_sample_top_p")
+    _lib.check(lib.vt_sample_top_p(_p(logits), rows, V, logits.stride(0), float(temperature), int(top_k or 0),
+                                   float(top_p if top_p else 1.0), int(seed) & (2 ** 64 - 1), int(step), _p(out), _p(kept),
+                                   _stream()), "vt_sample_top_p")
     return (out, kept) if return_kept else out

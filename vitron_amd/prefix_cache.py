@@ -27,18 +27,13 @@ _MASK40 = (1 << 40) - 1
 
 
 def tensor_key(t: torch.Tensor) -> Tuple:
-    """Content key of a pixel tensor: shape, dtype and two 64-bit checksums over its raw 16-bit words (one plain, one
-    position-weighted). One tiny reduction on the device + one scalar read-back per tensor."""
+    """Content key of a pixel tensor: shape, dtype and a 128-bit BLAKE2b digest of its bytes (one device -> host copy of
+    the tensor: 0.3 MB for a 224 px image, 5.4 MB for an 8-frame 336 px clip). A cryptographic digest, not a checksum: two
+    different images sharing a key would silently reuse each other's visual tokens and KV prefix."""
+    import hashlib
     x = t.detach().contiguous()
-    if x.element_size() == 2:
-        w = x.view(torch.int16).reshape(-1).to(torch.int64)
-    elif x.element_size() == 4:
-        w = x.view(torch.int32).reshape(-1).to(torch.int64)
-    else:
-        w = x.reshape(-1).to(torch.float64).view(torch.int64)
-    pos = (torch.arange(w.numel(), device=w.device, dtype=torch.int64) % 65521) + 1
-    s = torch.stack([w.sum(), (w * pos).sum()]).tolist()
-    return (tuple(x.shape), str(x.dtype), int(s[0]), int(s[1]))
+    raw = x.view(torch.uint8).reshape(-1).cpu().numpy()
+    return (tuple(x.shape), str(x.dtype), hashlib.blake2b(raw.tobytes(), digest_size=16).hexdigest())
 
 
 def key64(key) -> int:

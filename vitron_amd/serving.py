@@ -92,26 +92,42 @@ class ServingEngine:
         mask = torch.tensor(m._last_splice[0][0], dtype=torch.bool, device=embeds.device)
         return embeds[0][mask]
 
-    def _admit(self, reqs: List[_Request]) -> None:
-        """Multimodal prefill of the admitted requests: towers + splice per request, decoder prefill per request (default) or
-        one packed pass for all of them (batch_prefill)."""
+    def _admit(self, reqs: List[_Request]) -> List[_Request]:
+        """Multimodal prefill of the requests that fit: towers + splice per request, decoder prefill per request (default) or
+        one packed pass for all of them (batch_prefill). Every admitted request RESERVES its worst case up front -- pages for
+        prompt + max_new_tokens are allocated here, so a sequence that is already decoding can never find the pool empty
+        because a later admission took its pages. Requests that do not fit right now are returned (in order) and go back to
+        the head of the queue; one that could never fit raises."""
         m = self.model
         llama = m.get_model().llama
-        flats = [self._embed(r) for r in reqs]
-        need = sum((f.shape[0] + r.max_new_tokens + 63) // 64 + 1 for f, r in zip(flats, reqs))
-        if m.kv is None or len(m.kv.free) < need:
-            if m.kv is not None and (self.active or len(m.kv.free) != m.kv.num_pages):
-                raise RuntimeError(f"ServingEngine: KV pool exhausted ({len(m.kv.free)} free pages, admission needs {need}); "
-                                   "construct the engine with a larger kv_pages")
-            m._ensure_kv(need)
-        if self.batch_prefill and len(reqs) > 1:
-            logits = llama_forward(llama, m.kv, [r.seq for r in reqs], torch.cat(flats, 0), [f.shape[0] for f in flats])
+        admitted: List[_Request] = []
+        flats: List[torch.Tensor] = []
+        for i, r in enumerate(reqs):
+            f = self._embed(r)
+            need = (f.shape[0] + r.max_new_tokens + 63) // 64 + 1
+            if m.kv is None or len(m.kv.free) < need:
+                idle = not self.active and not admitted
+                if idle:
+                    m._ensure_kv(need)      # nothing of this engine is live: drop the kept prefix / grow the pool (raises if others hold pages)
+                elif m.kv is not None and need > m.kv.num_pages:
+                    raise RuntimeError(f"ServingEngine: request needs {need} KV pages, the pool has {m.kv.num_pages}; "
+                                       "construct the engine with a larger kv_pages")
+                else:
+                    break                                   # wait for running requests to retire
+            r.seq.pages = m.kv.alloc(need)
+            admitted.append(r)
+            flats.append(f)
+        rest = reqs[len(admitted):]
+        if self.batch_prefill and len(admitted) > 1:
+            logits = llama_forward(llama, m.kv, [r.seq for r in admitted], torch.cat(flats, 0), [f.shape[0] for f in flats])
             nxt = self._pick(logits)
-            for i, r in enumerate(reqs):
+            for i, r in enumerate(admitted):
                 r.last = nxt[i:i + 1]
         else:
-            for r, f in zip(reqs, flats):
+            for r, f in zip(admitted, flats):
                 r.last = self._pick(llama_forward(llama, m.kv, [r.seq], f, [f.shape[0]]))
+        self.active += admitted
+        return rest
 
     def _retire(self, r: _Request) -> None:
         r.done = True
@@ -121,12 +137,12 @@ class ServingEngine:
 
     def step(self) -> List[Tuple[int, int]]:
         """Admit waiting requests while there is room, emit one token for every active request. Returns [(request id, token)]."""
-        admitted: List[_Request] = []
-        while self.waiting and len(self.active) + len(admitted) < self.max_batch:
-            admitted.append(self.waiting.popleft())
-        if admitted:
-            self._admit(admitted)
-            self.active += admitted
+        cand: List[_Request] = []
+        while self.waiting and len(self.active) + len(cand) < self.max_batch:
+            cand.append(self.waiting.popleft())
+        if cand:
+            for r in reversed(self._admit(cand)):          # what did not fit keeps its place at the head of the queue
+                self.waiting.appendleft(r)
         if not self.active:
             return []
         # tokens chosen at the end of the previous step (or by the prefill) become visible now: ONE read-back per step
