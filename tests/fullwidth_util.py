@@ -1,0 +1,64 @@
+"""Shared helpers of the BASELINE-width parity tests (tests/test_oracle_fullwidth.py on the CPU, tests/test_gpu_parity_fullwidth.py
+on the GPU): the weights / inputs of tests/golden/cases.py's FW_* cases regenerated from their seeds, and the comparison of a big
+[rows, dim] tensor against its compact pin in tests/golden/fullwidth.npz (projections of every row on fixed directions + a few
+whole rows + top-5 ids, written by tests/golden/make_golden.gen_fullwidth from the REFERENCE's own modules)."""
+import os
+
+import numpy as np
+import torch
+
+from tests.golden import cases
+from vitron_amd import synth
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "fullwidth.npz")
+
+
+def golden():
+    return np.load(GOLDEN)
+
+
+def llama_case(name):
+    S, L = cases.FW_LLAMA[name]
+    cfg = dict(synth.VICUNA_7B, num_hidden_layers=L)
+    sd = synth.llama_state(cfg, synth.make_generator(cases.FW_SEED + L), **cases.FW_INIT)
+    return cfg, sd, cases.fw_llama_embeds(S, cases.FW_SEED + S)
+
+
+def vit_case(name):
+    video = name == "video336"
+    cfg = dict(synth.VIT_L14, image_size=336, add_time_attn=video, num_frames=8 if video else 1, num_hidden_layers=cases.FW_VIT_LAYERS)
+    sd = synth.vit_state(cfg, synth.make_generator(cases.FW_SEED + 7), **cases.FW_INIT)
+    return cfg, sd, cases.pixels(cases.FW_VIDEO_SHAPE if video else cases.FW_IMAGE_SHAPE, cases.FW_SEED + 8)
+
+
+def projector_case():
+    sd = synth.projector_state(1024, 4096, synth.make_generator(cases.FW_SEED + 9), **cases.FW_INIT)
+    return sd, cases.features((cases.FW_PROJ_ROWS, 1024), cases.FW_SEED + 10)
+
+
+def region_case(canvas):
+    sd = synth.region_state(1024, 4096, synth.make_generator(cases.FW_SEED + 11), **cases.FW_INIT)
+    boxes = cases.FW_BOXES_224 if canvas == 224 else cases.FW_BOXES_336
+    return sd, cases.features((len(boxes), 24 * 24, 1024), cases.FW_SEED + 12), boxes
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def vs_pin(t, g, tag):
+    """Distances of tensor t [rows, dim] from its pin: (rel-L2 over the projections of ALL rows, rel-L2 over the stored whole rows)."""
+    t = torch.as_tensor(t).reshape(-1, t.shape[-1]).cpu()
+    proj = t.double() @ cases.fw_directions(t.shape[-1])
+    rows = g[f"{tag}_rowidx"].tolist()
+    return rel(proj, g[f"{tag}_proj"]), rel(t[rows].float(), g[f"{tag}_rows"])
+
+
+def topk_agreement(logits, g, tag):
+    """(top-1 agreement, mean top-5 overlap) of `logits` [rows, V] with the reference's stored top-5 ids."""
+    ref = torch.as_tensor(g[f"{tag}_top5"]).long()
+    got = torch.as_tensor(logits).float().cpu().topk(5, dim=-1).indices
+    top1 = float((got[:, 0] == ref[:, 0]).double().mean())
+    overlap = float(torch.tensor([len(set(a.tolist()) & set(b.tolist())) / 5.0 for a, b in zip(got, ref)]).mean())
+    return top1, overlap

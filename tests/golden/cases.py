@@ -159,3 +159,50 @@ def glue_projection(hidden):
     """The fixed direction the random-case goldens are projected on (float64)."""
     g = torch.Generator().manual_seed(424242)
     return torch.randn((hidden,), generator=g, dtype=torch.float64)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE-width cases (SURVEY.md 8(d) widths, bench.py's init: N(0, 0.02^2) weights, zero biases, unit norm gains). The
+# reference's own modules are run on them by make_golden.gen_fullwidth; stored compactly in fullwidth.npz: for every big
+# tensor its projection on FW_NPROJ fixed random directions (float64, every row pinned) + FW_ROWS whole rows + top-5 ids.
+# ---------------------------------------------------------------------------------------------------------------------
+FW_SEED = 20260925
+FW_NPROJ, FW_ROWS = 4, 12
+FW_INIT = dict(w_std=0.02)                         # == bench.py / init_synthetic defaults
+FW_LLAMA = {"s1088_l2": (1088, 2), "s2048_l1": (2048, 1)}      # name -> (sequence length, decoder layers) at H=4096 / I=11008 / 32 heads
+FW_VIT_LAYERS = 2                                  # encoder layers of the 336 px towers that are pinned
+FW_VIDEO_SHAPE = (1, 3, 8, 336, 336)               # one 8-frame clip: 4616 token rows (C3)
+FW_IMAGE_SHAPE = (2, 3, 336, 336)                  # two images: 2 x 577 rows (C2 / C5)
+FW_PROJ_ROWS = 1152
+# boxes for the region extractor at G = 24 (336 px tower) on the reference's 224 canvas (scale 9.33) and on a 336 canvas (scale 14)
+FW_BOXES_224 = [[0, 0, 224, 224], [10.5, 20.25, 120.75, 200.0], [100, 20, 180, 200], [7, 7, 8, 8], [0, 0, 6, 6], [215, 0, 224, 224],
+                [37.3, 112.0, 37.9, 113.0], [112, 112, 224, 224]]
+FW_BOXES_336 = [[0, 0, 336, 336], [10.5, 20.25, 320.75, 200.0], [100, 20, 180, 300], [7, 7, 8, 8], [0, 0, 6, 6], [335, 0, 336, 336],
+                [55.9, 168.0, 56.1, 169.0], [168, 168, 336, 336]]
+
+
+def fw_directions(dim, n=FW_NPROJ, seed=FW_SEED):
+    g = torch.Generator().manual_seed(seed + dim)
+    return torch.randn((dim, n), generator=g, dtype=torch.float64)
+
+
+def fw_rows(total, n=FW_ROWS):
+    """Evenly spread row indices incl. the first and the last row."""
+    return sorted({int(round(i * (total - 1) / (n - 1))) for i in range(n)})
+
+
+def fw_llama_embeds(S, seed):
+    """Decoder input rows of the size spliced embeddings have under the bench init (token embeddings ~ N(0, 0.02^2))."""
+    g = torch.Generator().manual_seed(seed)
+    return bf16r(torch.randn((S, 4096), generator=g) * 0.02)
+
+
+# user turns of the drop-in acceptance test, composed exactly as the reference composes them:
+#   image:        inference_image.py:38      DEFAULT_IMAGE_TOKEN + '\n' + inp
+#   image_region: app.py:525-534             ' ' + <image> + '\n' + <objs> + ' ' + user_input
+#   video:        inference_image.py:88      ' '.join([<image>] * num_frames) + '\n' + inp      (num_frames = 4 on the tiny tower)
+ACCEPTANCE_USER_TURNS = {
+    "image": "<image>\nCould you help me transform the image into a video?",
+    "image_region": " <image>\n<objs> What is in this region?",
+    "video": " ".join(["<image>"] * 4) + "\nWhy is this video funny?",
+}

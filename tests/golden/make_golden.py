@@ -228,9 +228,123 @@ def gen_glue_random(ns):
     print("glue_random.npz", {k: v.shape for k, v in out.items() if k.endswith("_mask")})
 
 
+def gen_state_dict_keys(ns):
+    """Parameter names and shapes of the reference's OWN LlavaLlamaForCausalLM.state_dict() (tiny config, towers / projector /
+    region extractor attached as the reference attaches them) and of its tower modules: what a checkpoint written by the
+    reference's save path contains. The loader test writes its synthetic checkpoint with THESE names, so a naming mistake cannot
+    be shared by the test's writer and the loader under test. Also renders the conversation prompts of the acceptance test."""
+    import importlib
+    import json
+    model = build_ref_llava(ns)
+    keys = {k: list(v.shape) for k, v in model.state_dict().items()}
+    conv = importlib.import_module("vitron.conversation")
+    prompts = {}
+    for name, inp in cases.ACCEPTANCE_USER_TURNS.items():
+        c = conv.conv_templates["llava_v1"].copy()
+        c.append_message(c.roles[0], inp)
+        c.append_message(c.roles[1], None)
+        prompts[name] = {"prompt": c.get_prompt(), "stop_str": c.sep if c.sep_style != conv.SeparatorStyle.TWO else c.sep2}
+    with open(os.path.join(OUT, "ref_state_dict_keys.json"), "w") as f:
+        json.dump({"llava_state_dict": keys, "acceptance_prompts": prompts}, f, indent=1)
+    print("ref_state_dict_keys.json", len(keys), "keys;", {k: v["prompt"][-60:] for k, v in prompts.items()})
+
+
+def _compact(t, tag, out, top5=False, nrows=cases.FW_ROWS):
+    """Compact pin of a big [rows, dim] tensor: projections of every row on fixed directions + a few whole rows (+ top-5 ids)."""
+    t = t.reshape(-1, t.shape[-1])
+    out[f"{tag}_proj"] = (t.double() @ cases.fw_directions(t.shape[-1])).numpy()
+    rows = cases.fw_rows(t.shape[0], nrows)
+    out[f"{tag}_rows"] = t[rows].float().numpy()
+    out[f"{tag}_rowidx"] = np.array(rows, dtype=np.int64)
+    out[f"{tag}_norm"] = np.float64(t.double().norm())
+    if top5:
+        out[f"{tag}_top5"] = t.float().topk(5, dim=-1).indices.numpy().astype(np.int32)
+
+
+def gen_fullwidth(ns):
+    """The reference's own modules at the BASELINE widths (H=4096 / I=11008 / 32 heads; ViT-L/14 at 336 px, T = 8; projector
+    1024 -> 4096; RegionExtractor(1024, 4096) on a 24 x 24 grid), weights drawn exactly as bench.py draws them."""
+    import contextlib
+    import io
+    import time
+    from vitron_amd.synth import VICUNA_7B, VIT_L14
+    out = {}
+    t0 = time.time()
+    # ---- decoder: LlavaLlamaForCausalLM.forward(inputs_embeds=...) ----------------------------------------------------
+    ll = ns.llava_llama
+    for name, (S, L) in cases.FW_LLAMA.items():
+        c = dict(VICUNA_7B, num_hidden_layers=L)
+        sd = synth.llama_state(c, synth.make_generator(cases.FW_SEED + L), **cases.FW_INIT)
+        cfg = ll.LlavaConfig(hidden_size=c["hidden_size"], intermediate_size=c["intermediate_size"], num_hidden_layers=L,
+                             num_attention_heads=c["num_attention_heads"], num_key_value_heads=c["num_attention_heads"],
+                             vocab_size=c["vocab_size"], rms_norm_eps=c["rms_norm_eps"], max_position_embeddings=4096,
+                             rope_theta=c["rope_theta"], tie_word_embeddings=False)
+        cfg._attn_implementation = "eager"
+        cfg.pretraining_tp = 1
+        with contextlib.redirect_stdout(io.StringIO()):
+            model = ll.LlavaLlamaForCausalLM(cfg).eval()
+        missing, unexpected = model.load_state_dict(f32(sd), strict=False)
+        assert not unexpected and all("rotary" in k or "inv_freq" in k for k in missing), (missing, unexpected)
+        x = cases.fw_llama_embeds(S, cases.FW_SEED + S)
+        grabbed = {}
+        hook = model.model.layers[-1].register_forward_hook(     # residual stream behind the last decoder layer (before model.norm)
+            lambda mod, args, res: grabbed.__setitem__("h", (res[0] if isinstance(res, tuple) else res).detach()))
+        with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+            o = model(inputs_embeds=x.unsqueeze(0), use_cache=False)
+        hook.remove()
+        out[f"llama_{name}_checksum"] = np.float64(synth.checksum(sd))
+        _compact(o.logits[0].float(), f"llama_{name}_logits", out, top5=True, nrows=4)
+        _compact(grabbed["h"].reshape(S, -1).float(), f"llama_{name}_hidden", out)
+        del model, sd
+        print(f"llama {name}: {time.time() - t0:.1f}s", flush=True)
+    # ---- towers: CLIPVisionTransformer (video / image) ---------------------------------------------------------------------
+    for name, shape, time_attn in (("video336", cases.FW_VIDEO_SHAPE, True), ("image336", cases.FW_IMAGE_SHAPE, False)):
+        c = dict(VIT_L14, image_size=336, add_time_attn=time_attn, num_frames=8 if time_attn else 1,
+                 num_hidden_layers=cases.FW_VIT_LAYERS)
+        sd = synth.vit_state(c, synth.make_generator(cases.FW_SEED + 7), **cases.FW_INIT)
+        m = build_ref_vit(ns, c, sd)
+        x = cases.pixels(shape, cases.FW_SEED + 8)
+        with torch.no_grad():
+            hs = m(x, output_hidden_states=True).hidden_states
+        out[f"vit_{name}_checksum"] = np.float64(synth.checksum(sd))
+        for i, h in enumerate(hs):
+            _compact(h.reshape(-1, h.shape[-1]).float(), f"vit_{name}_hidden_{i}", out)
+        print(f"vit {name}: {time.time() - t0:.1f}s", flush=True)
+    # ---- projector ------------------------------------------------------------------------------------------------------------
+    sd = synth.projector_state(1024, 4096, synth.make_generator(cases.FW_SEED + 9), **cases.FW_INIT)
+    cfg = types.SimpleNamespace(mm_projector_type="mlp2x_gelu", mm_hidden_size=1024, hidden_size=4096)
+    pm = ns.projector_builder.build_vision_projector(cfg).eval()
+    pm.load_state_dict(f32(sd))
+    x = cases.features((cases.FW_PROJ_ROWS, 1024), cases.FW_SEED + 10)
+    with torch.no_grad():
+        _compact(pm(x), "projector", out)
+    out["projector_checksum"] = np.float64(synth.checksum(sd))
+    # ---- region extractor at G = 24 on the 224 canvas (reference default) and on a 336 canvas -----------------------------------
+    sd = synth.region_state(1024, 4096, synth.make_generator(cases.FW_SEED + 11), **cases.FW_INIT)
+    for canvas, boxes in ((224, cases.FW_BOXES_224), (336, cases.FW_BOXES_336)):
+        m = ns.region_layer.RegionExtractor(1024, 4096, image_size=canvas).eval()
+        m.load_state_dict(f32(sd))
+        feats = cases.features((len(boxes), 24 * 24, 1024), cases.FW_SEED + 12)
+        with torch.no_grad():
+            r = m(feats, boxes)
+            cv = m.transform_bbox_2_mask(boxes, m.image_size, feats.device, feats.dtype).unsqueeze(1)
+            grid = torch.nn.functional.interpolate(cv, size=(24, 24), mode="bilinear", align_corners=False)
+        out[f"region_c{canvas}_out"] = r[:, 0].numpy()
+        out[f"region_c{canvas}_cells"] = (grid > 0).reshape(len(boxes), -1).numpy().astype(np.int32)
+    out["region_checksum"] = np.float64(synth.checksum(sd))
+    np.savez_compressed(os.path.join(OUT, "fullwidth.npz"), **out)
+    print("fullwidth.npz", {k: getattr(v, "shape", v) for k, v in out.items()}, f"{time.time() - t0:.1f}s")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     ns = ref_shim.install()
+    if "--keys-only" in sys.argv:
+        gen_state_dict_keys(ns)
+        sys.exit(0)
+    if "--fullwidth-only" in sys.argv:
+        gen_fullwidth(ns)
+        sys.exit(0)
     gen_mm_utils(ns)
     gen_output_parser()
     gen_vit(ns)
@@ -238,3 +352,5 @@ if __name__ == "__main__":
     gen_region_projector(ns)
     gen_glue(ns)
     gen_glue_random(ns)
+    gen_state_dict_keys(ns)
+    gen_fullwidth(ns)

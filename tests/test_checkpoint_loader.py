@@ -120,3 +120,77 @@ def test_load_pretrained_model_matches_direct_construction(tmp_path):
     b = ref(input_ids=ids, images=images, regions=case["regions"], use_cache=False).logits
     assert rel_l2(a, b) <= 2e-2   # merged weights are re-rounded to bf16 on both paths, in a different order
     assert float((a.argmax(-1) == b.argmax(-1)).float().mean()) >= 0.9
+
+
+REF_KEYS = os.path.join(os.path.dirname(__file__), "golden", "ref_state_dict_keys.json")
+
+
+def _ref_names():
+    with open(REF_KEYS) as f:
+        return json.load(f)["llava_state_dict"]
+
+
+def _state_by_reference_names():
+    """A full state dict whose KEYS are the reference's own (LlavaLlamaForCausalLM.state_dict() under the shim, committed by
+    tests/golden/make_golden.gen_state_dict_keys) and whose values come from synth, matched by name and checked by shape."""
+    ref = _ref_names()
+    L = cases.LLM
+    src = dict(synth.llama_state(L, synth.make_generator(cases.SEED_LLM), **cases.LLM_INIT))
+    src.update({"model.mm_projector." + k: v for k, v in
+                synth.projector_state(cases.MM_HIDDEN, L["hidden_size"], synth.make_generator(cases.SEED_PROJ), **cases.MLP_INIT).items()})
+    src.update({"model.region_extractor." + k: v for k, v in
+                synth.region_state(cases.MM_HIDDEN, L["hidden_size"], synth.make_generator(cases.SEED_REGION), **cases.MLP_INIT).items()})
+    src.update({"model.image_tower.image_tower." + k: v for k, v in
+                synth.vit_state(cases.VIT_IMAGE, synth.make_generator(cases.SEED_VIT), **cases.VIT_INIT).items()})
+    src.update({"model.video_tower.video_tower." + k: v for k, v in
+                synth.vit_state(cases.VIT_VIDEO, synth.make_generator(cases.SEED_VIT), **cases.VIT_INIT).items()})
+    return ref, src
+
+
+def test_parameter_names_are_the_references_own():
+    """Every name the reference's state_dict() holds is a name synth / the loader use, with the same shape, and vice versa (the
+    only extras on the reference side are buffers such as position_ids / rotary inv_freq that are not weights)."""
+    ref, src = _state_by_reference_names()
+    buffers = [k for k in ref if k.endswith(("position_ids", "inv_freq"))]
+    missing = [k for k in ref if k not in src and k not in buffers]
+    extra = [k for k in src if k not in ref]
+    assert not missing, missing[:10]
+    assert not extra, extra[:10]
+    for k, shp in ref.items():
+        if k in src:
+            assert list(src[k].shape) == shp, (k, shp, tuple(src[k].shape))
+
+
+@pytest.mark.gpu
+def test_full_checkpoint_written_with_reference_names_loads(tmp_path):
+    """A plain (non-LoRA) checkpoint directory whose pytorch_model.bin carries exactly the reference's state_dict() names
+    (tower weights included, as a checkpoint saved with loaded towers has them) goes through load_pretrained_model and gives
+    the logits of a model constructed directly from the same tensors."""
+    from tests.util import rel_l2
+    from vitron_amd.model import LlavaConfig, LlavaLlamaForCausalLM, load_pretrained_model
+    ref, src = _state_by_reference_names()
+    root = str(tmp_path)
+    ck = os.path.join(root, "vitron-llava-full")
+    img, vid = os.path.join(root, "LanguageBind_Image"), os.path.join(root, "LanguageBind_Video_merge")
+    for d in (ck, img, vid):
+        os.makedirs(d)
+    torch.save({k: src[k] for k in ref if k in src}, os.path.join(ck, "pytorch_model.bin"))
+    json.dump(dict(cases.LLM, mm_hidden_size=cases.MM_HIDDEN, mm_image_tower=img, mm_video_tower=vid, mm_projector_type="mlp2x_gelu",
+                   mm_vision_select_layer=-2), open(os.path.join(ck, "config.json"), "w"))
+    for d, pre, cfg in ((img, "model.image_tower.image_tower.", cases.VIT_IMAGE), (vid, "model.video_tower.video_tower.", cases.VIT_VIDEO)):
+        torch.save({"vision_model." + k[len(pre):]: v for k, v in src.items() if k.startswith(pre)}, os.path.join(d, "pytorch_model.bin"))
+        json.dump({"vision_config": dict(cfg)}, open(os.path.join(d, "config.json"), "w"))
+    tok, model, procs, _ = load_pretrained_model(ck, None, "vitron-llava-7b", device="cuda", tokenizer=object())
+    dev = torch.device("cuda:0")
+    direct = LlavaLlamaForCausalLM(LlavaConfig(**cases.LLM, mm_hidden_size=cases.MM_HIDDEN, mm_image_tower="x/LanguageBind_Image",
+                                               mm_video_tower="x/LanguageBind_Video_merge"))
+    direct.get_image_tower().load_state(cases.VIT_IMAGE, {k[len("model.image_tower.image_tower."):]: v for k, v in src.items() if k.startswith("model.image_tower.")})
+    direct.get_video_tower().load_state(cases.VIT_VIDEO, {k[len("model.video_tower.video_tower."):]: v for k, v in src.items() if k.startswith("model.video_tower.")})
+    direct.load_state_dict({k: v for k, v in src.items() if not k.startswith(("model.image_tower.", "model.video_tower."))})
+    direct.to(dev)
+    case = cases.glue_cases()["image_region"]
+    ids = case["input_ids"].to(dev)
+    images = [im.to(dev).bfloat16() for im in case["images"]]
+    a = model(input_ids=ids, images=images, regions=case["regions"], use_cache=False).logits
+    b = direct(input_ids=ids, images=images, regions=case["regions"], use_cache=False).logits
+    assert torch.equal(a, b)          # same tensors, same packing: bit-identical

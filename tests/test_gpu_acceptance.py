@@ -1,0 +1,216 @@
+"""Drop-in acceptance (BASELINE configs[0]): the reference's inference_image.py, line for line, against vitron_amd.
+
+/root/reference/inference_image.py:10-64 (image), :67-112 (video) and the image + box turn of app.py:515-571 are reproduced
+statement by statement with `vitron` replaced by `vitron_amd`: load_pretrained_model -> processor[...] -> conversation prompt ->
+tokenizer_image_(region_)token -> KeywordsStoppingCriteria -> model.generate(input_ids, images=fp16 tensor, regions=..., do_sample=True,
+temperature=..., max_new_tokens=..., use_cache=True, stopping_criteria=[...]) -> tokenizer.decode. What cannot exist offline is
+replaced by the smallest stand-in: the checkpoint by `synthetic=` random-init weights of a tiny architecture, the SentencePiece
+tokenizer by a character-level stub with the same surface (bos/eos ids, __call__().input_ids, decode, batch_decode, add_tokens,
+__len__), and conv_templates["llava_v1"] by the prompt strings the REFERENCE's vitron/conversation.py rendered for these turns
+(tests/golden/ref_state_dict_keys.json, written by tests/golden/make_golden.gen_state_dict_keys).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.golden import cases
+
+pytestmark = pytest.mark.gpu
+FIX = os.path.join(os.path.dirname(__file__), "golden", "ref_state_dict_keys.json")
+
+
+class StubSentencePiece:
+    """Character-level stand-in for LlamaTokenizer(use_fast=False): id 0 <unk>, 1 <s>, 2 </s>, then one id per character."""
+    bos_token_id, eos_token_id, pad_token_id, unk_token_id = 1, 2, 0, 0
+
+    def __init__(self, vocab_size):
+        self.base = vocab_size
+        self.added = []
+
+    def _enc(self, text):
+        out, i = [], 0
+        while i < len(text):
+            if text.startswith("</s>", i):
+                out.append(2)
+                i += 4
+                continue
+            hit = next((k for k, t in enumerate(self.added) if text.startswith(t, i)), None)
+            if hit is not None:
+                out.append(self.base + hit)
+                i += len(self.added[hit])
+                continue
+            out.append(3 + (ord(text[i]) % (self.base - 3)))
+            i += 1
+        return out
+
+    def __call__(self, text):
+        class R:
+            pass
+        r = R()
+        r.input_ids = [1] + self._enc(text)
+        return r
+
+    def add_tokens(self, toks, special_tokens=False):
+        new = [t for t in toks if t not in self.added]
+        self.added += new
+        return len(new)
+
+    def __len__(self):
+        return self.base + len(self.added)
+
+    def decode(self, ids, skip_special_tokens=False):
+        out = []
+        for t in (ids.tolist() if hasattr(ids, "tolist") else ids):
+            if t >= self.base:
+                out.append("" if skip_special_tokens else self.added[t - self.base])
+            elif t in (0, 1, 2):
+                out.append("" if skip_special_tokens else ("<unk>", "<s>", "</s>")[t])
+            else:
+                out.append(chr(32 + (t - 3) % 95))
+        return "".join(out)
+
+    def batch_decode(self, rows, skip_special_tokens=False):
+        return [self.decode(r, skip_special_tokens) for r in rows]
+
+
+@pytest.fixture(scope="module")
+def loaded():
+    from vitron_amd.model.builder import load_pretrained_model
+    tokenizer = StubSentencePiece(cases.LLM["vocab_size"])
+    spec = dict(llm=dict(cases.LLM, eos_token_id=2, bos_token_id=1, pad_token_id=0), image=cases.VIT_IMAGE, video=cases.VIT_VIDEO, seed=99,
+                w_std=0.05)
+    return load_pretrained_model("synthetic", None, "vitron-llava-7b-lora-4", False, False, device="cuda", synthetic=spec,
+                                 tokenizer=tokenizer)
+
+
+def _prompts():
+    with open(FIX) as f:
+        return json.load(f)["acceptance_prompts"]
+
+
+def _jpeg(tmp_path, w=570, h=380):
+    from PIL import Image
+    rng = np.random.RandomState(5)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.stack([(xx * 255 // w), (yy * 255 // h), ((xx + yy) % 256)], -1).astype(np.uint8)
+    img = np.clip(img.astype(np.int32) + rng.randint(-20, 20, img.shape), 0, 255).astype(np.uint8)
+    p = os.path.join(str(tmp_path), "extreme_ironing.jpg")
+    Image.fromarray(img).save(p, quality=90)
+    return p
+
+
+def test_load_pretrained_model_adds_special_tokens_and_resizes(loaded):
+    tokenizer, model, processor, context_len = loaded
+    # builder.py:136-146: <im_patch> added once (image and video patch tokens are the same string), embeddings resized
+    assert len(tokenizer) == cases.LLM["vocab_size"] + 1 and tokenizer.added == ["<im_patch>"]
+    assert model.config.vocab_size == len(tokenizer)
+    llama = model.get_model().llama
+    assert llama.V == len(tokenizer) and llama.embed_rows == len(tokenizer) and llama.V_pad % 4 == 0
+    assert context_len == 2048 and processor["image"] is not None and processor["video"] is not None
+    ids = torch.tensor([[1, 5, 6, len(tokenizer) - 1]], device="cuda")         # the added id embeds (zero row) and scores
+    out = model(input_ids=ids, use_cache=False)
+    assert out.logits.shape == (1, 4, len(tokenizer)) and torch.isfinite(out.logits).all()
+    with pytest.raises(IndexError):
+        model(input_ids=torch.tensor([[1, len(tokenizer)]], device="cuda"), use_cache=False)
+
+
+def test_inference_image_flow(loaded, tmp_path):
+    """inference_image.py:10-64 (the `regions` argument commented out there is left out here too)."""
+    from PIL import Image
+    from vitron_amd.constants import OBJS_TOKEN_INDEX
+    from vitron_amd.mm_utils import KeywordsStoppingCriteria, preprocess_region, tokenizer_image_region_token
+    tokenizer, model, processor, _ = loaded
+    image = _jpeg(tmp_path)
+    image_processor = processor["image"]
+    image_tensor = image_processor.preprocess(image, return_tensors="pt")["pixel_values"]
+    if type(image_tensor) is list:
+        tensor = [im.to(model.device, dtype=torch.float16) for im in image_tensor]
+    else:
+        tensor = image_tensor.to(model.device, dtype=torch.float16)
+    assert tuple(tensor.shape) == (1, 3, 56, 56)
+    ori_im_size = [Image.open(image).convert("RGB").width, Image.open(image).convert("RGB").height]
+    assert ori_im_size == [570, 380]
+    bbox = [0, 100, 300, 200]
+    region = [preprocess_region(bbox, ori_im_size, [224, 224])]
+    assert region == [[0.0, 100 * 224 / 380, 300 * 224 / 570, 200 * 224 / 380]]
+    p = _prompts()["image"]
+    prompt, stop_str = p["prompt"], p["stop_str"]
+    input_ids = tokenizer_image_region_token(prompt, tokenizer, OBJS_TOKEN_INDEX, return_tensors="pt").unsqueeze(0).cuda()
+    assert int((input_ids == -200).sum()) == 1
+    keywords = [stop_str]
+    stopping_criteria = KeywordsStoppingCriteria(keywords, tokenizer, input_ids)
+    outs = []
+    for seed in (7, 7, 8):
+        torch.manual_seed(seed)
+        with torch.inference_mode():
+            output_ids = model.generate(input_ids, images=tensor, do_sample=True, temperature=0.2, max_new_tokens=24, use_cache=True,
+                                        stopping_criteria=[stopping_criteria])
+        assert torch.equal(output_ids[:, :input_ids.shape[1]].cpu(), input_ids.cpu())
+        new = output_ids[0, input_ids.shape[1]:]
+        assert 1 <= new.numel() <= 24 and int(new.min()) >= 0 and int(new.max()) < len(tokenizer)
+        if 2 in new.tolist():                                   # EOS ends the reply: nothing is generated behind it
+            assert new.tolist().index(2) == new.numel() - 1
+        outputs = tokenizer.decode(new).strip()
+        assert isinstance(outputs, str)
+        outs.append(new.tolist())
+    assert outs[0] == outs[1]                                   # torch.manual_seed makes sampling reproducible
+
+
+def test_app_image_with_box_flow(loaded, tmp_path):
+    """app.py:515-571 for an image with a drawn box: ' <image>\\n<objs> ' + question, regions=[rescaled box], temperature / top_p sampling."""
+    from vitron_amd.constants import OBJS_TOKEN_INDEX
+    from vitron_amd.mm_utils import KeywordsStoppingCriteria, preprocess_region, tokenizer_image_region_token
+    tokenizer, model, processor, _ = loaded
+    image_tensor = processor["image"].preprocess(_jpeg(tmp_path), return_tensors="pt")["pixel_values"][0]
+    input_region = [preprocess_region([0, 100, 300, 200], [570, 380], [224, 224])]
+    p = _prompts()["image_region"]
+    input_ids = tokenizer_image_region_token(p["prompt"], tokenizer, OBJS_TOKEN_INDEX, return_tensors="pt").unsqueeze(0).cuda()
+    assert int((input_ids == -200).sum()) == 1 and int((input_ids == -300).sum()) == 1
+    stopping_criteria = KeywordsStoppingCriteria([p["stop_str"]], tokenizer, input_ids)
+    image_tensors = [image_tensor.to(model.device, dtype=torch.float16)]
+    torch.manual_seed(3)
+    with torch.inference_mode():
+        output_ids = model.generate(input_ids, images=image_tensors, regions=input_region, do_sample=True, temperature=0.2, top_p=0.7,
+                                    max_new_tokens=16, use_cache=True, stopping_criteria=[stopping_criteria])
+    new = output_ids[0, input_ids.shape[1]:]
+    assert 1 <= new.numel() <= 16 and int(new.max()) < len(tokenizer)
+    # greedy with the same inputs: the first new token is the arg-max of the prefill logits the forward() surface returns
+    with torch.inference_mode():
+        greedy = model.generate(input_ids, images=image_tensors, regions=input_region, do_sample=False, max_new_tokens=1)
+        logits = model(input_ids=input_ids, images=image_tensors, regions=input_region, use_cache=False).logits
+    assert int(greedy[0, -1]) == int(logits[0, -1].argmax())
+
+
+def test_inference_video_flow(loaded):
+    """inference_image.py:67-112: ' '.join([<image>] * num_frames) + question, images = one clip, regions passed along (unused: no <objs>)."""
+    from vitron_amd.constants import IMAGE_TOKEN_INDEX
+    from vitron_amd.mm_utils import KeywordsStoppingCriteria, preprocess_region, tokenizer_image_token
+    tokenizer, model, processor, _ = loaded
+    video_processor = processor["video"]
+    T = model.get_video_tower().config.num_frames
+    assert T == 4
+    g = torch.Generator().manual_seed(12)
+    frames = torch.randint(0, 256, (23, 96, 128, 3), generator=g, dtype=torch.uint8)      # a decoded 23-frame video (no codec offline)
+    video_tensor = video_processor(frames, return_tensors="pt")["pixel_values"]
+    if type(video_tensor) is list:
+        tensor = [v.to(model.device, dtype=torch.float16) for v in video_tensor]
+    else:
+        tensor = video_tensor.to(model.device, dtype=torch.float16)
+    assert tuple(tensor.shape) == (1, 3, T, 56, 56)
+    p = _prompts()["video"]
+    input_ids = tokenizer_image_token(p["prompt"], tokenizer, IMAGE_TOKEN_INDEX, return_tensors="pt").unsqueeze(0).cuda()
+    assert int((input_ids == -200).sum()) == T
+    stopping_criteria = KeywordsStoppingCriteria([p["stop_str"]], tokenizer, input_ids)
+    region = [preprocess_region([0, 100, 300, 200], (480, 600), [224, 224])]
+    torch.manual_seed(11)
+    with torch.inference_mode():
+        output_ids = model.generate(input_ids, images=tensor, regions=region, do_sample=True, temperature=0.1, max_new_tokens=12,
+                                    use_cache=True, stopping_criteria=[stopping_criteria])
+    new = output_ids[0, input_ids.shape[1]:]
+    assert 1 <= new.numel() <= 12 and int(new.max()) < len(tokenizer)
+    assert isinstance(tokenizer.decode(new).strip(), str)
+    with pytest.raises(ImportError):                          # a file path needs a decoder library; the error names it
+        video_processor("examples/sample_demo_1.mp4", return_tensors="pt")

@@ -274,8 +274,8 @@ def test_bench_distributed_path_on_one_gpu(dev):
     port = str(random.randint(20000, 40000))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", port, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1",
-           "--no-cpu-baseline", "--decode-steps", "0"]
-    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+           "--no-cpu-baseline", "--decode-steps", "0", "--c4-steps", "1"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -284,3 +284,11 @@ def test_bench_distributed_path_on_one_gpu(dev):
               "dtype", "data", "config", "roofline"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["scaling"] == "weak" and d["roofline"]["bound"] == "mfma"
+    # the C4 object (fixed global batch of 8 clips: all eight through this one GPU, 40 960 packed decoder rows) and the exchange
+    # step's two transports went through the distributed code path too
+    c4 = d["config"]["c4"]
+    assert c4["global_clips"] == 8 and c4["clips_per_gpu"] == 8 and c4["scaling"] == "strong" and c4["tokens_per_s"] > 0
+    assert c4["tokens_per_s"] > 0.5 * d["value"]              # eight clips packed are no slower per token than one
+    ex = d["config"]["visual_token_exchange"]
+    assert isinstance(ex["rccl_all_gather_ms"], float) and isinstance(ex["direct_p2p_ms"], float), ex
+    assert d["config"]["ms_per_step_hipevent_median"] > 0

@@ -462,3 +462,40 @@ def test_gemm_row_scale(dev, M, N, K, epi_name, cfg):
     assert torch.equal(plain, base)                      # a factor of 1.0 changes nothing, bit for bit
     with pytest.raises(Exception):
         ops.gemm(a.to(dev), w.to(dev), None, epi, row_scale=rs[:-1].to(dev))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("V", [32000, 513, 40000])
+def test_sample_top_k_keep_set(dev, V):
+    """TopKLogitsWarper on the device (both kernels: rows in registers for V <= 32768, the streaming kernel above): the keep-set is
+    exactly {logit >= k-th largest} (ties with the k-th value stay, transformers 4.31), applied before the softmax / top-p stage,
+    and every draw comes from it."""
+    from vitron_amd import ops
+    g = torch.Generator().manual_seed(V)
+    logits = torch.randn((6, V), generator=g) * 3
+    logits[1, 100:104] = logits[1].topk(7).values[-1]            # four more values tie with the 7th largest
+    logits[2] = logits[2].round()                                 # many ties everywhere
+    ld = logits.to(dev)
+    for k in (1, 7, 50):
+        for temp in (1.0, 0.3):
+            ids, kept = ops.sample_top_p(ld, temp, 1.0, seed=5, step=k, return_kept=True, top_k=k)
+            scaled = logits / temp
+            kth = scaled.topk(k, dim=-1).values[:, -1:]
+            want = (scaled >= kth).sum(-1)
+            assert kept.cpu().tolist() == want.tolist(), (k, temp, kept.cpu().tolist(), want.tolist())
+            picked = scaled[torch.arange(6), ids.cpu().long()]
+            assert bool((picked >= kth[:, 0]).all())
+    # top-k then top-p: the nucleus is taken over the renormalised top-k distribution
+    k, p = 50, 0.6
+    ids, kept = ops.sample_top_p(ld, 1.0, p, seed=9, step=0, return_kept=True, top_k=k)
+    for r in range(6):
+        s = logits[r].clone()
+        s[s < s.topk(k).values[-1]] = float("-inf")
+        sl, _ = torch.sort(s, descending=False)
+        cp = sl.softmax(-1).cumsum(-1)
+        want = int((~(cp <= 1 - p)).sum()) if True else 0
+        assert abs(int(kept[r]) - want) <= 1, (r, int(kept[r]), want)      # +-1: the cumulative sum's last ulp at the boundary
+    # k >= V or k = 0: no filter
+    a = ops.sample_top_p(ld, 1.0, 0.9, seed=1, step=2, top_k=0)
+    b = ops.sample_top_p(ld, 1.0, 0.9, seed=1, step=2, top_k=V + 5)
+    assert torch.equal(a, b)

@@ -1,0 +1,66 @@
+"""Pin the CPU oracle at the BASELINE widths: oracle/vitron_oracle.py against outputs of the REFERENCE's own modules at
+H = 4096 / I = 11008 / 32 heads (decoder), ViT-L/14 at 336 px with T = 8 (towers), 1024 -> 4096 (projector) and RegionExtractor
+(1024, 4096) on the 24 x 24 grid of the 336 px tower, with weights drawn exactly as bench.py draws them (N(0, 0.02^2), zero
+biases). tests/golden/fullwidth.npz was written by tests/golden/make_golden.gen_fullwidth. CPU only; ~1-2 minutes on 8 cores."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vitron_oracle as O
+from tests import fullwidth_util as FW
+from tests.golden import cases
+from vitron_amd import synth
+
+TOL = 2e-5      # fp32 vs fp32, different summation orders over K = 4096 / 11008
+
+
+def f32(sd):
+    return {k: v.float() for k, v in sd.items()}
+
+
+@pytest.mark.parametrize("name", list(cases.FW_LLAMA))
+def test_oracle_decoder_at_7b_width(name):
+    g = FW.golden()
+    cfg, sd, x = FW.llama_case(name)
+    assert synth.checksum(sd) == pytest.approx(float(g[f"llama_{name}_checksum"]), rel=1e-12)
+    with torch.no_grad():
+        logits, _, hidden = O.llama_forward(f32(sd), cfg, x.unsqueeze(0), return_hidden=True)
+    for t, tag in ((logits[0], f"llama_{name}_logits"), (hidden[0], f"llama_{name}_hidden")):
+        dp, dr = FW.vs_pin(t, g, tag)
+        assert dp <= TOL and dr <= TOL, (tag, dp, dr)
+    top1, top5 = FW.topk_agreement(logits[0], g, f"llama_{name}_logits")
+    assert top1 >= 0.999 and top5 >= 0.999, (top1, top5)
+
+
+@pytest.mark.parametrize("name", ["video336", "image336"])
+def test_oracle_towers_at_vit_l_336(name):
+    g = FW.golden()
+    cfg, sd, x = FW.vit_case(name)
+    assert synth.checksum(sd) == pytest.approx(float(g[f"vit_{name}_checksum"]), rel=1e-12)
+    with torch.no_grad():
+        for nl in range(cases.FW_VIT_LAYERS + 1):
+            h = O.vit_forward(f32(sd), cfg, x, num_layers=nl)
+            dp, dr = FW.vs_pin(h.reshape(-1, h.shape[-1]), g, f"vit_{name}_hidden_{nl}")
+            assert dp <= TOL and dr <= TOL, (name, nl, dp, dr)
+
+
+def test_oracle_projector_and_region_at_full_width():
+    g = FW.golden()
+    sd, x = FW.projector_case()
+    assert synth.checksum(sd) == pytest.approx(float(g["projector_checksum"]), rel=1e-12)
+    with torch.no_grad():
+        dp, dr = FW.vs_pin(O.projector_forward(f32(sd), x), g, "projector")
+    assert dp <= TOL and dr <= TOL, (dp, dr)
+    for canvas in (224, 336):
+        sd, feats, boxes = FW.region_case(canvas)
+        assert synth.checksum(sd) == pytest.approx(float(g["region_checksum"]), rel=1e-12)
+        with torch.no_grad():
+            out, cells, count = O.region_forward(f32(sd), feats, boxes, canvas)
+        assert np.array_equal(cells.numpy(), g[f"region_c{canvas}_cells"])              # bit exact: the G = 24 geometry of C5
+        assert count.tolist() == g[f"region_c{canvas}_cells"].sum(-1).tolist()
+        assert FW.rel(out[:, 0], g[f"region_c{canvas}_out"]) <= TOL
+    # the boxes exercise the regimes of the rule: whole canvas, interior boxes, and boxes so small that no bilinear tap of the
+    # 24 x 24 grid lands inside them (empty mask -> pooled feature 0, the reference's 1e-8 denominator)
+    for canvas in (224, 336):
+        cells = g[f"region_c{canvas}_cells"].sum(-1).tolist()
+        assert cells[0] == 576 and min(cells) == 0 and len({c for c in cells if c}) >= 4, cells

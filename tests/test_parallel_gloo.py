@@ -8,7 +8,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from vitron_amd.parallel import all_gather_visual_tokens, encode_clips_parallel, shard_range, start_all_gather_visual_tokens
+from vitron_amd.parallel import (all_gather_direct_p2p, all_gather_visual_tokens, encode_clips_parallel, shard_range,
+                                 start_all_gather_visual_tokens)
 
 
 def _free_port():
@@ -43,6 +44,12 @@ def _worker(rank, world, port, n_clips, q):
         busy = torch.ones(8).sum()
         ga = h.wait()
         ok = ok and busy.item() == 8 and ga.shape == (world, 2, 3) and all(bool((ga[r] == r).all()) for r in range(world))
+        # direct full-mesh point-to-point variant: same result as the collective, blocking and asynchronous
+        loc2 = torch.full((2, 3, 5), float(rank + 1)) + torch.arange(5)
+        ref2 = torch.cat([torch.full((2, 3, 5), float(r + 1)) + torch.arange(5) for r in range(world)], 0)
+        ok = ok and torch.equal(all_gather_direct_p2p(loc2), ref2)
+        hp = all_gather_direct_p2p(loc2, async_op=True)
+        ok = ok and torch.equal(hp.wait(), ref2) and torch.equal(hp.wait(), ref2)
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

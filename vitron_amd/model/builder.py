@@ -55,6 +55,20 @@ def _merge_llm_lora(base_sd, adapter_sd, lora_alpha, r=None):
     return out
 
 
+def _add_special_tokens(tokenizer, cfg):
+    """Special tokens of reference builder.py:136-145; returns len(tokenizer) for resize_token_embeddings (:146), or None when
+    the caller's tokenizer object cannot add tokens."""
+    if tokenizer is None or not hasattr(tokenizer, "add_tokens"):
+        return None
+    if getattr(cfg, "mm_use_im_patch_token", True):
+        tokenizer.add_tokens([DEFAULT_IMAGE_PATCH_TOKEN], special_tokens=True)
+        tokenizer.add_tokens([DEFAULT_VIDEO_PATCH_TOKEN], special_tokens=True)
+    if getattr(cfg, "mm_use_im_start_end", False):
+        tokenizer.add_tokens([DEFAULT_IM_START_TOKEN, DEFAULT_IM_END_TOKEN], special_tokens=True)
+        tokenizer.add_tokens([DEFAULT_VID_START_TOKEN, DEFAULT_VID_END_TOKEN], special_tokens=True)
+    return len(tokenizer)
+
+
 def _processors(model):
     """{'image': processor, 'video': processor} like the reference's builder (builder.py:149-171): device-side processors
     (vitron_amd.processing) exposing what app.py / mm_utils read -- preprocess(...)['pixel_values'], crop_size, image_mean."""
@@ -84,7 +98,7 @@ def load_pretrained_model(model_path, model_base, model_name, load_8bit=False, l
         cfg = LlavaConfig(**spec.get("llm", {}), mm_hidden_size=spec.get("image", spec.get("video", {})).get("hidden_size", 1024))
         model = LlavaLlamaForCausalLM(cfg)
         model.init_synthetic(device, seed=spec.get("seed", 1234), vit_image=spec.get("image"), vit_video=spec.get("video"),
-                             w_std=spec.get("w_std", 0.02))
+                             w_std=spec.get("w_std", 0.02), resize_for=lambda: _add_special_tokens(tokenizer, cfg))
         context_len = getattr(cfg, "max_sequence_length", 2048)
         return tokenizer, model, _processors(model), context_len
 
@@ -129,15 +143,9 @@ def load_pretrained_model(model_path, model_base, model_name, load_8bit=False, l
             w = sd[key]
             sd[key] = torch.cat([w, torch.zeros((cfg.vocab_size - w.shape[0], w.shape[1]), dtype=w.dtype)], 0)
     model.load_state_dict(sd, strict=False)
-    # special tokens + embedding resize, reference builder.py:136-146
-    if tokenizer is not None and hasattr(tokenizer, "add_tokens"):
-        if getattr(cfg, "mm_use_im_patch_token", True):
-            tokenizer.add_tokens([DEFAULT_IMAGE_PATCH_TOKEN], special_tokens=True)
-            tokenizer.add_tokens([DEFAULT_VIDEO_PATCH_TOKEN], special_tokens=True)
-        if getattr(cfg, "mm_use_im_start_end", False):
-            tokenizer.add_tokens([DEFAULT_IM_START_TOKEN, DEFAULT_IM_END_TOKEN], special_tokens=True)
-            tokenizer.add_tokens([DEFAULT_VID_START_TOKEN, DEFAULT_VID_END_TOKEN], special_tokens=True)
-        model.resize_token_embeddings(len(tokenizer))
+    n_tok = _add_special_tokens(tokenizer, cfg)
+    if n_tok is not None:
+        model.resize_token_embeddings(n_tok)
     # towers (reference builder.py:149-163): LanguageBind checkpoint directories named by the config
     for get in (model.get_image_tower, model.get_video_tower):
         t = get()

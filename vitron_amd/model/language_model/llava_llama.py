@@ -185,7 +185,7 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
         return self.to("cuda")
 
     def init_synthetic(self, device, seed=1234, vit_image: Optional[dict] = None, vit_video: Optional[dict] = None,
-                       w_std=0.02):
+                       w_std=0.02, resize_for=None):
         """Random-init weights of the configured architecture, generated on `device` (no checkpoints exist offline)."""
         gen = synth.make_generator(seed, device)
         cfg = self.config
@@ -203,6 +203,10 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
             self.model.region_extractor = build_region_extractor(cfg)
         self.model.mm_projector.init_synthetic(gen, device, w_std)
         self.model.region_extractor.init_synthetic(gen, device, w_std)
+        if resize_for is not None:            # load_pretrained_model: tokenizer.add_tokens + resize_token_embeddings before packing
+            n = resize_for()
+            if n is not None:
+                self.resize_token_embeddings(n)
         return self.to(device)
 
     # ---- KV pool ----------------------------------------------------------------------------------------------
@@ -309,7 +313,7 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
     # ---- GenerationMixin.generate / sample, as app.py:562-571 drives it ----------------------------------------
     @torch.no_grad()
     def generate(self, input_ids=None, images=None, regions=None, attention_mask=None, do_sample=False,
-                 temperature=1.0, top_p=1.0, top_k=0, max_new_tokens=None, max_length=None, use_cache=True,
+                 temperature=1.0, top_p=1.0, top_k=None, max_new_tokens=None, max_length=None, use_cache=True,
                  stopping_criteria=None, eos_token_id=None, pad_token_id=None, num_beams=1, seed=None,
                  return_logits=False, **kwargs):
         if num_beams != 1:
@@ -322,6 +326,8 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
         pad = pad_token_id if pad_token_id is not None else (self.config.pad_token_id if self.config.pad_token_id is not None else 0)
         if max_new_tokens is None:
             max_new_tokens = (max_length - input_ids.shape[1]) if max_length else 20
+        if top_k is None:     # GenerationConfig's default: the reference's sampling calls (app.py:562-571) run TopKLogitsWarper(50)
+            top_k = int(getattr(self.config, "top_k", 50) or 0)
         # seed of the counter-based sampler: drawn from torch's global CPU generator (so torch.manual_seed makes sampling
         # reproducible, as with GenerationMixin.sample) and only when sampling -- greedy calls leave the RNG state alone
         sample_seed = 0

@@ -48,7 +48,48 @@ def preprocess_frames(frames: torch.Tensor, size: int, bicubic: bool, clip_layou
     return out
 
 
+def decode_video_frames(path: str, num_frames: int, backend: str = "opencv") -> torch.Tensor:
+    """The decode + uniform sampling half of the reference's load_and_transform_video (processing_video.py:72-114, 'decord' and
+    'opencv' back-ends; 'pytorchvideo' decodes through decord as well): ONLY the `num_frames` frames at
+    linspace(0, duration-1, num_frames) are decoded and returned as one uint8 [T,H,W,3] host tensor, so one upload feeds the
+    fused resize/crop/normalise kernel. Video codecs stay a host-library matter (no decoder library ships in the offline image:
+    the import error says which one to install); frames that are already decoded go straight to LanguageBindVideoProcessor."""
+    idx = None
+    if backend in ("decord", "pytorchvideo"):
+        try:
+            import decord
+        except ImportError as e:
+            raise ImportError("video files need the `decord` package (or backend='opencv' with `opencv-python`); "
+                              "already decoded frames can be passed as a uint8 [frames,H,W,3] tensor") from e
+        vr = decord.VideoReader(path, ctx=decord.cpu(0))
+        idx = sample_frame_indices(len(vr), num_frames)
+        batch = vr.get_batch(idx.tolist())
+        return torch.from_numpy(batch.asnumpy() if hasattr(batch, "asnumpy") else np.asarray(batch))
+    if backend == "opencv":
+        try:
+            import cv2
+        except ImportError as e:
+            raise ImportError("video files need `opencv-python` (or backend='decord'); already decoded frames can be passed "
+                              "as a uint8 [frames,H,W,3] tensor") from e
+        cap = cv2.VideoCapture(path)
+        idx = sample_frame_indices(int(cap.get(cv2.CAP_PROP_FRAME_COUNT)), num_frames)
+        frames = []
+        for i in idx.tolist():
+            cap.set(1, i)
+            ok, frame = cap.read()
+            if not ok:
+                cap.release()
+                raise ValueError(f"could not read frame {i} of {path}")
+            frames.append(torch.from_numpy(cv2.cvtColor(frame, cv2.COLOR_BGR2RGB)))
+        cap.release()
+        return torch.stack(frames)
+    raise NameError("video_decode_backend should specify in (pytorchvideo, decord, opencv)")   # reference processing_video.py:113
+
+
 def _to_u8_hwc(img, device) -> torch.Tensor:
+    if isinstance(img, str):        # a file path, as inference_image.py:24 passes it (processing_image.py:29-31)
+        from PIL import Image
+        img = Image.open(img).convert("RGB")
     if isinstance(img, torch.Tensor):
         t = img
     else:
@@ -80,8 +121,10 @@ class LanguageBindVideoProcessor:
     """__call__(videos)['pixel_values'] -> [N,3,T,S,S]; a video is a decoded uint8 tensor [frames,H,W,3] (all frames of
     the file: `num_frames` are sampled uniformly like the reference) or an already sampled [T,H,W,3] one."""
 
-    def __init__(self, config=None, image_size: int = 224, num_frames: int = 8, device="cuda", dtype=torch.bfloat16, flip: bool = False):
+    def __init__(self, config=None, image_size: int = 224, num_frames: int = 8, device="cuda", dtype=torch.bfloat16, flip: bool = False,
+                 video_decode_backend: str = "opencv"):
         vc = getattr(config, "vision_config", config)
+        self.video_decode_backend = getattr(vc, "video_decode_backend", video_decode_backend) or video_decode_backend
         self.size = int(getattr(vc, "image_size", image_size) or image_size)
         self.num_frames = int(getattr(vc, "num_frames", num_frames) or num_frames)
         self.device, self.dtype, self.flip = device, dtype, flip
@@ -92,6 +135,8 @@ class LanguageBindVideoProcessor:
         videos = videos if isinstance(videos, (list, tuple)) else [videos]
         outs = []
         for v in videos:
+            if isinstance(v, str):      # a file: decode only the sampled frames, one upload, one kernel
+                v = decode_video_frames(v, self.num_frames, self.video_decode_backend)
             if not isinstance(v, torch.Tensor):
                 v = torch.from_numpy(np.asarray(v))
             if v.shape[0] != self.num_frames:
