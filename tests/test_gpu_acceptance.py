@@ -135,7 +135,7 @@ def test_inference_image_flow(loaded, tmp_path):
     assert ori_im_size == [570, 380]
     bbox = [0, 100, 300, 200]
     region = [preprocess_region(bbox, ori_im_size, [224, 224])]
-    assert region == [[0.0, 100 * 224 / 380, 300 * 224 / 570, 200 * 224 / 380]]
+    assert region[0] == pytest.approx([0.0, 100 * 224 / 380, 300 * 224 / 570, 200 * 224 / 380], rel=1e-12)
     p = _prompts()["image"]
     prompt, stop_str = p["prompt"], p["stop_str"]
     input_ids = tokenizer_image_region_token(prompt, tokenizer, OBJS_TOKEN_INDEX, return_tensors="pt").unsqueeze(0).cuda()

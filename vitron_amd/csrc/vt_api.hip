@@ -376,6 +376,7 @@ struct LlamaWs {
   size_t splitk_bytes;
   float* attn_scratch;
   size_t attn_scratch_bytes;
+  int* row_slot;        // prefill: cache slot of every new row (fused QKV epilogue)
   size_t total;
 };
 LlamaWs llama_carve(const vt_llama_model* m, int rows, int n_logit, int nseq, int max_kv_len, void* p, size_t n) {
@@ -396,6 +397,7 @@ LlamaWs llama_carve(const vt_llama_model* m, int rows, int n_logit, int nseq, in
   w.splitk = w.splitk_bytes ? (float*)ws.take(w.splitk_bytes) : nullptr;
   w.attn_scratch_bytes = vt_attn_decode_scratch_bytes(nseq > 0 ? nseq : 1, m->heads, m->head_dim, max_kv_len > 0 ? max_kv_len : 64);
   w.attn_scratch = (float*)ws.take(w.attn_scratch_bytes);
+  w.row_slot = (int*)ws.take((size_t)rows * 4);
   w.total = ws.off + 256;
   return w;
 }
@@ -444,6 +446,10 @@ int vt_llama_forward(const vt_llama_model* m, const vt_kv_cache* kv, const uint1
   consume_a.in_n = consume_b.in_n = H / 16;
   consume_a.inv_dim = consume_b.inv_dim = 1.0f / (float)H;
   consume_a.eps = consume_b.eps = m->rms_eps;
+  // prefill with the QKV projection on ONE launch of the 256x256 ping-pong kernel: its epilogue writes rotated q / K pages / V^T
+  // pages itself (no vt_kv_tiles pass: 252 MB of traffic and a launch per layer at S = 5120); switch: vt_llama_model.no_qkv_fuse
+  const bool fuse_qkv = max_q_len > 1 && !fold_tile && !m->no_qkv_fuse && vt_gemm_qkv_fused_supported(rows, H, HD);
+  if (fuse_qkv) VT_TRY(vt_row_slot_launch((const VtAttnSeq*)seq_desc, nseq, max_q_len, tile_table, w.row_slot, s));
   for (int l = 0; l < m->num_layers; ++l) {
     const vt_llama_layer& L = m->layers[l];
     bf16_t* kt = kv->k + l * layer_stride;
@@ -484,6 +490,17 @@ int vt_llama_forward(const vt_llama_model* m, const vt_kv_cache* kv, const uint1
     cons_t.row_scale = w.rstd;
     if (fold_tile && l > 0) {
       VT_TRY(vt_gemm_launch(w.y, H, L.wqkv, H, w.qkv, 3 * H, nullptr, rows, 3 * H, H, VT_EPI_BF16, AUTO, s, &cons_t));
+    } else if (fuse_qkv) {
+      VT_TRY(vt_rmsnorm_launch(w.x, nullptr, L.rms1, w.y, rows, H, m->rms_eps, s));
+      VtQkvFuse qf;
+      qf.k_pages = kt;
+      qf.vt_pages = vt;
+      qf.row_slot = w.row_slot;
+      qf.positions = positions;
+      qf.rope_cos = m->rope_cos;
+      qf.rope_sin = m->rope_sin;
+      qf.heads = heads;
+      VT_TRY(vt_gemm_qkv_fused_launch(w.y, H, L.wqkv, H, w.qkv, 3 * H, rows, H, qf, s));
     } else {
       VT_TRY(vt_rmsnorm_launch(w.x, nullptr, L.rms1, w.y, rows, H, m->rms_eps, s));
       VT_TRY(vt_gemm_launch(w.y, H, L.wqkv, H, w.qkv, 3 * H, nullptr, rows, 3 * H, H, VT_EPI_BF16, AUTO, s));
@@ -492,8 +509,9 @@ int vt_llama_forward(const vt_llama_model* m, const vt_kv_cache* kv, const uint1
       VT_TRY(vt_attn_decode_fused_launch(w.qkv, 3 * H, 0, H, 2 * H, kt, vt, tile_table, (const VtAttnSeq*)seq_desc, nseq, w.att, H,
                                          heads, HD, scale, m->rope_cos, m->rope_sin, positions, s));
     } else {
-      VT_TRY(vt_kv_tiles_launch(w.qkv, 3 * H, 0, H, 2 * H, kt, vt, tile_table, (const VtAttnSeq*)seq_desc, nseq,
-                                max_new_tiles, heads, HD, m->rope_cos, m->rope_sin, positions, s));
+      if (!fuse_qkv)
+        VT_TRY(vt_kv_tiles_launch(w.qkv, 3 * H, 0, H, 2 * H, kt, vt, tile_table, (const VtAttnSeq*)seq_desc, nseq,
+                                  max_new_tiles, heads, HD, m->rope_cos, m->rope_sin, positions, s));
       VT_TRY(vt_flash_attn_launch(w.qkv, 3 * H, kt, vt, tile_table, (const VtAttnSeq*)seq_desc, nseq, max_q_len, w.att, H,
                                   heads, HD, 1, scale, s));
     }

@@ -754,7 +754,7 @@ int vt_gemm_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, 
   VT_REQUIRE(ldc % 4 == 0, "vt_gemm: ldc must be a multiple of 4");
   if (nf && !nf->row_scale && !nf->out_partials) nf = nullptr;
   if (nf) {   // folded RMSNorm on the MFMA tile kernels (vt_kernels.h)
-    const bool tile_cfg = cfg == VT_GEMM_CFG_AUTO || cfg == VT_GEMM_CFG_256x256_P4 || cfg == VT_GEMM_CFG_256x256_P4X || cfg == VT_GEMM_CFG_256x256_P8 ||
+    const bool tile_cfg = cfg == VT_GEMM_CFG_AUTO || cfg == VT_GEMM_CFG_256x256_P4 || cfg == VT_GEMM_CFG_256x256_P8 ||
                           cfg == VT_GEMM_CFG_128x128 || cfg == VT_GEMM_CFG_256x128 || cfg == VT_GEMM_CFG_256x256 || cfg == VT_GEMM_CFG_64x128;
     VT_REQUIRE((N % 32) == 0 && (K % 64) == 0 && tile_cfg,
                "vt_gemm: row scale / norm fold needs N %% 32 == 0, K %% 64 == 0 and an MFMA tile configuration (N=%d K=%d cfg=%d)", N, K, cfg);
@@ -832,7 +832,6 @@ int vt_gemm_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, 
   if (cfg >= 301 && cfg <= 303) return vt_gemm_rp_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, (cfg - 300) << 8, s);
 #endif
   if (cfg == VT_GEMM_CFG_256x256_P4) return vt_gemm_p8_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, epi | 0x1000, s, nf);
-  if (cfg == VT_GEMM_CFG_256x256_P4X) return vt_gemm_p8_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, epi | 0x2000, s, nf);
   if (cfg == VT_GEMM_CFG_256x256_RP) return vt_gemm_rp_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, epi, s);
   switch (epi) {
     case VT_EPI_BF16: return launch_cfg<VT_EPI_BF16>(p, cfg, s);

@@ -45,6 +45,7 @@ struct GemmP8 {
   int ksplit;        // > 1 (fp32-out epilogue only): blocks [s*tiles, (s+1)*tiles) compute K range s of every tile into slab s of C
   size_t slab;       // elements between consecutive slabs
   VtGemmNormFuse nf; // folded RMSNorm (tile flavour, vt_kernels.h): row_scale on the consumer side, out_* on the producer side
+  VtQkvFuse qf;      // EPI == VT_EPI_QKV_PAGES only
 };
 
 __device__ __forceinline__ float gelu_erf8(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
@@ -153,16 +154,17 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmP8 p) {
       DST[ni][1] = *(const bf16x8*)(_s + ni * 2048 + fo1);                                     \
     }                                                                                          \
   } while (0)
-#define MFMA_Q(QM, QN, BF)                                                                     \
+#define MFMA_QA(QM, QN, BF, AF)                                                                \
   do {                                                                                         \
     if (ABL & 4) break;                                                                        \
     __builtin_amdgcn_s_setprio(1);                                                             \
     _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                           \
       _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                         \
         _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                       \
-          acc[QM][QN][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[ni][kk], af[mi][kk], acc[QM][QN][mi][ni], 0, 0, 0); \
+          acc[QM][QN][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[ni][kk], AF[mi][kk], acc[QM][QN][mi][ni], 0, 0, 0); \
     __builtin_amdgcn_s_setprio(0);                                                             \
   } while (0)
+#define MFMA_Q(QM, QN, BF) MFMA_QA(QM, QN, BF, af)
   // one phase = load section | barrier | MFMA section + counted wait | barrier
 #define SECTION_SPLIT()                        \
   do {                                         \
@@ -336,6 +338,136 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmP8 p) {
   // folded RMSNorm: consumer = accumulators of row m scaled by row_scale[m]; producer (residual epilogue) = also bf16(x_new *
   // out_w[n]) and the sum of x_new^2 per row and 32-column group (the 4 lanes lane>>4 of a row hold one group: 2 x 16 columns)
   const float* const row_scale = p.nf.row_scale;
+  if constexpr (EPI == VT_EPI_QKV_PAGES) {
+    // Fused QKV epilogue. A 256-column tile is two whole heads of ONE section (q, k or v: H % 256 == 0). Per head (qn = 0, 1) the
+    // eight waves park their accumulators as bf16 in the LDS the main loop no longer needs -- bf16 because the reference rounds
+    // the projection to the storage dtype BEFORE the rotary embedding (and the oracle's emulation does the same) -- then all 512
+    // threads write the head out from there with 16-byte accesses:
+    //   q, k : thread (row, half h) rotates dims [32h, 32h+32) against their partners 64 further up (apply_rotary_pos_emb, half-
+    //          split) with the fp32 cos / sin rows of the row's position, the same expression vt_kv_tiles evaluates; q goes back to
+    //          the fused-QKV buffer in place, k to its page slot;
+    //   v    : parked TRANSPOSED (dim-major), thread (dim, 64-token chunk) moves 8 tokens per store into the V^T page.
+    // The last new row of a sequence also zero-fills the rest of its page (k rows, v^t columns), as vt_kv_tiles does.
+    const int Hq = p.qf.heads * 128;
+    const int sect = bn0 / Hq;                       // 0 = q, 1 = k, 2 = v (uniform over the workgroup)
+    const int head0 = (bn0 - sect * Hq) >> 7;
+    bf16_t* const T = (bf16_t*)smem;
+    constexpr int LDT = 136;                         // row-major parking: 256 rows x (128 + 8) bf16
+    constexpr int LDV = 264;                         // transposed parking: 128 dims x (256 + 8) bf16
+    const int heads = p.qf.heads;
+#pragma unroll
+    for (int qn = 0; qn < 2; ++qn) {
+      __syncthreads();                               // main loop / previous head: nobody reads this LDS any more
+      if (sect < 2) {
+#pragma unroll
+        for (int qm = 0; qm < 2; ++qm)
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi) {
+            const int row = qm * 128 + wr * 64 + mi * 16 + (lane & 15);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+              const f32x4 v = acc[qm][qn][mi][ni];
+              u32x2 o;
+              o.x = pack_bf16x2(v[0], v[1]);
+              o.y = pack_bf16x2(v[2], v[3]);
+              *(u32x2*)(T + row * LDT + wc * 32 + ni * 16 + ((lane >> 4) << 2)) = o;
+            }
+          }
+      } else {
+#pragma unroll
+        for (int qm = 0; qm < 2; ++qm)
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi) {
+            const int row = qm * 128 + wr * 64 + mi * 16 + (lane & 15);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+              const f32x4 v = acc[qm][qn][mi][ni];
+              const int col = wc * 32 + ni * 16 + ((lane >> 4) << 2);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) T[(col + j) * LDV + row] = f32_to_bf16(v[j]);
+            }
+          }
+      }
+      __syncthreads();
+      const int head = head0 + qn;
+      if (sect < 2) {
+        const int row = threadIdx.x >> 1, hh = threadIdx.x & 1;
+        const int m = bm0 + row;
+        if (m < p.M) {
+          const int enc = p.qf.row_slot[m];
+          const int slot = enc & 0x3ffffff, tail = (unsigned)enc >> 26;
+          const int rp = p.qf.positions[m];
+          const float* cs = p.qf.rope_cos + (size_t)rp * 64 + hh * 32;
+          const float* sn = p.qf.rope_sin + (size_t)rp * 64 + hh * 32;
+          bf16_t* dst = (sect == 0) ? (bf16_t*)p.C + (size_t)m * p.ldc + head * 128
+                                    : p.qf.k_pages + (((size_t)(slot >> 6) * heads + head) * 64 + (slot & 63)) * 128;
+          const bf16_t* src = T + row * LDT + hh * 32;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const u32x4 lo = *(const u32x4*)(src + c * 8);
+            const u32x4 hi = *(const u32x4*)(src + 64 + c * 8);
+            const f32x4 c0 = *(const f32x4*)(cs + c * 8), c1 = *(const f32x4*)(cs + c * 8 + 4);
+            const f32x4 s0 = *(const f32x4*)(sn + c * 8), s1 = *(const f32x4*)(sn + c * 8 + 4);
+            const float cc[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+            const float ss[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+            u32x4 lo_o, hi_o;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+              const float a0 = bf16lo_to_f32(lo[w]), a1 = bf16hi_to_f32(lo[w]);
+              const float b0 = bf16lo_to_f32(hi[w]), b1 = bf16hi_to_f32(hi[w]);
+              lo_o[w] = pack_bf16x2(a0 * cc[2 * w] - b0 * ss[2 * w], a1 * cc[2 * w + 1] - b1 * ss[2 * w + 1]);
+              hi_o[w] = pack_bf16x2(b0 * cc[2 * w] + a0 * ss[2 * w], b1 * cc[2 * w + 1] + a1 * ss[2 * w + 1]);
+            }
+            *(u32x4*)(dst + hh * 32 + c * 8) = lo_o;
+            *(u32x4*)(dst + 64 + hh * 32 + c * 8) = hi_o;
+          }
+          if (sect == 1 && tail) {                   // last new row of its sequence: zero the k rows behind it in the page
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            for (int t = 1; t <= tail; ++t)
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                *(u32x4*)(dst + t * 128 + hh * 32 + c * 8) = z;
+                *(u32x4*)(dst + t * 128 + 64 + hh * 32 + c * 8) = z;
+              }
+          }
+        }
+      } else {
+        const int dd = threadIdx.x & 127, ch = threadIdx.x >> 7;
+        const bf16_t* src = T + dd * LDV + ch * 64;
+#pragma unroll 2
+        for (int j = 0; j < 8; ++j) {
+          const int m0 = bm0 + ch * 64 + j * 8;
+          if (m0 >= p.M) break;
+          const u32x4 vals = *(const u32x4*)(src + j * 8);
+          const int e0 = p.qf.row_slot[m0], e7 = p.qf.row_slot[min(m0 + 7, p.M - 1)];
+          const int s0 = e0 & 0x3ffffff, s7 = e7 & 0x3ffffff;
+          if (m0 + 7 < p.M && s7 - s0 == 7 && (s0 & 7) == 0 && ((unsigned)e0 >> 26) == 0) {
+            // 8 consecutive rows -> 8 consecutive slots of one page, none of rows 0..6 ends a sequence (s7 - s0 == 7 says so)
+            *(u32x4*)(p.qf.vt_pages + (((size_t)(s0 >> 6) * heads + head) * 128 + dd) * 64 + (s0 & 63)) = vals;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              if (m0 + e >= p.M) break;
+              const int se = p.qf.row_slot[m0 + e] & 0x3ffffff;
+              const uint32_t wv = vals[e >> 1];
+              p.qf.vt_pages[(((size_t)(se >> 6) * heads + head) * 128 + dd) * 64 + (se & 63)] = (bf16_t)((e & 1) ? (wv >> 16) : (wv & 0xffffu));
+            }
+          }
+          // page tail behind the last new row of a sequence (at most one row in 8 carries it)
+          for (int e = 0; e < 8; ++e) {
+            if (m0 + e >= p.M) break;
+            const int ee = p.qf.row_slot[m0 + e];
+            const int tl = (unsigned)ee >> 26;
+            if (tl) {
+              const int se = ee & 0x3ffffff;
+              bf16_t* col = p.qf.vt_pages + (((size_t)(se >> 6) * heads + head) * 128 + dd) * 64 + (se & 63);
+              for (int t = 1; t <= tl; ++t) col[t] = 0;
+            }
+          }
+        }
+      }
+    }
+  } else
   if constexpr (EPI == VT_EPI_F32_RESID) {
     // residual epilogue: C += acc (+ bias). The 4 x 16-byte reads of a row are issued together and one row ahead of the
     // stores (the compiler cannot move a load across the stores of the previous row: it cannot prove they do not alias), so
@@ -431,278 +563,6 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmP8 p) {
               if (n >= p.N) continue;
               f32x4 v = acc[qm][qn][mi][ni] * rs;
               if (p.bias && split == 0) v += *(const f32x4*)(p.bias + n);   // split-K: the bias goes in once
-              if constexpr (EPI == VT_EPI_BF16_GELU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_erf8(v[r]);
-              } else if constexpr (EPI == VT_EPI_BF16_QGELU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = quick_gelu8(v[r]);
-              } else if constexpr (EPI == VT_EPI_BF16_RELU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-              }
-              if constexpr (EPI == VT_EPI_F32) {
-                *(f32x4*)((float*)p.C + (size_t)split * p.slab + (size_t)m * p.ldc + n) = v;
-              } else {
-                u32x2 o;
-                o.x = pack_bf16x2(v[0], v[1]);
-                o.y = pack_bf16x2(v[2], v[3]);
-                *(u32x2*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
-              }
-            }
-          }
-        }
-      }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// gemm_p4x_kernel: the 4-phase ping-pong schedule above on v_mfma_f32_32x32x16_bf16.
-//
-// Same tile (256x256x64), same 8 waves as two staggered rows, same LDS image / DMA schedule / vmcnt counts / hazard argument as
-// gemm_p8_kernel<.., P4 = true>; only the matrix instruction and therefore the fragment shapes differ. A wave's 64x32 quadrant
-// is two 32x32 blocks (mi = 0, 1) and a K step is four k-slices of 16: one section (two quadrants that share the A half tile)
-// is 16 MFMAs of 32 cycles instead of 32 of ~17 (the 16x16x32 instruction issues at ~17 cycles per MFMA on one SIMD,
-// MI355X_MICROARCH.md constants table: 5 % more matrix-pipe cycles for the same FLOPs), with half the operand-register reads
-// per FLOP. The four accumulators of a section are visited round-robin, so two MFMAs on the same accumulator are four issue
-// slots (128 cycles) apart -- the 8-phase attempt with this instruction had two accumulators per phase and
-// stalled on the dependent chain.
-// Fragment reads: lane l supplies row (l & 31), k-chunk (2*ks + (l >> 5)) of the 8 16-byte chunks of a 64-element row; with the
-// source-side XOR swizzle chunk ^ ((row >> 1) & 7) the 16 lanes of every ds_read_b128 service group hit 16 distinct 16-byte
-// slots of the 256-byte bank row (rows {0-3,12-15,20-27}: ((row>>1)&7, row&1) are all different).
-// Epilogue layout (W fragment is the MFMA "A" operand): lane holds m = lane & 31 and n = 8*g + 4*(lane>>5) + {0..3}, g = reg>>2.
-// ------------------------------------------------------------------------------------------------------------------
-template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_p4x_kernel(GemmP8 p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wr = wave >> 2, wc = wave & 3;
-
-  const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 255) / 256;
-  const int nwg = tiles_m * tiles_n;
-  const int ksplit = (EPI == VT_EPI_F32) ? p.ksplit : 1;
-  const int split = (ksplit > 1) ? (int)blockIdx.x / nwg : 0;
-  const int sid = xcd_remap((int)blockIdx.x - split * nwg, nwg);
-  const int ku = p.K >> 7;
-  const int u_begin = (int)((long)ku * split / ksplit), u_end = (int)((long)ku * (split + 1) / ksplit);
-  const int k_begin = u_begin * 128;
-  constexpr int GROUP_M = 8;
-  const int per_group = GROUP_M * tiles_n;
-  const int first_m = (sid / per_group) * GROUP_M;
-  const int gsz = min(tiles_m - first_m, GROUP_M);
-  const int tm = first_m + (sid % per_group) % gsz;
-  const int tn = (sid % per_group) / gsz;
-  const int bm0 = tm * 256, bn0 = tn * 256;
-
-  const int lrow = lane >> 3, lchk = lane & 7;
-  const bf16_t* src[4][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = (wave * 2 + i) * 8 + lrow;
-    const int coff = (lchk ^ ((row >> 1) & 7)) * 8;
-    src[SLOT_A0][i] = p.A + (size_t)min(bm0 + row, p.M - 1) * p.lda + coff + k_begin;
-    src[SLOT_A1][i] = p.A + (size_t)min(bm0 + 128 + row, p.M - 1) * p.lda + coff + k_begin;
-    src[SLOT_B0][i] = p.W + (size_t)min(bn0 + row, p.N - 1) * p.ldw + coff + k_begin;
-    src[SLOT_B1][i] = p.W + (size_t)min(bn0 + 128 + row, p.N - 1) * p.ldw + coff + k_begin;
-  }
-  const int dma_off = wave * 2048;
-#define XSTAGE(BUF, SLOT)                                                                       \
-  do {                                                                                          \
-    char* _d = smem + (BUF) * BUF_BYTES + slot_offset(SLOT) + dma_off;                          \
-    glds16(src[SLOT][0], _d);                                                                   \
-    glds16(src[SLOT][1], _d + 1024);                                                            \
-    src[SLOT][0] += 64;                                                                         \
-    src[SLOT][1] += 64;                                                                         \
-  } while (0)
-
-  const int l31 = lane & 31, hi = lane >> 5;
-  const int f = (l31 >> 1) & 7;
-  int fo[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) fo[ks] = l31 * 128 + ((((2 * ks) | hi) ^ f) << 4);
-  const int a_row_off = wr * 64 * 128;
-  const int b_row_off = wc * 32 * 128;
-
-  f32x16 acc[2][2][2];   // [qm][qn][mi]
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][b][mi][r] = 0.f;
-  bf16x8 af[2][4], b0f[4], b1f[4];
-
-#define XREAD_A(BUF, SLOT)                                                                     \
-  do {                                                                                         \
-    const char* _s = smem + (BUF) * BUF_BYTES + slot_offset(SLOT) + a_row_off;                 \
-    _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                           \
-      _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) af[mi][ks] = *(const bf16x8*)(_s + mi * 4096 + fo[ks]); \
-  } while (0)
-#define XREAD_B(BUF, SLOT, DST)                                                                \
-  do {                                                                                         \
-    const char* _s = smem + (BUF) * BUF_BYTES + slot_offset(SLOT) + b_row_off;                 \
-    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) DST[ks] = *(const bf16x8*)(_s + fo[ks]);  \
-  } while (0)
-  // one section: the two quadrants (QM, QNA) and (QM, QNB) share the A fragments; accumulators visited round-robin
-#define XMFMA_2Q(QM, QNA, BFA, QNB, BFB)                                                       \
-  do {                                                                                         \
-    __builtin_amdgcn_s_setprio(1);                                                             \
-    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                         \
-      _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                         \
-        acc[QM][QNA][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BFA[ks], af[mi][ks], acc[QM][QNA][mi], 0, 0, 0); \
-      _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                         \
-        acc[QM][QNB][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BFB[ks], af[mi][ks], acc[QM][QNB][mi], 0, 0, 0); \
-    }                                                                                          \
-    __builtin_amdgcn_s_setprio(0);                                                             \
-  } while (0)
-
-  const int nt = (u_end - u_begin) * 2;
-
-  float rsv[2][2];
-  if constexpr (EPI != VT_EPI_F32_RESID && EPI != VT_EPI_F32) {
-#pragma unroll
-    for (int qm = 0; qm < 2; ++qm)
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-        rsv[qm][mi] = p.nf.row_scale ? p.nf.row_scale[min(bm0 + qm * 128 + wr * 64 + mi * 32 + l31, p.M - 1)] : 1.f;
-  }
-  XSTAGE(0, SLOT_A0);
-  XSTAGE(0, SLOT_B0);
-  XSTAGE(0, SLOT_B1);
-  XSTAGE(0, SLOT_A1);
-  XSTAGE(1, SLOT_A0);
-  XSTAGE(1, SLOT_B0);
-  XSTAGE(1, SLOT_B1);
-  VT_VMCNT(0);
-  if constexpr (EPI != VT_EPI_F32_RESID && EPI != VT_EPI_F32) {
-#pragma unroll
-    for (int qm = 0; qm < 2; ++qm)
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi) asm volatile("" : "+v"(rsv[qm][mi]));
-  }
-  SECTION_SPLIT();
-  if (wr == 1) __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_sched_barrier(0);
-
-  // stage schedule, waits and hazards: exactly the 4-phase loop of gemm_p8_kernel (see there)
-  for (int it = 0; it < nt / 2; ++it) {
-    const int u = it * 2;
-    if (u + 1 < nt) XSTAGE(1, SLOT_A1);
-    XREAD_B(0, SLOT_B0, b0f);
-    XREAD_B(0, SLOT_B1, b1f);
-    XREAD_A(0, SLOT_A0);
-    LOAD_SECTION_END();
-    XMFMA_2Q(0, 0, b0f, 1, b1f);
-    PHASE_END4(u + 1 < nt, 2);
-    if (u + 2 < nt) {
-      XSTAGE(0, SLOT_A0);
-      XSTAGE(0, SLOT_B0);
-      XSTAGE(0, SLOT_B1);
-    }
-    XREAD_A(0, SLOT_A1);
-    LOAD_SECTION_END();
-    XMFMA_2Q(1, 1, b1f, 0, b0f);
-    PHASE_END4(u + 2 < nt, 6);
-    if (u + 2 < nt) XSTAGE(0, SLOT_A1);
-    XREAD_B(1, SLOT_B0, b0f);
-    XREAD_B(1, SLOT_B1, b1f);
-    XREAD_A(1, SLOT_A0);
-    LOAD_SECTION_END();
-    XMFMA_2Q(0, 0, b0f, 1, b1f);
-    PHASE_END4(u + 2 < nt, 2);
-    if (u + 3 < nt) {
-      XSTAGE(1, SLOT_A0);
-      XSTAGE(1, SLOT_B0);
-      XSTAGE(1, SLOT_B1);
-    }
-    XREAD_A(1, SLOT_A1);
-    LOAD_SECTION_END();
-    XMFMA_2Q(1, 1, b1f, 0, b0f);
-    PHASE_END4(u + 3 < nt, 6);
-  }
-  if (wr == 0) __builtin_amdgcn_s_barrier();
-#undef XSTAGE
-#undef XREAD_A
-#undef XREAD_B
-#undef XMFMA_2Q
-
-  // ---- epilogue ------------------------------------------------------------------------------------------------------------
-  if constexpr (EPI == VT_EPI_F32_RESID) {
-    // C += acc (+ bias): the 8 x 16-byte reads of a row slot are issued together and one slot ahead of the stores
-    float* const __restrict__ Cf = (float*)p.C;
-    auto row_of = [&](int r) { return bm0 + (r >> 1) * 128 + wr * 64 + (r & 1) * 32 + l31; };
-    auto col_of = [&](int qn, int g) { return bn0 + qn * 128 + wc * 32 + 8 * g + 4 * hi; };
-    auto load_row = [&](int r, f32x4 (&dst)[2][4]) {
-      const int m = min(row_of(r), p.M - 1);
-#pragma unroll
-      for (int qn = 0; qn < 2; ++qn)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) dst[qn][g] = *(const f32x4*)(Cf + (size_t)m * p.ldc + min(col_of(qn, g), p.N - 4));
-    };
-    f32x4 b4[2][4];
-#pragma unroll
-    for (int qn = 0; qn < 2; ++qn)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) b4[qn][g] = p.bias ? *(const f32x4*)(p.bias + min(col_of(qn, g), p.N - 4)) : (f32x4){0.f, 0.f, 0.f, 0.f};
-    float rs4[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) rs4[r] = p.nf.row_scale ? p.nf.row_scale[min(row_of(r), p.M - 1)] : 1.f;
-    f32x4 cur[2][4], nxt[2][4];
-    load_row(0, cur);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (r + 1 < 4) load_row(r + 1, nxt);
-      const int m = row_of(r);
-      if (m < p.M) {
-#pragma unroll
-        for (int qn = 0; qn < 2; ++qn) {
-          const f32x16 a = acc[r >> 1][qn][r & 1];
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int n = col_of(qn, g);
-            if (n >= p.N) continue;
-            const f32x4 v = {a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]};
-            *(f32x4*)(Cf + (size_t)m * p.ldc + n) = cur[qn][g] + (v * rs4[r] + b4[qn][g]);
-          }
-        }
-      }
-#pragma unroll
-      for (int qn = 0; qn < 2; ++qn)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) cur[qn][g] = nxt[qn][g];
-    }
-  } else {
-#pragma unroll
-    for (int qm = 0; qm < 2; ++qm)
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        const int m = bm0 + qm * 128 + wr * 64 + mi * 32 + l31;
-        if (m >= p.M) continue;
-        const float rs = (EPI == VT_EPI_F32) ? 1.f : rsv[qm][mi];
-#pragma unroll
-        for (int qn = 0; qn < 2; ++qn) {
-          const int nfrag = bn0 + qn * 128 + wc * 32;     // multiple of 32; N % 32 == 0: the fragment is whole or absent
-          if (nfrag >= p.N) continue;
-          const f32x16 a = acc[qm][qn][mi];
-          if constexpr (EPI == VT_EPI_SWIGLU_BF16) {
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-              const int nl = 8 * g + 4 * hi;
-              u32x2 o;
-              o.x = pack_bf16x2(silu8(a[4 * g + 0] * rs) * (a[4 * g + 8] * rs), silu8(a[4 * g + 1] * rs) * (a[4 * g + 9] * rs));
-              o.y = pack_bf16x2(silu8(a[4 * g + 2] * rs) * (a[4 * g + 10] * rs), silu8(a[4 * g + 3] * rs) * (a[4 * g + 11] * rs));
-              *(u32x2*)((bf16_t*)p.C + (size_t)m * p.ldc + (nfrag >> 1) + nl) = o;
-            }
-          } else {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              const int n = nfrag + 8 * g + 4 * hi;
-              f32x4 v = {a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]};
-              v = v * rs;
-              if (p.bias && split == 0) v += *(const f32x4*)(p.bias + n);
               if constexpr (EPI == VT_EPI_BF16_GELU) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = gelu_erf8(v[r]);
@@ -943,21 +803,6 @@ int launch_rp(const GemmP8& p, hipStream_t s) {
   return VT_OK;
 }
 
-template <int EPI>
-int launch_p4x(const GemmP8& p, hipStream_t s) {
-  constexpr int smem = 2 * BUF_BYTES;  // 128 KiB
-  auto kern = gemm_p4x_kernel<EPI>;
-  static bool done = false;
-  if (!done) {
-    VT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    done = true;
-  }
-  const int nwg = cdiv(p.M, 256) * cdiv(p.N, 256) * (p.ksplit > 1 ? p.ksplit : 1);
-  hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), smem, s, p);
-  VT_LAUNCH_CHECK();
-  return VT_OK;
-}
-
 template <int EPI, int ABL = 0, bool P4 = false>
 int launch_p8(const GemmP8& p, hipStream_t s) {
   constexpr int smem = 2 * BUF_BYTES;  // 128 KiB
@@ -1057,6 +902,44 @@ int vt_gemm_p4_splitk_resid_launch(const bf16_t* A, int lda, const bf16_t* W, in
   return VT_OK;
 }
 
+// ---- fused QKV epilogue: host side ------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void row_slot_kernel(const VtAttnSeq* __restrict__ seqs, const int* __restrict__ tile_table,
+                                                       int* __restrict__ row_slot) {
+  const VtAttnSeq sq = seqs[blockIdx.y];
+  const int past = sq.kv_len - sq.q_len;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < sq.q_len; i += gridDim.x * blockDim.x) {
+    const int pos = past + i;
+    const int page = tile_table[sq.table_off + (pos >> 6)];
+    const int tail = (i == sq.q_len - 1) ? 63 - (pos & 63) : 0;
+    row_slot[sq.q_row0 + i] = (tail << 26) | (page * 64 + (pos & 63));
+  }
+}
+}  // namespace
+
+int vt_row_slot_launch(const VtAttnSeq* seqs, int nseq, int max_q_len, const int* tile_table, int* row_slot, hipStream_t s) {
+  VT_REQUIRE(seqs && tile_table && row_slot && nseq > 0 && max_q_len > 0, "vt_row_slot: bad arguments");
+  hipLaunchKernelGGL(row_slot_kernel, dim3(std::min(cdiv(max_q_len, 256), 64), nseq), dim3(256), 0, s, seqs, tile_table, row_slot);
+  VT_LAUNCH_CHECK();
+  return VT_OK;
+}
+
+bool vt_gemm_qkv_fused_supported(int rows, int H, int head_dim) {
+  return head_dim == 128 && (H % 256) == 0 && rows > 64 && vt_gemm_p8_supported(rows, 3 * H, H) &&
+         vt_gemm_pick_cfg(rows, 3 * H, H) == VT_GEMM_CFG_256x256_P4;
+}
+
+int vt_gemm_qkv_fused_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, bf16_t* qkv, int ldqkv, int M, int H,
+                             const VtQkvFuse& qf, hipStream_t s) {
+  VT_REQUIRE(A && W && qkv && qf.k_pages && qf.vt_pages && qf.row_slot && qf.positions && qf.rope_cos && qf.rope_sin,
+             "vt_gemm(qkv fused): null pointer");
+  VT_REQUIRE(qf.heads * 128 == H && vt_gemm_qkv_fused_supported(M, H, 128), "vt_gemm(qkv fused): unsupported shape (M=%d H=%d)", M, H);
+  VT_REQUIRE((lda % 8) == 0 && (ldw % 8) == 0 && (ldqkv % 8) == 0, "vt_gemm(qkv fused): misaligned leading dimensions");
+  GemmP8 p{A, W, qkv, nullptr, M, 3 * H, H, lda, ldw, ldqkv, 1, 0, VtGemmNormFuse{}, qf};
+  VtProfScope prof(VT_PROF_GEMM_TILE, 2.0 * (double)M * 3.0 * (double)H * (double)H, s);
+  return launch_p8<VT_EPI_QKV_PAGES, 0, true>(p, s);
+}
+
 int vt_gemm_p8_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, const float* bias, int M,
                       int N, int K, int epi, hipStream_t s, const VtGemmNormFuse* nf) {
   VT_REQUIRE(vt_gemm_p8_supported(M, N, K), "vt_gemm(p8): needs K %% 128 == 0, K >= 256, N %% 32 == 0 (K=%d N=%d)", K, N);
@@ -1065,7 +948,7 @@ int vt_gemm_p8_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* 
     VT_REQUIRE((epi & 0xff) == VT_EPI_F32_RESID && p.nf.out_w && p.nf.out_xw && p.nf.out_np >= N / 32 && p.nf.out_ldp >= M,
                "vt_gemm(p8): norm-fold producer needs the residual epilogue and its buffers");
 #ifdef VT_ABLATIONS
-  if (epi >= 0x100 && !(epi & 0x3000)) {  // timing ablations (tools/gemm_ablate.py); test library only
+  if (epi >= 0x100 && !(epi & 0x1000)) {  // timing ablations (tools/gemm_ablate.py); test library only
     switch (epi >> 8) {
       case 1: return launch_p8<VT_EPI_BF16, 1>(p, s);
       case 2: return launch_p8<VT_EPI_BF16, 2>(p, s);
@@ -1088,19 +971,6 @@ int vt_gemm_p8_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* 
     }
   }
 #endif
-  if (epi & 0x2000) {   // 4-phase schedule on the 32x32x16 instruction (no norm-fold producer side)
-    VT_REQUIRE(!p.nf.out_partials, "vt_gemm(p4x): the norm-fold producer epilogue lives in the 16x16x32 kernel");
-    switch (epi & 0xff) {
-      case VT_EPI_BF16: return launch_p4x<VT_EPI_BF16>(p, s);
-      case VT_EPI_BF16_GELU: return launch_p4x<VT_EPI_BF16_GELU>(p, s);
-      case VT_EPI_BF16_QGELU: return launch_p4x<VT_EPI_BF16_QGELU>(p, s);
-      case VT_EPI_BF16_RELU: return launch_p4x<VT_EPI_BF16_RELU>(p, s);
-      case VT_EPI_F32_RESID: return launch_p4x<VT_EPI_F32_RESID>(p, s);
-      case VT_EPI_F32: return launch_p4x<VT_EPI_F32>(p, s);
-      case VT_EPI_SWIGLU_BF16: return launch_p4x<VT_EPI_SWIGLU_BF16>(p, s);
-      default: vt_set_error("vt_gemm(p4x): unknown epilogue %d", epi & 0xff); return VT_ERR_ARG;
-    }
-  }
   if (epi & 0x1000) {   // 4-phase variant
     switch (epi & 0xff) {
       case VT_EPI_BF16: return launch_p8<VT_EPI_BF16, 0, true>(p, s);

@@ -50,6 +50,27 @@ inline VtGemmNormFuse vt_nf_rows(const VtGemmNormFuse& nf, long m0) {
 int vt_gemm_skinny_norm_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, int M, int N, int K,
                                int epi, const VtGemmNormFuse& nf, hipStream_t s);
 
+// ---- fused QKV epilogue (vt_gemm8.hip) ---------------------------------------------------------------------
+// The QKV projection of a prefill writes its result where the attention kernels read it: q rotated in place in the fused-QKV
+// buffer, k rotated into the K pages, v transposed into the V^T pages -- what vt_kv_tiles does as a separate pass over 252 MB
+// per layer. Internal epilogue id (not part of the public enum); head_dim 128, rotary on.
+#define VT_EPI_QKV_PAGES 7
+struct VtQkvFuse {
+  bf16_t* k_pages = nullptr;        // this layer's K pages  [page][head][64][128]
+  bf16_t* vt_pages = nullptr;       // this layer's V^T pages [page][head][128][64]
+  const int* row_slot = nullptr;    // [M]: (tail << 26) | (page * 64 + slot); tail = slots to zero behind the LAST new row of a sequence
+  const int* positions = nullptr;   // [M] rotary position of every row
+  const float* rope_cos = nullptr;  // [rope_len][64]
+  const float* rope_sin = nullptr;
+  int heads = 0;                    // heads per q / k / v section (H = heads * 128)
+};
+// row -> cache slot of every new row (one launch per decoder pass)
+int vt_row_slot_launch(const VtAttnSeq* seqs, int nseq, int max_q_len, const int* tile_table, int* row_slot, hipStream_t s);
+// true when the QKV GEMM of (rows x 3H x H) runs as ONE launch of the 256x256 ping-pong kernel, i.e. can carry the fused epilogue
+bool vt_gemm_qkv_fused_supported(int rows, int H, int head_dim);
+int vt_gemm_qkv_fused_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, bf16_t* qkv, int ldqkv, int M, int H,
+                             const VtQkvFuse& qf, hipStream_t s);
+
 // ---- vt_gemm8.hip (256x256 tile, 8-phase pipeline) ---------------------------------------------------
 bool vt_gemm_p8_supported(int M, int N, int K);
 bool vt_gemm_splitk_pays(int M, int N, int K, int ksplit);

@@ -188,7 +188,7 @@ __global__ __launch_bounds__(1024) void sample_top_p_kernel(const float* __restr
   float kept = 0.f, cnt = 0.f;
   for (int i = tid; i < V; i += 1024) {
     const float p = VT_P_OF(i) * inv_z;
-    if (p >= thr) {
+    if (p >= thr && row[i] * inv_temp >= floor_logit) {      // (thr == 0 at top_p >= 1: the top-k filter still applies)
       kept += p;
       cnt += 1.f;
     }
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(1024) void sample_top_p_kernel(const float* __restr
   float mine = 0.f;
   for (int i = i0; i < i1; ++i) {
     const float p = VT_P_OF(i) * inv_z;
-    if (p >= thr) mine += p;
+    if (p >= thr && row[i] * inv_temp >= floor_logit) mine += p;
   }
   // exclusive prefix over threads: wave scan + scan of the 16 wave totals
   float incl = mine;
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(1024) void sample_top_p_kernel(const float* __restr
     int pick = -1;
     for (int i = i0; i < i1; ++i) {
       const float p = VT_P_OF(i) * inv_z;
-      if (p >= thr) {
+      if (p >= thr && row[i] * inv_temp >= floor_logit) {
         pick = i;
         c += p;
         if (u < c) break;
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(1024) void sample_top_p_kernel(const float* __restr
   if (chosen < 0 && mine > 0.f) {  // u landed on a rounding seam: take the last kept token of the highest owning range
     int last = -1;
     for (int i = i0; i < i1; ++i)
-      if (VT_P_OF(i) * inv_z >= thr) last = i;
+      if (VT_P_OF(i) * inv_z >= thr && row[i] * inv_temp >= floor_logit) last = i;
     atomicMax(&chosen, last);
   }
   __syncthreads();
@@ -300,6 +300,7 @@ __global__ __launch_bounds__(1024) void sample_top_p_reg_kernel(const float* __r
     mx = t;
     buf ^= 1;
   }
+  uint32_t valid = 0xffffffffu;   // bit j: slot j is inside the top-k set (all slots when the filter is off)
   if (top_k > 0 && top_k < V) {   // TopKLogitsWarper: everything below the k-th largest scaled logit leaves the distribution
     uint64_t lo = 0, hi = 0x100000000ull;
     for (int it = 0; it < 32; ++it) {
@@ -310,8 +311,13 @@ __global__ __launch_bounds__(1024) void sample_top_p_reg_kernel(const float* __r
       c = block_sum(c);
       if (c >= (float)top_k) lo = mid; else hi = mid;
     }
+    valid = 0u;
 #pragma unroll
-    for (int j = 0; j < NPT; ++j) p[j] = ((uint64_t)order_key(p[j]) >= lo) ? p[j] : -INFINITY;
+    for (int j = 0; j < NPT; ++j) {
+      const bool in = (uint64_t)order_key(p[j]) >= lo;
+      valid |= in ? (1u << j) : 0u;
+      p[j] = in ? p[j] : -INFINITY;
+    }
   }
   float zl = 0.f;
 #pragma unroll
@@ -336,7 +342,7 @@ __global__ __launch_bounds__(1024) void sample_top_p_reg_kernel(const float* __r
   float mine = 0.f, cnt = 0.f;
 #pragma unroll
   for (int j = 0; j < NPT; ++j) {
-    const bool keep = p[j] >= thr && i0 + j < V;
+    const bool keep = p[j] >= thr && i0 + j < V && ((valid >> j) & 1u);
     p[j] = keep ? p[j] : 0.f;       // from here on p holds kept probabilities only
     mine += p[j];
     cnt += keep ? 1.f : 0.f;

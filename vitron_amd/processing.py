@@ -93,7 +93,7 @@ def _to_u8_hwc(img, device) -> torch.Tensor:
     if isinstance(img, torch.Tensor):
         t = img
     else:
-        t = torch.from_numpy(np.asarray(img.convert("RGB") if hasattr(img, "convert") else img))
+        t = torch.from_numpy(np.array(img.convert("RGB") if hasattr(img, "convert") else img))   # np.array: a writable copy
     if t.dim() != 3 or t.shape[-1] != 3:
         raise ValueError(f"expected an HxWx3 image, got {tuple(t.shape)}")
     return t.to(device)
