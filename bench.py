@@ -86,7 +86,9 @@ def cpu_baseline(image_size, frames, text_len, seed):
     from oracle import vitron_oracle as O
     from vitron_amd import synth
 
-    cores = os.cpu_count() or 1
+    # PyTorch's CPU GEMMs stop scaling long before the 256 hardware threads of the GPU box (the sampled estimate on all of them came
+    # out 8x SLOWER than the reference measured on 8 cores, profiles/r2_cpu_reference.json): use at most 64, and say how many
+    cores = min(os.cpu_count() or 1, 64)
     torch.set_num_threads(cores)
     gen = synth.make_generator(seed)
     G = image_size // 14
@@ -121,7 +123,7 @@ def cpu_baseline(image_size, frames, text_len, seed):
         t_llm = t_head + 32 * t_layer
     total = t_vit + t_proj + t_llm
     return {"value": S / total, "unit": "tokens/s", "cores": cores, "kind": "port",
-            "sample": (f"oracle fp32 on {cores} host threads: ViT embeddings + 1 of 23 layers on the full {frames}-frame {image_size}px clip, "
+            "sample": (f"oracle fp32 on {cores} host threads (of {os.cpu_count()}): ViT embeddings + 1 of 23 layers on the full {frames}-frame {image_size}px clip, "
                        f"projector on all {n_vis} visual tokens, final-norm+lm_head and 1 of 32 decoder layers on the first {Ss} of {S} "
                        "positions; extrapolated linearly in depth and sequence length (attention's quadratic term is under-counted, "
                        "which flatters the CPU)"),

@@ -160,6 +160,12 @@ int vt_argmax(const float* logits, int rows, int V, int ldl, int* out_ids, void*
  * so the next decoder pass can be enqueued before the host has seen the token. */
 int vt_decode_feed(const uint16_t* tok_table, int H, int vocab, const int* next_ids, int* finished, const int* eos_ids, int n_eos,
                    int pad_id, int* tokens_out, uint16_t* x, int* seq_desc, int* positions, int nseq, void* stream);
+/* Mean cross entropy over the rows whose label is not `ignore_index`: loss[0] = mean_r(logsumexp(logits[r]) - logits[r][labels[r]]).
+ * The caller shifts (row r scores the token at position r + 1). row_nll: fp32 scratch [rows] (per-row losses, -1 = skipped).
+ * Replaces the CrossEntropyLoss of LlamaForCausalLM.forward when `labels` are passed (reference llava_llama.py:91-102). */
+int vt_cross_entropy(const float* logits, int rows, int V, int ldl, const int* labels, int ignore_index, float* row_nll,
+                     float* loss, void* stream);
+
 /* one sampled token per row, the warper chain of GenerationMixin.sample in transformers' order: logits / temperature,
  * TopKLogitsWarper (top_k > 0: everything below the k-th largest value is removed, ties stay; 0 = off), softmax,
  * TopPLogitsWarper keep-set (top_p >= 1 keeps all), inverse-CDF draw with a counter-based uniform of (seed, step, row).
@@ -282,8 +288,9 @@ typedef struct vt_llama_model {
   int prefill_norm_fold;        /* 1: prefills (rows > 64) fold RMSNorm into the MFMA tile GEMMs (residual epilogues emit bf16(x .* w)
                                    and partial sums of x^2, the consumer GEMMs scale their rows); same accuracy, measured no faster:
                                    default 0. Decode steps (<= 16 rows) always fold. */
-  int no_qkv_fuse;              /* 1: prefills keep rotary + K / V^T page writes as a separate pass (vt_kv_tiles) instead of the
-                                   QKV projection's epilogue (same bits either way; the switch exists for tests and A/B). */
+  int qkv_fuse;                 /* 1: prefills write rotated q / K pages / V^T pages from the QKV projection's epilogue instead of the
+                                   separate vt_kv_tiles pass. Bit-identical results; measured 20 us per launch SLOWER at S = 5120 (the
+                                   epilogue of a one-workgroup-per-CU kernel overlaps with nothing: 455 vs 386 + 48.5 us): default 0. */
 } vt_llama_model;
 
 /* KV pool: k  [num_layers][num_pages][heads][64][head_dim]   (K rows, rotary applied)

@@ -51,7 +51,7 @@ class VtLlamaModel(C.Structure):
     _fields_ = [("hidden", C.c_int), ("heads", C.c_int), ("head_dim", C.c_int), ("intermediate", C.c_int),
                 ("num_layers", C.c_int), ("vocab", C.c_int), ("rms_eps", C.c_float), ("final_norm", vp),
                 ("lm_head", vp), ("rope_cos", vp), ("rope_sin", vp), ("rope_len", C.c_int),
-                ("layers", C.POINTER(VtLlamaLayer)), ("prefill_norm_fold", C.c_int), ("no_qkv_fuse", C.c_int)]
+                ("layers", C.POINTER(VtLlamaLayer)), ("prefill_norm_fold", C.c_int), ("qkv_fuse", C.c_int)]
 
 
 class VtKvCache(C.Structure):
@@ -79,6 +79,7 @@ SIGNATURES = {
     "vt_embed_splice": (_i, [vp, _i, vp, _i, vp, _i, vp, _i, _i, vp, vp]),
     "vt_argmax": (_i, [vp, _i, _i, _i, vp, vp]),
     "vt_decode_feed": (_i, [vp, _i, _i, vp, vp, vp, _i, _i, vp, vp, vp, vp, _i, vp]),
+    "vt_cross_entropy": (_i, [vp, _i, _i, _i, vp, _i, vp, vp, vp]),
     "vt_sample_top_p": (_i, [vp, _i, _i, _i, _f, _i, _f, C.c_uint64, C.c_uint64, vp, vp, vp]),
     "vt_projector_workspace_bytes": (_sz, [_i, _i]),
     "vt_projector_forward": (_i, [vp, _i, _i, vp, vp, _i, vp, vp, _i, vp, vp, _sz, vp]),

@@ -207,6 +207,11 @@ int vt_preprocess(const void* src, int src_u8, int hwc, int F, int H, int W, int
                               S_(stream));
 }
 
+int vt_cross_entropy(const float* logits, int rows, int V, int ldl, const int* labels, int ignore_index, float* row_nll,
+                     float* loss, void* stream) {
+  return vt_cross_entropy_launch(logits, rows, V, ldl, labels, ignore_index, row_nll, loss, S(stream));
+}
+
 int vt_sample_top_p(const float* logits, int rows, int V, int ldl, float temperature, int top_k, float top_p, uint64_t seed,
                     uint64_t step, int* out_ids, int* kept_count, void* stream) {
   return vt_sample_top_p_launch(logits, rows, V, ldl, temperature, top_k, top_p, seed, step, out_ids, kept_count, S(stream));
@@ -446,9 +451,9 @@ int vt_llama_forward(const vt_llama_model* m, const vt_kv_cache* kv, const uint1
   consume_a.in_n = consume_b.in_n = H / 16;
   consume_a.inv_dim = consume_b.inv_dim = 1.0f / (float)H;
   consume_a.eps = consume_b.eps = m->rms_eps;
-  // prefill with the QKV projection on ONE launch of the 256x256 ping-pong kernel: its epilogue writes rotated q / K pages / V^T
-  // pages itself (no vt_kv_tiles pass: 252 MB of traffic and a launch per layer at S = 5120); switch: vt_llama_model.no_qkv_fuse
-  const bool fuse_qkv = max_q_len > 1 && !fold_tile && !m->no_qkv_fuse && vt_gemm_qkv_fused_supported(rows, H, HD);
+  // opt-in (vt_llama_model.qkv_fuse): prefill with the QKV projection on ONE launch of the 256x256 ping-pong kernel whose epilogue
+  // writes rotated q / K pages / V^T pages itself (no vt_kv_tiles pass). Bit-identical, measured slower: default off
+  const bool fuse_qkv = max_q_len > 1 && !fold_tile && m->qkv_fuse == 1 && vt_gemm_qkv_fused_supported(rows, H, HD);
   if (fuse_qkv) VT_TRY(vt_row_slot_launch((const VtAttnSeq*)seq_desc, nseq, max_q_len, tile_table, w.row_slot, s));
   for (int l = 0; l < m->num_layers; ++l) {
     const vt_llama_layer& L = m->layers[l];

@@ -348,14 +348,14 @@ __global__ __launch_bounds__(256) void kv_tiles_kernel(bf16_t* __restrict__ qkv,
           {
             const float a0 = bf16lo_to_f32(lo[w]), a1 = bf16hi_to_f32(lo[w]);
             const float b0 = bf16lo_to_f32(hi[w]), b1 = bf16hi_to_f32(hi[w]);
-            klo_o[w] = pack_bf16x2(a0 * c0 - b0 * s0, a1 * c1 - b1 * s1);
-            khi_o[w] = pack_bf16x2(b0 * c0 + a0 * s0, b1 * c1 + a1 * s1);
+            klo_o[w] = pack_bf16x2(rope_lo(a0, b0, c0, s0), rope_lo(a1, b1, c1, s1));
+            khi_o[w] = pack_bf16x2(rope_hi(a0, b0, c0, s0), rope_hi(a1, b1, c1, s1));
           }
           {
             const float a0 = bf16lo_to_f32(qlo[w]), a1 = bf16hi_to_f32(qlo[w]);
             const float b0 = bf16lo_to_f32(qhi[w]), b1 = bf16hi_to_f32(qhi[w]);
-            qlo_o[w] = pack_bf16x2(a0 * c0 - b0 * s0, a1 * c1 - b1 * s1);
-            qhi_o[w] = pack_bf16x2(b0 * c0 + a0 * s0, b1 * c1 + a1 * s1);
+            qlo_o[w] = pack_bf16x2(rope_lo(a0, b0, c0, s0), rope_lo(a1, b1, c1, s1));
+            qhi_o[w] = pack_bf16x2(rope_hi(a0, b0, c0, s0), rope_hi(a1, b1, c1, s1));
           }
         }
         lo = klo_o;
@@ -687,7 +687,7 @@ __global__ __launch_bounds__(512) void attn_decode_fused_kernel(
       const float a0 = bf16lo_to_f32(lo[w]), a1 = bf16hi_to_f32(lo[w]);
       const float b0 = bf16lo_to_f32(hi[w]), b1 = bf16hi_to_f32(hi[w]);
       const float c0 = cs[2 * w], c1 = cs[2 * w + 1], s0 = sn[2 * w], s1 = sn[2 * w + 1];
-      o[w] = upper ? pack_bf16x2(b0 * c0 + a0 * s0, b1 * c1 + a1 * s1) : pack_bf16x2(a0 * c0 - b0 * s0, a1 * c1 - b1 * s1);
+      o[w] = upper ? pack_bf16x2(rope_hi(a0, b0, c0, s0), rope_hi(a1, b1, c1, s1)) : pack_bf16x2(rope_lo(a0, b0, c0, s0), rope_lo(a1, b1, c1, s1));
     }
     return o;
   };

@@ -87,6 +87,12 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 __device__ __forceinline__ float bf16lo_to_f32(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16hi_to_f32(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
+// half-split rotary embedding of one (low, high) pair: (a, b) -> (a cos - b sin, b cos + a sin). Spelled with explicit fused
+// multiply-adds so that every kernel that rotates (vt_kv_tiles, the fused decode attention, the QKV GEMM epilogue) rounds the
+// same way -- their K pages are compared bit for bit.
+__device__ __forceinline__ float rope_lo(float a, float b, float c, float s) { return __builtin_fmaf(a, c, -(b * s)); }
+__device__ __forceinline__ float rope_hi(float a, float b, float c, float s) { return __builtin_fmaf(b, c, a * s); }
+
 // ---- wave-level reductions (64 lanes) -----------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

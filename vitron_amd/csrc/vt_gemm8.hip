@@ -339,131 +339,153 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmP8 p) {
   // out_w[n]) and the sum of x_new^2 per row and 32-column group (the 4 lanes lane>>4 of a row hold one group: 2 x 16 columns)
   const float* const row_scale = p.nf.row_scale;
   if constexpr (EPI == VT_EPI_QKV_PAGES) {
-    // Fused QKV epilogue. A 256-column tile is two whole heads of ONE section (q, k or v: H % 256 == 0). Per head (qn = 0, 1) the
-    // eight waves park their accumulators as bf16 in the LDS the main loop no longer needs -- bf16 because the reference rounds
-    // the projection to the storage dtype BEFORE the rotary embedding (and the oracle's emulation does the same) -- then all 512
-    // threads write the head out from there with 16-byte accesses:
-    //   q, k : thread (row, half h) rotates dims [32h, 32h+32) against their partners 64 further up (apply_rotary_pos_emb, half-
-    //          split) with the fp32 cos / sin rows of the row's position, the same expression vt_kv_tiles evaluates; q goes back to
-    //          the fused-QKV buffer in place, k to its page slot;
-    //   v    : parked TRANSPOSED (dim-major), thread (dim, 64-token chunk) moves 8 tokens per store into the V^T page.
+    // Fused QKV epilogue. A 256-column tile is two whole heads of ONE section (q, k or v: H % 256 == 0). Every lane writes its own
+    // accumulator elements, as in the plain epilogue (a lane holds row m = ..+(lane & 15) and 4 consecutive dims per fragment):
+    //   v    : the 4 lanes of a quad hold 4 consecutive rows (tokens) x 4 dims; a 4x4 transpose inside the quad (two xor-shuffles
+    //          per fragment) turns that into 4 consecutive tokens of ONE dim per lane = one 8-byte store into the V^T page;
+    //   q, k : the rotary partner of dim d is dim d +- 64, held by the wave two columns over: the eight waves park the head as
+    //          bf16 in the LDS the main loop no longer needs -- bf16 because the reference rounds the projection to the storage
+    //          dtype BEFORE the rotary embedding (the oracle's emulation does the same) -- every lane reads its partner values back
+    //          and evaluates the same fp32 expression as vt_kv_tiles; q goes to the fused-QKV buffer, k to its page slot.
     // The last new row of a sequence also zero-fills the rest of its page (k rows, v^t columns), as vt_kv_tiles does.
     const int Hq = p.qf.heads * 128;
     const int sect = bn0 / Hq;                       // 0 = q, 1 = k, 2 = v (uniform over the workgroup)
     const int head0 = (bn0 - sect * Hq) >> 7;
-    bf16_t* const T = (bf16_t*)smem;
-    constexpr int LDT = 136;                         // row-major parking: 256 rows x (128 + 8) bf16
-    constexpr int LDV = 264;                         // transposed parking: 128 dims x (256 + 8) bf16
     const int heads = p.qf.heads;
+    int enc[8], rpos[8];
 #pragma unroll
-    for (int qn = 0; qn < 2; ++qn) {
-      __syncthreads();                               // main loop / previous head: nobody reads this LDS any more
-      if (sect < 2) {
+    for (int r = 0; r < 8; ++r) {
+      const int m = min(bm0 + (r >> 2) * 128 + wr * 64 + (r & 3) * 16 + (lane & 15), p.M - 1);
+      enc[r] = (sect >= 1) ? p.qf.row_slot[m] : 0;
+      rpos[r] = (sect < 2) ? p.qf.positions[m] : 0;
+    }
+    if (sect == 2) {
 #pragma unroll
-        for (int qm = 0; qm < 2; ++qm)
+      for (int qn = 0; qn < 2; ++qn) {
+        const int head = head0 + qn;
 #pragma unroll
-          for (int mi = 0; mi < 4; ++mi) {
-            const int row = qm * 128 + wr * 64 + mi * 16 + (lane & 15);
+        for (int r = 0; r < 8; ++r) {
+          const int qm = r >> 2, mi = r & 3;
+          const int m = bm0 + qm * 128 + wr * 64 + mi * 16 + (lane & 15);
+          // slots of the quad's first and last row: 4 consecutive rows -> 4 consecutive slots of one page (the common case)
+          const int e0 = __shfl(enc[r], lane & ~3, 64), e3 = __shfl(enc[r], lane | 3, 64);
+          const bool quad_ok = (bm0 + qm * 128 + wr * 64 + mi * 16 + ((lane & 15) | 3)) < p.M &&
+                               ((e3 & 0x3ffffff) - (e0 & 0x3ffffff)) == 3 && ((e0 & 3) == 0);
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-              const f32x4 v = acc[qm][qn][mi][ni];
+          for (int ni = 0; ni < 2; ++ni) {
+            const f32x4 v = acc[qm][qn][mi][ni];
+            const int n0 = wc * 32 + ni * 16 + ((lane >> 4) << 2);
+            // 4x4 transpose over the quad: afterwards lane j = lane & 3 holds dim n0 + j of rows (lane & ~3) .. +3
+            float t0 = v[0], t1 = v[1], t2 = v[2], t3 = v[3];
+            {
+              const float s01 = __shfl_xor((lane & 1) ? t0 : t1, 1, 64), s23 = __shfl_xor((lane & 1) ? t2 : t3, 1, 64);
+              if (lane & 1) { t0 = s01; t2 = s23; } else { t1 = s01; t3 = s23; }
+              const float u02 = __shfl_xor((lane & 2) ? t0 : t2, 2, 64), u13 = __shfl_xor((lane & 2) ? t1 : t3, 2, 64);
+              if (lane & 2) { t0 = u02; t1 = u13; } else { t2 = u02; t3 = u13; }
+            }
+            // now t_i = element (row quad_base + i, dim n0 + (lane & 3))
+            const int dim = n0 + (lane & 3);
+            if (quad_ok) {
+              const int sl = e0 & 0x3ffffff;
               u32x2 o;
-              o.x = pack_bf16x2(v[0], v[1]);
-              o.y = pack_bf16x2(v[2], v[3]);
-              *(u32x2*)(T + row * LDT + wc * 32 + ni * 16 + ((lane >> 4) << 2)) = o;
-            }
-          }
-      } else {
+              o.x = pack_bf16x2(t0, t1);
+              o.y = pack_bf16x2(t2, t3);
+              *(u32x2*)(p.qf.vt_pages + (((size_t)(sl >> 6) * heads + head) * 128 + dim) * 64 + (sl & 63)) = o;
+            } else {
+              const float tv[4] = {t0, t1, t2, t3};
 #pragma unroll
-        for (int qm = 0; qm < 2; ++qm)
-#pragma unroll
-          for (int mi = 0; mi < 4; ++mi) {
-            const int row = qm * 128 + wr * 64 + mi * 16 + (lane & 15);
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-              const f32x4 v = acc[qm][qn][mi][ni];
-              const int col = wc * 32 + ni * 16 + ((lane >> 4) << 2);
-#pragma unroll
-              for (int j = 0; j < 4; ++j) T[(col + j) * LDV + row] = f32_to_bf16(v[j]);
-            }
-          }
-      }
-      __syncthreads();
-      const int head = head0 + qn;
-      if (sect < 2) {
-        const int row = threadIdx.x >> 1, hh = threadIdx.x & 1;
-        const int m = bm0 + row;
-        if (m < p.M) {
-          const int enc = p.qf.row_slot[m];
-          const int slot = enc & 0x3ffffff, tail = (unsigned)enc >> 26;
-          const int rp = p.qf.positions[m];
-          const float* cs = p.qf.rope_cos + (size_t)rp * 64 + hh * 32;
-          const float* sn = p.qf.rope_sin + (size_t)rp * 64 + hh * 32;
-          bf16_t* dst = (sect == 0) ? (bf16_t*)p.C + (size_t)m * p.ldc + head * 128
-                                    : p.qf.k_pages + (((size_t)(slot >> 6) * heads + head) * 64 + (slot & 63)) * 128;
-          const bf16_t* src = T + row * LDT + hh * 32;
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const u32x4 lo = *(const u32x4*)(src + c * 8);
-            const u32x4 hi = *(const u32x4*)(src + 64 + c * 8);
-            const f32x4 c0 = *(const f32x4*)(cs + c * 8), c1 = *(const f32x4*)(cs + c * 8 + 4);
-            const f32x4 s0 = *(const f32x4*)(sn + c * 8), s1 = *(const f32x4*)(sn + c * 8 + 4);
-            const float cc[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
-            const float ss[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
-            u32x4 lo_o, hi_o;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-              const float a0 = bf16lo_to_f32(lo[w]), a1 = bf16hi_to_f32(lo[w]);
-              const float b0 = bf16lo_to_f32(hi[w]), b1 = bf16hi_to_f32(hi[w]);
-              lo_o[w] = pack_bf16x2(a0 * cc[2 * w] - b0 * ss[2 * w], a1 * cc[2 * w + 1] - b1 * ss[2 * w + 1]);
-              hi_o[w] = pack_bf16x2(b0 * cc[2 * w] + a0 * ss[2 * w], b1 * cc[2 * w + 1] + a1 * ss[2 * w + 1]);
-            }
-            *(u32x4*)(dst + hh * 32 + c * 8) = lo_o;
-            *(u32x4*)(dst + 64 + hh * 32 + c * 8) = hi_o;
-          }
-          if (sect == 1 && tail) {                   // last new row of its sequence: zero the k rows behind it in the page
-            const u32x4 z = {0u, 0u, 0u, 0u};
-            for (int t = 1; t <= tail; ++t)
-#pragma unroll
-              for (int c = 0; c < 4; ++c) {
-                *(u32x4*)(dst + t * 128 + hh * 32 + c * 8) = z;
-                *(u32x4*)(dst + t * 128 + 64 + hh * 32 + c * 8) = z;
+              for (int i = 0; i < 4; ++i) {
+                const int ei = __shfl(enc[r], (lane & ~3) | i, 64);
+                const int mi_row = bm0 + qm * 128 + wr * 64 + mi * 16 + ((lane & 12) | i);
+                if (mi_row < p.M) {
+                  const int sl = ei & 0x3ffffff;
+                  p.qf.vt_pages[(((size_t)(sl >> 6) * heads + head) * 128 + dim) * 64 + (sl & 63)] = f32_to_bf16(tv[i]);
+                }
               }
+            }
+            const int tl = (unsigned)enc[r] >> 26;      // this lane's OWN row ends a sequence: zero its 4 dims behind the slot
+            if (tl && m < p.M) {
+              const int sl = enc[r] & 0x3ffffff;
+              for (int j = 0; j < 4; ++j) {
+                bf16_t* col = p.qf.vt_pages + (((size_t)(sl >> 6) * heads + head) * 128 + n0 + j) * 64 + (sl & 63);
+                for (int t = 1; t <= tl; ++t) col[t] = 0;
+              }
+            }
           }
         }
-      } else {
-        const int dd = threadIdx.x & 127, ch = threadIdx.x >> 7;
-        const bf16_t* src = T + dd * LDV + ch * 64;
-#pragma unroll 2
-        for (int j = 0; j < 8; ++j) {
-          const int m0 = bm0 + ch * 64 + j * 8;
-          if (m0 >= p.M) break;
-          const u32x4 vals = *(const u32x4*)(src + j * 8);
-          const int e0 = p.qf.row_slot[m0], e7 = p.qf.row_slot[min(m0 + 7, p.M - 1)];
-          const int s0 = e0 & 0x3ffffff, s7 = e7 & 0x3ffffff;
-          if (m0 + 7 < p.M && s7 - s0 == 7 && (s0 & 7) == 0 && ((unsigned)e0 >> 26) == 0) {
-            // 8 consecutive rows -> 8 consecutive slots of one page, none of rows 0..6 ends a sequence (s7 - s0 == 7 says so)
-            *(u32x4*)(p.qf.vt_pages + (((size_t)(s0 >> 6) * heads + head) * 128 + dd) * 64 + (s0 & 63)) = vals;
-          } else {
+      }
+    } else {
+      bf16_t* const T = (bf16_t*)smem;
+      constexpr int LDT = 136;                       // 256 rows x (128 + 8) bf16
+      const float* __restrict__ const cos_t = p.qf.rope_cos;
+      const float* __restrict__ const sin_t = p.qf.rope_sin;
+      const bool upper = wc >= 2;                    // this wave holds dims 64..127 of the head: out = x*cos + partner*sin
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              if (m0 + e >= p.M) break;
-              const int se = p.qf.row_slot[m0 + e] & 0x3ffffff;
-              const uint32_t wv = vals[e >> 1];
-              p.qf.vt_pages[(((size_t)(se >> 6) * heads + head) * 128 + dd) * 64 + (se & 63)] = (bf16_t)((e & 1) ? (wv >> 16) : (wv & 0xffffu));
+      for (int qn = 0; qn < 2; ++qn) {
+        const int head = head0 + qn;
+        __syncthreads();                             // main loop / previous head: nobody reads this LDS any more
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const int row = (r >> 2) * 128 + wr * 64 + (r & 3) * 16 + (lane & 15);
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) {
+            const f32x4 v = acc[r >> 2][qn][r & 3][ni];
+            u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            *(u32x2*)(T + row * LDT + wc * 32 + ni * 16 + ((lane >> 4) << 2)) = o;
+          }
+        }
+        __syncthreads();
+        // one row at a time: ALL its loads (partner values from LDS, cos / sin rows from L2) are issued before its first store --
+        // a load behind a store to memory the compiler cannot tell apart waits for it, which serialises the L2 round trips
+#pragma unroll
+        for (int rp = 0; rp < 8; ++rp) {
+          u32x2 part[1][2];
+          f32x4 c4[1][2], s4[1][2];
+#pragma unroll
+          for (int h = 0; h < 1; ++h) {
+            const int r = rp + h;
+            const int row = (r >> 2) * 128 + wr * 64 + (r & 3) * 16 + (lane & 15);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+              const int col = wc * 32 + ni * 16 + ((lane >> 4) << 2);
+              part[h][ni] = *(const u32x2*)(T + row * LDT + (col ^ 64));
+              c4[h][ni] = *(const f32x4*)(cos_t + (size_t)rpos[r] * 64 + (col & 63));
+              s4[h][ni] = *(const f32x4*)(sin_t + (size_t)rpos[r] * 64 + (col & 63));
             }
           }
-          // page tail behind the last new row of a sequence (at most one row in 8 carries it)
-          for (int e = 0; e < 8; ++e) {
-            if (m0 + e >= p.M) break;
-            const int ee = p.qf.row_slot[m0 + e];
-            const int tl = (unsigned)ee >> 26;
-            if (tl) {
-              const int se = ee & 0x3ffffff;
-              bf16_t* col = p.qf.vt_pages + (((size_t)(se >> 6) * heads + head) * 128 + dd) * 64 + (se & 63);
-              for (int t = 1; t <= tl; ++t) col[t] = 0;
+#pragma unroll
+          for (int h = 0; h < 1; ++h) {
+            const int r = rp + h;
+            const int m = bm0 + (r >> 2) * 128 + wr * 64 + (r & 3) * 16 + (lane & 15);
+            if (m >= p.M) continue;
+            const int sl = enc[r] & 0x3ffffff, tl = (unsigned)enc[r] >> 26;
+            bf16_t* __restrict__ dst = (sect == 0) ? (bf16_t*)p.C + (size_t)m * p.ldc + head * 128
+                                                   : p.qf.k_pages + (((size_t)(sl >> 6) * heads + head) * 64 + (sl & 63)) * 128;
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+              const int col = wc * 32 + ni * 16 + ((lane >> 4) << 2);
+              const f32x4 v = acc[r >> 2][qn][r & 3][ni];
+              const uint32_t xo[2] = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};   // the bf16 values parked above
+              const uint32_t po[2] = {part[h][ni].x, part[h][ni].y};
+              uint32_t ov[2];
+#pragma unroll
+              for (int w = 0; w < 2; ++w) {
+                // a = low-half value, b = high-half value of the pair; the shared rope_lo / rope_hi of vt_kv_tiles
+                const float a0 = bf16lo_to_f32(upper ? po[w] : xo[w]), a1 = bf16hi_to_f32(upper ? po[w] : xo[w]);
+                const float b0 = bf16lo_to_f32(upper ? xo[w] : po[w]), b1 = bf16hi_to_f32(upper ? xo[w] : po[w]);
+                const float c0 = c4[h][ni][2 * w], c1 = c4[h][ni][2 * w + 1], s0 = s4[h][ni][2 * w], s1 = s4[h][ni][2 * w + 1];
+                ov[w] = upper ? pack_bf16x2(rope_hi(a0, b0, c0, s0), rope_hi(a1, b1, c1, s1))
+                              : pack_bf16x2(rope_lo(a0, b0, c0, s0), rope_lo(a1, b1, c1, s1));
+              }
+              const u32x2 o = {ov[0], ov[1]};
+              *(u32x2*)(dst + col) = o;
+              if (sect == 1 && tl) {                 // last new row of its sequence: zero the k rows behind it in the page
+                const u32x2 z = {0u, 0u};
+                for (int t = 1; t <= tl; ++t) *(u32x2*)(dst + t * 128 + col) = z;
+              }
             }
           }
+          if (rp & 1) __builtin_amdgcn_sched_barrier(0);   // at most two rows' loads in flight: no spills (accumulators stay live)
         }
       }
     }

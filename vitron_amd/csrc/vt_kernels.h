@@ -137,6 +137,8 @@ int vt_argmax_launch(const float* logits, int rows, int V, int ldl, int* out_ids
 int vt_decode_feed_launch(const bf16_t* tok_table, int H, int vocab, const int* next_ids, int* finished, const int* eos_ids,
                           int n_eos, int pad_id, int* tokens_out, bf16_t* x, int* seq_desc, int* positions, int nseq,
                           hipStream_t s);
+int vt_cross_entropy_launch(const float* logits, int rows, int V, int ldl, const int* labels, int ignore_index, float* row_nll,
+                            float* loss, hipStream_t s);
 int vt_sample_top_p_launch(const float* logits, int rows, int V, int ldl, float temperature, int top_k, float top_p, uint64_t seed,
                            uint64_t step, int* out_ids, int* kept_count, hipStream_t s);
 

@@ -393,7 +393,54 @@ __global__ __launch_bounds__(1024) void sample_top_p_reg_kernel(const float* __r
   if (tid == 0) out_ids[blockIdx.x] = chosen;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Shifted-token cross entropy of LlamaForCausalLM.forward(labels=...) (ignore_index rows skipped, mean over the rest):
+//   nll[r] = logsumexp(logits[r]) - logits[r][label[r]]    one 1024-thread block per row, then one block averages.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void cross_entropy_rows_kernel(const float* __restrict__ logits, int V, int ldl,
+                                                                  const int* __restrict__ labels, int ignore_index,
+                                                                  float* __restrict__ nll) {
+  __shared__ float sh[16];
+  const int r = blockIdx.x;
+  const int lab = labels[r];
+  if (lab == ignore_index || lab < 0 || lab >= V) {     // (an out-of-range label cannot index the row: it is skipped like ignore_index)
+    if (threadIdx.x == 0) nll[r] = -1.f;                // marker: not counted
+    return;
+  }
+  const float* row = logits + (size_t)r * ldl;
+  float mx = -INFINITY;
+  for (int i = threadIdx.x; i < V; i += 1024) mx = fmaxf(mx, row[i]);
+  mx = block_max_1024(mx, sh);
+  float z = 0.f;
+  for (int i = threadIdx.x; i < V; i += 1024) z += expf(row[i] - mx);
+  z = block_sum_1024(z, sh);
+  if (threadIdx.x == 0) nll[r] = fmaxf(logf(z) + mx - row[lab], 0.f);
+}
+__global__ __launch_bounds__(1024) void cross_entropy_mean_kernel(const float* __restrict__ nll, int rows, float* __restrict__ loss) {
+  __shared__ float sh[16];
+  float s = 0.f, c = 0.f;
+  for (int i = threadIdx.x; i < rows; i += 1024) {
+    const float v = nll[i];
+    if (v >= 0.f) {
+      s += v;
+      c += 1.f;
+    }
+  }
+  s = block_sum_1024(s, sh);
+  c = block_sum_1024(c, sh);
+  if (threadIdx.x == 0) loss[0] = s / c;                // no valid row: 0/0 = NaN, as torch's mean over nothing
+}
+
 }  // namespace
+
+int vt_cross_entropy_launch(const float* logits, int rows, int V, int ldl, const int* labels, int ignore_index, float* row_nll,
+                            float* loss, hipStream_t s) {
+  VT_REQUIRE(logits && labels && row_nll && loss && rows > 0 && V > 0, "vt_cross_entropy: bad arguments");
+  hipLaunchKernelGGL(cross_entropy_rows_kernel, dim3(rows), dim3(1024), 0, s, logits, V, ldl, labels, ignore_index, row_nll);
+  hipLaunchKernelGGL(cross_entropy_mean_kernel, dim3(1), dim3(1024), 0, s, row_nll, rows, loss);
+  VT_LAUNCH_CHECK();
+  return VT_OK;
+}
 
 int vt_sample_top_p_launch(const float* logits, int rows, int V, int ldl, float temperature, int top_k, float top_p, uint64_t seed,
                            uint64_t step, int* out_ids, int* kept_count, hipStream_t s) {

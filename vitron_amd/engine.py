@@ -368,13 +368,14 @@ class PackedLlama:
         m.rope_cos, m.rope_sin, m.rope_len = self.rope_cos.data_ptr(), self.rope_sin.data_ptr(), self.rope_len
         m.layers = C.cast(self.layers, C.POINTER(_lib.VtLlamaLayer))
         m.prefill_norm_fold = int(bool(cfg.get("prefill_norm_fold", False)))
-        m.no_qkv_fuse = int(bool(cfg.get("no_qkv_fuse", False)))
+        m.qkv_fuse = int(bool(cfg.get("qkv_fuse", False)))
         self.model = m
         self.ws = Workspace(dev)
 
     def set_qkv_fuse(self, on: bool) -> None:
-        """Prefill: rotary + K / V^T page writes inside the QKV GEMM's epilogue (default) or as the separate vt_kv_tiles pass."""
-        self.model.no_qkv_fuse = int(not on)
+        """Prefill: rotary + K / V^T page writes inside the QKV GEMM's epilogue instead of the separate vt_kv_tiles pass
+        (vt_llama_model.qkv_fuse; bit-identical, measured slower at the benchmark shape: default off)."""
+        self.model.qkv_fuse = int(bool(on))
 
     def set_prefill_norm_fold(self, on: bool) -> None:
         """RMSNorm folded into the prefill tile GEMMs (vt_llama_model.prefill_norm_fold; measured neutral, default off)."""

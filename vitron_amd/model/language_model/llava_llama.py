@@ -272,8 +272,9 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
             idx = list(range(B * S))
             past.padded_len += S
         flat = inputs_embeds.reshape(B * S, H)
-        if len(idx) != B * S:
-            flat = flat.index_select(0, torch.tensor(idx, device=flat.device))
+        if len(idx) != B * S:   # pack the valid rows (padding never enters the decoder): a row gather by the splice kernel
+            rowsel = torch.tensor(idx, dtype=torch.int32, device=flat.device)
+            flat = ops.embed_splice(flat.contiguous(), None, None, torch.stack([torch.zeros_like(rowsel), rowsel], 1).contiguous())
         rows = flat.shape[0]
         logits_p, hidden = llama_forward(llama, past.kv, seqs, flat, lens, logit_rows=list(range(rows)), return_hidden=True)
         if len(idx) != B * S:
@@ -284,8 +285,10 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
         logits = logits.view(B, S, llama.V)
         loss = None
         if labels is not None:  # shifted cross entropy, ignore_index -100 (LlamaForCausalLM.forward)
-            loss = torch.nn.functional.cross_entropy(logits[:, :-1].reshape(-1, llama.V), labels[:, 1:].reshape(-1).to(logits.device),
-                                                     ignore_index=-100)
+            # one row per (sample, position < S-1): position j scores label j+1; the last position of every sample scores nothing
+            shifted = torch.full((B, S), -100, dtype=torch.int32, device=logits.device)
+            shifted[:, :-1] = labels[:, 1:].to(device=logits.device, dtype=torch.int32)
+            loss = ops.cross_entropy(logits.view(B * S, llama.V), shifted.reshape(-1), ignore_index=-100)
         if not use_cache and past_key_values is None:
             past.release()
             past = None
@@ -357,7 +360,8 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
         idx = [b * S + j for b in range(B) for j in range(S) if mask_host[b][j]]
         flat = embeds.reshape(B * S, H)
         if len(idx) != B * S:
-            flat = flat.index_select(0, torch.tensor(idx, device=dev))
+            rowsel = torch.tensor(idx, dtype=torch.int32, device=dev)
+            flat = ops.embed_splice(flat.contiguous(), None, None, torch.stack([torch.zeros_like(rowsel), rowsel], 1).contiguous())
         seqs = [SequenceState() for _ in range(B)]
         # ---- multi-turn KV reuse (batch 1): keep the pages of the longest common whole-page prefix of the last call ------------
         sig = None

@@ -235,3 +235,16 @@ def sample_top_p(logits: torch.Tensor, temperature: float, top_p: float, seed: i
                                    float(top_p if top_p else 1.0), int(seed) & (2 ** 64 - 1), int(step), _p(out), _p(kept),
                                    _stream()), "vt_sample_top_p")
     return (out, kept) if return_kept else out
+
+
+def cross_entropy(logits: torch.Tensor, labels: torch.Tensor, ignore_index: int = -100) -> torch.Tensor:
+    """Mean cross entropy of fp32 logits [rows, V] against int labels [rows] (rows with `ignore_index` skipped); 0-dim tensor."""
+    lib = _lib.load()
+    _chk_rows(logits, torch.float32, "cross_entropy.logits")
+    rows, V = logits.shape
+    lab = labels.to(device=logits.device, dtype=torch.int32).contiguous()
+    nll = torch.empty((rows,), device=logits.device, dtype=torch.float32)
+    loss = torch.empty((1,), device=logits.device, dtype=torch.float32)
+    _lib.check(lib.vt_cross_entropy(_p(logits), rows, V, logits.stride(0), _p(lab), int(ignore_index), _p(nll), _p(loss), _stream()),
+               "vt_cross_entropy")
+    return loss[0]
