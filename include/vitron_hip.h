@@ -49,8 +49,9 @@ enum {
   /* 7: reserved (a 4-wave 128x128-register-tile experiment, slower than the 8-phase kernel; removed) */
   VT_GEMM_CFG_256x256_RP = 8, /* 256x256 tile, 8 waves, register-pipelined 32x32x16 main loop, one barrier per K tile */
   VT_GEMM_CFG_SKINNY_REG = 9, /* M <= 16: weight rows loaded straight into MFMA operand registers; fallback when K % 64 != 0 */
-  VT_GEMM_CFG_256x256_P4 = 10 /* the 8-phase kernel with its phases merged pairwise: 32 MFMAs per section, half the barriers */
+  VT_GEMM_CFG_256x256_P4 = 10, /* the 8-phase kernel with its phases merged pairwise: 32 MFMAs per section, half the barriers */
   /* 11: reserved (the 4-phase schedule on v_mfma_f32_32x32x16_bf16: correct, 25 % slower on every decoder shape; removed) */
+  VT_GEMM_CFG_256x256_W4 = 13, /* 256x256 tile, 4 waves x (128x128), one wave per SIMD, software-pipelined by hand */
   /* 12: reserved (2-phase schedule, one 64-MFMA section per K step: correct, 8 % slower than the 4-phase one; removed) */
 };
 enum { VT_DTYPE_BF16 = 0, VT_DTYPE_F32 = 1 };

@@ -501,3 +501,25 @@ def test_sample_top_k_keep_set(dev, V):
     a = ops.sample_top_p(ld, 1.0, 0.9, seed=1, step=2, top_k=0)
     b = ops.sample_top_p(ld, 1.0, 0.9, seed=1, step=2, top_k=V + 5)
     assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(300, 384, 256), (577, 1024, 640 + 128), (1000, 544, 1024), (512, 512, 384), (2048, 1024, 2048)])
+def test_gemm_four_wave_kernel(dev, M, N, K):
+    """cfg 13: 256x256 tile, four waves of 128x128, accumulators pinned to the accumulator file, hand-placed K step
+    (ragged M / N, short and long K loops, every epilogue, repeated launches bit-identical)."""
+    from vitron_amd import _lib, ops
+    a, w, b = randn((M, K), 41), randn((N, K), 42, 0.05), randn((N,), 43)
+    resid = randn((M, N), 44)
+    ad, wd = a.to(dev).bfloat16(), w.to(dev).bfloat16()
+    cfg = _lib.CFG_256x256_W4
+    for epi in (ops.EPI_BF16, ops.EPI_BF16_GELU, ops.EPI_BF16_QGELU, ops.EPI_BF16_RELU):
+        assert rel_l2(ops.gemm(ad, wd, b.to(dev), epi, cfg=cfg).float(), _gemm_ref(a, w, b, epi)) <= TOL, epi
+    assert rel_l2(ops.gemm(ad, wd, None, ops.EPI_SWIGLU_BF16, cfg=cfg).float(), _gemm_ref(a, w, None, ops.EPI_SWIGLU_BF16)) <= TOL
+    assert rel_l2(ops.gemm(ad, wd, b.to(dev), ops.EPI_F32, cfg=cfg), _gemm_ref(a, w, b, ops.EPI_F32)) <= 1e-5
+    got = ops.gemm(ad, wd, b.to(dev), ops.EPI_F32_RESID, out=resid.to(dev).clone(), cfg=cfg)
+    assert rel_l2(got, _gemm_ref(a, w, b, ops.EPI_F32_RESID, resid)) <= 1e-5
+    for _ in range(3):
+        assert torch.equal(got, ops.gemm(ad, wd, b.to(dev), ops.EPI_F32_RESID, out=resid.to(dev).clone(), cfg=cfg))
+    # the same tile through the ping-pong kernel: same fragments, same fp32 accumulation order per output -> identical bits
+    assert torch.equal(ops.gemm(ad, wd, b.to(dev), ops.EPI_BF16, cfg=cfg), ops.gemm(ad, wd, b.to(dev), ops.EPI_BF16, cfg=_lib.CFG_256x256_P4))

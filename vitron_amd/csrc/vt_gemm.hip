@@ -736,6 +736,17 @@ int vt_gemm_pick_cfg(int M, int N, int K) {
   return VT_GEMM_CFG_64x128;
 }
 
+// Which of the two 256x256 kernels runs a whole-round grid (vt_gemm_pick_cfg says "P4" for the family). Sustained interleaved A/B
+// on MI355X (tools/gemm_ab.cpp, round 2): the four-wave kernel is 2..8 % faster wherever the epilogue is a plain store (qkv
+// 1408 vs 1331 TFLOP/s, gate/up SwiGLU 1415 vs 1363, down_proj 1412 vs 1380, ViT qkv 876 vs 840, ViT fc2 472 vs 438) and equal on
+// o_proj (1201 vs 1200: a third of that launch is the fp32 read-modify-write of C); its one wave per SIMD is SLOWER where the
+// epilogue is VALU-heavy (erf-GELU 366 vs 488, quick-GELU 586 vs 601). It carries no folded RMSNorm.
+static int vt_gemm_256_variant(int epi, const VtGemmNormFuse* nf) {
+  const bool plain = epi == VT_EPI_BF16 || epi == VT_EPI_F32_RESID || epi == VT_EPI_F32 || epi == VT_EPI_SWIGLU_BF16;
+  static const bool force_p4 = getenv("VT_GEMM_FORCE_P4") != nullptr;   // TEMP: in-step A/B
+  return (plain && !nf && !force_p4) ? VT_GEMM_CFG_256x256_W4 : VT_GEMM_CFG_256x256_P4;
+}
+
 // measured on MI355X (tools/splitk_bench.py): see the table in DESIGN.md 3.1
 // (1088x4096x11008: 149 -> 108 us at ksplit 3; 1024x4096x11008: 114 -> 91 at 4; 300x4096x11008: 96 -> 56 at 8; 577x1024x4096:
 // 39 -> 29 at 8; K = 4096 with ksplit < 8 and everything at K = 1024: no gain, the reduce pass eats it)
@@ -796,12 +807,13 @@ int vt_gemm_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, 
         const long M1 = (M / unit) * unit;
         if (M1 >= unit && M1 < M) {
           const size_t esz = (epi == VT_EPI_F32 || epi == VT_EPI_F32_RESID) ? 4 : 2;
-          VT_TRY(vt_gemm_launch(A, lda, W, ldw, C, ldc, bias, (int)M1, N, K, epi, VT_GEMM_CFG_256x256_P4, s, nf));
+          VT_TRY(vt_gemm_launch(A, lda, W, ldw, C, ldc, bias, (int)M1, N, K, epi, vt_gemm_256_variant(epi, nf), s, nf));
           const VtGemmNormFuse rest = nf ? vt_nf_rows(*nf, M1) : VtGemmNormFuse{};
           return vt_gemm_launch(A + (size_t)M1 * lda, lda, W, ldw, (char*)C + (size_t)M1 * ldc * esz, ldc, bias, M - (int)M1, N, K,
                                 epi, VT_GEMM_CFG_AUTO, s, nf ? &rest : nullptr);
         }
       }
+      if (cfg == VT_GEMM_CFG_256x256_P4) cfg = vt_gemm_256_variant(epi, nf);
     }
   }
   // algorithmic work: 2*M*N*K FLOP for the MFMA tile kernel; weight bytes for the weight-streaming kernel
@@ -832,6 +844,7 @@ int vt_gemm_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, 
   if (cfg >= 301 && cfg <= 303) return vt_gemm_rp_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, (cfg - 300) << 8, s);
 #endif
   if (cfg == VT_GEMM_CFG_256x256_P4) return vt_gemm_p8_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, epi | 0x1000, s, nf);
+  if (cfg == VT_GEMM_CFG_256x256_W4) return vt_gemm_p8_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, epi | 0x4000, s, nf);
   if (cfg == VT_GEMM_CFG_256x256_RP) return vt_gemm_rp_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, epi, s);
   switch (epi) {
     case VT_EPI_BF16: return launch_cfg<VT_EPI_BF16>(p, cfg, s);
@@ -889,7 +902,7 @@ int vt_gemm_resid_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, flo
       const long unit = 256L * (256 / g);
       const long M1 = (M / unit) * unit;
       if (M1 >= unit && M1 < M) {
-        VT_TRY(vt_gemm_launch(A, lda, W, ldw, C, ldc, bias, (int)M1, N, K, VT_EPI_F32_RESID, VT_GEMM_CFG_256x256_P4, s, nf));
+        VT_TRY(vt_gemm_launch(A, lda, W, ldw, C, ldc, bias, (int)M1, N, K, VT_EPI_F32_RESID, vt_gemm_256_variant(VT_EPI_F32_RESID, nf), s, nf));
         const VtGemmNormFuse rest = nf ? vt_nf_rows(*nf, M1) : VtGemmNormFuse{};
         return vt_gemm_resid_launch(A + (size_t)M1 * lda, lda, W, ldw, C + (size_t)M1 * ldc, ldc, bias, M - (int)M1, N, K, 0, partials,
                                     partial_bytes, s, nf ? &rest : nullptr);

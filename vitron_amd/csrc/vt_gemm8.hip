@@ -610,6 +610,238 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmP8 p) {
   }
 }
 
+// epilogue of the four-wave kernels: lane holds row m = ..+(lane & 15), 4 consecutive columns per 16-column fragment
+template <int EPI>
+__device__ __forceinline__ void w4_epilogue(const GemmP8& p, f32x4 (&acc)[8][8], int bm0, int bn0, int wr, int wc, int lane) {
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi) {
+    const int m = bm0 + wr * 128 + mi * 16 + (lane & 15);
+    if (m >= p.M) continue;
+    if constexpr (EPI == VT_EPI_F32_RESID) {
+      float* const Cf = (float*)p.C;
+      f32x4 cur[8];
+#pragma unroll
+      for (int ni = 0; ni < 8; ++ni) cur[ni] = *(const f32x4*)(Cf + (size_t)m * p.ldc + min(bn0 + wc * 128 + ni * 16 + ((lane >> 4) << 2), p.N - 4));
+#pragma unroll
+      for (int ni = 0; ni < 8; ++ni) {
+        const int n = bn0 + wc * 128 + ni * 16 + ((lane >> 4) << 2);
+        if (n >= p.N) continue;
+        f32x4 v = acc[mi][ni];
+        if (p.bias) v += *(const f32x4*)(p.bias + n);
+        *(f32x4*)(Cf + (size_t)m * p.ldc + n) = cur[ni] + v;
+      }
+    } else if constexpr (EPI == VT_EPI_SWIGLU_BF16) {
+#pragma unroll
+      for (int nj = 0; nj < 4; ++nj) {
+        const int nbase = bn0 + wc * 128 + nj * 32;
+        if (nbase + ((lane >> 4) << 2) >= p.N) continue;
+        const f32x4 g = acc[mi][2 * nj], u2 = acc[mi][2 * nj + 1];
+        u32x2 o;
+        o.x = pack_bf16x2(silu8(g[0]) * u2[0], silu8(g[1]) * u2[1]);
+        o.y = pack_bf16x2(silu8(g[2]) * u2[2], silu8(g[3]) * u2[3]);
+        *(u32x2*)((bf16_t*)p.C + (size_t)m * p.ldc + (nbase >> 1) + ((lane >> 4) << 2)) = o;
+      }
+    } else {
+#pragma unroll
+      for (int ni = 0; ni < 8; ++ni) {
+        const int n = bn0 + wc * 128 + ni * 16 + ((lane >> 4) << 2);
+        if (n >= p.N) continue;
+        f32x4 v = acc[mi][ni];
+        if (p.bias) v += *(const f32x4*)(p.bias + n);
+        if constexpr (EPI == VT_EPI_BF16_GELU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = gelu_erf8(v[r]);
+        } else if constexpr (EPI == VT_EPI_BF16_QGELU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = quick_gelu8(v[r]);
+        } else if constexpr (EPI == VT_EPI_BF16_RELU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        if constexpr (EPI == VT_EPI_F32) {
+          *(f32x4*)((float*)p.C + (size_t)m * p.ldc + n) = v;
+        } else {
+          u32x2 o;
+          o.x = pack_bf16x2(v[0], v[1]);
+          o.y = pack_bf16x2(v[2], v[3]);
+          *(u32x2*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// gemm_w4_kernel: 256x256x64 tile, FOUR waves (2 x 2), 128x128 per wave, ONE wave per SIMD (512-register budget: the 64 16x16
+// accumulators = 256 registers pinned to the accumulator file, two sets of 8 + 8 fragment quads = 128 VGPRs).
+//
+// Why: per K step a wave of this shape reads 32 KB of fragments from LDS for 4.2 MFLOP (15 KB/MFLOP); the 8-wave ping-pong tile
+// (64x32 quadrants) reads 24 KB for 2.1 MFLOP (22.9 KB/MFLOP) and leaves a third of the matrix pipe idle in hand-offs between its
+// two wave rows (PMC: 67 % MFMA busy). With one instruction stream per SIMD nothing hides a memory instruction behind
+// another wave, so the K step is scheduled by hand, MFMA by MFMA (the MFMAs are asm statements - pinned accumulators, opaque to the
+// scheduler - and every gap is fenced with sched_barrier). What the timing ablations of the first versions showed (DESIGN.md 3.1:
+// the 16 LDS-DMA pieces cost 15 %, the 32 fragment reads 8 %, a barrier nothing) shaped the schedule:
+//   * at most ONE memory instruction per MFMA gap, every second gap;
+//   * LDS-DMA through a buffer resource (`buffer_load_dwordx4 .. offen lds`: SGPR base + one constant VGPR offset per piece + the
+//     K offset in an SGPR) - no address arithmetic on the vector pipe;
+//   * the A and B halves of an LDS buffer are released and refilled SEPARATELY (four barriers per K step), which spreads the 16
+//     pieces over three quarters of the K step and leaves every piece 1.25 K steps to land (counted vmcnt).
+//   K step t lives in LDS buffer b = t & 1 (same half-tile slots and source-side XOR swizzle as the ping-pong kernel; wave (wr, wc)
+//   reads half tile A{wr} and B{wc}); MFMAs 0..63 work on fragment set 0 (k-half 0), 64..127 on set 1; a set is refilled only
+//   while the other one is in use. Gap n = the slot behind MFMA n:
+//       gap   0..14   read B fragments of k-half 1 (buffer b)             19: lgkmcnt(0)   20: barrier  -> B half of buffer b is free
+//       gap  21..51   DMA B of K step t+2 -> buffer b | read A fragments of k-half 1
+//                                                                          55: lgkmcnt(0)   56: barrier  -> A half of buffer b is free
+//       gap  57..61   DMA A of K step t+2 (3 pieces)                      62: vmcnt(19)    63: barrier  -> B of K step t+1 has landed
+//       gap  64..81   read B fragments of (t+1, k-half 0) from buffer b^1 | DMA A (5 pieces)
+//                                                                          92: vmcnt(16)    93: barrier  -> A of K step t+1 has landed
+//       gap  94..108  read A fragments of (t+1, k-half 0)
+//   vmcnt: a wave issues its pieces in the order B(t) A(t) B(t+1) A(t+1) ..; at gap 62 the ones younger than B(t+1) are A(t+1) 8 +
+//   B(t+2) 8 + A(t+2) 3, at gap 92 the ones younger than A(t+1) are B(t+2) 8 + A(t+2) 8.
+//   WAR: the last reads of a half (lgkmcnt(0)) precede the barrier behind which ANY wave refills it. RAW: every wave waits for its
+//   own pieces of a half before the barrier behind which any wave reads it.
+// ------------------------------------------------------------------------------------------------------------------
+// ABL (timing ablations, wrong results; test library only): 1 = no LDS-DMA in the loop, 2 = no barriers, 4 = no fragment reads, 8 = no
+// counted waits, 16 = unswizzled DMA sources. AUX_A / AUX_B = cache-policy bits of the DMA instructions (1 sc0, 2 nt, 16 sc1): measured,
+// sc0 / sc1 make no difference and nt costs 20 %, so they stay 0.
+template <int EPI, int ABL = 0, int AUX_A = 0, int AUX_B = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_w4_kernel(GemmP8 p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+
+  const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 255) / 256;
+  const int nwg = tiles_m * tiles_n;
+  const int sid = xcd_remap((int)blockIdx.x, nwg);
+  constexpr int GROUP_M = 8;
+  const int per_group = GROUP_M * tiles_n;
+  const int first_m = (sid / per_group) * GROUP_M;
+  const int gsz = min(tiles_m - first_m, GROUP_M);
+  const int tm = first_m + (sid % per_group) % gsz;
+  const int tn = (sid % per_group) / gsz;
+  const int bm0 = tm * 256, bn0 = tn * 256;
+
+  // DMA sources. Pieces 0..7 of a K step are this wave's share of B (half tile B0: 0..3, B1: 4..7), pieces 8..15 its share of A.
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (size_t)bm0 * p.lda), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (size_t)bn0 * p.ldw), 0, 0x7fffffff, 0x00020000);
+  const int lrow = lane >> 3, lchk = lane & 7;
+  int voff[16];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int row = (i >> 2) * 128 + (wave * 4 + (i & 3)) * 8 + lrow;      // row inside the 256-row tile
+    const int coff = ((ABL & 16) ? lchk : (lchk ^ ((row >> 1) & 7))) * 16;   // source-side XOR swizzle, bytes
+    voff[i] = (min(bn0 + row, p.N - 1) - bn0) * p.ldw * 2 + coff;
+    voff[8 + i] = (min(bm0 + row, p.M - 1) - bm0) * p.lda * 2 + coff;
+  }
+  const int dma_off = wave * 4096;
+#define W4S_DMA_X(BUF, P, KB, AUX)                                                                                    \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                                      \
+      (P) < 8 ? rsrc_b : rsrc_a,                                                                                 \
+      (__attribute__((address_space(3))) void*)(smem + (BUF) * BUF_BYTES +                                       \
+                                                 slot_offset((P) < 4 ? SLOT_B0 : (P) < 8 ? SLOT_B1 : (P) < 12 ? SLOT_A0 : SLOT_A1) + \
+                                                 dma_off + ((P) & 3) * 1024),                                    \
+      16, voff[P], KB, 0, AUX)
+#define W4S_DMA(BUF, P, KB) do { if ((P) < 8) W4S_DMA_X(BUF, P, KB, AUX_B); else W4S_DMA_X(BUF, P, KB, AUX_A); } while (0)
+
+  const int f = (lane >> 1) & 7;
+  const int fo[2] = {(lane & 15) * 128 + (((lane >> 4) ^ f) << 4), (lane & 15) * 128 + ((((lane >> 4) | 4) ^ f) << 4)};
+  const int a_base = (wr ? slot_offset(SLOT_A1) : slot_offset(SLOT_A0));
+  const int b_base = (wc ? slot_offset(SLOT_B1) : slot_offset(SLOT_B0));
+
+  f32x4 acc[8][8];
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 8; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  bf16x8 fa[2][8], fb[2][8];
+#define W4S_MFMA(N)                                                                                              \
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"                                                         \
+               : "+a"(acc[((N) >> 3) & 7][(N) & 7]) : "v"(fb[(N) >> 6][(N) & 7]), "v"(fa[(N) >> 6][((N) >> 3) & 7]))
+#define W4S_RDB(SET, BUF, KK, I) fb[SET][I] = *(const bf16x8*)(smem + (BUF) * BUF_BYTES + b_base + fo[KK] + (I) * 2048)
+#define W4S_RDA(SET, BUF, KK, I) fa[SET][I] = *(const bf16x8*)(smem + (BUF) * BUF_BYTES + a_base + fo[KK] + (I) * 2048)
+#define W4S_LGKM0() __builtin_amdgcn_s_waitcnt(0xc07f)
+
+  const int nt = p.K >> 6;                         // K % 64 == 0, checked by the launcher
+  const int kb1 = min(1, nt - 1) * 128;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) W4S_DMA(0, i, 0);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) W4S_DMA(1, i, kb1);
+  VT_VMCNT(16);                                    // K step 0 has landed, K step 1 may still be in flight
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    W4S_RDB(0, 0, 0, i);
+    W4S_RDA(0, 0, 0, i);
+  }
+  W4S_LGKM0();
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_nop 4");                         // accumulator zeroes (v_accvgpr_write) -> first MFMA reading them as C
+
+  // the memory / synchronisation instruction that follows MFMA n of a K step living in LDS buffer B
+#define W4S_GAP(n, B, KB)                                                                                        \
+  do {                                                                                                           \
+    if ((n) < 16) { if (!((n) & 1) && !(ABL & 4)) W4S_RDB(1, B, 1, ((n) >> 1) & 7); }                            \
+    else if ((n) == 19 || (n) == 55) { if (!(ABL & 8)) W4S_LGKM0(); }                                            \
+    else if ((n) == 20 || (n) == 56 || (n) == 63 || (n) == 93) { if (!(ABL & 2)) __builtin_amdgcn_s_barrier(); } \
+    else if ((n) >= 21 && (n) <= 51) {                                                                           \
+      if (((n) & 3) == 1) { if (!(ABL & 1)) W4S_DMA(B, (((n) - 21) >> 2) & 7, KB); }                             \
+      else if (((n) & 3) == 3) { if (!(ABL & 4)) W4S_RDA(1, B, 1, (((n) - 23) >> 2) & 7); }                      \
+    }                                                                                                            \
+    else if ((n) == 57 || (n) == 59 || (n) == 61) { if (!(ABL & 1)) W4S_DMA(B, 8 + ((((n) - 57) >> 1) & 3), KB); } \
+    else if ((n) == 62) { if (!(ABL & 9)) VT_VMCNT(19); }                                                        \
+    else if ((n) >= 64 && (n) <= 81) {                                                                           \
+      if (!((n) & 1)) { if ((n) <= 78 && !(ABL & 4)) W4S_RDB(0, (B) ^ 1, 0, (((n) - 64) >> 1) & 7); }            \
+      else if (((n) & 3) == 1) { if (!(ABL & 1)) W4S_DMA(B, 11 + ((((n) - 65) >> 2) & 7) % 5, KB); }             \
+    }                                                                                                            \
+    else if ((n) == 92) { if (!(ABL & 9)) VT_VMCNT(16); }                                                        \
+    else if ((n) >= 94 && (n) <= 108 && !((n) & 1)) { if (!(ABL & 4)) W4S_RDA(0, (B) ^ 1, 0, (((n) - 94) >> 1) & 7); } \
+  } while (0)
+#define W4S_N(n, B, KB) W4S_MFMA(n); W4S_GAP(n, B, KB); __builtin_amdgcn_sched_barrier(0);
+#define W4S_8(n, B, KB) W4S_N((n), B, KB) W4S_N((n) + 1, B, KB) W4S_N((n) + 2, B, KB) W4S_N((n) + 3, B, KB) \
+                        W4S_N((n) + 4, B, KB) W4S_N((n) + 5, B, KB) W4S_N((n) + 6, B, KB) W4S_N((n) + 7, B, KB)
+#define W4S_32(n, B, KB) W4S_8((n), B, KB) W4S_8((n) + 8, B, KB) W4S_8((n) + 16, B, KB) W4S_8((n) + 24, B, KB)
+#define W4S_KSTEP(B, T)   /* spelled out: the optimiser does not unroll a loop around asm statements */           \
+  do {                                                                                                           \
+    const int _kb = min((T) + 2, nt - 1) * 128;    /* past the end of K: re-fetch the last K step, harmless */    \
+    W4S_32(0, B, _kb) W4S_32(32, B, _kb) W4S_32(64, B, _kb) W4S_32(96, B, _kb)                                    \
+  } while (0)
+  for (int t = 0; t < nt; t += 2) {
+    W4S_KSTEP(0, t);
+    W4S_KSTEP(1, t + 1);
+  }
+  VT_VMCNT(0);                                     // the tail's redundant pieces
+  asm volatile("s_nop 15\n\ts_nop 7");            // last MFMA result -> the epilogue's v_accvgpr_read (the compiler cannot see the hazard)
+#undef W4S_KSTEP
+#undef W4S_32
+#undef W4S_8
+#undef W4S_N
+#undef W4S_GAP
+#undef W4S_LGKM0
+#undef W4S_RDA
+#undef W4S_RDB
+#undef W4S_MFMA
+#undef W4S_DMA
+#undef W4S_DMA_X
+  w4_epilogue<EPI>(p, acc, bm0, bn0, wr, wc, lane);
+}
+
+template <int EPI, int ABL = 0, int AUX_A = 0, int AUX_B = 0>
+int launch_w4(const GemmP8& p, hipStream_t s) {
+  constexpr int smem = 2 * BUF_BYTES;  // 128 KiB
+  auto kern = gemm_w4_kernel<EPI, ABL, AUX_A, AUX_B>;
+  static bool done = false;
+  if (!done) {
+    VT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(cdiv(p.M, 256) * cdiv(p.N, 256)), dim3(256), smem, s, p);
+  VT_LAUNCH_CHECK();
+  return VT_OK;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // gemm_rp_kernel ("register-pipelined"): 256x256x64 tile, 8 waves (2 x 4, two per SIMD), 128x64 per wave as 4 x 2
 // fragments of v_mfma_f32_32x32x16_bf16. No load/compute phase split: inside every wave the fragment reads of k-step
@@ -970,7 +1202,7 @@ int vt_gemm_p8_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* 
     VT_REQUIRE((epi & 0xff) == VT_EPI_F32_RESID && p.nf.out_w && p.nf.out_xw && p.nf.out_np >= N / 32 && p.nf.out_ldp >= M,
                "vt_gemm(p8): norm-fold producer needs the residual epilogue and its buffers");
 #ifdef VT_ABLATIONS
-  if (epi >= 0x100 && !(epi & 0x1000)) {  // timing ablations (tools/gemm_ablate.py); test library only
+  if (epi >= 0x100 && !(epi & 0x5000)) {  // timing ablations (tools/gemm_ablate.py); test library only
     switch (epi >> 8) {
       case 1: return launch_p8<VT_EPI_BF16, 1>(p, s);
       case 2: return launch_p8<VT_EPI_BF16, 2>(p, s);
@@ -993,6 +1225,34 @@ int vt_gemm_p8_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* 
     }
   }
 #endif
+  if (epi & 0x4000) {   // 4-wave kernel (128x128 per wave)
+    VT_REQUIRE(!nf, "vt_gemm(w4): no norm fold in the 4-wave kernel");
+    switch (epi & 0xff) {
+      case VT_EPI_BF16: {
+#ifdef VT_ABLATIONS
+        static const int abl = getenv("VT_W4_ABL") ? atoi(getenv("VT_W4_ABL")) : 0;   // timing ablations, see the kernel
+        switch (abl) {
+          case 1: return launch_w4<VT_EPI_BF16, 1>(p, s);
+          case 2: return launch_w4<VT_EPI_BF16, 2>(p, s);
+          case 4: return launch_w4<VT_EPI_BF16, 4>(p, s);
+          case 5: return launch_w4<VT_EPI_BF16, 5>(p, s);
+          case 8: return launch_w4<VT_EPI_BF16, 8>(p, s);
+          case 15: return launch_w4<VT_EPI_BF16, 15>(p, s);
+          case 16: return launch_w4<VT_EPI_BF16, 16>(p, s);
+          default: break;
+        }
+#endif
+        return launch_w4<VT_EPI_BF16>(p, s);
+      }
+      case VT_EPI_BF16_GELU: return launch_w4<VT_EPI_BF16_GELU>(p, s);
+      case VT_EPI_BF16_QGELU: return launch_w4<VT_EPI_BF16_QGELU>(p, s);
+      case VT_EPI_BF16_RELU: return launch_w4<VT_EPI_BF16_RELU>(p, s);
+      case VT_EPI_F32_RESID: return launch_w4<VT_EPI_F32_RESID>(p, s);
+      case VT_EPI_F32: return launch_w4<VT_EPI_F32>(p, s);
+      case VT_EPI_SWIGLU_BF16: return launch_w4<VT_EPI_SWIGLU_BF16>(p, s);
+      default: vt_set_error("vt_gemm(w4): epilogue %d not instantiated", epi & 0xff); return VT_ERR_ARG;
+    }
+  }
   if (epi & 0x1000) {   // 4-phase variant
     switch (epi & 0xff) {
       case VT_EPI_BF16: return launch_p8<VT_EPI_BF16, 0, true>(p, s);
