@@ -51,7 +51,8 @@ enum {
   VT_GEMM_CFG_SKINNY_REG = 9, /* M <= 16: weight rows loaded straight into MFMA operand registers; fallback when K % 64 != 0 */
   VT_GEMM_CFG_256x256_P4 = 10, /* the 8-phase kernel with its phases merged pairwise: 32 MFMAs per section, half the barriers */
   /* 11: reserved (the 4-phase schedule on v_mfma_f32_32x32x16_bf16: correct, 25 % slower on every decoder shape; removed) */
-  VT_GEMM_CFG_256x256_W4 = 13, /* 256x256 tile, 4 waves x (128x128), one wave per SIMD, software-pipelined by hand */
+  VT_GEMM_CFG_256x256_W4 = 13,
+  VT_GEMM_CFG_320x256_W4 = 14,   /* the four-wave kernel on 320-row tiles (160x128 per wave): rows that fill whole rounds only this way */ /* 256x256 tile, 4 waves x (128x128), one wave per SIMD, software-pipelined by hand */
   /* 12: reserved (2-phase schedule, one 64-MFMA section per K step: correct, 8 % slower than the 4-phase one; removed) */
 };
 enum { VT_DTYPE_BF16 = 0, VT_DTYPE_F32 = 1 };
@@ -76,6 +77,12 @@ int vt_last_error(char* buf, size_t buf_len);
  * reference call sites modeling_video.py:69,71,81; llava_llama.py:49,91-102; multimodal_projector/builder.py:33-51). */
 int vt_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, void* C, int ldc, const float* bias, int M,
                  int N, int K, int epi, int cfg, const float* row_scale, void* stream);
+
+/* Which tile configuration vt_gemm_bf16(.., cfg = VT_GEMM_CFG_AUTO, row_scale = NULL) runs for this shape and epilogue (host logic
+ * only, no launch): *cfg = the VT_GEMM_CFG_* of the first launch, *rows_first = 0 when that launch covers all M rows, else the
+ * number of leading rows it covers (the remaining rows are planned again, as a GEMM of their own). Introspection for tests and
+ * tools; no reference counterpart (torch.nn.Linear hides cuBLAS's heuristics the same way). */
+int vt_gemm_plan_query(int M, int N, int K, int epi, int* cfg, int* rows_first);
 
 /* y_bf16[rows][D] = LayerNorm(x_f32) * gamma + beta. If temb != NULL first x[row] += temb[(row / tokens_per_frame) % T]
  * (written back): the video tower's temporal_embedding add (reference modeling_video.py:110-114) fused with

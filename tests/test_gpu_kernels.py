@@ -377,9 +377,10 @@ def test_im2col_splice_argmax(dev):
 
 def test_profile_api_counts_split_gemm(dev):
     """vt_profile_begin/end bracket every launch with events on the kernel's stream; the auto-split GEMM (whole rounds on the
-    8-phase kernel + remainder on the small-tile kernel) must show up as two timed launches with the full 2*M*N*K work."""
+    big-tile kernel + remainder on the small-tile kernel) must show up as two timed launches with the full 2*M*N*K work."""
     from vitron_amd import _lib, ops
-    M, N, K = 4352, 4096, 2048   # 17 x 16 tiles of 256: one whole round (4096 rows) + 256 remainder rows
+    M, N, K = 8704, 4096, 2048   # 34 x 16 tiles of 256: two whole rounds (8192 rows) + 512 remainder rows (cheaper than 2 rounds of 320-row tiles)
+    assert ops.gemm_plan(M, N, K, ops.EPI_BF16) == (_lib.CFG_256x256_W4, 8192)
     a, w = randn((M, K), 61), randn((N, K), 62, 0.05)
     ad, wd = a.to(dev).bfloat16(), w.to(dev).bfloat16()
     _lib.profile_begin()
@@ -504,22 +505,22 @@ def test_sample_top_k_keep_set(dev, V):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("M,N,K", [(300, 384, 256), (577, 1024, 640 + 128), (1000, 544, 1024), (512, 512, 384), (2048, 1024, 2048)])
+@pytest.mark.parametrize("M,N,K", [(300, 384, 256), (577, 1024, 640 + 128), (1000, 544, 1024), (512, 512, 384), (2048, 1024, 2048), (650, 256, 512)])
 def test_gemm_four_wave_kernel(dev, M, N, K):
-    """cfg 13: 256x256 tile, four waves of 128x128, accumulators pinned to the accumulator file, hand-placed K step
-    (ragged M / N, short and long K loops, every epilogue, repeated launches bit-identical)."""
+    """cfg 13 / 14: 256x256 (320x256) tile, four waves of 128x128 (160x128), accumulators pinned to the accumulator file, hand-placed
+    K step (ragged M / N, short and long K loops, every epilogue, repeated launches bit-identical)."""
     from vitron_amd import _lib, ops
     a, w, b = randn((M, K), 41), randn((N, K), 42, 0.05), randn((N,), 43)
     resid = randn((M, N), 44)
     ad, wd = a.to(dev).bfloat16(), w.to(dev).bfloat16()
-    cfg = _lib.CFG_256x256_W4
-    for epi in (ops.EPI_BF16, ops.EPI_BF16_GELU, ops.EPI_BF16_QGELU, ops.EPI_BF16_RELU):
-        assert rel_l2(ops.gemm(ad, wd, b.to(dev), epi, cfg=cfg).float(), _gemm_ref(a, w, b, epi)) <= TOL, epi
-    assert rel_l2(ops.gemm(ad, wd, None, ops.EPI_SWIGLU_BF16, cfg=cfg).float(), _gemm_ref(a, w, None, ops.EPI_SWIGLU_BF16)) <= TOL
-    assert rel_l2(ops.gemm(ad, wd, b.to(dev), ops.EPI_F32, cfg=cfg), _gemm_ref(a, w, b, ops.EPI_F32)) <= 1e-5
-    got = ops.gemm(ad, wd, b.to(dev), ops.EPI_F32_RESID, out=resid.to(dev).clone(), cfg=cfg)
-    assert rel_l2(got, _gemm_ref(a, w, b, ops.EPI_F32_RESID, resid)) <= 1e-5
-    for _ in range(3):
-        assert torch.equal(got, ops.gemm(ad, wd, b.to(dev), ops.EPI_F32_RESID, out=resid.to(dev).clone(), cfg=cfg))
-    # the same tile through the ping-pong kernel: same fragments, same fp32 accumulation order per output -> identical bits
-    assert torch.equal(ops.gemm(ad, wd, b.to(dev), ops.EPI_BF16, cfg=cfg), ops.gemm(ad, wd, b.to(dev), ops.EPI_BF16, cfg=_lib.CFG_256x256_P4))
+    for cfg in (_lib.CFG_256x256_W4, _lib.CFG_320x256_W4):
+        for epi in (ops.EPI_BF16, ops.EPI_BF16_GELU, ops.EPI_BF16_QGELU, ops.EPI_BF16_RELU):
+            assert rel_l2(ops.gemm(ad, wd, b.to(dev), epi, cfg=cfg).float(), _gemm_ref(a, w, b, epi)) <= TOL, (cfg, epi)
+        assert rel_l2(ops.gemm(ad, wd, None, ops.EPI_SWIGLU_BF16, cfg=cfg).float(), _gemm_ref(a, w, None, ops.EPI_SWIGLU_BF16)) <= TOL
+        assert rel_l2(ops.gemm(ad, wd, b.to(dev), ops.EPI_F32, cfg=cfg), _gemm_ref(a, w, b, ops.EPI_F32)) <= 1e-5
+        got = ops.gemm(ad, wd, b.to(dev), ops.EPI_F32_RESID, out=resid.to(dev).clone(), cfg=cfg)
+        assert rel_l2(got, _gemm_ref(a, w, b, ops.EPI_F32_RESID, resid)) <= 1e-5
+        for _ in range(3):
+            assert torch.equal(got, ops.gemm(ad, wd, b.to(dev), ops.EPI_F32_RESID, out=resid.to(dev).clone(), cfg=cfg))
+        # the same GEMM through the ping-pong kernel: same fragments, same fp32 accumulation order per output -> identical bits
+        assert torch.equal(ops.gemm(ad, wd, b.to(dev), ops.EPI_BF16, cfg=cfg), ops.gemm(ad, wd, b.to(dev), ops.EPI_BF16, cfg=_lib.CFG_256x256_P4))

@@ -427,3 +427,36 @@ def test_prefix_cache_signatures_and_page_rounding():
     assert cache.get("a") is not None
     cache.put("c", torch.zeros(1), None)       # evicts "b" (least recently used)
     assert cache.get("b") is None and cache.get("a") is not None and cache.get("c") is not None
+
+
+def test_gemm_planner_fills_whole_rounds_of_the_chip():
+    """Host logic of the tile-GEMM dispatcher (vt_gemm_plan_query, no launch): one big-tile workgroup per CU, so the planner must
+    pick the tile height / row split that fills WHOLE rounds of 256 workgroups on the benchmark's shapes, keep the ping-pong
+    kernel where the epilogue is VALU-heavy, and fall back to small tiles when a big-tile grid would cover a fraction of the chip."""
+    from vitron_amd import _lib, ops
+    W4, W4_320, P4 = _lib.CFG_256x256_W4, _lib.CFG_320x256_W4, _lib.CFG_256x256_P4
+    small = (_lib.CFG_64x128, _lib.CFG_128x128)
+    # decoder at S = 5120 (BASELINE configs[2]): qkv 3.75 rounds of 256-row tiles = 3 of 320-row tiles; o_proj / down_proj 1.25 -> 1
+    assert ops.gemm_plan(5120, 12288, 4096, ops.EPI_BF16) == (W4_320, 0)
+    assert ops.gemm_plan(5120, 4096, 4096, ops.EPI_F32_RESID) == (W4_320, 0)
+    assert ops.gemm_plan(5120, 4096, 11008, ops.EPI_F32_RESID) == (W4_320, 0)
+    assert ops.gemm_plan(5120, 22016, 4096, ops.EPI_SWIGLU_BF16) == (W4, 0)            # 6.72 rounds of 256 vs 6 x 1.25 of 320
+    assert ops.gemm_plan(4096, 4096, 4096, ops.EPI_F32_RESID) == (W4, 0)               # exactly one round
+    # projector at 8 x 576 visual tokens: 288 tiles of 256 rows = 2 rounds, 240 of 320 rows = 1
+    assert ops.gemm_plan(4608, 4096, 4096, ops.EPI_BF16) == (W4_320, 0)
+    assert ops.gemm_plan(4608, 4096, 1024, ops.EPI_BF16_GELU) == (W4_320, 0)
+    # a VALU-heavy epilogue on a whole-round grid of 256-row tiles stays on the ping-pong kernel
+    assert ops.gemm_plan(4096, 4096, 1024, ops.EPI_BF16_QGELU) == (P4, 0)
+    # ViT qkv (4616 x 3072): 228 tiles of 256 rows in one round beat 180 taller ones
+    assert ops.gemm_plan(4616, 3072, 1024, ops.EPI_BF16) == (W4, 0)
+    # a single-image prompt (1088 rows) covers a quarter of the chip with big tiles: small tiles
+    assert ops.gemm_plan(1088, 4096, 4096, ops.EPI_F32_RESID)[0] in small
+    assert ops.gemm_plan(4616, 1024, 4096, ops.EPI_F32_RESID)[0] in small
+    # K not a multiple of 128 (no big-tile kernel) and the weight-streaming range
+    assert ops.gemm_plan(4096, 4096, 4096 + 64, ops.EPI_BF16)[0] in small
+    assert ops.gemm_plan(16, 4096, 4096, ops.EPI_BF16) == (_lib.CFG_SKINNY, 0)
+    # row split: whole rounds on big tiles first, the remaining rows planned again
+    cfg, first = ops.gemm_plan(8192 + 512, 4096, 4096, ops.EPI_F32_RESID)    # 2 rounds + a 512-row remainder < 2 rounds of 320-row tiles
+    assert cfg == W4 and first == 8192 and ops.gemm_plan(512, 4096, 4096, ops.EPI_F32_RESID)[1] == 0
+    with pytest.raises(RuntimeError):
+        ops.gemm_plan(0, 4096, 4096)

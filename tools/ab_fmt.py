@@ -4,7 +4,7 @@ import sys
 
 for l in sys.stdin:
     l = l.strip()
-    if l.startswith("{"):
+    if l.startswith('{"shape"'):
         d = json.loads(l)
         print("  ", d["shape"], d["epi"], {k: (v["tflops"], v["maxdiff_vs_first"]) if v else None for k, v in d["results"].items()})
     elif l and not l.startswith("[gpurun]") and "amdgpu.ids" not in l:

@@ -17,6 +17,7 @@ LIB_PATH = PKG_DIR / "libvitron_hip.so"
 EPI_BF16, EPI_BF16_GELU, EPI_BF16_QGELU, EPI_BF16_RELU, EPI_F32_RESID, EPI_F32, EPI_SWIGLU_BF16 = range(7)
 CFG_AUTO, CFG_SKINNY, CFG_128x128, CFG_256x128, CFG_256x256, CFG_64x128, CFG_256x256_P8, _CFG_RESERVED_7, CFG_256x256_RP, CFG_SKINNY_REG, CFG_256x256_P4 = range(11)
 CFG_256x256_W4 = 13
+CFG_320x256_W4 = 14
 DTYPE_BF16, DTYPE_F32 = 0, 1
 ACT_GELU, ACT_QUICK_GELU = 0, 1
 PAGE_TOKENS = 64
@@ -70,6 +71,7 @@ SIGNATURES = {
     "vt_flash_attn": (_i, [vp, _i, vp, vp, vp, vp, _i, _i, vp, _i, _i, _i, _i, _f, vp]),
     "vt_attn_decode_scratch_bytes": (_sz, [_i, _i, _i, _i]),
     "vt_attn_decode": (_i, [vp, _i, vp, vp, vp, vp, _i, vp, _i, _i, _i, _f, _i, vp, _sz, vp]),
+    "vt_gemm_plan_query": (_i, [_i, _i, _i, _i, vp, vp]),
     "vt_gemm_bf16_resid_splitk": (_i, [vp, _i, vp, _i, vp, _i, vp, _i, _i, _i, _i, vp, _sz, vp]),
     "vt_attn_decode_fused": (_i, [vp, _i, _i, _i, _i, vp, vp, vp, vp, _i, vp, _i, _i, _i, _f, vp, vp, vp, vp]),
     "vt_kv_tiles": (_i, [vp, _i, _i, _i, _i, vp, vp, vp, vp, _i, _i, _i, _i, vp, vp, vp, vp]),

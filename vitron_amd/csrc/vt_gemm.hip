@@ -736,15 +736,93 @@ int vt_gemm_pick_cfg(int M, int N, int K) {
   return VT_GEMM_CFG_64x128;
 }
 
-// Which of the two 256x256 kernels runs a whole-round grid (vt_gemm_pick_cfg says "P4" for the family). Sustained interleaved A/B
-// on MI355X (tools/gemm_ab.cpp, round 2): the four-wave kernel is 2..8 % faster wherever the epilogue is a plain store (qkv
-// 1408 vs 1331 TFLOP/s, gate/up SwiGLU 1415 vs 1363, down_proj 1412 vs 1380, ViT qkv 876 vs 840, ViT fc2 472 vs 438) and equal on
-// o_proj (1201 vs 1200: a third of that launch is the fp32 read-modify-write of C); its one wave per SIMD is SLOWER where the
-// epilogue is VALU-heavy (erf-GELU 366 vs 488, quick-GELU 586 vs 601). It carries no folded RMSNorm.
+// ---- the tile-GEMM planner ---------------------------------------------------------------------------------------------------
+// A big-tile kernel keeps ONE workgroup per CU, so its time is (rounds of 256 workgroups) x (tile height); the small tiles fill the
+// chip at any size but run at about half the rate. The planner prices the candidates in units of "one round of 256-row tiles":
+//   256-row tiles   ceil(tiles / 256)                       four-wave kernel for plain-store epilogues (sustained interleaved A/B,
+//                                                            tools/gemm_ab.cpp, round 2: qkv 1408 vs 1331 TFLOP/s on the 4-phase
+//                                                            ping-pong kernel, gate/up SwiGLU 1415 vs 1363, down_proj 1412 vs 1380,
+//                                                            ViT qkv 876 vs 840); the ping-pong kernel where the epilogue is VALU-heavy
+//                                                            (erf-GELU 366 vs 488 on the four-wave kernel's single wave per SIMD,
+//                                                            quick-GELU 586 vs 601) or carries a folded RMSNorm
+//   320-row tiles   ceil(tiles320 / 256) x 1.25 x 1.04      four-wave kernel, 160x128 per wave: 5120 x 4096 is ONE round of 256 tiles
+//                                                            instead of 1.25 (o_proj 1245 vs 1075 TFLOP/s for whole rounds + small-tile
+//                                                            remainder, down_proj 1341 vs 1173, projector 4608x4096x4096 1329 vs 1131);
+//                                                            on multi-round grids the tile itself is ~4 % slower (qkv 1420 vs 1405)
+//   small tiles     ceil(tiles64x128 / 512) x 0.4545        two workgroups per CU at ~0.55 of the big tiles' rate (remainders of 512 /
+//                                                            1024 rows x 4096: 0.40 / 0.39 of a big round measured; 2560 x 4096 x 4096: 827
+//                                                            TFLOP/s on small tiles vs 1005 on 160 big tiles)
+//   M-split         whole rounds of 256-row tiles + the plan of the remaining rows (only with a long K loop)
+// and takes the cheapest. VtGemmPlan.M1 > 0: rows [0, M1) go to cfg, the rest is planned again by the caller.
+struct VtGemmPlan {
+  int cfg;
+  int M1;
+};
+
+static bool vt_epi_plain(int epi) { return epi == VT_EPI_BF16 || epi == VT_EPI_F32_RESID || epi == VT_EPI_F32 || epi == VT_EPI_SWIGLU_BF16; }
+
 static int vt_gemm_256_variant(int epi, const VtGemmNormFuse* nf) {
-  const bool plain = epi == VT_EPI_BF16 || epi == VT_EPI_F32_RESID || epi == VT_EPI_F32 || epi == VT_EPI_SWIGLU_BF16;
-  static const bool force_p4 = getenv("VT_GEMM_FORCE_P4") != nullptr;   // TEMP: in-step A/B
-  return (plain && !nf && !force_p4) ? VT_GEMM_CFG_256x256_W4 : VT_GEMM_CFG_256x256_P4;
+  return (vt_epi_plain(epi) && !nf) ? VT_GEMM_CFG_256x256_W4 : VT_GEMM_CFG_256x256_P4;
+}
+
+static double vt_gemm_plan_cost(int M, int N, int K, int epi, const VtGemmNormFuse* nf, VtGemmPlan* plan, bool allow_split) {
+  // 64x128 tiles: two workgroups per CU = 512 slots; a round of them moves 512 x 64 x 128 outputs at ~0.55 of the big tiles' rate
+  const double small = (double)(((long)cdiv(M, 64) * cdiv(N, 128) + 511) / 512) * (512.0 * 64 * 128 / 65536.0 / 256.0 / 0.55);
+  double best = small;
+  *plan = VtGemmPlan{vt_gemm_pick_cfg(M, N, K), 0};
+  if (plan->cfg == VT_GEMM_CFG_256x256_P4) plan->cfg = VT_GEMM_CFG_64x128;   // (the family is priced below)
+  if (M <= 64 || !vt_gemm_p8_supported(M, N, K)) return best;
+  const int tiles_n = cdiv(N, 256);
+  const double c256 = (double)((cdiv(M, 256) * (long)tiles_n + 255) / 256);
+  if (c256 < best) {
+    best = c256;
+    *plan = VtGemmPlan{vt_gemm_256_variant(epi, nf), 0};
+  }
+  if (!nf) {
+    const double c320 = (double)((cdiv(M, 320) * (long)tiles_n + 255) / 256) * 1.25 * 1.04;
+    if (c320 < best) {
+      best = c320;
+      *plan = VtGemmPlan{VT_GEMM_CFG_320x256_W4, 0};
+    }
+  }
+  if (allow_split && K >= 2048 && M > 256) {
+    int g = tiles_n, b = 256;
+    while (b) {   // gcd(tiles_n, 256)
+      const int t = g % b;
+      g = b;
+      b = t;
+    }
+    const long unit = 256L * (256 / g);   // rows per whole round
+    const long M1 = (M / unit) * unit;
+    if (M1 >= unit && M1 < M) {
+      VtGemmPlan rest;
+      const double c = (double)(M1 / 256 * tiles_n / 256) + vt_gemm_plan_cost(M - (int)M1, N, K, epi, nf, &rest, false) + 0.02;   // + a launch
+      if (c < best) {
+        best = c;
+        *plan = VtGemmPlan{vt_gemm_256_variant(epi, nf), (int)M1};
+      }
+    }
+  }
+  return best;
+}
+
+static VtGemmPlan vt_gemm_plan(int M, int N, int K, int epi, const VtGemmNormFuse* nf) {
+  VtGemmPlan plan;
+  vt_gemm_plan_cost(M, N, K, epi, nf, &plan, true);
+  return plan;
+}
+
+int vt_gemm_plan_describe(int M, int N, int K, int epi, int* cfg, int* rows_first) {
+  VT_REQUIRE(M > 0 && N > 0 && K > 0 && cfg && rows_first, "vt_gemm_plan_query: bad arguments");
+  if (M <= 64 || (K % 64) != 0) {   // the weight-streaming kernels / the ragged-K fallback, not a tile configuration
+    *cfg = VT_GEMM_CFG_SKINNY;
+    *rows_first = 0;
+    return VT_OK;
+  }
+  const VtGemmPlan plan = vt_gemm_plan(M, N, K, epi, nullptr);
+  *cfg = plan.cfg;
+  *rows_first = plan.M1;
+  return VT_OK;
 }
 
 // measured on MI355X (tools/splitk_bench.py): see the table in DESIGN.md 3.1
@@ -791,29 +869,18 @@ int vt_gemm_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, 
   if (!skinny_path) {
     VT_REQUIRE((K % 64) == 0, "vt_gemm(tile): K=%d must be a multiple of 64", K);
     if (cfg == VT_GEMM_CFG_AUTO || cfg == VT_GEMM_CFG_SKINNY || cfg == VT_GEMM_CFG_SKINNY_REG) {
-      cfg = vt_gemm_pick_cfg(M, N, K);
-      // Wave quantisation: when the 256x256 grid would leave most of its last round of CUs idle (e.g. M=5120, N=4096:
-      // 320 tiles = 1.25 rounds), run the rows that fill WHOLE rounds on the 256x256 kernel and the remaining rows on the
-      // small-tile kernel (4x more, 4x shorter tiles fill the CUs again). Both launches are plain row ranges of the same GEMM.
-      if (cfg != VT_GEMM_CFG_256x256_P4 && vt_gemm_p8_supported(M, N, K) && K >= 2048 && M > 256) {
-        const int tiles_n = cdiv(N, 256);
-        int g = tiles_n, b = 256;
-        while (b) {   // gcd(tiles_n, 256)
-          const int t = g % b;
-          g = b;
-          b = t;
-        }
-        const long unit = 256L * (256 / g);   // rows per whole round
-        const long M1 = (M / unit) * unit;
-        if (M1 >= unit && M1 < M) {
-          const size_t esz = (epi == VT_EPI_F32 || epi == VT_EPI_F32_RESID) ? 4 : 2;
-          VT_TRY(vt_gemm_launch(A, lda, W, ldw, C, ldc, bias, (int)M1, N, K, epi, vt_gemm_256_variant(epi, nf), s, nf));
-          const VtGemmNormFuse rest = nf ? vt_nf_rows(*nf, M1) : VtGemmNormFuse{};
-          return vt_gemm_launch(A + (size_t)M1 * lda, lda, W, ldw, (char*)C + (size_t)M1 * ldc * esz, ldc, bias, M - (int)M1, N, K,
-                                epi, VT_GEMM_CFG_AUTO, s, nf ? &rest : nullptr);
-        }
+      // Wave quantisation: when 256-row tiles would leave most of the last round of CUs idle (M = 5120, N = 4096: 320 tiles = 1.25
+      // rounds) the planner switches to 320-row tiles, or runs the rows that fill WHOLE rounds on the big tiles and plans the
+      // remaining rows again (small tiles fill the CUs at any size). Both launches are plain row ranges of the same GEMM.
+      const VtGemmPlan plan = vt_gemm_plan(M, N, K, epi, nf);
+      cfg = plan.cfg;
+      if (plan.M1 > 0) {
+        const size_t esz = (epi == VT_EPI_F32 || epi == VT_EPI_F32_RESID) ? 4 : 2;
+        VT_TRY(vt_gemm_launch(A, lda, W, ldw, C, ldc, bias, plan.M1, N, K, epi, plan.cfg, s, nf));
+        const VtGemmNormFuse rest = nf ? vt_nf_rows(*nf, plan.M1) : VtGemmNormFuse{};
+        return vt_gemm_launch(A + (size_t)plan.M1 * lda, lda, W, ldw, (char*)C + (size_t)plan.M1 * ldc * esz, ldc, bias, M - plan.M1, N, K,
+                              epi, VT_GEMM_CFG_AUTO, s, nf ? &rest : nullptr);
       }
-      if (cfg == VT_GEMM_CFG_256x256_P4) cfg = vt_gemm_256_variant(epi, nf);
     }
   }
   // algorithmic work: 2*M*N*K FLOP for the MFMA tile kernel; weight bytes for the weight-streaming kernel
@@ -845,6 +912,7 @@ int vt_gemm_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, 
 #endif
   if (cfg == VT_GEMM_CFG_256x256_P4) return vt_gemm_p8_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, epi | 0x1000, s, nf);
   if (cfg == VT_GEMM_CFG_256x256_W4) return vt_gemm_p8_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, epi | 0x4000, s, nf);
+  if (cfg == VT_GEMM_CFG_320x256_W4) return vt_gemm_p8_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, epi | 0xc000, s, nf);
   if (cfg == VT_GEMM_CFG_256x256_RP) return vt_gemm_rp_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, epi, s);
   switch (epi) {
     case VT_EPI_BF16: return launch_cfg<VT_EPI_BF16>(p, cfg, s);
@@ -890,21 +958,13 @@ int vt_gemm_resid_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, flo
     if (tiles <= 128 && cand >= 2 && (long)tiles * cand >= 128 && vt_gemm_splitk_pays(M, N, K, cand) &&
         partial_bytes >= (size_t)cand * M * N * sizeof(float))
       ks = cand;
-    if (ks == 0 && tiles > 256 && K >= 2048 && vt_gemm_pick_cfg(M, N, K) != VT_GEMM_CFG_256x256_P4) {
-      // the dispatcher's M-split (whole rounds of 256x256 tiles + remainder), done here so that the remainder can split K
-      const int tiles_n = cdiv(N, 256);
-      int g = tiles_n, b = 256;
-      while (b) {
-        const int t = g % b;
-        g = b;
-        b = t;
-      }
-      const long unit = 256L * (256 / g);
-      const long M1 = (M / unit) * unit;
-      if (M1 >= unit && M1 < M) {
-        VT_TRY(vt_gemm_launch(A, lda, W, ldw, C, ldc, bias, (int)M1, N, K, VT_EPI_F32_RESID, vt_gemm_256_variant(VT_EPI_F32_RESID, nf), s, nf));
-        const VtGemmNormFuse rest = nf ? vt_nf_rows(*nf, M1) : VtGemmNormFuse{};
-        return vt_gemm_resid_launch(A + (size_t)M1 * lda, lda, W, ldw, C + (size_t)M1 * ldc, ldc, bias, M - (int)M1, N, K, 0, partials,
+    if (ks == 0) {
+      // the planner's M-split (whole rounds of big tiles + remainder), done here so that the remainder can split K
+      const VtGemmPlan plan = vt_gemm_plan(M, N, K, VT_EPI_F32_RESID, nf);
+      if (plan.M1 > 0) {
+        VT_TRY(vt_gemm_launch(A, lda, W, ldw, C, ldc, bias, plan.M1, N, K, VT_EPI_F32_RESID, plan.cfg, s, nf));
+        const VtGemmNormFuse rest = nf ? vt_nf_rows(*nf, plan.M1) : VtGemmNormFuse{};
+        return vt_gemm_resid_launch(A + (size_t)plan.M1 * lda, lda, W, ldw, C + (size_t)plan.M1 * ldc, ldc, bias, M - plan.M1, N, K, 0, partials,
                                     partial_bytes, s, nf ? &rest : nullptr);
       }
     }

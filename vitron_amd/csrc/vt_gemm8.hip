@@ -611,11 +611,11 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmP8 p) {
 }
 
 // epilogue of the four-wave kernels: lane holds row m = ..+(lane & 15), 4 consecutive columns per 16-column fragment
-template <int EPI>
-__device__ __forceinline__ void w4_epilogue(const GemmP8& p, f32x4 (&acc)[8][8], int bm0, int bn0, int wr, int wc, int lane) {
+template <int EPI, int MT>
+__device__ __forceinline__ void w4_epilogue(const GemmP8& p, f32x4 (&acc)[MT][8], int bm0, int bn0, int wr, int wc, int lane) {
 #pragma unroll
-  for (int mi = 0; mi < 8; ++mi) {
-    const int m = bm0 + wr * 128 + mi * 16 + (lane & 15);
+  for (int mi = 0; mi < MT; ++mi) {
+    const int m = bm0 + wr * (MT * 16) + mi * 16 + (lane & 15);
     if (m >= p.M) continue;
     if constexpr (EPI == VT_EPI_F32_RESID) {
       float* const Cf = (float*)p.C;
@@ -701,17 +701,27 @@ __device__ __forceinline__ void w4_epilogue(const GemmP8& p, f32x4 (&acc)[8][8],
 //   WAR: the last reads of a half (lgkmcnt(0)) precede the barrier behind which ANY wave refills it. RAW: every wave waits for its
 //   own pieces of a half before the barrier behind which any wave reads it.
 // ------------------------------------------------------------------------------------------------------------------
+// MT = 16-row fragments per wave along M: 8 -> the 256x256 tile above; 10 -> a 320x256 tile (160x128 per wave: 80 accumulator quads,
+// the last 16 of them in VGPRs; 144 KiB of LDS; 160 MFMAs, 18 pieces and 36 fragment reads per K step, same gap pattern stretched):
+// for row counts that fill WHOLE rounds of the 256 CUs only with 320-row tiles (5120 x 4096: 256 tiles instead of 320 = 1.25 rounds).
 // ABL (timing ablations, wrong results; test library only): 1 = no LDS-DMA in the loop, 2 = no barriers, 4 = no fragment reads, 8 = no
 // counted waits, 16 = unswizzled DMA sources. AUX_A / AUX_B = cache-policy bits of the DMA instructions (1 sc0, 2 nt, 16 sc1): measured,
 // sc0 / sc1 make no difference and nt costs 20 %, so they stay 0.
-template <int EPI, int ABL = 0, int AUX_A = 0, int AUX_B = 0>
+__host__ __device__ __forceinline__ constexpr int w4_vmcnt_imm(int n) { return (n & 15) | ((n >> 4) << 14) | (7 << 4) | (15 << 8); }   // s_waitcnt vmcnt(n) only
+
+template <int EPI, int MT = 8, int ABL = 0, int AUX_A = 0, int AUX_B = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_w4_kernel(GemmP8 p) {
+  static_assert(MT == 8 || MT == 10, "wave tile height: 128 or 160 rows");
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BM = MT * 32;                       // tile rows
+  constexpr int A_BYTES = BM * 128, B_BYTES = 256 * 128, BUFB = A_BYTES + B_BYTES;   // one K step in LDS: A rows, then B rows
+  constexpr int NPA = MT, NPB = 8, NP = NPA + NPB;  // LDS-DMA pieces (8 rows x 128 B) per wave and K step
+  constexpr int H = MT * 8, NM = 2 * H;             // MFMAs per k-half / per K step
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wr = wave >> 1, wc = wave & 1;
 
-  const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 255) / 256;
+  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + 255) / 256;
   const int nwg = tiles_m * tiles_n;
   const int sid = xcd_remap((int)blockIdx.x, nwg);
   constexpr int GROUP_M = 8;
@@ -720,84 +730,97 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int gsz = min(tiles_m - first_m, GROUP_M);
   const int tm = first_m + (sid % per_group) % gsz;
   const int tn = (sid % per_group) / gsz;
-  const int bm0 = tm * 256, bn0 = tn * 256;
+  const int bm0 = tm * BM, bn0 = tn * 256;
 
-  // DMA sources. Pieces 0..7 of a K step are this wave's share of B (half tile B0: 0..3, B1: 4..7), pieces 8..15 its share of A.
+  // DMA sources. Pieces 0..7 of a K step are this wave's share of B (rows (8 wave + j) * 8 ..), pieces 8.. its share of A.
   const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (size_t)bm0 * p.lda), 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (size_t)bn0 * p.ldw), 0, 0x7fffffff, 0x00020000);
   const int lrow = lane >> 3, lchk = lane & 7;
-  int voff[16];
+  int voff[18];   // NP entries used; sized by a literal: with a size that depends on MT, clang's HOST pass silently drops the kernel stub
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int row = (i >> 2) * 128 + (wave * 4 + (i & 3)) * 8 + lrow;      // row inside the 256-row tile
-    const int coff = ((ABL & 16) ? lchk : (lchk ^ ((row >> 1) & 7))) * 16;   // source-side XOR swizzle, bytes
-    voff[i] = (min(bn0 + row, p.N - 1) - bn0) * p.ldw * 2 + coff;
-    voff[8 + i] = (min(bm0 + row, p.M - 1) - bm0) * p.lda * 2 + coff;
+  for (int i = 0; i < NP; ++i) {
+    const int row = (i < NPB ? wave * NPB + i : wave * NPA + (i - NPB)) * 8 + lrow;   // row inside the tile
+    const int coff = ((ABL & 16) ? lchk : (lchk ^ ((row >> 1) & 7))) * 16;            // source-side XOR swizzle, bytes
+    voff[i] = i < NPB ? (min(bn0 + row, p.N - 1) - bn0) * p.ldw * 2 + coff : (min(bm0 + row, p.M - 1) - bm0) * p.lda * 2 + coff;
   }
-  const int dma_off = wave * 4096;
 #define W4S_DMA_X(BUF, P, KB, AUX)                                                                                    \
   __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                                      \
-      (P) < 8 ? rsrc_b : rsrc_a,                                                                                 \
-      (__attribute__((address_space(3))) void*)(smem + (BUF) * BUF_BYTES +                                       \
-                                                 slot_offset((P) < 4 ? SLOT_B0 : (P) < 8 ? SLOT_B1 : (P) < 12 ? SLOT_A0 : SLOT_A1) + \
-                                                 dma_off + ((P) & 3) * 1024),                                    \
+      (P) < NPB ? rsrc_b : rsrc_a,                                                                               \
+      (__attribute__((address_space(3))) void*)(smem + (BUF) * BUFB +                                            \
+                                                 ((P) < NPB ? A_BYTES + (wave * NPB + (P)) * 1024 : (wave * NPA + (P) - NPB) * 1024)), \
       16, voff[P], KB, 0, AUX)
-#define W4S_DMA(BUF, P, KB) do { if ((P) < 8) W4S_DMA_X(BUF, P, KB, AUX_B); else W4S_DMA_X(BUF, P, KB, AUX_A); } while (0)
+#define W4S_DMA(BUF, P, KB) do { if ((P) < NPB) W4S_DMA_X(BUF, P, KB, AUX_B); else W4S_DMA_X(BUF, P, KB, AUX_A); } while (0)
 
   const int f = (lane >> 1) & 7;
   const int fo[2] = {(lane & 15) * 128 + (((lane >> 4) ^ f) << 4), (lane & 15) * 128 + ((((lane >> 4) | 4) ^ f) << 4)};
-  const int a_base = (wr ? slot_offset(SLOT_A1) : slot_offset(SLOT_A0));
-  const int b_base = (wc ? slot_offset(SLOT_B1) : slot_offset(SLOT_B0));
+  const int a_base = wr * (MT * 16 * 128);
+  const int b_base = A_BYTES + wc * (128 * 128);
 
-  f32x4 acc[8][8];
+  f32x4 acc[MT][8];
 #pragma unroll
-  for (int mi = 0; mi < 8; ++mi)
+  for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
     for (int ni = 0; ni < 8; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  bf16x8 fa[2][8], fb[2][8];
+  bf16x8 fa[2][MT], fb[2][8];
+  // MFMA n of a K step: fragment set n / H, accumulator row (n % H) / 8, column n % 8; rows 0..7 live in the accumulator file
 #define W4S_MFMA(N)                                                                                              \
-  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"                                                         \
-               : "+a"(acc[((N) >> 3) & 7][(N) & 7]) : "v"(fb[(N) >> 6][(N) & 7]), "v"(fa[(N) >> 6][((N) >> 3) & 7]))
-#define W4S_RDB(SET, BUF, KK, I) fb[SET][I] = *(const bf16x8*)(smem + (BUF) * BUF_BYTES + b_base + fo[KK] + (I) * 2048)
-#define W4S_RDA(SET, BUF, KK, I) fa[SET][I] = *(const bf16x8*)(smem + (BUF) * BUF_BYTES + a_base + fo[KK] + (I) * 2048)
+  do {                                                                                                           \
+    if ((((N) % H) >> 3) < 8)                                                                                    \
+      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"                                                     \
+                   : "+a"(acc[(((N) % H) >> 3) & 7][(N) & 7]) : "v"(fb[((N) / H) & 1][(N) & 7]), "v"(fa[((N) / H) & 1][(((N) % H) >> 3) % MT])); \
+    else                                                                                                         \
+      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"                                                     \
+                   : "+v"(acc[(((N) % H) >> 3) % MT][(N) & 7]) : "v"(fb[((N) / H) & 1][(N) & 7]), "v"(fa[((N) / H) & 1][(((N) % H) >> 3) % MT])); \
+  } while (0)
+#define W4S_RDB(SET, BUF, KK, I) fb[SET][I] = *(const bf16x8*)(smem + (BUF) * BUFB + b_base + fo[KK] + (I) * 2048)
+#define W4S_RDA(SET, BUF, KK, I) fa[SET][I] = *(const bf16x8*)(smem + (BUF) * BUFB + a_base + fo[KK] + (I) * 2048)
 #define W4S_LGKM0() __builtin_amdgcn_s_waitcnt(0xc07f)
 
-  const int nt = p.K >> 6;                         // K % 64 == 0, checked by the launcher
+  const int nt = p.K >> 6;                         // K % 128 == 0, checked by the launcher
   const int kb1 = min(1, nt - 1) * 128;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) W4S_DMA(0, i, 0);
+  for (int i = 0; i < NP; ++i) W4S_DMA(0, i, 0);
 #pragma unroll
-  for (int i = 0; i < 16; ++i) W4S_DMA(1, i, kb1);
-  VT_VMCNT(16);                                    // K step 0 has landed, K step 1 may still be in flight
+  for (int i = 0; i < NP; ++i) W4S_DMA(1, i, kb1);
+  __builtin_amdgcn_s_waitcnt(w4_vmcnt_imm(NP));    // K step 0 has landed, K step 1 may still be in flight
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    W4S_RDB(0, 0, 0, i);
-    W4S_RDA(0, 0, 0, i);
-  }
+  for (int i = 0; i < 8; ++i) W4S_RDB(0, 0, 0, i);
+#pragma unroll
+  for (int i = 0; i < MT; ++i) W4S_RDA(0, 0, 0, i);
   W4S_LGKM0();
   __builtin_amdgcn_sched_barrier(0);
   asm volatile("s_nop 4");                         // accumulator zeroes (v_accvgpr_write) -> first MFMA reading them as C
 
-  // the memory / synchronisation instruction that follows MFMA n of a K step living in LDS buffer B
+  // The memory / synchronisation instruction that follows MFMA n of a K step living in LDS buffer B (gap table of the header; the
+  // positions for MT = 10 are the same pattern stretched: 18 slots in the first section, 8 early + 2 late A pieces).
+  constexpr int S1_N = NPB + MT;                    // slots of section 1: DMA B / read A alternating, then the extra A reads
+  constexpr int LG2 = 21 + 2 * S1_N + 2, BAR2 = LG2 + 1;                    // 55, 56  | 59, 60
+  constexpr int NE = MT == 8 ? 3 : 8;               // A pieces issued before the k-half boundary
+  constexpr int VM3 = BAR2 + 2 * NE, BAR3 = VM3 + 1;                        // 62, 63  | 76, 77
+  constexpr int VM4 = MT == 8 ? 92 : 100, BAR4 = VM4 + 1;                   // 92, 93  | 100, 101
+#define W4S_IX(x, m) ((((x) % (m)) + (m)) % (m))   /* keeps the indices of the untaken branches inside their arrays */
 #define W4S_GAP(n, B, KB)                                                                                        \
   do {                                                                                                           \
     if ((n) < 16) { if (!((n) & 1) && !(ABL & 4)) W4S_RDB(1, B, 1, ((n) >> 1) & 7); }                            \
-    else if ((n) == 19 || (n) == 55) { if (!(ABL & 8)) W4S_LGKM0(); }                                            \
-    else if ((n) == 20 || (n) == 56 || (n) == 63 || (n) == 93) { if (!(ABL & 2)) __builtin_amdgcn_s_barrier(); } \
-    else if ((n) >= 21 && (n) <= 51) {                                                                           \
-      if (((n) & 3) == 1) { if (!(ABL & 1)) W4S_DMA(B, (((n) - 21) >> 2) & 7, KB); }                             \
-      else if (((n) & 3) == 3) { if (!(ABL & 4)) W4S_RDA(1, B, 1, (((n) - 23) >> 2) & 7); }                      \
+    else if ((n) == 19 || (n) == LG2) { if (!(ABL & 8)) W4S_LGKM0(); }                                           \
+    else if ((n) == 20 || (n) == BAR2 || (n) == BAR3 || (n) == BAR4) { if (!(ABL & 2)) __builtin_amdgcn_s_barrier(); } \
+    else if ((n) >= 21 && (n) < 21 + 2 * S1_N) {                                                                 \
+      if ((n) & 1) {                                                                                             \
+        if ((((n) - 21) >> 1) >= 16) { if (!(ABL & 4)) W4S_RDA(1, B, 1, W4S_IX((((n) - 21) >> 1) - 8, MT)); }         \
+        else if (((n) & 3) == 1) { if (!(ABL & 1)) W4S_DMA(B, W4S_IX(((n) - 21) >> 2, 8), KB); }                      \
+        else { if (!(ABL & 4)) W4S_RDA(1, B, 1, W4S_IX(((n) - 23) >> 2, 8)); }                                        \
+      }                                                                                                          \
     }                                                                                                            \
-    else if ((n) == 57 || (n) == 59 || (n) == 61) { if (!(ABL & 1)) W4S_DMA(B, 8 + ((((n) - 57) >> 1) & 3), KB); } \
-    else if ((n) == 62) { if (!(ABL & 9)) VT_VMCNT(19); }                                                        \
-    else if ((n) >= 64 && (n) <= 81) {                                                                           \
-      if (!((n) & 1)) { if ((n) <= 78 && !(ABL & 4)) W4S_RDB(0, (B) ^ 1, 0, (((n) - 64) >> 1) & 7); }            \
-      else if (((n) & 3) == 1) { if (!(ABL & 1)) W4S_DMA(B, 11 + ((((n) - 65) >> 2) & 7) % 5, KB); }             \
+    else if ((n) > BAR2 && (n) < VM3) { if (((n) - BAR2) & 1) { if (!(ABL & 1)) W4S_DMA(B, NPB + W4S_IX(((n) - BAR2) >> 1, NE), KB); } } \
+    else if ((n) == VM3) { if (!(ABL & 9)) __builtin_amdgcn_s_waitcnt(w4_vmcnt_imm(NPA + NPB + NE)); }           \
+    else if ((n) >= H && (n) <= H + 17) {                                                                        \
+      if (!(((n) - H) & 1)) { if ((n) <= H + 14 && !(ABL & 4)) W4S_RDB(0, (B) ^ 1, 0, W4S_IX(((n) - H) >> 1, 8)); }   \
+      else if ((((n) - H) & 3) == 1 && (((n) - H) >> 2) < NPA - NE) { if (!(ABL & 1)) W4S_DMA(B, NPB + NE + W4S_IX(((n) - H) >> 2, NPA - NE), KB); } \
     }                                                                                                            \
-    else if ((n) == 92) { if (!(ABL & 9)) VT_VMCNT(16); }                                                        \
-    else if ((n) >= 94 && (n) <= 108 && !((n) & 1)) { if (!(ABL & 4)) W4S_RDA(0, (B) ^ 1, 0, (((n) - 94) >> 1) & 7); } \
+    else if ((n) == VM4) { if (!(ABL & 9)) __builtin_amdgcn_s_waitcnt(w4_vmcnt_imm(NPA + NPB)); }                \
+    else if ((n) > BAR4 && (n) <= BAR4 + 2 * MT && (((n) - BAR4) & 1)) { if (!(ABL & 4)) W4S_RDA(0, (B) ^ 1, 0, W4S_IX(((n) - BAR4) >> 1, MT)); } \
   } while (0)
 #define W4S_N(n, B, KB) W4S_MFMA(n); W4S_GAP(n, B, KB); __builtin_amdgcn_sched_barrier(0);
 #define W4S_8(n, B, KB) W4S_N((n), B, KB) W4S_N((n) + 1, B, KB) W4S_N((n) + 2, B, KB) W4S_N((n) + 3, B, KB) \
@@ -807,6 +830,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   do {                                                                                                           \
     const int _kb = min((T) + 2, nt - 1) * 128;    /* past the end of K: re-fetch the last K step, harmless */    \
     W4S_32(0, B, _kb) W4S_32(32, B, _kb) W4S_32(64, B, _kb) W4S_32(96, B, _kb)                                    \
+    if constexpr (NM > 128) { W4S_32(128, B, _kb) }                                                              \
   } while (0)
   for (int t = 0; t < nt; t += 2) {
     W4S_KSTEP(0, t);
@@ -819,25 +843,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #undef W4S_8
 #undef W4S_N
 #undef W4S_GAP
+#undef W4S_IX
 #undef W4S_LGKM0
 #undef W4S_RDA
 #undef W4S_RDB
 #undef W4S_MFMA
 #undef W4S_DMA
 #undef W4S_DMA_X
-  w4_epilogue<EPI>(p, acc, bm0, bn0, wr, wc, lane);
+  w4_epilogue<EPI, MT>(p, acc, bm0, bn0, wr, wc, lane);
 }
 
-template <int EPI, int ABL = 0, int AUX_A = 0, int AUX_B = 0>
+template <int EPI, int MT = 8, int ABL = 0, int AUX_A = 0, int AUX_B = 0>
 int launch_w4(const GemmP8& p, hipStream_t s) {
-  constexpr int smem = 2 * BUF_BYTES;  // 128 KiB
-  auto kern = gemm_w4_kernel<EPI, ABL, AUX_A, AUX_B>;
+  constexpr int BM = MT * 32;
+  constexpr int smem = 2 * (BM * 128 + 256 * 128);  // 128 KiB | 144 KiB
+  auto kern = gemm_w4_kernel<EPI, MT, ABL, AUX_A, AUX_B>;
   static bool done = false;
   if (!done) {
     VT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     done = true;
   }
-  hipLaunchKernelGGL(kern, dim3(cdiv(p.M, 256) * cdiv(p.N, 256)), dim3(256), smem, s, p);
+  hipLaunchKernelGGL(kern, dim3(cdiv(p.M, BM) * cdiv(p.N, 256)), dim3(256), smem, s, p);
   VT_LAUNCH_CHECK();
   return VT_OK;
 }
@@ -1202,7 +1228,7 @@ int vt_gemm_p8_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* 
     VT_REQUIRE((epi & 0xff) == VT_EPI_F32_RESID && p.nf.out_w && p.nf.out_xw && p.nf.out_np >= N / 32 && p.nf.out_ldp >= M,
                "vt_gemm(p8): norm-fold producer needs the residual epilogue and its buffers");
 #ifdef VT_ABLATIONS
-  if (epi >= 0x100 && !(epi & 0x5000)) {  // timing ablations (tools/gemm_ablate.py); test library only
+  if (epi >= 0x100 && !(epi & 0xd000)) {  // timing ablations (tools/gemm_ablate.py); test library only
     switch (epi >> 8) {
       case 1: return launch_p8<VT_EPI_BF16, 1>(p, s);
       case 2: return launch_p8<VT_EPI_BF16, 2>(p, s);
@@ -1225,6 +1251,19 @@ int vt_gemm_p8_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* 
     }
   }
 #endif
+  if ((epi & 0x4000) && (epi & 0x8000)) {   // 4-wave kernel, 320-row tile (160x128 per wave)
+    VT_REQUIRE(!nf, "vt_gemm(w4): no norm fold in the 4-wave kernel");
+    switch (epi & 0xff) {
+      case VT_EPI_BF16: return launch_w4<VT_EPI_BF16, 10>(p, s);
+      case VT_EPI_BF16_GELU: return launch_w4<VT_EPI_BF16_GELU, 10>(p, s);
+      case VT_EPI_BF16_QGELU: return launch_w4<VT_EPI_BF16_QGELU, 10>(p, s);
+      case VT_EPI_BF16_RELU: return launch_w4<VT_EPI_BF16_RELU, 10>(p, s);
+      case VT_EPI_F32_RESID: return launch_w4<VT_EPI_F32_RESID, 10>(p, s);
+      case VT_EPI_F32: return launch_w4<VT_EPI_F32, 10>(p, s);
+      case VT_EPI_SWIGLU_BF16: return launch_w4<VT_EPI_SWIGLU_BF16, 10>(p, s);
+      default: vt_set_error("vt_gemm(w4, 320-row tile): epilogue %d not instantiated", epi & 0xff); return VT_ERR_ARG;
+    }
+  }
   if (epi & 0x4000) {   // 4-wave kernel (128x128 per wave)
     VT_REQUIRE(!nf, "vt_gemm(w4): no norm fold in the 4-wave kernel");
     switch (epi & 0xff) {
@@ -1232,13 +1271,13 @@ int vt_gemm_p8_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* 
 #ifdef VT_ABLATIONS
         static const int abl = getenv("VT_W4_ABL") ? atoi(getenv("VT_W4_ABL")) : 0;   // timing ablations, see the kernel
         switch (abl) {
-          case 1: return launch_w4<VT_EPI_BF16, 1>(p, s);
-          case 2: return launch_w4<VT_EPI_BF16, 2>(p, s);
-          case 4: return launch_w4<VT_EPI_BF16, 4>(p, s);
-          case 5: return launch_w4<VT_EPI_BF16, 5>(p, s);
-          case 8: return launch_w4<VT_EPI_BF16, 8>(p, s);
-          case 15: return launch_w4<VT_EPI_BF16, 15>(p, s);
-          case 16: return launch_w4<VT_EPI_BF16, 16>(p, s);
+          case 1: return launch_w4<VT_EPI_BF16, 8, 1>(p, s);
+          case 2: return launch_w4<VT_EPI_BF16, 8, 2>(p, s);
+          case 4: return launch_w4<VT_EPI_BF16, 8, 4>(p, s);
+          case 5: return launch_w4<VT_EPI_BF16, 8, 5>(p, s);
+          case 8: return launch_w4<VT_EPI_BF16, 8, 8>(p, s);
+          case 15: return launch_w4<VT_EPI_BF16, 8, 15>(p, s);
+          case 16: return launch_w4<VT_EPI_BF16, 8, 16>(p, s);
           default: break;
         }
 #endif

@@ -32,6 +32,15 @@ def _chk(t: torch.Tensor, dtype, name: str):
         raise _lib.VitronHipError(f"{name}: tensor must be contiguous")
 
 
+def gemm_plan(M: int, N: int, K: int, epi: int = EPI_BF16):
+    """(cfg, rows_first) the dispatcher picks for an AUTO vt_gemm_bf16 of this shape (host logic, no launch; include/vitron_hip.h)."""
+    import ctypes
+    lib = _lib.load()
+    cfg, rows = ctypes.c_int(0), ctypes.c_int(0)
+    _lib.check(lib.vt_gemm_plan_query(M, N, K, epi, ctypes.byref(cfg), ctypes.byref(rows)), "vt_gemm_plan_query")
+    return cfg.value, rows.value
+
+
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, epi: int = EPI_BF16,
          out: Optional[torch.Tensor] = None, cfg: int = CFG_AUTO, row_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out = epi(row_scale[:, None] * (a[M,K] @ w[N,K]^T) + bias). EPI_F32_RESID accumulates into `out` (fp32, required)."""
