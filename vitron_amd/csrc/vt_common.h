@@ -87,6 +87,21 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 __device__ __forceinline__ float bf16lo_to_f32(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16hi_to_f32(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
+// GELU (exact-erf flavour: nn.GELU(), CLIP 'gelu') for the GEMM epilogues: 0.5 x (1 + erf(x / sqrt 2)) with 1 - erf(|z|) from
+// Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 store that follows): branch-free, one rcp and one exp2 -- the
+// library erff (two polynomial branches, both executed by a divergent wave) made the epilogue of the ViT's fc1 GEMM as long as
+// its 16 K steps. The negative side uses q = 1 - erf(|z|) directly, so the tail keeps its relative accuracy.
+__device__ __forceinline__ float vt_gelu_erf(float x) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+  float q = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+  q = __builtin_fmaf(q, t, 1.421413741f);
+  q = __builtin_fmaf(q, t, -0.284496736f);
+  q = __builtin_fmaf(q, t, 0.254829592f);
+  q *= t * __builtin_amdgcn_exp2f(z * z * -1.4426950408889634f);   // 1 - erf(|z|)
+  return 0.5f * x * (x >= 0.f ? 2.0f - q : q);
+}
+
 // half-split rotary embedding of one (low, high) pair: (a, b) -> (a cos - b sin, b cos + a sin). Spelled with explicit fused
 // multiply-adds so that every kernel that rotates (vt_kv_tiles, the fused decode attention, the QKV GEMM epilogue) rounds the
 // same way -- their K pages are compared bit for bit.

@@ -47,7 +47,7 @@ struct GemmP {
   VtGemmNormFuse nf;   // folded RMSNorm / row scale (vt_kernels.h): skinny LDS-DMA kernel (decode flavour), tile kernel (row_scale, out_*)
 };
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf(float x) { return vt_gelu_erf(x); }
 __device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
 

@@ -48,7 +48,7 @@ struct GemmP8 {
   VtQkvFuse qf;      // EPI == VT_EPI_QKV_PAGES only
 };
 
-__device__ __forceinline__ float gelu_erf8(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf8(float x) { return vt_gelu_erf(x); }
 __device__ __forceinline__ float quick_gelu8(float x) { return x / (1.0f + __expf(-1.702f * x)); }
 __device__ __forceinline__ float silu8(float x) { return x / (1.0f + __expf(-x)); }
 
