@@ -1,6 +1,6 @@
-"""Sustained (>= 1 s per measurement, alternating) throughput of the 4-phase ping-pong GEMM vs torch.matmul (hipBLASLt) on one
-decoder shape: 8-ms micro-benchmarks ride on the thermal / power state the previous kernel left behind, so
-kernel-vs-kernel comparisons are made on windows long enough for the power limit to settle. python tools/gemm_sustained.py"""
+"""Sustained (>= 1 s per measurement, alternating) throughput of the dispatcher's choice (AUTO: four-wave kernel on 256- or 320-row
+tiles), the 4-phase ping-pong GEMM and torch.matmul (hipBLASLt) on decoder shapes (bf16 store epilogue on all three): 8-ms micro-benchmarks ride on the thermal / power state the previous kernel left behind, so
+kernel-vs-kernel comparisons are made on windows long enough for the power limit to settle. python tools/gemm_sustained.py [M N K | all]"""
 import json
 import os
 import sys
@@ -27,17 +27,22 @@ def run(fn, seconds):
 def main():
     _lib.load()
     dev = torch.device("cuda:0")
-    shapes = [(5120, 12288, 4096)] if len(sys.argv) < 4 else [tuple(int(x) for x in sys.argv[1:4])]
+    if len(sys.argv) > 1 and sys.argv[1] == "all":   # the four big GEMM shapes of the benchmark step
+        shapes = [(5120, 12288, 4096), (5120, 22016, 4096), (5120, 4096, 11008), (5120, 4096, 4096)]
+    else:
+        shapes = [(5120, 12288, 4096)] if len(sys.argv) < 4 else [tuple(int(x) for x in sys.argv[1:4])]
+    secs = float(os.environ.get("GEMM_SUSTAINED_SECONDS", "1.5"))
     for (M, N, K) in shapes:
         a = torch.randn((M, K), device=dev).bfloat16()
         w = (torch.randn((N, K), device=dev) * 0.02).bfloat16()
         out = torch.empty((M, N), device=dev, dtype=torch.bfloat16)
         flops = 2.0 * M * N * K
         for rep in range(3):
-            row = {"shape": [M, N, K], "rep": rep}
-            for name, fn in (("p4", lambda: ops.gemm(a, w, None, ops.EPI_BF16, out=out, cfg=_lib.CFG_256x256_P4)),
+            row = {"shape": [M, N, K], "rep": rep, "plan": list(ops.gemm_plan(M, N, K, ops.EPI_BF16))}
+            for name, fn in (("auto", lambda: ops.gemm(a, w, None, ops.EPI_BF16, out=out)),
+                             ("p4", lambda: ops.gemm(a, w, None, ops.EPI_BF16, out=out, cfg=_lib.CFG_256x256_P4)),
                              ("hipBLASLt", lambda: torch.matmul(a, w.t(), out=out))):
-                s = run(fn, 1.5)
+                s = run(fn, secs)
                 row[name] = {"us": round(s * 1e6, 1), "tflops": round(flops / s / 1e12, 1)}
             print(json.dumps(row), flush=True)
 
