@@ -610,61 +610,86 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmP8 p) {
   }
 }
 
-// epilogue of the four-wave kernels: lane holds row m = ..+(lane & 15), 4 consecutive columns per 16-column fragment
+// Epilogue of the four-wave kernel: lane holds row m = .. + (lane & 15) and 4 consecutive columns of every 16-column fragment.
+// One wave per SIMD: nothing overlaps a round trip to memory here. The fp32 residual rows are therefore requested THREE fragment
+// rows ahead of their use (the fragment registers of the main loop are free by now; rows / columns past the edge are clamped for
+// the loads and masked for the stores, the bias is fetched once): with a load / wait / store round per fragment row the
+// read-modify-write of C cost 12 % of a one-round o_proj launch (5120 x 4096 x 4096: 1245 -> 1292 TFLOP/s, 1381 with a bf16 store).
+// The store-only epilogues keep the plain skip-past-the-edge form (the same restructuring measured 8 % SLOWER on them at K = 1024).
 template <int EPI, int MT>
 __device__ __forceinline__ void w4_epilogue(const GemmP8& p, f32x4 (&acc)[MT][8], int bm0, int bn0, int wr, int wc, int lane) {
+  if constexpr (EPI == VT_EPI_F32_RESID) {
+    const int row0 = bm0 + wr * (MT * 16) + (lane & 15);
+    const int col0 = bn0 + wc * 128 + ((lane >> 4) << 2);
+    const bool has_bias = p.bias != nullptr;
+    f32x4 b4[8];
 #pragma unroll
-  for (int mi = 0; mi < MT; ++mi) {
-    const int m = bm0 + wr * (MT * 16) + mi * 16 + (lane & 15);
-    if (m >= p.M) continue;
-    if constexpr (EPI == VT_EPI_F32_RESID) {
-      float* const Cf = (float*)p.C;
-      f32x4 cur[8];
+    for (int ni = 0; ni < 8; ++ni)
+      b4[ni] = has_bias ? *(const f32x4*)(p.bias + min(col0 + ni * 16, p.N - 4)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    float* const Cf = (float*)p.C;
+    constexpr int PF = 3;
+    f32x4 cur[PF][8];
+#define W4E_LOAD(MI)                                                                                              \
+  do {                                                                                                            \
+    const float* _r = Cf + (size_t)min(row0 + (MI) * 16, p.M - 1) * p.ldc;                                        \
+    _Pragma("unroll") for (int ni = 0; ni < 8; ++ni) cur[(MI) % PF][ni] = *(const f32x4*)(_r + min(col0 + ni * 16, p.N - 4)); \
+  } while (0)
 #pragma unroll
-      for (int ni = 0; ni < 8; ++ni) cur[ni] = *(const f32x4*)(Cf + (size_t)m * p.ldc + min(bn0 + wc * 128 + ni * 16 + ((lane >> 4) << 2), p.N - 4));
+    for (int mi = 0; mi < PF; ++mi) W4E_LOAD(mi);
 #pragma unroll
-      for (int ni = 0; ni < 8; ++ni) {
-        const int n = bn0 + wc * 128 + ni * 16 + ((lane >> 4) << 2);
-        if (n >= p.N) continue;
-        f32x4 v = acc[mi][ni];
-        if (p.bias) v += *(const f32x4*)(p.bias + n);
-        *(f32x4*)(Cf + (size_t)m * p.ldc + n) = cur[ni] + v;
-      }
-    } else if constexpr (EPI == VT_EPI_SWIGLU_BF16) {
-#pragma unroll
-      for (int nj = 0; nj < 4; ++nj) {
-        const int nbase = bn0 + wc * 128 + nj * 32;
-        if (nbase + ((lane >> 4) << 2) >= p.N) continue;
-        const f32x4 g = acc[mi][2 * nj], u2 = acc[mi][2 * nj + 1];
-        u32x2 o;
-        o.x = pack_bf16x2(silu8(g[0]) * u2[0], silu8(g[1]) * u2[1]);
-        o.y = pack_bf16x2(silu8(g[2]) * u2[2], silu8(g[3]) * u2[3]);
-        *(u32x2*)((bf16_t*)p.C + (size_t)m * p.ldc + (nbase >> 1) + ((lane >> 4) << 2)) = o;
-      }
-    } else {
+    for (int mi = 0; mi < MT; ++mi) {
+      const int m = row0 + mi * 16;
 #pragma unroll
       for (int ni = 0; ni < 8; ++ni) {
-        const int n = bn0 + wc * 128 + ni * 16 + ((lane >> 4) << 2);
-        if (n >= p.N) continue;
-        f32x4 v = acc[mi][ni];
-        if (p.bias) v += *(const f32x4*)(p.bias + n);
-        if constexpr (EPI == VT_EPI_BF16_GELU) {
+        const int n = col0 + ni * 16;
+        const f32x4 v = has_bias ? acc[mi][ni] + b4[ni] : acc[mi][ni];
+        const f32x4 o = cur[mi % PF][ni] + v;
+        if (m < p.M && n < p.N) *(f32x4*)(Cf + (size_t)m * p.ldc + n) = o;
+      }
+      if (mi + PF < MT) W4E_LOAD(mi + PF);
+    }
+#undef W4E_LOAD
+  } else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = gelu_erf8(v[r]);
-        } else if constexpr (EPI == VT_EPI_BF16_QGELU) {
+    for (int mi = 0; mi < MT; ++mi) {
+      const int m = bm0 + wr * (MT * 16) + mi * 16 + (lane & 15);
+      if (m >= p.M) continue;
+      if constexpr (EPI == VT_EPI_SWIGLU_BF16) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = quick_gelu8(v[r]);
-        } else if constexpr (EPI == VT_EPI_BF16_RELU) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-        }
-        if constexpr (EPI == VT_EPI_F32) {
-          *(f32x4*)((float*)p.C + (size_t)m * p.ldc + n) = v;
-        } else {
+        for (int nj = 0; nj < 4; ++nj) {
+          const int nbase = bn0 + wc * 128 + nj * 32;
+          if (nbase + ((lane >> 4) << 2) >= p.N) continue;
+          const f32x4 g = acc[mi][2 * nj], u2 = acc[mi][2 * nj + 1];
           u32x2 o;
-          o.x = pack_bf16x2(v[0], v[1]);
-          o.y = pack_bf16x2(v[2], v[3]);
-          *(u32x2*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
+          o.x = pack_bf16x2(silu8(g[0]) * u2[0], silu8(g[1]) * u2[1]);
+          o.y = pack_bf16x2(silu8(g[2]) * u2[2], silu8(g[3]) * u2[3]);
+          *(u32x2*)((bf16_t*)p.C + (size_t)m * p.ldc + (nbase >> 1) + ((lane >> 4) << 2)) = o;
+        }
+      } else {
+#pragma unroll
+        for (int ni = 0; ni < 8; ++ni) {
+          const int n = bn0 + wc * 128 + ni * 16 + ((lane >> 4) << 2);
+          if (n >= p.N) continue;
+          f32x4 v = acc[mi][ni];
+          if (p.bias) v += *(const f32x4*)(p.bias + n);
+          if constexpr (EPI == VT_EPI_BF16_GELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = gelu_erf8(v[r]);
+          } else if constexpr (EPI == VT_EPI_BF16_QGELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = quick_gelu8(v[r]);
+          } else if constexpr (EPI == VT_EPI_BF16_RELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+          }
+          if constexpr (EPI == VT_EPI_F32) {
+            *(f32x4*)((float*)p.C + (size_t)m * p.ldc + n) = v;
+          } else {
+            u32x2 o;
+            o.x = pack_bf16x2(v[0], v[1]);
+            o.y = pack_bf16x2(v[2], v[3]);
+            *(u32x2*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
+          }
         }
       }
     }
