@@ -44,7 +44,8 @@ __device__ __forceinline__ int v_swz(int d) { return (d >> 1) & 7; }
 // NWAVES waves x 32 query rows share one K / V^T tile ring of NSTAGES 64-key tiles (LDS-DMA, counted vmcnt):
 //   <4 waves, 2 stages>  128-row blocks, 64 KiB LDS (HD=128), two blocks per CU      -- ViT (many short sequences)
 //   <8 waves, 3 stages>  256-row blocks, 96 KiB LDS, one block per CU, two tiles of DMA lead -- long causal prefill
-// ABL (timing ablations, results are garbage): bit0 = no exp / max / sum (softmax VALU), bit1 = no MFMA
+// ABL (timing ablations, results are garbage): bit0 = no exp / max / sum (softmax VALU), bit1 = no MFMA;
+// experiment knobs (results correct): bit2 = s_setprio 3 around the softmax section, bit3 = s_setprio 3 around the MFMA sections
 template <int HD, bool CAUSAL, int NWAVES, int NSTAGES, int ABL = 0>
 __global__ __launch_bounds__(64 * NWAVES, (NWAVES == 8) ? 2 : 2) void flash_attn_kernel(const bf16_t* __restrict__ Q, int ldq,
                                                          const bf16_t* __restrict__ Kt,
@@ -166,6 +167,7 @@ __global__ __launch_bounds__(64 * NWAVES, (NWAVES == 8) ? 2 : 2) void flash_attn
     const char* vb = kb + TILE_BYTES;
 
     // ---- S^T = K . Q^T ---------------------------------------------------------------------------------
+    if (ABL & 8) __builtin_amdgcn_s_setprio(3);
     // (the two 32-key sub tiles alternate so consecutive MFMAs never depend on each other: a 32x32x16 result is
     //  only available ~64 cycles after issue, twice its 32-cycle issue slot)
     f32x16 sacc[2];
@@ -185,6 +187,8 @@ __global__ __launch_bounds__(64 * NWAVES, (NWAVES == 8) ? 2 : 2) void flash_attn
     }
     // lane (q,h): sacc[sub][r] = S[q][t*64 + sub*32 + 16h + r]
 
+    if (ABL & 8) __builtin_amdgcn_s_setprio(0);
+    if (ABL & 4) __builtin_amdgcn_s_setprio(3);
     // ---- mask (only tiles that touch the diagonal or the end of the keys) ----------------------------------
     const int key0 = t * 64;
     const bool need_mask = (key0 + 64 > sq.kv_len) || (CAUSAL && (key0 + 63 > past + q0 + wave * 32));
@@ -259,6 +263,8 @@ __global__ __launch_bounds__(64 * NWAVES, (NWAVES == 8) ? 2 : 2) void flash_attn
     psum = psum2.x + psum2.y;
     l_run += psum;
 
+    if (ABL & 4) __builtin_amdgcn_s_setprio(0);
+    if (ABL & 8) __builtin_amdgcn_s_setprio(3);
     // ---- O^T += V^T . P^T --------------------------------------------------------------------------------------
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
@@ -272,6 +278,7 @@ __global__ __launch_bounds__(64 * NWAVES, (NWAVES == 8) ? 2 : 2) void flash_attn
           else oacc[db][j] += __builtin_bit_cast(float, (uint32_t)vf[0] << 16);
         }
       }
+    if (ABL & 8) __builtin_amdgcn_s_setprio(0);
     FA_TILE_SYNC(t);
     slot = (slot + 1 == NSTAGES) ? 0 : slot + 1;
     pre_slot = (pre_slot + 1 == NSTAGES) ? 0 : pre_slot + 1;
@@ -998,6 +1005,8 @@ int vt_flash_attn_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf16_
     if (causal && abl == 1) VT_FA(128, true, 4, 2, 1);
     else if (causal && abl == 2) VT_FA(128, true, 4, 2, 2);
     else if (causal && abl == 3) VT_FA(128, true, 4, 2, 3);
+    else if (causal && abl == 4) VT_FA(128, true, 4, 2, 4);
+    else if (causal && abl == 8) VT_FA(128, true, 4, 2, 8);
     else
 #endif
     if (causal) VT_FA(128, true, 4, 2); else VT_FA(128, false, 4, 2);
