@@ -1,9 +1,14 @@
-// vt_gemm8.hip -- the large-shape bf16 GEMM: 256x256x64 tile, 8 wavefronts in two staggered rows (ping-pong).
+// vt_gemm8.hip -- the large-shape bf16 GEMMs: 256x256x64 (320x256x64) tiles, one workgroup per CU.
 //
-// Three main loops share the tile, the LDS image and the epilogues: the 8-phase schedule described first (gemm_p8_kernel, P4 =
-// false), the 4-phase schedule that merges its phases pairwise (P4 = true: half the barriers, 32 MFMAs per section, +8..14 %,
-// the DEFAULT -- its stage schedule and hazard argument sit next to its loop), and a register-pipelined variant
-// (gemm_rp_kernel, opt-in). The two-pass split-K of the residual epilogue (vt_gemm_p4_splitk_resid_launch) lives here too.
+// Two kernel families share the tile, the LDS image (half tiles, source-side XOR swizzle) and the epilogue semantics:
+//   * gemm_w4_kernel (round 2, the DEFAULT for plain-store epilogues and for 320-row tiles): four waves of 128x128 (160x128),
+//     one per SIMD, accumulators pinned to the accumulator file, the K step placed by hand -- described at its definition;
+//   * the 8-wave ping-pong kernel described first below: the 8-phase schedule (gemm_p8_kernel, P4 = false), the 4-phase schedule
+//     that merges its phases pairwise (P4 = true: half the barriers, 32 MFMAs per section, +8..14 % -- its stage schedule and
+//     hazard argument sit next to its loop; used for VALU-heavy epilogues on 256-row tiles, the folded RMSNorm, the fused QKV
+//     epilogue and the split-K passes), and a register-pipelined variant (gemm_rp_kernel, opt-in).
+// The two-pass split-K of the residual epilogue (vt_gemm_p4_splitk_resid_launch) lives here too; which kernel runs a given shape
+// is decided by the planner in vt_gemm.hip.
 //
 // Same contract and epilogues as vt_gemm.hip's tile kernel (C = epi(A[M,K].W[N,K]^T + bias)); used for the
 // decoder's big projections where >92 % of the prefill FLOPs live.
