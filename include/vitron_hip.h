@@ -51,9 +51,10 @@ enum {
   VT_GEMM_CFG_SKINNY_REG = 9, /* M <= 16: weight rows loaded straight into MFMA operand registers; fallback when K % 64 != 0 */
   VT_GEMM_CFG_256x256_P4 = 10, /* the 8-phase kernel with its phases merged pairwise: 32 MFMAs per section, half the barriers */
   /* 11: reserved (the 4-phase schedule on v_mfma_f32_32x32x16_bf16: correct, 25 % slower on every decoder shape; removed) */
-  VT_GEMM_CFG_256x256_W4 = 13,
-  VT_GEMM_CFG_320x256_W4 = 14,   /* the four-wave kernel on 320-row tiles (160x128 per wave): rows that fill whole rounds only this way */ /* 256x256 tile, 4 waves x (128x128), one wave per SIMD, software-pipelined by hand */
   /* 12: reserved (2-phase schedule, one 64-MFMA section per K step: correct, 8 % slower than the 4-phase one; removed) */
+  VT_GEMM_CFG_256x256_W4 = 13, /* 256x256 tile, 4 waves x (128x128), one wave per SIMD, K step placed by hand (plain-store epilogues) */
+  VT_GEMM_CFG_320x256_W4 = 14, /* the same kernel on 320-row tiles (160x128 per wave): rows that fill whole rounds only this way */
+  VT_GEMM_CFG_160x128_W4 = 15, /* four waves of 80x64 on a 160x128 tile, four-deep LDS ring: N = 1024 projections (K % 256 == 0) */
 };
 enum { VT_DTYPE_BF16 = 0, VT_DTYPE_F32 = 1 };
 enum { VT_ACT_GELU = 0, VT_ACT_QUICK_GELU = 1 };

@@ -524,3 +524,25 @@ def test_gemm_four_wave_kernel(dev, M, N, K):
             assert torch.equal(got, ops.gemm(ad, wd, b.to(dev), ops.EPI_F32_RESID, out=resid.to(dev).clone(), cfg=cfg))
         # the same GEMM through the ping-pong kernel: same fragments, same fp32 accumulation order per output -> identical bits
         assert torch.equal(ops.gemm(ad, wd, b.to(dev), ops.EPI_BF16, cfg=cfg), ops.gemm(ad, wd, b.to(dev), ops.EPI_BF16, cfg=_lib.CFG_256x256_P4))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(300, 384, 256), (577, 1024, 1024), (1000, 544, 512), (4616, 1024, 1024), (161, 128, 768)])
+def test_gemm_four_wave_ring_kernel(dev, M, N, K):
+    """cfg 15: 160x128 tile, four waves of 80x64, four-deep LDS ring with one barrier per K step (ragged M / N, the shortest legal K
+    loop, every epilogue, repeated launches bit-identical, and bit-identical to the ping-pong kernel)."""
+    from vitron_amd import _lib, ops
+    a, w, b = randn((M, K), 71), randn((N, K), 72, 0.05), randn((N,), 73)
+    resid = randn((M, N), 74)
+    ad, wd = a.to(dev).bfloat16(), w.to(dev).bfloat16()
+    cfg = _lib.CFG_160x128_W4
+    for epi in (ops.EPI_BF16, ops.EPI_BF16_GELU, ops.EPI_BF16_QGELU, ops.EPI_BF16_RELU):
+        assert rel_l2(ops.gemm(ad, wd, b.to(dev), epi, cfg=cfg).float(), _gemm_ref(a, w, b, epi)) <= TOL, epi
+    if N % 32 == 0:
+        assert rel_l2(ops.gemm(ad, wd, None, ops.EPI_SWIGLU_BF16, cfg=cfg).float(), _gemm_ref(a, w, None, ops.EPI_SWIGLU_BF16)) <= TOL
+    assert rel_l2(ops.gemm(ad, wd, b.to(dev), ops.EPI_F32, cfg=cfg), _gemm_ref(a, w, b, ops.EPI_F32)) <= 1e-5
+    got = ops.gemm(ad, wd, b.to(dev), ops.EPI_F32_RESID, out=resid.to(dev).clone(), cfg=cfg)
+    assert rel_l2(got, _gemm_ref(a, w, b, ops.EPI_F32_RESID, resid)) <= 1e-5
+    for _ in range(3):
+        assert torch.equal(got, ops.gemm(ad, wd, b.to(dev), ops.EPI_F32_RESID, out=resid.to(dev).clone(), cfg=cfg))
+    assert torch.equal(ops.gemm(ad, wd, b.to(dev), ops.EPI_BF16, cfg=cfg), ops.gemm(ad, wd, b.to(dev), ops.EPI_BF16, cfg=_lib.CFG_256x256_P4))

@@ -449,14 +449,18 @@ def test_gemm_planner_fills_whole_rounds_of_the_chip():
     assert ops.gemm_plan(4096, 4096, 1024, ops.EPI_BF16_QGELU) == (P4, 0)
     # ViT qkv (4616 x 3072): 228 tiles of 256 rows in one round beat 180 taller ones
     assert ops.gemm_plan(4616, 3072, 1024, ops.EPI_BF16) == (W4, 0)
-    # a single-image prompt (1088 rows) covers a quarter of the chip with big tiles: small tiles
-    assert ops.gemm_plan(1088, 4096, 4096, ops.EPI_F32_RESID)[0] in small
-    assert ops.gemm_plan(4616, 1024, 4096, ops.EPI_F32_RESID)[0] in small
+    # a single-image prompt (1088 rows) covers a quarter of the chip with big tiles, and the ViT's N = 1024 projections need 584
+    # tiles of 64x128 for 512 slots: 160x128 tiles on the four-deep ring (224 / 232 workgroups, one round)
+    W4R = _lib.CFG_160x128_W4
+    assert ops.gemm_plan(1088, 4096, 4096, ops.EPI_F32_RESID) == (W4R, 0)
+    assert ops.gemm_plan(4616, 1024, 4096, ops.EPI_F32_RESID) == (W4R, 0)
+    assert ops.gemm_plan(1088, 12288, 4096, ops.EPI_BF16) == (W4, 0)                    # 240 big tiles: one round
+    assert ops.gemm_plan(1088, 4096, 4096 + 128, ops.EPI_F32_RESID)[0] in small         # the ring walks K in steps of 256
     # K not a multiple of 128 (no big-tile kernel) and the weight-streaming range
     assert ops.gemm_plan(4096, 4096, 4096 + 64, ops.EPI_BF16)[0] in small
     assert ops.gemm_plan(16, 4096, 4096, ops.EPI_BF16) == (_lib.CFG_SKINNY, 0)
     # row split: whole rounds on big tiles first, the remaining rows planned again
     cfg, first = ops.gemm_plan(8192 + 512, 4096, 4096, ops.EPI_F32_RESID)    # 2 rounds + a 512-row remainder < 2 rounds of 320-row tiles
-    assert cfg == W4 and first == 8192 and ops.gemm_plan(512, 4096, 4096, ops.EPI_F32_RESID)[1] == 0
+    assert cfg == W4 and first == 8192 and ops.gemm_plan(512, 4096, 4096, ops.EPI_F32_RESID) == (W4R, 0)
     with pytest.raises(RuntimeError):
         ops.gemm_plan(0, 4096, 4096)

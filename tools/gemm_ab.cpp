@@ -94,14 +94,15 @@ int main(int argc, char** argv) {
     const bool f32out = epi == VT_EPI_F32 || epi == VT_EPI_F32_RESID;
     const int ldc = epi == VT_EPI_SWIGLU_BF16 ? N / 2 : N;
     const size_t cbytes = (size_t)M * ldc * (f32out ? 4 : 2);
-    uint16_t *A, *W;
+    const int nrot = getenv("GEMM_AB_ROTATE") ? std::max(1, atoi(getenv("GEMM_AB_ROTATE"))) : 1;   // weight copies visited round-robin:
+    uint16_t *A, *W;                                                                                // > 1 keeps W out of the Infinity Cache
     void *C, *Cref;
     CK(hipMalloc(&A, (size_t)M * K * 2));
-    CK(hipMalloc(&W, (size_t)N * K * 2));
+    CK(hipMalloc(&W, (size_t)N * K * 2 * nrot));
     CK(hipMalloc(&C, cbytes));
     CK(hipMalloc(&Cref, cbytes));
     fill(A, (size_t)M * K, 1.0f, 1);
-    fill(W, (size_t)N * K, 0.02f, 2);
+    for (int r = 0; r < nrot; ++r) fill(W + (size_t)r * N * K, (size_t)N * K, 0.02f, 2);   // identical copies: same result whichever is used
     std::vector<std::vector<double>> us(cfgs.size());
     std::vector<double> maxdiff(cfgs.size(), 0.0);
     std::vector<char> hc(cbytes), hr(cbytes);
@@ -141,7 +142,7 @@ int main(int argc, char** argv) {
         const auto t0 = std::chrono::steady_clock::now();
         double el = 0;
         while (el < seconds) {
-          for (int i = 0; i < 20; ++i) vt_gemm_bf16(A, K, W, K, C, ldc, nullptr, M, N, K, epi, cfgs[ci], nullptr, st);
+          for (int i = 0; i < 20; ++i) vt_gemm_bf16(A, K, W + (size_t)((n + i) % nrot) * N * K, K, C, ldc, nullptr, M, N, K, epi, cfgs[ci], nullptr, st);
           CK(hipStreamSynchronize(st));
           n += 20;
           el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -18,6 +18,7 @@ EPI_BF16, EPI_BF16_GELU, EPI_BF16_QGELU, EPI_BF16_RELU, EPI_F32_RESID, EPI_F32, 
 CFG_AUTO, CFG_SKINNY, CFG_128x128, CFG_256x128, CFG_256x256, CFG_64x128, CFG_256x256_P8, _CFG_RESERVED_7, CFG_256x256_RP, CFG_SKINNY_REG, CFG_256x256_P4 = range(11)
 CFG_256x256_W4 = 13
 CFG_320x256_W4 = 14
+CFG_160x128_W4 = 15
 DTYPE_BF16, DTYPE_F32 = 0, 1
 ACT_GELU, ACT_QUICK_GELU = 0, 1
 PAGE_TOKENS = 64

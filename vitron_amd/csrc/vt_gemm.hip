@@ -752,6 +752,9 @@ int vt_gemm_pick_cfg(int M, int N, int K) {
 //   small tiles     ceil(tiles64x128 / 512) x 0.4545        two workgroups per CU at ~0.55 of the big tiles' rate (remainders of 512 /
 //                                                            1024 rows x 4096: 0.40 / 0.39 of a big round measured; 2560 x 4096 x 4096: 827
 //                                                            TFLOP/s on small tiles vs 1005 on 160 big tiles)
+//   160x128 tiles   ceil(tiles160 / 256) x 0.42             four-wave kernel on a four-deep LDS ring (K % 256 == 0): one workgroup per CU, a
+//                                                            round of them costs 0.41 of a big round (4616 x 1024 x 4096: 41 us, 935 TFLOP/s
+//                                                            against 692 on 64x128 tiles; 1088 x 4096 x 4096: 906 vs 637)
 //   M-split         whole rounds of 256-row tiles + the plan of the remaining rows (only with a long K loop)
 // and takes the cheapest. VtGemmPlan.M1 > 0: rows [0, M1) go to cfg, the rest is planned again by the caller.
 struct VtGemmPlan {
@@ -783,6 +786,15 @@ static double vt_gemm_plan_cost(int M, int N, int K, int epi, const VtGemmNormFu
     if (c320 < best) {
       best = c320;
       *plan = VtGemmPlan{VT_GEMM_CFG_320x256_W4, 0};
+    }
+    // (a grid under half a round with a short K loop stays on small tiles: 577 x 3072 x 1024, 96 tiles, 281 vs 339 TFLOP/s)
+    const long t160 = cdiv(M, 160) * (long)cdiv(N, 128);
+    if ((K % 256) == 0 && (t160 >= 128 || K >= 4096)) {
+      const double c160 = (double)((t160 + 255) / 256) * 0.42;
+      if (c160 < best) {
+        best = c160;
+        *plan = VtGemmPlan{VT_GEMM_CFG_160x128_W4, 0};
+      }
     }
   }
   if (allow_split && K >= 2048 && M > 256) {
@@ -913,6 +925,7 @@ int vt_gemm_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, 
   if (cfg == VT_GEMM_CFG_256x256_P4) return vt_gemm_p8_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, epi | 0x1000, s, nf);
   if (cfg == VT_GEMM_CFG_256x256_W4) return vt_gemm_p8_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, epi | 0x4000, s, nf);
   if (cfg == VT_GEMM_CFG_320x256_W4) return vt_gemm_p8_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, epi | 0xc000, s, nf);
+  if (cfg == VT_GEMM_CFG_160x128_W4) return vt_gemm_p8_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, epi | 0x10000, s, nf);
   if (cfg == VT_GEMM_CFG_256x256_RP) return vt_gemm_rp_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, epi, s);
   switch (epi) {
     case VT_EPI_BF16: return launch_cfg<VT_EPI_BF16>(p, cfg, s);
@@ -952,6 +965,12 @@ int vt_gemm_skinny_norm_launch(const bf16_t* A, int lda, const bf16_t* W, int ld
 int vt_gemm_resid_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, float* C, int ldc, const float* bias, int M, int N,
                          int K, int ksplit, float* partials, size_t partial_bytes, hipStream_t s, const VtGemmNormFuse* nf) {
   int ks = ksplit;
+  if (ks == 0 && M > 64 && vt_gemm_p8_supported(M, N, K)) {
+    // a 160x128 grid that covers at least half the chip beats the two-pass split-K (1088 x 4096 x 11008: 1077 vs 724 TFLOP/s)
+    const VtGemmPlan plan = vt_gemm_plan(M, N, K, VT_EPI_F32_RESID, nf);
+    if (plan.M1 == 0 && plan.cfg == VT_GEMM_CFG_160x128_W4 && (long)cdiv(M, 160) * cdiv(N, 128) >= 128)
+      return vt_gemm_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, VT_EPI_F32_RESID, plan.cfg, s, nf);
+  }
   if (ks == 0 && partials && M > 64 && vt_gemm_p8_supported(M, N, K) && (N % 4) == 0) {
     const int tiles = cdiv(M, 256) * cdiv(N, 256);
     const int cand = std::min(std::min(256 / std::max(tiles, 1), (K >> 7) / 2), 8);

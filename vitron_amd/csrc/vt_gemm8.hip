@@ -621,23 +621,24 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmP8 p) {
 // the loads and masked for the stores, the bias is fetched once): with a load / wait / store round per fragment row the
 // read-modify-write of C cost 12 % of a one-round o_proj launch (5120 x 4096 x 4096: 1245 -> 1292 TFLOP/s, 1381 with a bf16 store).
 // The store-only epilogues keep the plain skip-past-the-edge form (the same restructuring measured 8 % SLOWER on them at K = 1024).
-template <int EPI, int MT>
-__device__ __forceinline__ void w4_epilogue(const GemmP8& p, f32x4 (&acc)[MT][8], int bm0, int bn0, int wr, int wc, int lane) {
+template <int EPI, int MT, int NI = 8>
+__device__ __forceinline__ void w4_epilogue(const GemmP8& p, f32x4 (&acc)[MT][NI], int bm0, int bn0, int wr, int wc, int lane) {
+  constexpr int WN = NI * 16;   // columns per wave
   if constexpr (EPI == VT_EPI_F32_RESID) {
     const int row0 = bm0 + wr * (MT * 16) + (lane & 15);
-    const int col0 = bn0 + wc * 128 + ((lane >> 4) << 2);
+    const int col0 = bn0 + wc * WN + ((lane >> 4) << 2);
     const bool has_bias = p.bias != nullptr;
-    f32x4 b4[8];
+    f32x4 b4[NI];
 #pragma unroll
-    for (int ni = 0; ni < 8; ++ni)
+    for (int ni = 0; ni < NI; ++ni)
       b4[ni] = has_bias ? *(const f32x4*)(p.bias + min(col0 + ni * 16, p.N - 4)) : (f32x4){0.f, 0.f, 0.f, 0.f};
     float* const Cf = (float*)p.C;
     constexpr int PF = 3;
-    f32x4 cur[PF][8];
+    f32x4 cur[PF][NI];
 #define W4E_LOAD(MI)                                                                                              \
   do {                                                                                                            \
     const float* _r = Cf + (size_t)min(row0 + (MI) * 16, p.M - 1) * p.ldc;                                        \
-    _Pragma("unroll") for (int ni = 0; ni < 8; ++ni) cur[(MI) % PF][ni] = *(const f32x4*)(_r + min(col0 + ni * 16, p.N - 4)); \
+    _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) cur[(MI) % PF][ni] = *(const f32x4*)(_r + min(col0 + ni * 16, p.N - 4)); \
   } while (0)
 #pragma unroll
     for (int mi = 0; mi < PF; ++mi) W4E_LOAD(mi);
@@ -645,7 +646,7 @@ __device__ __forceinline__ void w4_epilogue(const GemmP8& p, f32x4 (&acc)[MT][8]
     for (int mi = 0; mi < MT; ++mi) {
       const int m = row0 + mi * 16;
 #pragma unroll
-      for (int ni = 0; ni < 8; ++ni) {
+      for (int ni = 0; ni < NI; ++ni) {
         const int n = col0 + ni * 16;
         const f32x4 v = has_bias ? acc[mi][ni] + b4[ni] : acc[mi][ni];
         const f32x4 o = cur[mi % PF][ni] + v;
@@ -661,8 +662,8 @@ __device__ __forceinline__ void w4_epilogue(const GemmP8& p, f32x4 (&acc)[MT][8]
       if (m >= p.M) continue;
       if constexpr (EPI == VT_EPI_SWIGLU_BF16) {
 #pragma unroll
-        for (int nj = 0; nj < 4; ++nj) {
-          const int nbase = bn0 + wc * 128 + nj * 32;
+        for (int nj = 0; nj < NI / 2; ++nj) {
+          const int nbase = bn0 + wc * WN + nj * 32;
           if (nbase + ((lane >> 4) << 2) >= p.N) continue;
           const f32x4 g = acc[mi][2 * nj], u2 = acc[mi][2 * nj + 1];
           u32x2 o;
@@ -672,8 +673,8 @@ __device__ __forceinline__ void w4_epilogue(const GemmP8& p, f32x4 (&acc)[MT][8]
         }
       } else {
 #pragma unroll
-        for (int ni = 0; ni < 8; ++ni) {
-          const int n = bn0 + wc * 128 + ni * 16 + ((lane >> 4) << 2);
+        for (int ni = 0; ni < NI; ++ni) {
+          const int n = bn0 + wc * WN + ni * 16 + ((lane >> 4) << 2);
           if (n >= p.N) continue;
           f32x4 v = acc[mi][ni];
           if (p.bias) v += *(const f32x4*)(p.bias + n);
@@ -894,6 +895,151 @@ int launch_w4(const GemmP8& p, hipStream_t s) {
     done = true;
   }
   hipLaunchKernelGGL(kern, dim3(cdiv(p.M, BM) * cdiv(p.N, 256)), dim3(256), smem, s, p);
+  VT_LAUNCH_CHECK();
+  return VT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// gemm_w4r_kernel: the four-wave kernel on a SMALL tile, 160x128x64 (four waves of 80x64: 20 accumulator quads), for GEMMs whose
+// big-tile grid would cover a fraction of the chip and whose 64x128 small-tile grid quantises badly -- the ViT's N = 1024
+// projections: 4616 x 1024 = 232 tiles of 160x128 (one round, one per CU) against 584 tiles of 64x128 for 512 slots.
+// A K step is only 40 MFMAs (0.35 us) here, far shorter than a trip to memory, so the LDS image is a RING OF FOUR K steps
+// (4 x 36 KiB): the 9 LDS-DMA pieces a wave issues in the second k-half of K step t fill the buffer K step t has just finished
+// with the data of K step t+4 -- three K steps (~1 us) of flight -- and ONE barrier per K step serves both hazards:
+//     gap  0..8    read the 4 + 5 fragments of k-half 1 (buffer t % 4)
+//     gap 17       lgkmcnt(0), vmcnt(18): this wave's reads of buffer t % 4 are done, its pieces of K step t+1 have landed
+//     gap 18       barrier  -> buffer t % 4 is free for K step t+4 (WAR), buffer (t+1) % 4 is complete (RAW)
+//     gap 20..23   read the B fragments of (t+1, k-half 0);  24, 26, .. 32: the A fragments
+//     gap 25, 27, .. 33, 34 .. 37   the 9 pieces of K step t+4
+//   (vmcnt: the pieces younger than K step t+1's are those of t+2 and t+3.) MFMA n: fragment set n / 20, accumulator row
+//   (n % 20) / 4, column n % 4. Same fragments and accumulation order per output as every other tile kernel: identical bits.
+// ------------------------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_w4r_kernel(GemmP8 p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int MT = 5, NI = 4, BM = 160, BN = 128;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUFB = A_BYTES + B_BYTES;   // 36 KiB per K step
+  constexpr int NPA = 5, NPB = 4, NP = NPA + NPB;
+  constexpr int H = MT * NI;                         // MFMAs per k-half
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+
+  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+  const int nwg = tiles_m * tiles_n;
+  const int sid = xcd_remap((int)blockIdx.x, nwg);
+  constexpr int GROUP_M = 8;
+  const int per_group = GROUP_M * tiles_n;
+  const int first_m = (sid / per_group) * GROUP_M;
+  const int gsz = min(tiles_m - first_m, GROUP_M);
+  const int tm = first_m + (sid % per_group) % gsz;
+  const int tn = (sid % per_group) / gsz;
+  const int bm0 = tm * BM, bn0 = tn * BN;
+
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (size_t)bm0 * p.lda), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (size_t)bn0 * p.ldw), 0, 0x7fffffff, 0x00020000);
+  const int lrow = lane >> 3, lchk = lane & 7;
+  int voff[9];   // pieces 0..3: B rows (4 wave + j) * 8 .., pieces 4..8: A rows (5 wave + j) * 8 ..
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int row = (i < NPB ? wave * NPB + i : wave * NPA + (i - NPB)) * 8 + lrow;
+    const int coff = (lchk ^ ((row >> 1) & 7)) * 16;
+    voff[i] = i < NPB ? (min(bn0 + row, p.N - 1) - bn0) * p.ldw * 2 + coff : (min(bm0 + row, p.M - 1) - bm0) * p.lda * 2 + coff;
+  }
+#define W4R_DMA(BUF, P, KB)                                                                                      \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                                      \
+      (P) < NPB ? rsrc_b : rsrc_a,                                                                               \
+      (__attribute__((address_space(3))) void*)(smem + (BUF) * BUFB +                                            \
+                                                 ((P) < NPB ? A_BYTES + (wave * NPB + (P)) * 1024 : (wave * NPA + (P) - NPB) * 1024)), \
+      16, voff[P], KB, 0, 0)
+
+  const int f = (lane >> 1) & 7;
+  const int fo[2] = {(lane & 15) * 128 + (((lane >> 4) ^ f) << 4), (lane & 15) * 128 + ((((lane >> 4) | 4) ^ f) << 4)};
+  const int a_base = wr * (MT * 16 * 128);
+  const int b_base = A_BYTES + wc * (NI * 16 * 128);
+
+  f32x4 acc[MT][NI];
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  bf16x8 fa[2][MT], fb[2][NI];
+#define W4R_MFMA(N)                                                                                              \
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"                                                         \
+               : "+a"(acc[((N) % H) / NI][(N) % NI]) : "v"(fb[((N) / H) & 1][(N) % NI]), "v"(fa[((N) / H) & 1][((N) % H) / NI]))
+#define W4R_RDB(SET, BUF, KK, I) fb[SET][I] = *(const bf16x8*)(smem + (BUF) * BUFB + b_base + fo[KK] + (I) * 2048)
+#define W4R_RDA(SET, BUF, KK, I) fa[SET][I] = *(const bf16x8*)(smem + (BUF) * BUFB + a_base + fo[KK] + (I) * 2048)
+
+  const int nt = p.K >> 6;                         // K % 256 == 0, checked by the launcher
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const int kb = min(b, nt - 1) * 128;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) W4R_DMA(b, i, kb);
+  }
+  __builtin_amdgcn_s_waitcnt(w4_vmcnt_imm(3 * NP));   // K step 0 has landed
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < NI; ++i) W4R_RDB(0, 0, 0, i);
+#pragma unroll
+  for (int i = 0; i < MT; ++i) W4R_RDA(0, 0, 0, i);
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_nop 4");                         // accumulator zeroes (v_accvgpr_write) -> first MFMA reading them as C
+
+#define W4R_IX(x, m) ((((x) % (m)) + (m)) % (m))   /* keeps the indices of the untaken branches inside their arrays */
+#define W4R_GAP(n, B, KB)                                                                                        \
+  do {                                                                                                           \
+    if ((n) < 4) W4R_RDB(1, B, 1, W4R_IX(n, 4));                                                                 \
+    else if ((n) < 9) W4R_RDA(1, B, 1, W4R_IX((n) - 4, 5));                                                      \
+    else if ((n) == 17) { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_s_waitcnt(w4_vmcnt_imm(2 * NP)); } \
+    else if ((n) == 18) __builtin_amdgcn_s_barrier();                                                            \
+    else if ((n) >= 20 && (n) < 24) W4R_RDB(0, ((B) + 1) & 3, 0, W4R_IX((n) - 20, 4));                           \
+    else if ((n) >= 24 && (n) <= 33) {                                                                           \
+      if (!((n) & 1)) W4R_RDA(0, ((B) + 1) & 3, 0, W4R_IX(((n) - 24) >> 1, 5));                                  \
+      else W4R_DMA(B, W4R_IX(((n) - 25) >> 1, 9), KB);                                                           \
+    }                                                                                                            \
+    else if ((n) >= 34 && (n) <= 37) W4R_DMA(B, 5 + W4R_IX((n) - 34, 4), KB);                                    \
+  } while (0)
+#define W4R_N(n, B, KB) W4R_MFMA(n); W4R_GAP(n, B, KB); __builtin_amdgcn_sched_barrier(0);
+#define W4R_8(n, B, KB) W4R_N((n), B, KB) W4R_N((n) + 1, B, KB) W4R_N((n) + 2, B, KB) W4R_N((n) + 3, B, KB) \
+                        W4R_N((n) + 4, B, KB) W4R_N((n) + 5, B, KB) W4R_N((n) + 6, B, KB) W4R_N((n) + 7, B, KB)
+#define W4R_KSTEP(B, T)                                                                                          \
+  do {                                                                                                           \
+    const int _kb = min((T) + 4, nt - 1) * 128;    /* past the end of K: re-fetch the last K step, harmless */    \
+    W4R_8(0, B, _kb) W4R_8(8, B, _kb) W4R_8(16, B, _kb) W4R_8(24, B, _kb) W4R_8(32, B, _kb)                       \
+  } while (0)
+  for (int t = 0; t < nt; t += 4) {
+    W4R_KSTEP(0, t);
+    W4R_KSTEP(1, t + 1);
+    W4R_KSTEP(2, t + 2);
+    W4R_KSTEP(3, t + 3);
+  }
+  VT_VMCNT(0);                                     // the tail's redundant pieces
+  asm volatile("s_nop 15\n\ts_nop 7");            // last MFMA result -> the epilogue's v_accvgpr_read
+#undef W4R_KSTEP
+#undef W4R_8
+#undef W4R_N
+#undef W4R_GAP
+#undef W4R_IX
+#undef W4R_RDA
+#undef W4R_RDB
+#undef W4R_MFMA
+#undef W4R_DMA
+  w4_epilogue<EPI, MT, NI>(p, acc, bm0, bn0, wr, wc, lane);
+}
+
+template <int EPI>
+int launch_w4r(const GemmP8& p, hipStream_t s) {
+  constexpr int smem = 4 * (160 + 128) * 128;      // 144 KiB
+  auto kern = gemm_w4r_kernel<EPI>;
+  static bool done = false;
+  if (!done) {
+    VT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(cdiv(p.M, 160) * cdiv(p.N, 128)), dim3(256), smem, s, p);
   VT_LAUNCH_CHECK();
   return VT_OK;
 }
@@ -1258,7 +1404,7 @@ int vt_gemm_p8_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* 
     VT_REQUIRE((epi & 0xff) == VT_EPI_F32_RESID && p.nf.out_w && p.nf.out_xw && p.nf.out_np >= N / 32 && p.nf.out_ldp >= M,
                "vt_gemm(p8): norm-fold producer needs the residual epilogue and its buffers");
 #ifdef VT_ABLATIONS
-  if (epi >= 0x100 && !(epi & 0xd000)) {  // timing ablations (tools/gemm_ablate.py); test library only
+  if (epi >= 0x100 && !(epi & 0x1d000)) {  // timing ablations (tools/gemm_ablate.py); test library only
     switch (epi >> 8) {
       case 1: return launch_p8<VT_EPI_BF16, 1>(p, s);
       case 2: return launch_p8<VT_EPI_BF16, 2>(p, s);
@@ -1281,6 +1427,19 @@ int vt_gemm_p8_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* 
     }
   }
 #endif
+  if (epi & 0x10000) {   // 4-wave kernel, 160x128 tile, four-deep ring
+    VT_REQUIRE(!nf && (K % 256) == 0, "vt_gemm(w4r): needs K %% 256 == 0 and no norm fold (K=%d)", K);
+    switch (epi & 0xff) {
+      case VT_EPI_BF16: return launch_w4r<VT_EPI_BF16>(p, s);
+      case VT_EPI_BF16_GELU: return launch_w4r<VT_EPI_BF16_GELU>(p, s);
+      case VT_EPI_BF16_QGELU: return launch_w4r<VT_EPI_BF16_QGELU>(p, s);
+      case VT_EPI_BF16_RELU: return launch_w4r<VT_EPI_BF16_RELU>(p, s);
+      case VT_EPI_F32_RESID: return launch_w4r<VT_EPI_F32_RESID>(p, s);
+      case VT_EPI_F32: return launch_w4r<VT_EPI_F32>(p, s);
+      case VT_EPI_SWIGLU_BF16: return launch_w4r<VT_EPI_SWIGLU_BF16>(p, s);
+      default: vt_set_error("vt_gemm(w4r): unknown epilogue %d", epi & 0xff); return VT_ERR_ARG;
+    }
+  }
   if ((epi & 0x4000) && (epi & 0x8000)) {   // 4-wave kernel, 320-row tile (160x128 per wave)
     VT_REQUIRE(!nf, "vt_gemm(w4): no norm fold in the 4-wave kernel");
     switch (epi & 0xff) {
