@@ -60,7 +60,7 @@ def pmc_traffic_per_launch():
         d = json.load(f)
     tot, n = 0.0, 0
     for k, v in d.items():
-        if k.startswith(("gemm_bt_kernel", "gemm_p8_kernel", "gemm_w4_kernel", "gemm_rp_kernel")) \
+        if k.startswith(("gemm_bt_kernel", "gemm_p8_kernel", "gemm_w4_kernel", "gemm_w4r_kernel", "gemm_rp_kernel")) \
                 and isinstance(v, dict) and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
             l = v["FETCH_SIZE"]["launches"]
             tot += l * (2.0 * v["FETCH_SIZE"]["mean_per_launch"] + v["WRITE_SIZE"]["mean_per_launch"]) * 1024.0
@@ -442,7 +442,7 @@ def main():
                 "kernel_ms_per_step": {k: v["ms"] / prof_steps for k, v in prof.items() if v["launches"]},
                 "kernel_ms_note": f"HIP-event time per kernel class from a separate pass of {prof_steps} steps after the timed region",
             },
-            "roofline": {"bound": "mfma", "kernel": "bf16 MFMA tile GEMM class: gemm_w4_kernel<*> (256x256 tile, four 128x128 waves, ~80 % of the class time) + gemm_p8_kernel<*,0,true> (256x256 4-phase ping-pong: activation epilogues, split-K) + gemm_bt_kernel<*> (small tiles) + splitk_reduce_resid_kernel, all epilogues",
+            "roofline": {"bound": "mfma", "kernel": "bf16 MFMA tile GEMM class: gemm_w4_kernel<*> (256x256 / 320x256 tile, four waves of 128x128 / 160x128, ~96 % of the class time) + gemm_w4r_kernel<*> (160x128 tile on a four-deep LDS ring: N = 1024 projections) + gemm_p8_kernel<*,0,true> (4-phase ping-pong: activation epilogues on 256-row tiles, split-K) + gemm_bt_kernel<*> (small tiles) + splitk_reduce_resid_kernel, all epilogues",
                          "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
                          "traffic_note": ("mean bytes per launch, FETCH_SIZE x2 + WRITE_SIZE (KiB) from the committed rocprofv3 --pmc passes "
