@@ -516,14 +516,11 @@ int vt_llama_forward(const vt_llama_model* m, const vt_kv_cache* kv, const uint1
       VT_TRY(vt_attn_decode_fused_launch(w.qkv, 3 * H, 0, H, 2 * H, kt, vt, tile_table, (const VtAttnSeq*)seq_desc, nseq, w.att, H,
                                          heads, HD, scale, m->rope_cos, m->rope_sin, positions, s));
     } else {
-      // q is rotated by the attention kernel on load, never rewritten in HBM (the fused QKV epilogue has rotated it already)
-      const bool q_on_load = !fuse_qkv && HD == 128;
       if (!fuse_qkv)
         VT_TRY(vt_kv_tiles_launch(w.qkv, 3 * H, 0, H, 2 * H, kt, vt, tile_table, (const VtAttnSeq*)seq_desc, nseq,
-                                  max_new_tiles, heads, HD, m->rope_cos, m->rope_sin, positions, s, !q_on_load));
+                                  max_new_tiles, heads, HD, m->rope_cos, m->rope_sin, positions, s));
       VT_TRY(vt_flash_attn_launch(w.qkv, 3 * H, kt, vt, tile_table, (const VtAttnSeq*)seq_desc, nseq, max_q_len, w.att, H,
-                                  heads, HD, 1, scale, s, q_on_load ? m->rope_cos : nullptr, q_on_load ? m->rope_sin : nullptr,
-                                  q_on_load ? positions : nullptr));
+                                  heads, HD, 1, scale, s));
     }
     if (fold_tile) {
       VtGemmNormFuse prod;

@@ -46,19 +46,13 @@ __device__ __forceinline__ int v_swz(int d) { return (d >> 1) & 7; }
 //   <8 waves, 3 stages>  256-row blocks, 96 KiB LDS, one block per CU, two tiles of DMA lead -- long causal prefill
 // ABL (timing ablations, results are garbage): bit0 = no exp / max / sum (softmax VALU), bit1 = no MFMA;
 // experiment knobs (results correct): bit2 = s_setprio 3 around the softmax section, bit3 = s_setprio 3 around the MFMA sections
-// QROPE: the query rows arrive UNROTATED and get their rotary embedding here, on load (a lane holds dims d and d + HD/2 of its row
-// in qf[ks] and qf[ks + KS/2]: the rotation is lane-local; same tables, pairing and fma helpers as kv_tiles_kernel, so the
-// rotated bf16 values are bit-identical to the ones that kernel used to write back): vt_llama_forward's prefill saves the
-// read-modify-write of q in HBM (84 of kv_tiles' 252 MB per layer at S = 5120).
-template <int HD, bool CAUSAL, int NWAVES, int NSTAGES, int ABL = 0, bool QROPE = false>
+template <int HD, bool CAUSAL, int NWAVES, int NSTAGES, int ABL = 0>
 __global__ __launch_bounds__(64 * NWAVES, (NWAVES == 8) ? 2 : 2) void flash_attn_kernel(const bf16_t* __restrict__ Q, int ldq,
                                                          const bf16_t* __restrict__ Kt,
                                                          const bf16_t* __restrict__ Vt,
                                                          const int* __restrict__ tile_table,
                                                          const VtAttnSeq* __restrict__ seqs, bf16_t* __restrict__ O,
-                                                         int ldo, int heads, float scale_log2e,
-                                                         const float* __restrict__ q_rope_cos, const float* __restrict__ q_rope_sin,
-                                                         const int* __restrict__ q_positions) {
+                                                         int ldo, int heads, float scale_log2e) {
   constexpr int KS = HD / 16;          // k-steps of the QK^T MFMA
   constexpr int DB = HD / 32;          // 32-wide d blocks of the output
   constexpr int KROW = HD * 2;         // bytes per K row
@@ -98,28 +92,6 @@ __global__ __launch_bounds__(64 * NWAVES, (NWAVES == 8) ? 2 : 2) void flash_attn
     const bf16_t* qp = Q + (size_t)(sq.q_row0 + qrow_c) * ldq + head * HD + hh * 8;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
-  }
-  if constexpr (QROPE) {
-    const int rp = q_positions[sq.q_row0 + qrow_c];
-#pragma unroll
-    for (int ks = 0; ks < KS / 2; ++ks) {
-      const float* cs = q_rope_cos + (size_t)rp * (HD / 2) + ks * 16 + hh * 8;
-      const float* sn = q_rope_sin + (size_t)rp * (HD / 2) + ks * 16 + hh * 8;
-      const f32x4 c_lo = *(const f32x4*)cs, c_hi = *(const f32x4*)(cs + 4), s_lo = *(const f32x4*)sn, s_hi = *(const f32x4*)(sn + 4);
-      const u32x4 lo = __builtin_bit_cast(u32x4, qf[ks]), hi = __builtin_bit_cast(u32x4, qf[ks + KS / 2]);
-      u32x4 lo_o, hi_o;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        const float c0 = w < 2 ? c_lo[2 * w] : c_hi[2 * w - 4], c1 = w < 2 ? c_lo[2 * w + 1] : c_hi[2 * w - 3];
-        const float s0 = w < 2 ? s_lo[2 * w] : s_hi[2 * w - 4], s1 = w < 2 ? s_lo[2 * w + 1] : s_hi[2 * w - 3];
-        const float a0 = bf16lo_to_f32(lo[w]), a1 = bf16hi_to_f32(lo[w]);
-        const float b0 = bf16lo_to_f32(hi[w]), b1 = bf16hi_to_f32(hi[w]);
-        lo_o[w] = pack_bf16x2(rope_lo(a0, b0, c0, s0), rope_lo(a1, b1, c1, s1));
-        hi_o[w] = pack_bf16x2(rope_hi(a0, b0, c0, s0), rope_hi(a1, b1, c1, s1));
-      }
-      qf[ks] = __builtin_bit_cast(bf16x8, lo_o);
-      qf[ks + KS / 2] = __builtin_bit_cast(bf16x8, hi_o);
-    }
   }
 
   // ---- DMA source offsets (elements inside a tile), swizzle applied on the source side -------------
@@ -346,7 +318,7 @@ __global__ __launch_bounds__(256) void kv_tiles_kernel(bf16_t* __restrict__ qkv,
                                                        const VtAttnSeq* __restrict__ seqs, int heads,
                                                        const float* __restrict__ rope_cos,
                                                        const float* __restrict__ rope_sin,
-                                                       const int* __restrict__ positions, int rotate_q) {
+                                                       const int* __restrict__ positions) {
   constexpr int CH = HD / 8;  // 16-B chunks per row
   __shared__ __attribute__((aligned(16))) bf16_t vs[64][HD + 8];  // V rows of this tile (padded)
   const VtAttnSeq sq = seqs[blockIdx.z];
@@ -374,11 +346,8 @@ __global__ __launch_bounds__(256) void kv_tiles_kernel(bf16_t* __restrict__ qkv,
         const float* cs = rope_cos + (size_t)rp * (HD / 2) + c * 8;
         const float* sn = rope_sin + (size_t)rp * (HD / 2) + c * 8;
         bf16_t* qp = qkv + (size_t)row * ldqkv + q_col0 + head * HD;
-        u32x4 qlo = {0u, 0u, 0u, 0u}, qhi = {0u, 0u, 0u, 0u};
-        if (rotate_q) {   // (block-uniform; off when the attention kernel rotates q on load)
-          qlo = *(const u32x4*)(qp + c * 8);
-          qhi = *(const u32x4*)(qp + HD / 2 + c * 8);
-        }
+        u32x4 qlo = *(const u32x4*)(qp + c * 8);
+        u32x4 qhi = *(const u32x4*)(qp + HD / 2 + c * 8);
         u32x4 klo_o, khi_o, qlo_o, qhi_o;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
@@ -398,10 +367,8 @@ __global__ __launch_bounds__(256) void kv_tiles_kernel(bf16_t* __restrict__ qkv,
         }
         lo = klo_o;
         hi = khi_o;
-        if (rotate_q) {
-          *(u32x4*)(qp + c * 8) = qlo_o;
-          *(u32x4*)(qp + HD / 2 + c * 8) = qhi_o;
-        }
+        *(u32x4*)(qp + c * 8) = qlo_o;
+        *(u32x4*)(qp + HD / 2 + c * 8) = qhi_o;
       }
       *(u32x4*)(kt + r * HD + c * 8) = lo;
       *(u32x4*)(kt + r * HD + HD / 2 + c * 8) = hi;
@@ -997,11 +964,8 @@ __global__ __launch_bounds__(256) void attn_temporal8_kernel(const bf16_t* __res
 
 int vt_flash_attn_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf16_t* Vt, const int* tile_table,
                          const VtAttnSeq* seqs, int nseq, int max_q_len, bf16_t* O, int ldo, int heads, int HD,
-                         int causal, float scale, hipStream_t s, const float* q_rope_cos, const float* q_rope_sin,
-                         const int* q_positions) {
+                         int causal, float scale, hipStream_t s) {
   VT_REQUIRE(Q && Kt && Vt && tile_table && seqs && O, "vt_flash_attn: null pointer");
-  const bool qrope = q_rope_cos != nullptr;
-  if (qrope) VT_REQUIRE(q_rope_sin && q_positions && HD == 128 && causal, "vt_flash_attn: query rotation needs the sin table, positions, head_dim 128 and a causal pass");
   VT_REQUIRE(HD == 64 || HD == 128, "vt_flash_attn: head_dim %d unsupported (64 or 128)", HD);
   VT_REQUIRE(nseq > 0 && max_q_len > 0 && heads > 0, "vt_flash_attn: empty problem");
   VT_REQUIRE(ldq % 8 == 0 && ldo % 4 == 0, "vt_flash_attn: ldq %% 8 and ldo %% 4 must be 0");
@@ -1027,7 +991,7 @@ int vt_flash_attn_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf16_
       done = true;                                                                                             \
     }                                                                                                          \
     dim3 grid(heads, cdiv(max_q_len, 32 * NW), nseq), block(64 * NW);                                          \
-    hipLaunchKernelGGL(kern, grid, block, smem, s, Q, ldq, Kt, Vt, tile_table, seqs, O, ldo, heads, sl2, q_rope_cos, q_rope_sin, q_positions); \
+    hipLaunchKernelGGL(kern, grid, block, smem, s, Q, ldq, Kt, Vt, tile_table, seqs, O, ldo, heads, sl2);      \
   } while (0)
   if (HD == 64) {
     if (causal) VT_FA(64, true, 4, 2); else VT_FA(64, false, 4, 2);
@@ -1045,8 +1009,7 @@ int vt_flash_attn_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf16_
     else if (causal && abl == 8) VT_FA(128, true, 4, 2, 8);
     else
 #endif
-    if (qrope) VT_FA(128, true, 4, 2, 0, true);
-    else if (causal) VT_FA(128, true, 4, 2); else VT_FA(128, false, 4, 2);
+    if (causal) VT_FA(128, true, 4, 2); else VT_FA(128, false, 4, 2);
   }
 #undef VT_FA
   VT_LAUNCH_CHECK();
@@ -1055,20 +1018,19 @@ int vt_flash_attn_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf16_
 
 int vt_kv_tiles_launch(bf16_t* qkv, int ldqkv, int q_col0, int k_col0, int v_col0, bf16_t* Kt, bf16_t* Vt,
                        const int* tile_table, const VtAttnSeq* seqs, int nseq, int max_new_tiles, int heads, int HD,
-                       const float* rope_cos, const float* rope_sin, const int* positions, hipStream_t s, bool rotate_q) {
+                       const float* rope_cos, const float* rope_sin, const int* positions, hipStream_t s) {
   VT_REQUIRE(qkv && Kt && Vt && tile_table && seqs, "vt_kv_tiles: null pointer");
-  const int rq = rotate_q ? 1 : 0;
   VT_REQUIRE(HD == 64 || HD == 128, "vt_kv_tiles: head_dim %d unsupported", HD);
   VT_REQUIRE(ldqkv % 8 == 0 && q_col0 % 8 == 0 && k_col0 % 8 == 0 && v_col0 % 8 == 0, "vt_kv_tiles: misaligned columns");
   dim3 grid(max_new_tiles, heads, nseq), block(256);
   const bool rope = rope_cos != nullptr;
   if (rope) VT_REQUIRE(rope_sin && positions, "vt_kv_tiles: rope needs sin table and positions");
   if (HD == 64) {
-    if (rope) hipLaunchKernelGGL((kv_tiles_kernel<64, true>), grid, block, 0, s, qkv, ldqkv, q_col0, k_col0, v_col0, Kt, Vt, tile_table, seqs, heads, rope_cos, rope_sin, positions, rq);
-    else hipLaunchKernelGGL((kv_tiles_kernel<64, false>), grid, block, 0, s, qkv, ldqkv, q_col0, k_col0, v_col0, Kt, Vt, tile_table, seqs, heads, rope_cos, rope_sin, positions, rq);
+    if (rope) hipLaunchKernelGGL((kv_tiles_kernel<64, true>), grid, block, 0, s, qkv, ldqkv, q_col0, k_col0, v_col0, Kt, Vt, tile_table, seqs, heads, rope_cos, rope_sin, positions);
+    else hipLaunchKernelGGL((kv_tiles_kernel<64, false>), grid, block, 0, s, qkv, ldqkv, q_col0, k_col0, v_col0, Kt, Vt, tile_table, seqs, heads, rope_cos, rope_sin, positions);
   } else {
-    if (rope) hipLaunchKernelGGL((kv_tiles_kernel<128, true>), grid, block, 0, s, qkv, ldqkv, q_col0, k_col0, v_col0, Kt, Vt, tile_table, seqs, heads, rope_cos, rope_sin, positions, rq);
-    else hipLaunchKernelGGL((kv_tiles_kernel<128, false>), grid, block, 0, s, qkv, ldqkv, q_col0, k_col0, v_col0, Kt, Vt, tile_table, seqs, heads, rope_cos, rope_sin, positions, rq);
+    if (rope) hipLaunchKernelGGL((kv_tiles_kernel<128, true>), grid, block, 0, s, qkv, ldqkv, q_col0, k_col0, v_col0, Kt, Vt, tile_table, seqs, heads, rope_cos, rope_sin, positions);
+    else hipLaunchKernelGGL((kv_tiles_kernel<128, false>), grid, block, 0, s, qkv, ldqkv, q_col0, k_col0, v_col0, Kt, Vt, tile_table, seqs, heads, rope_cos, rope_sin, positions);
   }
   VT_LAUNCH_CHECK();
   return VT_OK;

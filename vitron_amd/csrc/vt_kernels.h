@@ -111,13 +111,10 @@ int vt_vit_attn_meta_launch(int* seq_desc, int* tile_table, int F, int N, hipStr
 // ---- vt_attn.hip ----------------------------------------------------------------------------------
 int vt_flash_attn_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf16_t* Vt, const int* tile_table,
                          const VtAttnSeq* seqs, int nseq, int max_q_len, bf16_t* O, int ldo, int heads, int HD,
-                         int causal, float scale, hipStream_t s,
-                         // optional (HD = 128): rotate the query rows on load (tables and positions as vt_kv_tiles takes them) --
-                         // the prefill pass of vt_llama_forward then never rewrites q in HBM (rotate_q = false below)
-                         const float* q_rope_cos = nullptr, const float* q_rope_sin = nullptr, const int* q_positions = nullptr);
+                         int causal, float scale, hipStream_t s);
 int vt_kv_tiles_launch(bf16_t* qkv, int ldqkv, int q_col0, int k_col0, int v_col0, bf16_t* Kt, bf16_t* Vt,
                        const int* tile_table, const VtAttnSeq* seqs, int nseq, int max_new_tiles, int heads, int HD,
-                       const float* rope_cos, const float* rope_sin, const int* positions, hipStream_t s, bool rotate_q = true);
+                       const float* rope_cos, const float* rope_sin, const int* positions, hipStream_t s);
 size_t vt_attn_decode_scratch_bytes(int nseq, int heads, int HD, int max_kv_len);
 int vt_attn_decode_fused_launch(const bf16_t* qkv, int ldqkv, int q_col0, int k_col0, int v_col0, bf16_t* Kt, bf16_t* Vt,
                                 const int* tile_table, const VtAttnSeq* seqs, int nseq, bf16_t* O, int ldo, int heads, int HD,
