@@ -1,0 +1,3 @@
+#!/bin/bash
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -4
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
