@@ -96,7 +96,10 @@ int vt_rmsnorm(const float* x, const int* idx, const float* w, uint16_t* y, int 
 
 /* Attention over 64-key tiles. seq_desc: device int32 [nseq][4] = {q_row0, q_len, kv_len, table_off};
  * tile_table: device int32, tile_table[table_off + t] = index of the sequence's t-th K / V^T tile.
- * K tile = [64 keys][HD], V^T tile = [HD][64 keys]; tile i of head h starts at (i*heads + h)*64*HD elements.
+ * K tile = [64 keys][HD] bf16, V^T tile = [HD][64 keys] holding IEEE fp16 bits (the bf16 values of the projection converted
+ * exactly, saturating at +-65504: the P.V product of the prefill kernel runs on the f16 MFMA with P at 11 mantissa bits; only
+ * vt_kv_tiles / vt_attn_decode_fused / the fused QKV epilogue write these tiles); tile i of head h starts at (i*heads + h)*64*HD
+ * elements.
  * q_len > 1 anywhere -> MFMA flash kernel (causal: query i sees keys <= kv_len - q_len + i); all q_len == 1 is
  * routed to the single-query kernel by vt_llama_forward. Replaces CLIPAttention (non-causal, modeling_video.py:136-146)
  * and LlamaAttention's softmax(QK^T/sqrt(d) + mask)V (reference restatement: llama_flash_attn_monkey_patch.py:30-66). */

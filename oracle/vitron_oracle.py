@@ -22,7 +22,8 @@ and tests/test_oracle_golden.py checks this file against them (fp32, rel-L2 <= 1
 Two numeric modes:
   emulate_bf16=False  pure fp32 on the given (bf16-representable) inputs and weights.
   emulate_bf16=True   same maths, but values are rounded to bf16 at exactly the points where the HIP path
-                      stores bf16 (GEMM operands: norm outputs, fused-QKV, attention outputs, activations);
+                      stores bf16 (GEMM operands: norm outputs, fused-QKV, attention outputs, activations) and the
+                      softmax weights to fp16 where the prefill attention kernel feeds them to its P.V MFMA;
                       accumulation, softmax, norms and the residual stream stay fp32 like the kernels.
 State dicts use the reference's parameter names.
 """
@@ -43,6 +44,11 @@ SD = Dict[str, torch.Tensor]
 
 def bf16_round(x: torch.Tensor) -> torch.Tensor:
     return x.to(torch.bfloat16).to(torch.float32)
+
+
+def fp16_round(x: torch.Tensor) -> torch.Tensor:
+    """Softmax weights as the flash kernel feeds them to its P.V MFMA: fp16 (11 mantissa bits), values in (0, 1]."""
+    return x.to(torch.float16).to(torch.float32)
 
 
 def _r(x: torch.Tensor, emulate: bool) -> torch.Tensor:
@@ -72,9 +78,9 @@ def clip_attention(x, sd: SD, prefix: str, heads: int, emulate: bool, round_p: b
     k = k.view(B, N, heads, hd).transpose(1, 2)
     v = v.view(B, N, heads, hd).transpose(1, 2)
     s = q @ k.transpose(-1, -2)
-    if emulate and round_p:  # flash kernel: P (relative to the row max) is rounded to bf16 for the PV MFMA, row sum fp32
+    if emulate and round_p:  # flash kernel: P (relative to the row max) is rounded to fp16 for the PV MFMA, row sum fp32
         p = torch.exp(s - s.amax(-1, keepdim=True))
-        o = (bf16_round(p) @ v) / p.sum(-1, keepdim=True)
+        o = (fp16_round(p) @ v) / p.sum(-1, keepdim=True)
     else:
         o = torch.softmax(s, dim=-1) @ v
     o = o.transpose(1, 2).reshape(B, N, D)
@@ -366,7 +372,7 @@ def llama_forward(sd: SD, cfg: dict, inputs_embeds: torch.Tensor, position_ids: 
         s = q @ k.transpose(-1, -2) / math.sqrt(hd) + mask
         if emulate_bf16:
             pr = torch.exp(s - s.amax(-1, keepdim=True))
-            o = (bf16_round(pr) @ v) / pr.sum(-1, keepdim=True)
+            o = (fp16_round(pr) @ v) / pr.sum(-1, keepdim=True)   # P in fp16 for the PV MFMA; V (bf16 values) is exact in fp16
         else:
             o = torch.softmax(s, dim=-1, dtype=torch.float32) @ v
         o = _r(o.transpose(1, 2).reshape(B, S, H), emulate_bf16)

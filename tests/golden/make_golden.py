@@ -336,6 +336,90 @@ def gen_fullwidth(ns):
     print("fullwidth.npz", {k: getattr(v, "shape", v) for k, v in out.items()}, f"{time.time() - t0:.1f}s")
 
 
+GREEDY_TINY = ("image_region", "video", "text_only", "video_image_trunc")   # the batch-1 glue cases (what app.py / inference_image.py run)
+GREEDY_STEPS_TINY, GREEDY_STEPS_7B = 12, 8
+
+
+def _greedy_over_reference_forward(model, embeds, embed_table, steps):
+    """Hand-written greedy loop over the REFERENCE's own forward (its generate() cannot run under transformers 5.x,
+    llava_arch.py:198 subscripts the cache object). Cache-free: every step re-runs LlavaLlamaForCausalLM.forward
+    (llava_llama.py:57-102) on the grown embedding sequence [prompt rows ; embed_tokens(generated ids)] -- for one unpadded
+    sequence that is what the cached loop computes with the decode-step fix-up of llava_arch.py:196-205 (mask of ones, position =
+    length - 1), in fp32. Returns per step: arg-max id, the whole last-position logits row."""
+    import contextlib
+    import io
+    cur = embeds
+    ids, rows = [], []
+    for _ in range(steps):
+        with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+            lg = model(inputs_embeds=cur, use_cache=False).logits[0, -1].float()
+        nxt = int(lg.argmax())
+        ids.append(nxt)
+        rows.append(lg)
+        cur = torch.cat([cur, embed_table[nxt].view(1, 1, -1).to(cur.dtype)], dim=1)
+    return ids, torch.stack(rows)
+
+
+def gen_greedy(ns):
+    """Greedy token ids pinned on the REFERENCE: ids, top-2 margin and logits scale of every step, so that a GPU
+    test can demand the exact id wherever the reference's margin exceeds the bf16 noise bound -- and must report where it does not.
+      * the batch-1 glue cases at tiny widths through the reference's prepare_inputs_labels_for_multimodal + forward (whole logits
+        rows stored: vocabulary 512);
+      * one Vicuna-7B-width case (H = 4096 / I = 11008 / 32 heads, 2 layers, 1088 prompt rows = fullwidth.npz's s1088_l2 weights and
+        rows): ids, top-5 ids / values, row rms and the projections on the fixed directions of every step."""
+    import contextlib
+    import io
+    import time
+    from vitron_amd.synth import VICUNA_7B
+    out = {}
+    t0 = time.time()
+    model = build_ref_llava(ns)
+    table = model.get_model().embed_tokens.weight.detach()
+    for name in GREEDY_TINY:
+        case = cases.glue_cases()[name]
+        model.config.tokenizer_model_max_length = case.get("max_length")
+        model.config.tokenizer_padding_side = case.get("padding_side", "right")
+        with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+            (_, _, _, _, embeds, _) = model.prepare_inputs_labels_for_multimodal(
+                case["input_ids"], None, case["attention_mask"], None, None, case["images"], case["regions"])
+        ids, rows = _greedy_over_reference_forward(model, embeds, table, GREEDY_STEPS_TINY)
+        top2 = rows.topk(2, dim=-1).values
+        out[f"{name}_ids"] = np.array(ids, dtype=np.int64)
+        out[f"{name}_margin"] = (top2[:, 0] - top2[:, 1]).numpy()
+        out[f"{name}_logits"] = rows.numpy()
+    del model
+    print(f"greedy tiny: {time.time() - t0:.1f}s", {k: v.tolist() for k, v in out.items() if k.endswith("_ids")}, flush=True)
+    # ---- 7B width ---------------------------------------------------------------------------------------------------------
+    ll = ns.llava_llama
+    name = "s1088_l2"
+    S, L = cases.FW_LLAMA[name]
+    c = dict(VICUNA_7B, num_hidden_layers=L)
+    sd = synth.llama_state(c, synth.make_generator(cases.FW_SEED + L), **cases.FW_INIT)
+    cfg = ll.LlavaConfig(hidden_size=c["hidden_size"], intermediate_size=c["intermediate_size"], num_hidden_layers=L,
+                         num_attention_heads=c["num_attention_heads"], num_key_value_heads=c["num_attention_heads"],
+                         vocab_size=c["vocab_size"], rms_norm_eps=c["rms_norm_eps"], max_position_embeddings=4096,
+                         rope_theta=c["rope_theta"], tie_word_embeddings=False)
+    cfg._attn_implementation = "eager"
+    cfg.pretraining_tp = 1
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = ll.LlavaLlamaForCausalLM(cfg).eval()
+    missing, unexpected = model.load_state_dict(f32(sd), strict=False)
+    assert not unexpected and all("rotary" in k or "inv_freq" in k for k in missing), (missing, unexpected)
+    x = cases.fw_llama_embeds(S, cases.FW_SEED + S).unsqueeze(0)
+    ids, rows = _greedy_over_reference_forward(model, x, sd["model.embed_tokens.weight"].float(), GREEDY_STEPS_7B)
+    top5 = rows.topk(5, dim=-1)
+    out[f"llama_{name}_checksum"] = np.float64(synth.checksum(sd))
+    out[f"llama_{name}_ids"] = np.array(ids, dtype=np.int64)
+    out[f"llama_{name}_margin"] = (top5.values[:, 0] - top5.values[:, 1]).numpy()
+    out[f"llama_{name}_top5_ids"] = top5.indices.numpy().astype(np.int32)
+    out[f"llama_{name}_top5_vals"] = top5.values.numpy()
+    out[f"llama_{name}_rms"] = rows.double().pow(2).mean(-1).sqrt().numpy()
+    out[f"llama_{name}_proj"] = (rows.double() @ cases.fw_directions(rows.shape[-1])).numpy()
+    np.savez_compressed(os.path.join(OUT, "greedy.npz"), **out)
+    print("greedy.npz", {k: (v.tolist() if v.size <= 16 else v.shape) for k, v in out.items() if not k.endswith("_logits")},
+          f"{time.time() - t0:.1f}s")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     ns = ref_shim.install()
@@ -344,6 +428,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--fullwidth-only" in sys.argv:
         gen_fullwidth(ns)
+        sys.exit(0)
+    if "--greedy-only" in sys.argv:
+        gen_greedy(ns)
         sys.exit(0)
     gen_mm_utils(ns)
     gen_output_parser()
@@ -354,3 +441,4 @@ if __name__ == "__main__":
     gen_glue_random(ns)
     gen_state_dict_keys(ns)
     gen_fullwidth(ns)
+    gen_greedy(ns)

@@ -64,3 +64,32 @@ def test_oracle_projector_and_region_at_full_width():
     for canvas in (224, 336):
         cells = g[f"region_c{canvas}_cells"].sum(-1).tolist()
         assert cells[0] == 576 and min(cells) == 0 and len({c for c in cells if c}) >= 4, cells
+
+
+def test_oracle_greedy_ids_at_7b_width():
+    """greedy.npz's Vicuna-7B-width case (2 layers, 1088 prompt rows): the oracle's cached greedy loop against the ids the
+    REFERENCE's forward produced; ids equal at every step, top-5 values and projections of every step's logits to fp32 accuracy."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "greedy.npz"))
+    name = "s1088_l2"
+    cfg, sd, x = FW.llama_case(name)
+    assert synth.checksum(sd) == pytest.approx(float(g[f"llama_{name}_checksum"]), rel=1e-12)
+    ref_ids = g[f"llama_{name}_ids"]
+    n = len(ref_ids)
+    S = x.shape[0]
+    sd32 = f32(sd)
+    emb = sd32["model.embed_tokens.weight"]
+    with torch.no_grad():
+        logits, past = O.llama_forward(sd32, cfg, x.unsqueeze(0))
+        rows = [logits[0, -1]]
+        for t in range(n - 1):
+            pos = torch.tensor([[S + t]])
+            logits, past = O.llama_forward(sd32, cfg, emb[int(ref_ids[t])].view(1, 1, -1), pos, None, past)
+            rows.append(logits[0, -1])
+    rows = torch.stack(rows)
+    assert float(g[f"llama_{name}_margin"].min()) > 1e-3
+    assert rows.argmax(-1).tolist() == ref_ids.tolist()
+    top5 = rows.topk(5, dim=-1)
+    assert np.array_equal(top5.indices.numpy(), g[f"llama_{name}_top5_ids"])
+    assert FW.rel(top5.values, g[f"llama_{name}_top5_vals"]) <= TOL
+    assert FW.rel(rows.double() @ cases.fw_directions(rows.shape[-1]), g[f"llama_{name}_proj"]) <= TOL

@@ -145,3 +145,34 @@ def test_glue_random_layouts_against_the_reference():
             assert np.array_equal(pos.numpy()[valid], g[f"{name}_pos"][valid]), name
         n += 1
     assert n == 24
+
+
+GREEDY_TINY = ("image_region", "video", "text_only", "video_image_trunc")
+
+
+@pytest.mark.parametrize("name", GREEDY_TINY)
+def test_greedy_ids_against_the_reference(name):
+    """tests/golden/greedy.npz (make_golden.gen_greedy): a hand-written greedy loop over the REFERENCE's own forward. The oracle's
+    greedy_generate -- KV cache + the decode-step mask / position fix-up of llava_arch.py:196-205 -- must produce the same ids
+    at every step (fp32 on both sides: margins are far above the summation-order noise) and the same logits rows."""
+    g = np.load(os.path.join(G, "greedy.npz"))
+    case = cases.glue_cases()[name]
+    w, cfgs = oracle_weights()
+    embeds, mask, pos = O.multimodal_prepare(w, cfgs, case["input_ids"], case["attention_mask"], case["images"], case["regions"],
+                                             case.get("max_length"), case.get("padding_side", "right"))
+    ref_ids, ref_rows, margin = g[f"{name}_ids"], g[f"{name}_logits"], g[f"{name}_margin"]
+    n = len(ref_ids)
+    assert float(margin.min()) > 1e-3                       # every stored step is decidable in fp32
+    ids = O.greedy_generate(w["llama"], cfgs["llama"], embeds, mask.long(), pos, n)
+    assert ids[0].tolist() == ref_ids.tolist()
+    # teacher-forced logits of every step through the cached decode path
+    emb = w["llama"]["model.embed_tokens.weight"]
+    logits, past = O.llama_forward(w["llama"], cfgs["llama"], embeds, pos, mask.long())
+    rows = [logits[0, -1]]
+    m = mask.long()
+    for t in range(n - 1):
+        m = torch.cat([m, torch.ones((1, 1), dtype=m.dtype)], 1)
+        p = m.sum(1, keepdim=True) - 1
+        logits, past = O.llama_forward(w["llama"], cfgs["llama"], emb[int(ref_ids[t])].view(1, 1, -1), p, m, past)
+        rows.append(logits[0, -1])
+    assert rel(torch.stack(rows), ref_rows) <= 1e-4

@@ -50,7 +50,7 @@ def main():
     mask = torch.triu(torch.full((S, S), float("-inf")), diagonal=1)
     s = qr @ kr.transpose(-1, -2) / math.sqrt(hd) + mask
     pr = torch.exp(s - s.amax(-1, keepdim=True))
-    o_emu = ((O.bf16_round(pr) @ v) / pr.sum(-1, keepdim=True)).transpose(0, 1).reshape(S, H)
+    o_emu = ((O.fp16_round(pr) @ v) / pr.sum(-1, keepdim=True)).transpose(0, 1).reshape(S, H)
     o32 = (torch.softmax(s, -1) @ v).transpose(0, 1).reshape(S, H)
     o = O.bf16_round(o_emu)
     x1 = x0 + o @ w[p + "self_attn.o_proj.weight"].t()

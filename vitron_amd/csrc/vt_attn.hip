@@ -40,6 +40,11 @@ __device__ __forceinline__ int k_swz(int key) {
 __device__ __forceinline__ int v_swz(int d) { return (d >> 1) & 7; }
 
 #define RESCALE_THR 8.0f
+// The softmax weights feed the P.V MFMA as fp16 (11 mantissa bits; V^T pages hold fp16, see vt_common.h). They are computed as
+// 2^(s - m_run + P_BIAS): with the deferred rescale P <= 2^(RESCALE_THR + P_BIAS) = 2^15 < 65504, and the smallest NORMAL fp16
+// (2^-14) sits 2^-21 below the running maximum's weight instead of 2^-14, so that the long tail of a peaked row is not lost to
+// fp16's narrow exponent range. The row sum l carries the same factor, which cancels in O / l.
+#define P_BIAS 7.0f
 
 // NWAVES waves x 32 query rows share one K / V^T tile ring of NSTAGES 64-key tiles (LDS-DMA, counted vmcnt):
 //   <4 waves, 2 stages>  128-row blocks, 64 KiB LDS (HD=128), two blocks per CU      -- ViT (many short sequences)
@@ -229,11 +234,11 @@ __global__ __launch_bounds__(64 * NWAVES, (NWAVES == 8) ? 2 : 2) void flash_attn
     }
     const float m_safe = (m_run == -INFINITY) ? 0.f : m_run;
     float psum = 0.f;
-    bf16x8 pf[2][2];
+    f16x8 pf[2][2];
     // packed fp32 math (v_pk_fma_f32 / v_pk_add_f32: two lanes' worth per instruction) for the scale-and-shift and the row sum:
     // the softmax VALU work, not the MFMAs, is what fills the SIMD here (PMC: VALU busy 45 %, MFMA busy 42 %, 16 % co-issue)
     typedef float f32x2 __attribute__((ext_vector_type(2)));
-    const f32x2 sc2 = {scale_log2e, scale_log2e}, ms2 = {-m_safe, -m_safe};
+    const f32x2 sc2 = {scale_log2e, scale_log2e}, ms2 = {P_BIAS - m_safe, P_BIAS - m_safe};
     f32x2 psum2 = {0.f, 0.f};
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
@@ -253,11 +258,11 @@ __global__ __launch_bounds__(64 * NWAVES, (NWAVES == 8) ? 2 : 2) void flash_attn
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         u32x4 w;
-        w.x = pack_bf16x2(sacc[sub][8 * j + 0], sacc[sub][8 * j + 1]);
-        w.y = pack_bf16x2(sacc[sub][8 * j + 2], sacc[sub][8 * j + 3]);
-        w.z = pack_bf16x2(sacc[sub][8 * j + 4], sacc[sub][8 * j + 5]);
-        w.w = pack_bf16x2(sacc[sub][8 * j + 6], sacc[sub][8 * j + 7]);
-        pf[sub][j] = __builtin_bit_cast(bf16x8, w);
+        w.x = pack_f16x2(sacc[sub][8 * j + 0], sacc[sub][8 * j + 1]);
+        w.y = pack_f16x2(sacc[sub][8 * j + 2], sacc[sub][8 * j + 3]);
+        w.z = pack_f16x2(sacc[sub][8 * j + 4], sacc[sub][8 * j + 5]);
+        w.w = pack_f16x2(sacc[sub][8 * j + 6], sacc[sub][8 * j + 7]);
+        pf[sub][j] = __builtin_bit_cast(f16x8, w);
       }
     }
     psum = psum2.x + psum2.y;
@@ -273,9 +278,9 @@ __global__ __launch_bounds__(64 * NWAVES, (NWAVES == 8) ? 2 : 2) void flash_attn
         const int chunk = (sub * 4 + 2 * hh + j) ^ v_sw;
 #pragma unroll
         for (int db = 0; db < DB; ++db) {   // DB independent accumulators back to back
-          const bf16x8 vf = *(const bf16x8*)(vb + (db * 32 + ql) * 128 + (chunk << 4));
-          if (!(ABL & 2)) oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[sub][j], oacc[db], 0, 0, 0);
-          else oacc[db][j] += __builtin_bit_cast(float, (uint32_t)vf[0] << 16);
+          const f16x8 vf = *(const f16x8*)(vb + (db * 32 + ql) * 128 + (chunk << 4));
+          if (!(ABL & 2)) oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[sub][j], oacc[db], 0, 0, 0);
+          else oacc[db][j] += (float)vf[0];
         }
       }
     if (ABL & 8) __builtin_amdgcn_s_setprio(0);
@@ -400,22 +405,22 @@ __global__ __launch_bounds__(256) void kv_tiles_kernel(bf16_t* __restrict__ qkv,
     const bool full = fresh || (pos0 >= p_lo && pos0 + 8 <= p_hi);
     const bool any_new = (pos0 < p_hi) && (pos0 + 8 > p_lo);
     if (!full && !any_new) continue;
-    bf16_t vals[8];
+    float vals[8];   // bf16 -> fp16 (exact in fp16's normal range, saturating): the V^T pages hold fp16, see vt_common.h
 #pragma unroll
-    for (int j = 0; j < 8; ++j) vals[j] = vs[kc * 8 + j][d];
-    bf16_t* dst = vt + d * 64 + kc * 8;
+    for (int j = 0; j < 8; ++j) vals[j] = vt_clamp_f16(bf16_to_f32(vs[kc * 8 + j][d]));
+    uint16_t* dst = vt + d * 64 + kc * 8;
+    u32x4 w;
+    w.x = pack_f16x2(vals[0], vals[1]);
+    w.y = pack_f16x2(vals[2], vals[3]);
+    w.z = pack_f16x2(vals[4], vals[5]);
+    w.w = pack_f16x2(vals[6], vals[7]);
     if (full) {
-      u32x4 w;
-      w.x = vals[0] | ((uint32_t)vals[1] << 16);
-      w.y = vals[2] | ((uint32_t)vals[3] << 16);
-      w.z = vals[4] | ((uint32_t)vals[5] << 16);
-      w.w = vals[6] | ((uint32_t)vals[7] << 16);
       *(u32x4*)dst = w;
     } else {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int pos = pos0 + j;
-        if (pos >= p_lo && pos < p_hi) dst[j] = vals[j];
+        if (pos >= p_lo && pos < p_hi) dst[j] = (uint16_t)((w[j >> 1] >> (16 * (j & 1))) & 0xffffu);
       }
     }
   }
@@ -541,14 +546,14 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
 #pragma unroll
     for (int i = 0; i < NACC; ++i) {
       float a = acc[i] * alpha;
-      a = fmaf(bf16lo_to_f32(vv[i][0]), pa[0], a);
-      a = fmaf(bf16hi_to_f32(vv[i][0]), pa[1], a);
-      a = fmaf(bf16lo_to_f32(vv[i][1]), pa[2], a);
-      a = fmaf(bf16hi_to_f32(vv[i][1]), pa[3], a);
-      a = fmaf(bf16lo_to_f32(vv[i][2]), pb[0], a);
-      a = fmaf(bf16hi_to_f32(vv[i][2]), pb[1], a);
-      a = fmaf(bf16lo_to_f32(vv[i][3]), pb[2], a);
-      a = fmaf(bf16hi_to_f32(vv[i][3]), pb[3], a);
+      a = fmaf(f16lo_to_f32(vv[i][0]), pa[0], a);
+      a = fmaf(f16hi_to_f32(vv[i][0]), pa[1], a);
+      a = fmaf(f16lo_to_f32(vv[i][1]), pa[2], a);
+      a = fmaf(f16hi_to_f32(vv[i][1]), pa[3], a);
+      a = fmaf(f16lo_to_f32(vv[i][2]), pb[0], a);
+      a = fmaf(f16hi_to_f32(vv[i][2]), pb[1], a);
+      a = fmaf(f16lo_to_f32(vv[i][3]), pb[2], a);
+      a = fmaf(f16hi_to_f32(vv[i][3]), pb[3], a);
       acc[i] = a;
     }
   }
@@ -752,7 +757,8 @@ __global__ __launch_bounds__(512) void attn_decode_fused_kernel(
       if (key_of_lane == r_new) s_mine = part_s;
       if (lane < CH) {
         *(u32x4*)(kt + r_new * HD + lane * 8) = kr;                                       // lane < CH: c == lane
-        *(u32x4*)(&sm_v[lane * 8]) = *(const u32x4*)(qrow + v_col0 + head * HD + lane * 8);
+        const u32x4 vn = *(const u32x4*)(qrow + v_col0 + head * HD + lane * 8);       // bf16 from the projection -> fp16 page format
+        *(u32x4*)(&sm_v[lane * 8]) = (u32x4){bf16x2_to_f16x2(vn.x), bf16x2_to_f16x2(vn.y), bf16x2_to_f16x2(vn.z), bf16x2_to_f16x2(vn.w)};
       }
       __builtin_amdgcn_wave_barrier();
       if (!fresh) {
@@ -794,19 +800,19 @@ __global__ __launch_bounds__(512) void attn_decode_fused_kernel(
 #pragma unroll
     for (int i = 0; i < NACC; ++i) {
       float a = acc[i] * alpha;
-      a = fmaf(bf16lo_to_f32(vv[i][0]), pa[0], a);
-      a = fmaf(bf16hi_to_f32(vv[i][0]), pa[1], a);
-      a = fmaf(bf16lo_to_f32(vv[i][1]), pa[2], a);
-      a = fmaf(bf16hi_to_f32(vv[i][1]), pa[3], a);
-      a = fmaf(bf16lo_to_f32(vv[i][2]), pb[0], a);
-      a = fmaf(bf16hi_to_f32(vv[i][2]), pb[1], a);
-      a = fmaf(bf16lo_to_f32(vv[i][3]), pb[2], a);
-      a = fmaf(bf16hi_to_f32(vv[i][3]), pb[3], a);
+      a = fmaf(f16lo_to_f32(vv[i][0]), pa[0], a);
+      a = fmaf(f16hi_to_f32(vv[i][0]), pa[1], a);
+      a = fmaf(f16lo_to_f32(vv[i][1]), pa[2], a);
+      a = fmaf(f16hi_to_f32(vv[i][1]), pa[3], a);
+      a = fmaf(f16lo_to_f32(vv[i][2]), pb[0], a);
+      a = fmaf(f16hi_to_f32(vv[i][2]), pb[1], a);
+      a = fmaf(f16lo_to_f32(vv[i][3]), pb[2], a);
+      a = fmaf(f16hi_to_f32(vv[i][3]), pb[3], a);
       acc[i] = a;
     }
     if (is_last && vchk == 0) {   // column r_new of the loaded tile carries no weight (see above): add the new value here
 #pragma unroll
-      for (int i = 0; i < NACC; ++i) acc[i] = fmaf(bf16_to_f32(sm_v[i * 8 + vrow]), p_new, acc[i]);
+      for (int i = 0; i < NACC; ++i) acc[i] = fmaf(f16_bits_to_f32(sm_v[i * 8 + vrow]), p_new, acc[i]);
     }
     t += NW;
     if (t < ntiles) toff = issue(t);

@@ -87,6 +87,30 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 __device__ __forceinline__ float bf16lo_to_f32(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16hi_to_f32(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
+// ---- fp16 helpers: the V^T pages and the softmax weights P of the attention kernels --------------------------------------
+// V is produced in bf16 by the QKV projection (8 mantissa bits) and STORED in the V^T pages as fp16 (11 bits): the conversion is
+// exact for 2^-14 <= |v| <= 65504 (smaller values keep an absolute error <= 2^-25, larger ones saturate at +-65504 -- stated
+// assumption: |V| <= 65504, five orders of magnitude above what a LayerNorm/RMSNorm-fed projection produces). What it buys: the
+// P.V product of the prefill attention runs on v_mfma_f32_32x32x16_f16 with P at 11 mantissa bits instead of bf16's 8.
+typedef _Float16 vt_f16v2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));   // 8 fp16 = one MFMA A/B fragment (4 VGPRs)
+// two floats -> packed fp16x2 (lo in bits 0..15): one v_cvt_pk_f16_f32, round-to-nearest-even
+__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
+  vt_f32v2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, vt_f16v2));
+}
+__device__ __forceinline__ float f16lo_to_f32(uint32_t w) { return (float)__builtin_bit_cast(vt_f16v2, w).x; }
+__device__ __forceinline__ float f16hi_to_f32(uint32_t w) { return (float)__builtin_bit_cast(vt_f16v2, w).y; }
+__device__ __forceinline__ float vt_clamp_f16(float x) { return __builtin_fminf(__builtin_fmaxf(x, -65504.f), 65504.f); }
+// packed bf16x2 -> packed fp16x2 (saturating)
+__device__ __forceinline__ uint32_t bf16x2_to_f16x2(uint32_t w) {
+  return pack_f16x2(vt_clamp_f16(bf16lo_to_f32(w)), vt_clamp_f16(bf16hi_to_f32(w)));
+}
+__device__ __forceinline__ uint16_t bf16_to_f16_bits(bf16_t h) {
+  return (uint16_t)(pack_f16x2(vt_clamp_f16(bf16_to_f32(h)), 0.f) & 0xffffu);
+}
+__device__ __forceinline__ float f16_bits_to_f32(uint16_t h) { return f16lo_to_f32((uint32_t)h); }
+
 // GELU (exact-erf flavour: nn.GELU(), CLIP 'gelu') for the GEMM epilogues: 0.5 x (1 + erf(x / sqrt 2)) with 1 - erf(|z|) from
 // Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 store that follows): branch-free, one rcp and one exp2 -- the
 // library erff (two polynomial branches, both executed by a divergent wave) made the epilogue of the ViT's fc1 GEMM as long as

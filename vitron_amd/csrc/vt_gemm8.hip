@@ -393,8 +393,8 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmP8 p) {
             if (quad_ok) {
               const int sl = e0 & 0x3ffffff;
               u32x2 o;
-              o.x = pack_bf16x2(t0, t1);
-              o.y = pack_bf16x2(t2, t3);
+              o.x = bf16x2_to_f16x2(pack_bf16x2(t0, t1));   // bf16 like the plain store epilogue, then the V^T pages' fp16 (vt_common.h)
+              o.y = bf16x2_to_f16x2(pack_bf16x2(t2, t3));
               *(u32x2*)(p.qf.vt_pages + (((size_t)(sl >> 6) * heads + head) * 128 + dim) * 64 + (sl & 63)) = o;
             } else {
               const float tv[4] = {t0, t1, t2, t3};
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmP8 p) {
                 const int mi_row = bm0 + qm * 128 + wr * 64 + mi * 16 + ((lane & 12) | i);
                 if (mi_row < p.M) {
                   const int sl = ei & 0x3ffffff;
-                  p.qf.vt_pages[(((size_t)(sl >> 6) * heads + head) * 128 + dim) * 64 + (sl & 63)] = f32_to_bf16(tv[i]);
+                  p.qf.vt_pages[(((size_t)(sl >> 6) * heads + head) * 128 + dim) * 64 + (sl & 63)] = bf16_to_f16_bits(f32_to_bf16(tv[i]));
                 }
               }
             }

@@ -383,7 +383,7 @@ class PackedLlama:
 
 
 class PagedKVCache:
-    """Paged KV pool: K pages [L][pages][heads][64][hd], V^T pages [L][pages][heads][hd][64]; 64 tokens per page.
+    """Paged KV pool: K pages [L][pages][heads][64][hd] bf16, V^T pages [L][pages][heads][hd][64] fp16; 64 tokens per page.
     A free list hands out pages; sequences own a list of page ids (their block table)."""
 
     def __init__(self, llama: PackedLlama, num_pages: int):
@@ -391,7 +391,7 @@ class PagedKVCache:
         self.num_pages = int(num_pages)
         n = llama.L * self.num_pages * llama.heads * PAGE_TOKENS * llama.hd
         self.k = torch.zeros(n, dtype=torch.bfloat16, device=llama.device)
-        self.vt = torch.zeros(n, dtype=torch.bfloat16, device=llama.device)
+        self.vt = torch.zeros(n, dtype=torch.float16, device=llama.device)    # V^T pages hold fp16 (include/vitron_hip.h)
         self.free = list(range(self.num_pages - 1, -1, -1))
         c = _lib.VtKvCache()
         c.k, c.vt, c.num_pages = self.k.data_ptr(), self.vt.data_ptr(), self.num_pages
