@@ -546,3 +546,24 @@ def test_gemm_four_wave_ring_kernel(dev, M, N, K):
     for _ in range(3):
         assert torch.equal(got, ops.gemm(ad, wd, b.to(dev), ops.EPI_F32_RESID, out=resid.to(dev).clone(), cfg=cfg))
     assert torch.equal(ops.gemm(ad, wd, b.to(dev), ops.EPI_BF16, cfg=cfg), ops.gemm(ad, wd, b.to(dev), ops.EPI_BF16, cfg=_lib.CFG_256x256_P4))
+
+
+@pytest.mark.parametrize("rows,V", [(37, 512), (300, 32000), (5, 32003)])
+def test_cross_entropy_matches_torch(dev, rows, V):
+    """vt_cross_entropy (the shifted-token loss of LlamaForCausalLM.forward(labels=...)) against torch.nn.functional.cross_entropy in
+    fp64: ignore_index rows are skipped, a label outside the vocabulary raises like torch does (it is not silently dropped)."""
+    from vitron_amd import ops
+    g = torch.Generator().manual_seed(rows + V)
+    logits = torch.randn((rows, V), generator=g) * 3.0
+    labels = torch.randint(0, V, (rows,), generator=g)
+    labels[::4] = -100
+    got = ops.cross_entropy(logits.to(dev), labels.to(dev), ignore_index=-100)
+    ref = torch.nn.functional.cross_entropy(logits.double(), labels, ignore_index=-100)
+    assert abs(float(got) - float(ref)) <= 1e-5 * abs(float(ref))
+    all_ignored = ops.cross_entropy(logits.to(dev), torch.full((rows,), -100), ignore_index=-100)
+    assert float(all_ignored) == 0.0 or math.isnan(float(all_ignored))     # torch returns nan for an empty mean
+    for bad in (V, -1, V + 7):
+        lab = labels.clone()
+        lab[1] = bad
+        with pytest.raises(IndexError):
+            ops.cross_entropy(logits.to(dev), lab.to(dev), ignore_index=-100)

@@ -354,6 +354,64 @@ def test_serving_engine_continuous_batching_matches_solo_runs(dev, model):
     model.config.kv_prefix_reuse = True
 
 
+def test_serving_engine_pool_sizing_and_waiting(dev, model):
+    """(1) the default engine (kv_pages=None) sizes its pool for the whole admitted batch, also when a later request
+    of the batch is larger than the first; (2) a request that does not fit waits (embedded once) until running requests retire;
+    (3) a request larger than the pool is admitted once the engine is idle and the pool can grow; (4) a failing admission leaves
+    the queue and the pool as they were. Tokens always equal the solo greedy run."""
+    from vitron_amd.serving import ServingEngine
+    g = torch.Generator().manual_seed(31)
+    V = cases.LLM["vocab_size"]
+    rnd = lambda n: torch.randint(3, V, (n,), generator=g).tolist()                     # noqa: E731
+    reqs = [dict(input_ids=torch.tensor([[1] + rnd(20)]), max_new_tokens=6),            # 1 + 1 pages
+            dict(input_ids=torch.tensor([[1] + rnd(200)]), max_new_tokens=40),          # 4 + 1 pages: larger than the first
+            dict(input_ids=torch.tensor([[1] + rnd(90)]), max_new_tokens=10)]
+    model.config.kv_prefix_reuse = False
+    solo = [model.generate(r["input_ids"].to(dev), do_sample=False, max_new_tokens=r["max_new_tokens"], eos_token_id=-1)[0, r["input_ids"].shape[1]:].tolist()
+            for r in reqs]
+    model.reset_prefix_cache()
+    model.kv, model.kv_pages = None, None
+    eng = ServingEngine(model, max_batch=4)                                             # (1) kv_pages=None, mixed sizes
+    for r in reqs:
+        eng.submit(r["input_ids"], max_new_tokens=r["max_new_tokens"], eos_token_id=-1)
+    eng.step()
+    assert len(eng.active) == 3 and not eng.waiting                                     # all three decode together
+    outs = eng.run()
+    assert [outs[i].tolist() for i in range(3)] == solo
+    assert len(model.kv.free) == model.kv.num_pages
+    # (2) a pool that the first two fill exactly: the third arrives later, waits, is embedded ONCE, and joins when pages come back
+    eng = ServingEngine(model, max_batch=4, kv_pages=7)
+    embeds = []
+    orig = eng._embed
+    eng._embed = lambda r: (embeds.append(r.rid), orig(r))[1]
+    for r in reqs[:2]:
+        eng.submit(r["input_ids"], max_new_tokens=r["max_new_tokens"], eos_token_id=-1)
+    eng.step()
+    eng.submit(reqs[2]["input_ids"], max_new_tokens=reqs[2]["max_new_tokens"], eos_token_id=-1)
+    eng.step()
+    assert len(eng.active) == 2 and len(eng.waiting) == 1                               # 3 pages wanted, none free
+    outs = eng.run()
+    assert [outs[i].tolist() for i in range(3)] == solo and sorted(embeds) == [0, 1, 2]
+    assert len(model.kv.free) == model.kv.num_pages == 7
+    # (3) a request larger than the pool: waits behind the running one, then the idle engine grows the pool
+    eng = ServingEngine(model, max_batch=4, kv_pages=3)
+    eng.submit(reqs[0]["input_ids"], max_new_tokens=reqs[0]["max_new_tokens"], eos_token_id=-1)
+    eng.step()
+    eng.submit(reqs[1]["input_ids"], max_new_tokens=reqs[1]["max_new_tokens"], eos_token_id=-1)     # needs 5 pages, the pool has 3
+    outs = eng.run()
+    assert outs[0].tolist() == solo[0] and outs[1].tolist() == solo[1] and model.kv.num_pages >= 5
+    # (4) pages held by someone else while the pool would have to grow: the error leaves everything in place
+    eng = ServingEngine(model, max_batch=4, kv_pages=3)
+    held = model.kv.alloc(1)
+    eng.submit(reqs[1]["input_ids"], max_new_tokens=reqs[1]["max_new_tokens"], eos_token_id=-1)
+    with pytest.raises(RuntimeError):
+        eng.step()
+    assert len(eng.waiting) == 1 and not eng.active and len(model.kv.free) == 2
+    model.kv.release(held)
+    assert eng.run()[0].tolist() == solo[1]
+    model.config.kv_prefix_reuse = True
+
+
 @pytest.mark.gpu
 def test_decode_feed_kernel(dev):
     """vt_decode_feed against its definition: pad once finished, EOS flags, embedding rows, metadata advance."""

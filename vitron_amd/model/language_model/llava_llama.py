@@ -274,7 +274,8 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
         flat = inputs_embeds.reshape(B * S, H)
         if len(idx) != B * S:   # pack the valid rows (padding never enters the decoder): a row gather by the splice kernel
             rowsel = torch.tensor(idx, dtype=torch.int32, device=flat.device)
-            flat = ops.embed_splice(flat.contiguous(), None, None, torch.stack([torch.zeros_like(rowsel), rowsel], 1).contiguous())
+            # (fp16 / fp32 inputs_embeds are legal here -- the reference model runs in fp16: the gather kernel moves bf16 rows)
+            flat = ops.embed_splice(flat.to(torch.bfloat16).contiguous(), None, None, torch.stack([torch.zeros_like(rowsel), rowsel], 1).contiguous())
         rows = flat.shape[0]
         logits_p, hidden = llama_forward(llama, past.kv, seqs, flat, lens, logit_rows=list(range(rows)), return_hidden=True)
         if len(idx) != B * S:
@@ -361,7 +362,7 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
         flat = embeds.reshape(B * S, H)
         if len(idx) != B * S:
             rowsel = torch.tensor(idx, dtype=torch.int32, device=dev)
-            flat = ops.embed_splice(flat.contiguous(), None, None, torch.stack([torch.zeros_like(rowsel), rowsel], 1).contiguous())
+            flat = ops.embed_splice(flat.to(torch.bfloat16).contiguous(), None, None, torch.stack([torch.zeros_like(rowsel), rowsel], 1).contiguous())
         seqs = [SequenceState() for _ in range(B)]
         # ---- multi-turn KV reuse (batch 1): keep the pages of the longest common whole-page prefix of the last call ------------
         sig = None

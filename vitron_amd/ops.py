@@ -252,6 +252,11 @@ def cross_entropy(logits: torch.Tensor, labels: torch.Tensor, ignore_index: int 
     _chk_rows(logits, torch.float32, "cross_entropy.logits")
     rows, V = logits.shape
     lab = labels.to(device=logits.device, dtype=torch.int32).contiguous()
+    # torch.nn.functional.cross_entropy raises on a label outside [0, V) that is not ignore_index; the kernel would drop such a
+    # row from the mean, i.e. turn a vocabulary mismatch into a plausible loss. (One read-back: this is the scoring path.)
+    bad = (lab != int(ignore_index)) & ((lab < 0) | (lab >= V))
+    if bool(bad.any()):
+        raise IndexError(f"cross_entropy: label {int(lab[bad][0])} outside the vocabulary ({V} columns)")
     nll = torch.empty((rows,), device=logits.device, dtype=torch.float32)
     loss = torch.empty((1,), device=logits.device, dtype=torch.float32)
     _lib.check(lib.vt_cross_entropy(_p(logits), rows, V, logits.stride(0), _p(lab), int(ignore_index), _p(nll), _p(loss), _stream()),

@@ -39,6 +39,8 @@ class _Request:
     tokens: List[int] = field(default_factory=list)
     last: Optional[torch.Tensor] = None      # device int32 [1]: the token to feed next
     done: bool = False
+    flat: Optional[torch.Tensor] = None      # spliced prompt rows [rows, H] (kept while the request waits for pages)
+    need: int = 0                            # KV pages for prompt + max_new_tokens
 
 
 class ServingEngine:
@@ -93,31 +95,41 @@ class ServingEngine:
         return embeds[0][mask]
 
     def _admit(self, reqs: List[_Request]) -> List[_Request]:
-        """Multimodal prefill of the requests that fit: towers + splice per request, decoder prefill per request (default) or
-        one packed pass for all of them (batch_prefill). Every admitted request RESERVES its worst case up front -- pages for
-        prompt + max_new_tokens are allocated here, so a sequence that is already decoding can never find the pool empty
-        because a later admission took its pages. Requests that do not fit right now are returned (in order) and go back to
-        the head of the queue; one that could never fit raises."""
+        """Multimodal prefill of the requests that fit: towers + splice per request (once: the rows and the page need stay on the
+        request while it waits), decoder prefill per request (default) or one packed pass for all of them (batch_prefill). Every
+        admitted request RESERVES its worst case up front -- pages for prompt + max_new_tokens are allocated here, so a sequence
+        that is already decoding can never find the pool empty because a later admission took its pages. When nothing of this
+        engine is live the pool is (re)built for the WHOLE candidate batch; otherwise requests that do not fit right now are
+        returned (in order) and go back to the head of the queue -- also one that is larger than the current pool: it is admitted
+        once the engine is idle and the pool can grow. A failure in here (e.g. pages held by someone else while the pool would
+        have to grow) leaves the engine as it was: pages taken by this call are released, the candidates stay queued."""
         m = self.model
         llama = m.get_model().llama
         admitted: List[_Request] = []
-        flats: List[torch.Tensor] = []
-        for i, r in enumerate(reqs):
-            f = self._embed(r)
-            need = (f.shape[0] + r.max_new_tokens + 63) // 64 + 1
-            if m.kv is None or len(m.kv.free) < need:
-                idle = not self.active and not admitted
-                if idle:
-                    m._ensure_kv(need)      # nothing of this engine is live: drop the kept prefix / grow the pool (raises if others hold pages)
-                elif m.kv is not None and need > m.kv.num_pages:
-                    raise RuntimeError(f"ServingEngine: request needs {need} KV pages, the pool has {m.kv.num_pages}; "
-                                       "construct the engine with a larger kv_pages")
-                else:
-                    break                                   # wait for running requests to retire
-            r.seq.pages = m.kv.alloc(need)
-            admitted.append(r)
-            flats.append(f)
+        try:
+            for r in reqs:
+                if r.flat is None:
+                    r.flat = self._embed(r)
+                    r.need = (r.flat.shape[0] + r.max_new_tokens + 63) // 64 + 1
+            if not self.active:
+                # idle: size the pool for every candidate (the first len(reqs) <= max_batch requests decode together)
+                total = sum(r.need for r in reqs)
+                if m.kv is None or len(m.kv.free) < total:
+                    m._ensure_kv(total)
+            for r in reqs:
+                if len(m.kv.free) < r.need:
+                    break                                   # wait for running requests to retire (or for an idle engine to grow the pool)
+                r.seq.pages = m.kv.alloc(r.need)
+                admitted.append(r)
+        except Exception:
+            for r in admitted:
+                m.kv.release(r.seq.pages)
+                r.seq.pages = []
+            for r in reversed(reqs):
+                self.waiting.appendleft(r)
+            raise
         rest = reqs[len(admitted):]
+        flats = [r.flat for r in admitted]
         if self.batch_prefill and len(admitted) > 1:
             logits = llama_forward(llama, m.kv, [r.seq for r in admitted], torch.cat(flats, 0), [f.shape[0] for f in flats])
             nxt = self._pick(logits)
@@ -126,6 +138,8 @@ class ServingEngine:
         else:
             for r, f in zip(admitted, flats):
                 r.last = self._pick(llama_forward(llama, m.kv, [r.seq], f, [f.shape[0]]))
+        for r in admitted:
+            r.flat = None                                   # the rows are in the cache now
         self.active += admitted
         return rest
 
