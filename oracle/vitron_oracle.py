@@ -152,13 +152,22 @@ def tower_features(sd: SD, cfg: dict, pixels: torch.Tensor, select_layer: int = 
 
 
 # =====================================================================================================================
-# mm_projector  (reference vitron/model/multimodal_projector/builder.py:33-51 -- 'mlp2x_gelu')
+# mm_projector  (reference vitron/model/multimodal_projector/builder.py:33-51 -- 'linear' / 'mlpNx_gelu'; Vitron: 'mlp2x_gelu')
 # =====================================================================================================================
 def projector_forward(sd: SD, x: torch.Tensor, emulate_bf16: bool = False):
-    if "2.weight" not in sd:  # 'linear'
+    if "0.weight" not in sd:  # 'linear'
         return _r(_lin(x.float(), sd["weight"], sd["bias"]), emulate_bf16)
-    h = _r(F.gelu(_lin(x.float(), sd["0.weight"], sd["0.bias"])), emulate_bf16)
-    return _r(_lin(h, sd["2.weight"], sd["2.bias"]), emulate_bf16)
+    # 'mlpNx_gelu': nn.Sequential(Linear, GELU, Linear[, GELU, Linear ...]) -- Linear layers at the even indices (builder.py:39-46)
+    n = 0
+    while f"{2 * n}.weight" in sd:
+        n += 1
+    h = x.float()
+    for i in range(n):
+        h = _lin(h, sd[f"{2 * i}.weight"], sd[f"{2 * i}.bias"])
+        if i + 1 < n:
+            h = F.gelu(h)
+        h = _r(h, emulate_bf16)
+    return h
 
 
 # =====================================================================================================================

@@ -19,6 +19,12 @@ VIT_VIDEO_B = dict(hidden_size=128, intermediate_size=192, num_hidden_layers=2, 
 VIT_IMAGE_B = dict(VIT_VIDEO_B, add_time_attn=False, num_frames=1)
 VIT_B_CASES = {"video_b": (VIT_VIDEO_B, (1, 3, 8, 70, 70)), "image_b": (VIT_IMAGE_B, (2, 3, 70, 70))}
 MM_HIDDEN = 128
+# F1 branches: the plain HF-CLIP image tower (reference clip_encoder.py) -- CLIPVisionConfig defaults
+# (quick_gelu), a 4 x 4 patch grid -- and an mlp3x_gelu projector (multimodal_projector/builder.py:39-46)
+CLIP_TOWER = dict(hidden_size=128, intermediate_size=256, num_hidden_layers=3, num_attention_heads=2, patch_size=14,
+                  image_size=56, hidden_act="quick_gelu", layer_norm_eps=1e-5, add_time_attn=False, num_frames=1)
+CLIP_TOWER_SHAPE = (3, 3, 56, 56)
+PROJ3_ROWS = 41
 LLM = dict(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2, vocab_size=512,
            rms_norm_eps=1e-5, rope_theta=10000.0, max_position_embeddings=512)
 

@@ -420,6 +420,54 @@ def gen_greedy(ns):
           f"{time.time() - t0:.1f}s")
 
 
+def gen_f1(ns):
+    """SURVEY.md 8(a) row F1's other branches, from the reference's own classes:
+      * CLIPVisionTower (vitron/model/multimodal_encoder/clip_encoder.py:7-78) around a transformers CLIPVisionModel with seeded
+        weights (no checkpoint / network: the model is attached the way load_model() would, :22-27): forward() for
+        select_feature 'patch' and 'cls_patch', select_layer -2, batched and list inputs;
+      * build_vision_projector with mm_projector_type = 'mlp3x_gelu' (multimodal_projector/builder.py:39-46)."""
+    import importlib
+    from transformers import CLIPVisionConfig, CLIPVisionModel
+    ce = importlib.import_module("vitron.model.multimodal_encoder.clip_encoder")
+    out = {}
+    cfg = cases.CLIP_TOWER
+    sd = synth.vit_state(cfg, synth.make_generator(cases.SEED_VIT + 2), **cases.VIT_INIT)
+    hc = CLIPVisionConfig(hidden_size=cfg["hidden_size"], intermediate_size=cfg["intermediate_size"],
+                          num_hidden_layers=cfg["num_hidden_layers"], num_attention_heads=cfg["num_attention_heads"],
+                          image_size=cfg["image_size"], patch_size=cfg["patch_size"], hidden_act=cfg["hidden_act"],
+                          layer_norm_eps=cfg["layer_norm_eps"])
+    hc._attn_implementation = "eager"
+    vm = CLIPVisionModel(hc).eval()
+    # transformers 4.31 (the reference's pin) names these tensors `vision_model.*`; the 5.x build installed here drops the prefix
+    pref = "vision_model." if any(k.startswith("vision_model.") for k in vm.state_dict()) else ""
+    missing, unexpected = vm.load_state_dict({pref + k: v.float() for k, v in sd.items()}, strict=False)
+    assert not unexpected and all("position_ids" in k for k in missing), (missing, unexpected)
+    x = cases.pixels(cases.CLIP_TOWER_SHAPE, cases.SEED_PIX + 21)
+    for feat in ("patch", "cls_patch"):
+        t = ce.CLIPVisionTower.__new__(ce.CLIPVisionTower)
+        nn.Module.__init__(t)
+        t.is_loaded, t.select_layer, t.select_feature, t.vision_tower = True, -2, feat, vm
+        with torch.no_grad():
+            out[f"clip_{feat}"] = t(x).numpy()
+            lst = t([x[0], x[2]])
+        out[f"clip_{feat}_list0"], out[f"clip_{feat}_list1"] = lst[0].numpy(), lst[1].numpy()
+    out["clip_checksum"] = np.float64(synth.checksum(sd))
+    H = cases.LLM["hidden_size"]
+    g = synth.make_generator(cases.SEED_PROJ + 3)
+    psd = synth.projector_state(cases.MM_HIDDEN, H, g, **cases.MLP_INIT)
+    extra = synth.projector_state(H, H, g, **cases.MLP_INIT)
+    psd["4.weight"], psd["4.bias"] = extra["2.weight"], extra["2.bias"]
+    pcfg = types.SimpleNamespace(mm_projector_type="mlp3x_gelu", mm_hidden_size=cases.MM_HIDDEN, hidden_size=H)
+    pm = ns.projector_builder.build_vision_projector(pcfg).eval()
+    pm.load_state_dict(f32(psd))
+    xp = cases.features((cases.PROJ3_ROWS, cases.MM_HIDDEN), cases.SEED_FEATS + 5)
+    with torch.no_grad():
+        out["proj3_out"] = pm(xp).numpy()
+    out["proj3_checksum"] = np.float64(synth.checksum(psd))
+    np.savez_compressed(os.path.join(OUT, "f1.npz"), **out)
+    print("f1.npz", {k: getattr(v, "shape", v) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     ns = ref_shim.install()
@@ -432,6 +480,9 @@ if __name__ == "__main__":
     if "--greedy-only" in sys.argv:
         gen_greedy(ns)
         sys.exit(0)
+    if "--f1-only" in sys.argv:
+        gen_f1(ns)
+        sys.exit(0)
     gen_mm_utils(ns)
     gen_output_parser()
     gen_vit(ns)
@@ -442,3 +493,4 @@ if __name__ == "__main__":
     gen_state_dict_keys(ns)
     gen_fullwidth(ns)
     gen_greedy(ns)
+    gen_f1(ns)

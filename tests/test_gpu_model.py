@@ -127,6 +127,61 @@ def test_projector_and_region(dev, model):
         assert rel_l2(out.float(), torch.as_tensor(g[f"region_{tag}_out"])) <= TOL_FP32
 
 
+def test_f1_branches_clip_tower_and_mlp3x_projector(dev, tmp_path):
+    """build_image_tower picks CLIPVisionTower for `openai*` names (reference multimodal_encoder/builder.py:12)
+    and build_vision_projector loops N Linear layers for mlpNx_gelu (multimodal_projector/builder.py:39-46). Both against outputs of
+    the REFERENCE's own classes (tests/golden/f1.npz) and the emulating oracle; the tower is loaded from a checkpoint DIRECTORY in
+    the transformers layout (vision_model.* names, safetensors), as load_model() reads it."""
+    import json
+    from types import SimpleNamespace
+    from safetensors.torch import save_file
+    from vitron_amd.model.multimodal_encoder.builder import build_image_tower
+    from vitron_amd.model.multimodal_encoder.clip_encoder import CLIPVisionTower
+    from vitron_amd.model.multimodal_projector.builder import build_vision_projector
+    g = np.load(os.path.join(G, "f1.npz"))
+    cfg = cases.CLIP_TOWER
+    sd = synth.vit_state(cfg, synth.make_generator(cases.SEED_VIT + 2), **cases.VIT_INIT)
+    ck = tmp_path / "openai" / "clip-vit-tiny-patch14"
+    ck.mkdir(parents=True)
+    (ck / "config.json").write_text(json.dumps({"model_type": "clip_vision_model", **{k: v for k, v in cfg.items() if k not in ("add_time_attn", "num_frames")}}))
+    save_file({"vision_model." + k: v.contiguous() for k, v in sd.items()}, str(ck / "model.safetensors"))
+    x = cases.pixels(cases.CLIP_TOWER_SHAPE, cases.SEED_PIX + 21)
+    emu = O.vit_forward(f32(sd), cfg, x, cfg["num_hidden_layers"] - 1, emulate_bf16=True)
+    for feat in ("patch", "cls_patch"):
+        args = SimpleNamespace(mm_image_tower="openai/clip-vit-tiny-patch14", mm_vision_select_layer=-2, mm_vision_select_feature=feat)
+        t = build_image_tower(args, delay_load=True, cache_dir=str(tmp_path))
+        assert isinstance(t, CLIPVisionTower) and not t.is_loaded and t.config.hidden_size == 128 and t.num_patches == 16
+        t.load_model()
+        t.to(dev)
+        out = t(x.to(dev).bfloat16())
+        ref = torch.as_tensor(g[f"clip_{feat}"])
+        assert tuple(out.shape) == ref.shape and out.dtype == torch.bfloat16
+        want = emu if feat == "cls_patch" else emu[:, 1:]
+        assert rel_l2(out.float(), O.bf16_round(want)) <= 5e-3, feat
+        assert rel_l2(out.float(), ref) <= TOL_FP32 and no_worse_than_emulation(out.float().cpu(), O.bf16_round(want), ref), feat
+        lst = t([x[0].to(dev).bfloat16(), x[2].to(dev).bfloat16()])             # list input: one [1, P, D] tensor per image (:41-47)
+        assert rel_l2(lst[1].float(), torch.as_tensor(g[f"clip_{feat}_list1"])) <= TOL_FP32 and lst[0].shape[0] == 1
+    with pytest.raises(FileNotFoundError):
+        build_image_tower(SimpleNamespace(mm_image_tower="laion/not-there", mm_vision_select_layer=-2), delay_load=True).load_model()
+    with pytest.raises(ValueError):
+        build_image_tower(SimpleNamespace(mm_image_tower="somewhere/else", mm_vision_select_layer=-2))
+    # mlp3x_gelu
+    H = cases.LLM["hidden_size"]
+    gp = synth.make_generator(cases.SEED_PROJ + 3)
+    psd = synth.projector_state(cases.MM_HIDDEN, H, gp, **cases.MLP_INIT)
+    extra = synth.projector_state(H, H, gp, **cases.MLP_INIT)
+    psd["4.weight"], psd["4.bias"] = extra["2.weight"], extra["2.bias"]
+    pm = build_vision_projector(SimpleNamespace(mm_projector_type="mlp3x_gelu", mm_hidden_size=cases.MM_HIDDEN, hidden_size=H))
+    pm.load_state_dict(psd)
+    pm.to(dev)
+    xp = cases.features((cases.PROJ3_ROWS, cases.MM_HIDDEN), cases.SEED_FEATS + 5)
+    y = pm(xp.to(dev).bfloat16())
+    assert rel_l2(y.float(), O.projector_forward(f32(psd), xp, True)) <= TOL
+    assert rel_l2(y.float(), torch.as_tensor(g["proj3_out"])) <= TOL_FP32
+    with pytest.raises(KeyError):
+        build_vision_projector(SimpleNamespace(mm_projector_type="mlp4x_gelu", mm_hidden_size=cases.MM_HIDDEN, hidden_size=H)).load_state_dict(psd)
+
+
 def test_encode_images_videos_api(dev, model):
     img = torch.stack([cases.pixels((3, 56, 56), cases.SEED_PIX + i) for i in range(2)]).to(dev).bfloat16()
     f, r = model.encode_images(img, [cases.BOXES[1], cases.BOXES[2]])

@@ -464,3 +464,44 @@ def test_gemm_planner_fills_whole_rounds_of_the_chip():
     assert cfg == W4 and first == 8192 and ops.gemm_plan(512, 4096, 4096, ops.EPI_F32_RESID) == (W4R, 0)
     with pytest.raises(RuntimeError):
         ops.gemm_plan(0, 4096, 4096)
+
+
+def test_tower_and_projector_factories_pick_the_reference_branches(tmp_path):
+    """reference multimodal_encoder/builder.py:7-24 and multimodal_projector/builder.py:33-51, host side only: `openai*` / `laion*`
+    names -> CLIPVisionTower (config read from the local checkpoint directory, nothing loaded under delay_load), `...LanguageBind_Image`
+    / `...LanguageBind_Video_merge` -> the LanguageBind towers, anything else raises; 'linear' / 'mlpNx_gelu' / 'identity'."""
+    import json
+    from types import SimpleNamespace
+
+    import pytest
+    from vitron_amd.model.multimodal_encoder.builder import build_image_tower, build_video_tower
+    from vitron_amd.model.multimodal_encoder.clip_encoder import CLIPVisionTower
+    from vitron_amd.model.multimodal_encoder.languagebind import LanguageBindImageTower, LanguageBindVideoTower
+    from vitron_amd.model.multimodal_projector.builder import IdentityMap, VisionProjector, build_vision_projector
+    ck = tmp_path / "openai" / "clip-vit-large-patch14-336"
+    ck.mkdir(parents=True)
+    (ck / "config.json").write_text(json.dumps({"vision_config": {"hidden_size": 1024, "image_size": 336, "patch_size": 14, "num_hidden_layers": 24,
+                                                                  "num_attention_heads": 16, "intermediate_size": 4096}}))
+    t = build_image_tower(SimpleNamespace(mm_image_tower="openai/clip-vit-large-patch14-336", mm_vision_select_layer=-2,
+                                          mm_vision_select_feature="cls_patch"), delay_load=True, cache_dir=str(tmp_path))
+    assert isinstance(t, CLIPVisionTower) and not t.is_loaded
+    assert t.config.hidden_size == 1024 and t.num_patches == 576 and t.hidden_size == 1024 and t.config.hidden_act == "quick_gelu"
+    assert isinstance(build_image_tower(SimpleNamespace(image_tower="x/LanguageBind_Image"), delay_load=True), LanguageBindImageTower)
+    assert isinstance(build_video_tower(SimpleNamespace(mm_video_tower="x/LanguageBind_Video_merge"), delay_load=True), LanguageBindVideoTower)
+    for bad in ("x/other", None):
+        with pytest.raises(ValueError):
+            build_image_tower(SimpleNamespace(mm_image_tower=bad))
+        with pytest.raises(ValueError):
+            build_video_tower(SimpleNamespace(mm_video_tower=bad))
+    with pytest.raises(ValueError):      # LanguageBind towers only know 'patch' (languagebind/__init__.py:96-104)
+        build_image_tower(SimpleNamespace(mm_image_tower="x/LanguageBind_Image", mm_vision_select_feature="cls_patch"), delay_load=True)
+    c = SimpleNamespace(mm_hidden_size=1024, hidden_size=4096)
+    for name, depth in (("linear", 1), ("mlp2x_gelu", 2), ("mlp3x_gelu", 3), ("mlp5x_gelu", 5)):
+        c.mm_projector_type = name
+        p = build_vision_projector(c)
+        assert isinstance(p, VisionProjector) and p.depth == depth
+    c.mm_projector_type = "identity"
+    assert isinstance(build_vision_projector(c), IdentityMap)
+    c.mm_projector_type = "mlp_gelu"
+    with pytest.raises(ValueError):
+        build_vision_projector(c)

@@ -176,3 +176,30 @@ def test_greedy_ids_against_the_reference(name):
         logits, past = O.llama_forward(w["llama"], cfgs["llama"], emb[int(ref_ids[t])].view(1, 1, -1), p, m, past)
         rows.append(logits[0, -1])
     assert rel(torch.stack(rows), ref_rows) <= 1e-4
+
+
+def _proj3_state():
+    H = cases.LLM["hidden_size"]
+    g = synth.make_generator(cases.SEED_PROJ + 3)
+    psd = synth.projector_state(cases.MM_HIDDEN, H, g, **cases.MLP_INIT)
+    extra = synth.projector_state(H, H, g, **cases.MLP_INIT)
+    psd["4.weight"], psd["4.bias"] = extra["2.weight"], extra["2.bias"]
+    return psd
+
+
+def test_f1_branches_clip_tower_and_mlp3x_projector():
+    """tests/golden/f1.npz (make_golden.gen_f1): the reference's CLIPVisionTower (clip_encoder.py:7-78) around a transformers
+    CLIPVisionModel, select_feature 'patch' / 'cls_patch', and build_vision_projector('mlp3x_gelu') (builder.py:39-46)."""
+    g = np.load(os.path.join(G, "f1.npz"))
+    cfg = cases.CLIP_TOWER
+    sd = synth.vit_state(cfg, synth.make_generator(cases.SEED_VIT + 2), **cases.VIT_INIT)
+    assert synth.checksum(sd) == pytest.approx(float(g["clip_checksum"]), rel=1e-12)
+    x = cases.pixels(cases.CLIP_TOWER_SHAPE, cases.SEED_PIX + 21)
+    h = O.vit_forward(f32(sd), cfg, x, num_layers=cfg["num_hidden_layers"] - 1)      # hidden_states[-2]
+    assert rel(h, g["clip_cls_patch"]) <= 1e-5 and rel(h[:, 1:], g["clip_patch"]) <= 1e-5
+    assert rel(O.tower_features(f32(sd), cfg, x, -2), g["clip_patch"]) <= 1e-5
+    assert rel(h[0:1], g["clip_cls_patch_list0"]) <= 1e-5 and rel(h[2:3, 1:], g["clip_patch_list1"]) <= 1e-5
+    psd = _proj3_state()
+    assert synth.checksum(psd) == pytest.approx(float(g["proj3_checksum"]), rel=1e-12)
+    xp = cases.features((cases.PROJ3_ROWS, cases.MM_HIDDEN), cases.SEED_FEATS + 5)
+    assert rel(O.projector_forward(f32(psd), xp), g["proj3_out"]) <= 1e-5

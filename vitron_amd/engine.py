@@ -196,19 +196,26 @@ class PackedVit:
 
 # =====================================================================================================================
 class PackedProjector:
-    """mm_projector ('mlp2x_gelu' or 'linear'), reference multimodal_projector/builder.py:33-51."""
+    """mm_projector ('linear', 'mlp2x_gelu', 'mlpNx_gelu'), reference multimodal_projector/builder.py:33-51. One and two layers
+    are ONE C call (vt_projector_forward); deeper stacks (N > 2: Linear-GELU-...-Linear) chain the same GEMM with the GELU
+    epilogue, one launch per layer."""
 
     def __init__(self, sd: SD, device):
         self.device = torch.device(device)
         if "0.weight" in sd:
-            self.w1, self.b1 = _bf(sd["0.weight"], device), _f32(sd["0.bias"], device)
-            self.w2, self.b2 = _bf(sd["2.weight"], device), _f32(sd["2.bias"], device)
-            self.dout = self.w2.shape[0]
+            n = 0
+            while f"{2 * n}.weight" in sd:
+                n += 1
+            self.layers = [(_bf(sd[f"{2 * i}.weight"], device), _f32(sd[f"{2 * i}.bias"], device)) for i in range(n)]
         else:
-            self.w1, self.b1 = _bf(sd["weight"], device), _f32(sd["bias"], device)
-            self.w2 = self.b2 = None
-            self.dout = self.w1.shape[0]
+            self.layers = [(_bf(sd["weight"], device), _f32(sd["bias"], device))]
+        for (w0, _), (w1, _) in zip(self.layers, self.layers[1:]):
+            if w1.shape[1] != w0.shape[0]:
+                raise _lib.VitronHipError(f"PackedProjector: layer widths do not chain ({tuple(w0.shape)} -> {tuple(w1.shape)})")
+        self.w1, self.b1 = self.layers[0]
+        self.w2, self.b2 = self.layers[1] if len(self.layers) > 1 else (None, None)
         self.din, self.dh = self.w1.shape[1], self.w1.shape[0]
+        self.dout = self.layers[-1][0].shape[0]
         self.ws = Workspace(device)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
@@ -216,6 +223,12 @@ class PackedProjector:
         shp = x.shape
         x2 = x.reshape(-1, shp[-1]).to(torch.bfloat16).contiguous()
         M = x2.shape[0]
+        if len(self.layers) > 2:
+            from . import ops
+            h = x2
+            for i, (w, b) in enumerate(self.layers):
+                h = ops.gemm(h, w, b, ops.EPI_BF16 if i + 1 == len(self.layers) else ops.EPI_BF16_GELU)
+            return h.view(*shp[:-1], self.dout)
         out = torch.empty((M, self.dout), device=self.device, dtype=torch.bfloat16)
         ws = self.ws.get(lib.vt_projector_workspace_bytes(M, self.dh))
         _lib.check(lib.vt_projector_forward(x2.data_ptr(), M, self.din, self.w1.data_ptr(), self.b1.data_ptr(), self.dh,

@@ -55,13 +55,14 @@ def _load_dir_state(path):
 
 class _Tower:
     kind = "image"
+    select_features = ("patch",)          # LanguageBind towers: feature_select always drops CLS (languagebind/__init__.py:96-104)
 
     def __init__(self, tower_name, args, delay_load=False, cache_dir="./cache_dir"):
         self.is_loaded = False
         self.tower_name = tower_name
         self.select_layer = getattr(args, "mm_vision_select_layer", -2)
         self.select_feature = getattr(args, "mm_vision_select_feature", "patch")
-        if self.select_feature != "patch":
+        if self.select_feature not in self.select_features:
             raise ValueError(f"Unexpected select feature: {self.select_feature}")
         self.cache_dir = cache_dir
         self.cfg_only = None

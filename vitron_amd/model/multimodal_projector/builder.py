@@ -24,17 +24,18 @@ class IdentityMap:
 
 class VisionProjector:
     """Linear / mlpNx_gelu projector running on the MFMA GEMM (bias + exact-erf GELU fused in the epilogue).
-    State-dict keys are nn.Sequential's ('0.weight', '0.bias', '2.weight', '2.bias') or nn.Linear's."""
+    State-dict keys are nn.Sequential's ('0.weight', '0.bias', '2.weight', '2.bias', '4.weight', ...) or nn.Linear's."""
 
     def __init__(self, mm_hidden_size: int, hidden_size: int, depth: int = 2):
-        if depth not in (1, 2):
-            raise ValueError(f"mlp{depth}x_gelu is not supported by the HIP projector (Vitron uses mlp2x_gelu)")
+        if depth < 1:
+            raise ValueError(f"mlp{depth}x_gelu: the projector needs at least one Linear layer")
         self.mm_hidden_size, self.hidden_size, self.depth = mm_hidden_size, hidden_size, depth
         self._sd = None
         self.packed = None
 
     def load_state_dict(self, sd, strict=True):
-        keys = ["0.weight", "0.bias", "2.weight", "2.bias"] if self.depth == 2 else ["weight", "bias"]
+        # nn.Sequential(Linear, GELU, Linear, GELU, Linear, ...): the Linear layers sit at the even indices (builder.py:41-45)
+        keys = [f"{2 * i}.{n}" for i in range(self.depth) for n in ("weight", "bias")] if self.depth >= 2 else ["weight", "bias"]
         missing = [k for k in keys if k not in sd]
         if missing and strict:
             raise KeyError(f"mm_projector: missing keys {missing}")
@@ -54,6 +55,9 @@ class VisionProjector:
         sd = synth.projector_state(self.mm_hidden_size, self.hidden_size, gen, device, w_std, b_std)
         if self.depth == 1:
             sd = {"weight": sd["0.weight"], "bias": sd["0.bias"]}
+        for i in range(2, self.depth):        # mlpNx_gelu, N > 2: further hidden -> hidden layers
+            extra = synth.projector_state(self.hidden_size, self.hidden_size, gen, device, w_std, b_std)
+            sd[f"{2 * i}.weight"], sd[f"{2 * i}.bias"] = extra["2.weight"], extra["2.bias"]
         self.load_state_dict(sd)
         return self.to(device)
 
