@@ -278,7 +278,7 @@ def test_bench_distributed_path_on_one_gpu(dev):
     port = str(random.randint(20000, 40000))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", port, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1",
-           "--no-cpu-baseline", "--decode-steps", "0", "--c4-steps", "1"]
+           "--no-cpu-baseline", "--decode-steps", "0", "--c2-reps", "0", "--no-empirical-peaks", "--c4-steps", "1"]
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]

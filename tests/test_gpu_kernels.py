@@ -567,3 +567,62 @@ def test_cross_entropy_matches_torch(dev, rows, V):
         lab[1] = bad
         with pytest.raises(IndexError):
             ops.cross_entropy(logits.to(dev), lab.to(dev), ignore_index=-100)
+
+
+@pytest.mark.parametrize("causal,lens,pasts", [(True, [700, 300, 64, 1], [0, 0, 0, 0]), (False, [577, 130], [0, 0]),
+                                                (True, [257, 40], [100, 1000]), (True, [2304], [0])])
+def test_flash_attention_ping_pong_kernel_matches_four_wave_kernel(dev, causal, lens, pasts):
+    """flash_attn_pp_kernel (8 waves, 256-row blocks, two wave groups half a tile apart; default for >= 2048 query rows at head_dim
+    128) forced onto small / ragged / multi-sequence / chunked (past > 0) problems through vt_flash_attn_set_pp_min_rows: waves past
+    the end of a sequence, blocks with one tile, causal waves that finish before their block does. Against fp64 attention on the
+    same bf16 q / k / v and against the four-wave kernel (same arithmetic, other schedule: equal up to the order of the fp32 sums)."""
+    from vitron_amd import _lib, ops
+    lib = _lib.load()
+    heads, hd = 3, 128
+    D = heads * hd
+    scale = 1.0 / math.sqrt(hd)
+    kv_lens = [p + q for p, q in zip(pasts, lens)]
+    ntl = [(n + 63) // 64 for n in kv_lens]
+    npages = sum(ntl)
+    perm = torch.randperm(npages, generator=torch.Generator().manual_seed(5)).tolist()
+    kt = torch.full((npages * heads * 64 * hd,), float("nan"), dtype=torch.bfloat16, device=dev)
+    vt = torch.full_like(kt, float("nan"))
+    table, desc_all, desc_new, q_rows, kv_full = [], [], [], [], []
+    row0 = 0
+    for i, (p, q) in enumerate(zip(pasts, lens)):
+        toff = len(table)
+        table += perm[toff:toff + ntl[i]]
+        x = randn((p + q, 3 * D), 200 + i).to(dev).bfloat16()
+        kv_full.append(x)
+        desc_all.append([0, p + q, p + q, toff])
+        desc_new.append([row0, q, p + q, toff])
+        row0 += q
+    table_t = torch.tensor(table, dtype=torch.int32, device=dev)
+    for i, x in enumerate(kv_full):           # fill every sequence's pages (no rotary) from its own fused-QKV rows
+        d = torch.tensor([desc_all[i]], dtype=torch.int32, device=dev)
+        ops.kv_tiles(x, 0, D, 2 * D, kt, vt, table_t, d, ntl[i], heads, hd)
+        q_rows.append(x[pasts[i]:, :D])
+    qcat = torch.cat(q_rows, 0).contiguous()
+    desc = torch.tensor(desc_new, dtype=torch.int32, device=dev)
+    prev = lib.vt_flash_attn_set_pp_min_rows(1)
+    try:
+        got = ops.flash_attn(qcat, kt, vt, table_t, desc, max(lens), heads, hd, causal, scale)
+        lib.vt_flash_attn_set_pp_min_rows(1 << 30)
+        old = ops.flash_attn(qcat, kt, vt, table_t, desc, max(lens), heads, hd, causal, scale)
+    finally:
+        lib.vt_flash_attn_set_pp_min_rows(prev)
+    torch.cuda.synchronize()
+    assert torch.isfinite(got.float()).all()
+    r0 = 0
+    for i, (p, q) in enumerate(zip(pasts, lens)):
+        x = kv_full[i].double().cpu()
+        qq = x[p:, :D].view(q, heads, hd)
+        kk, vv = x[:, D:2 * D].view(p + q, heads, hd), x[:, 2 * D:].view(p + q, heads, hd)
+        s = torch.einsum("qhd,khd->hqk", qq, kk) * scale
+        if causal:
+            mask = torch.arange(p + q)[None, :] > (p + torch.arange(q))[:, None]
+            s = s.masked_fill(mask[None], float("-inf"))
+        ref = torch.einsum("hqk,khd->qhd", torch.softmax(s, -1), vv).reshape(q, D).float()
+        assert rel_l2(got[r0:r0 + q].float(), bf16r(ref)) <= 3e-3, (i, rel_l2(got[r0:r0 + q].float(), bf16r(ref)))
+        assert rel_l2(got[r0:r0 + q].float(), old[r0:r0 + q].float()) <= 2e-3
+        r0 += q

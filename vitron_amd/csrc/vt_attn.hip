@@ -40,6 +40,7 @@ __device__ __forceinline__ int k_swz(int key) {
 __device__ __forceinline__ int v_swz(int d) { return (d >> 1) & 7; }
 
 #define RESCALE_THR 8.0f
+#define VT_FLASH_PP_MIN_ROWS 2048   // prefills at least this long (head_dim 128) run flash_attn_pp_kernel
 // The softmax weights feed the P.V MFMA as fp16 (11 mantissa bits; V^T pages hold fp16, see vt_common.h). They are computed as
 // 2^(s - m_run + P_BIAS): with the deferred rescale P <= 2^(RESCALE_THR + P_BIAS) = 2^15 < 65504, and the smallest NORMAL fp16
 // (2^-14) sits 2^-21 below the running maximum's weight instead of 2^-14, so that the long tail of a peaked row is not lost to
@@ -291,6 +292,284 @@ __global__ __launch_bounds__(64 * NWAVES, (NWAVES == 8) ? 2 : 2) void flash_attn
 #undef FA_TILE_SYNC
 
   // ---- epilogue ------------------------------------------------------------------------------------------------
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = (l_tot > 0.f) ? 1.f / l_tot : 0.f;
+  if (qrow < sq.q_len) {
+    bf16_t* op = O + (size_t)(sq.q_row0 + qrow) * ldo + head * HD + 4 * hh;
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x2 o;
+        o.x = pack_bf16x2(oacc[db][4 * g + 0] * inv, oacc[db][4 * g + 1] * inv);
+        o.y = pack_bf16x2(oacc[db][4 * g + 2] * inv, oacc[db][4 * g + 3] * inv);
+        *(u32x2*)(op + db * 32 + 8 * g) = o;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// flash_attn_pp_kernel<CAUSAL, W>: the long-prefill attention (head_dim 128, >= 2048 query rows) as a PING-PONG of two wave groups.
+//
+// Same arithmetic as flash_attn_kernel (all-swapped S^T = K.Q^T / O^T = V^T.P^T, permuted K rows, fp16 P and V^T, deferred
+// rescale), other schedule. flash_attn_kernel runs two independent 4-wave blocks per CU: the two waves that share a SIMD fall into
+// the same phase (both want the matrix pipe, then both want the VALU) and every fragment read is followed by its wait -- its MFMA,
+// VALU and "skeleton" (LDS reads, staging, barriers) times ADD UP (135 + 60 + 95 us). Here ONE block of 8 waves owns
+// 256 query rows; waves w and w + 4 share a SIMD and are forced half a tile apart by the barriers:
+//
+//     slot        2x                2x+1              2x+2              2x+3
+//     group 0     MFMA(x)           softmax(x)        MFMA(x+1)         softmax(x+1)
+//     group 1     softmax(x-1)      MFMA(x)           softmax(x)        MFMA(x+1)
+//
+//   MFMA(x)    = QK(x) then PV(x-1): 32 v_mfma_f32_32x32x16 back to back on operands that are already in registers -- the 32
+//                fragments stream through a W-deep register window, each read issued W MFMAs before its use, so the section is paced
+//                by the matrix pipe and not by LDS round trips (what made an earlier ping-pong attempt 30 % slower);
+//   softmax(x) = mask, row max, (rare) rescale, exp2, row sum, fp16 pack of S(x) -- pure VALU beside the partner's MFMAs -- plus
+//                this wave's share of the LDS-DMA for the tiles three / two slots of work ahead.
+// A SIMD's matrix pipe therefore sees MFMA sections back to back (1024 cycles each): the kernel is MFMA-bound by construction as
+// long as a softmax slot (~500 VALU cycles + 4 DMA issues) fits under the partner's section.
+// LDS: a ring of 4 K tiles + 4 V^T tiles (128 KiB, one block per CU). A wave issues its pieces of K(x + 3 + g) and V(x + 2 + g) in
+// softmax(x) and waits for the pieces of the slot before at the end of MFMA(x + 1): three slots of flight, and by the time any wave reads
+// a tile every wave's wait for it lies behind a barrier (group 1 runs a slot late, so it stages one tile further ahead).
+// Causal: a wave whose rows end before tile x skips the arithmetic of that tile but keeps staging and meeting the barriers.
+// ------------------------------------------------------------------------------------------------------------------
+template <bool CAUSAL, int W>
+__global__ __launch_bounds__(512, 2) void flash_attn_pp_kernel(const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ Kt,
+                                                              const bf16_t* __restrict__ Vt, const int* __restrict__ tile_table,
+                                                              const VtAttnSeq* __restrict__ seqs, bf16_t* __restrict__ O, int ldo,
+                                                              int heads, float scale_log2e) {
+  constexpr int HD = 128, KS = 8, DB = 4, KROW = 256, TILE = 64 * HD * 2, NST = 4, QBLK = 256, PPW = 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const kring = smem;
+  char* const vring = smem + NST * TILE;
+
+  const VtAttnSeq sq = seqs[blockIdx.z];
+  const int nqb = (sq.q_len + QBLK - 1) / QBLK;
+  const int qb = nqb - 1 - (int)blockIdx.y;            // heavy (late) causal blocks first, as in flash_attn_kernel
+  if (qb < 0) return;
+  const int head = blockIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int grp = wave >> 2;
+  const int ql = lane & 31, hh = lane >> 5;
+  const int past = sq.kv_len - sq.q_len;
+  const int q0 = qb * QBLK;
+  const int qrow = q0 + wave * 32 + ql;
+  const int qrow_c = min(qrow, sq.q_len - 1);
+
+  int ntiles = (sq.kv_len + 63) >> 6;                  // tiles the BLOCK walks
+  if (CAUSAL) ntiles = min(ntiles, ((past + min(q0 + QBLK - 1, sq.q_len - 1)) >> 6) + 1);
+  int wtiles = ntiles;                                  // tiles THIS WAVE has work in
+  if (CAUSAL) wtiles = min(ntiles, ((past + min(q0 + wave * 32 + 31, sq.q_len - 1)) >> 6) + 1);
+  if (q0 + wave * 32 >= sq.q_len) wtiles = 0;          // a wave past the end of the sequence only stages and meets barriers
+
+  bf16x8 qf[KS];
+  {
+    const bf16_t* qp = Q + (size_t)(sq.q_row0 + qrow_c) * ldq + head * HD + hh * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
+  }
+  // LDS-DMA source offsets of this wave's two 1-KiB pieces of a K tile / a V^T tile (swizzle on the source side)
+  int k_src_off[PPW], v_src_off[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int byte = (wave * PPW + i) * 1024 + lane * 16;
+    {
+      const int row = byte / KROW, c = (byte % KROW) >> 4;
+      k_src_off[i] = row * HD + ((c ^ k_swz<HD>(row)) << 3);
+    }
+    {
+      const int row = byte >> 7, c = (byte & 127) >> 4;
+      v_src_off[i] = row * 64 + ((c ^ v_swz(row)) << 3);
+    }
+  }
+  const size_t head_off = (size_t)head * 64 * HD;
+  const size_t tile_stride = (size_t)heads * 64 * HD;
+  const int* table = tile_table + sq.table_off;
+  auto stage_k = [&](int t) {
+    const size_t toff = (size_t)table[t] * tile_stride + head_off;
+    char* base = kring + (t & (NST - 1)) * TILE;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) glds16(Kt + toff + k_src_off[i], base + (wave * PPW + i) * 1024);
+  };
+  auto stage_v = [&](int t) {
+    const size_t toff = (size_t)table[t] * tile_stride + head_off;
+    char* base = vring + (t & (NST - 1)) * TILE;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) glds16(Vt + toff + v_src_off[i], base + (wave * PPW + i) * 1024);
+  };
+
+  // fragment read offsets (identical to flash_attn_kernel)
+  const int pi = 16 * ((ql >> 2) & 1) + (ql & 3) + 4 * (ql >> 3);
+  const int k_sw0 = k_swz<HD>(pi);
+  const int v_sw = v_swz(ql);
+  int k_lane[KS], v_lane[4];                               // per-lane byte offsets inside a tile
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) k_lane[ks] = pi * KROW + (((ks * 2 + hh) ^ k_sw0) << 4);          // + sub * 32 * KROW
+#pragma unroll
+  for (int c = 0; c < 4; ++c) v_lane[c] = ql * 128 + ((((c >> 1) * 4 + 2 * hh + (c & 1)) ^ v_sw) << 4);   // + db * 32 * 128
+
+  f32x16 oacc[DB];
+#pragma unroll
+  for (int db = 0; db < DB; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[db][r] = 0.f;
+  f32x16 sacc[2];
+  f16x8 pf[2][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) pf[i >> 1][i & 1] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+  float m_run = -INFINITY, l_run = 0.f;
+
+  // fragment i of an MFMA section: 0..15 = K fragments of QK(x) in issue order (ks = i >> 1, sub = i & 1), 16..31 = V^T fragments of
+  // PV(x - 1) (c = (i - 16) >> 2 -> (sub, j); db = i & 3). QK first: S(x) then never shares registers with the fragment window.
+  // The reads are asm statements with hand-counted waits: left to the compiler, every read sinks next to its use, and pinned with
+  // sched_barrier its own waitcnt pass still emitted a full lgkmcnt(0) every W-th MFMA. LDS returns in order, so before MFMA i (reads
+  // 0 .. min(i + W, 32) - 1 issued) at most min(W - 1, 31 - i) younger reads may be outstanding; the wait names the fragment
+  // register "+v", which is what orders the MFMA (a builtin: the compiler pads its hazards) behind it.
+  const uint32_t k_ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)kring;
+  const uint32_t v_ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)vring;
+#define FA_PP_READ(I, DST)                                                                                          \
+  do {                                                                                                              \
+    if ((I) < 16) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(k_addr[((I) >> 1) & 7]), "n"(((I) & 1) * (32 * KROW))); \
+    else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(v_addr[(((I) - 16) >> 2) & 3]), "n"(((I) & 3) * (32 * 128))); \
+  } while (0)
+#define FA_PP_SECTION()                                                                                             \
+  do {                                                                                                              \
+    u32x4 win[W];                                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < W; ++i) FA_PP_READ(i, win[i]);                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                              \
+    _Pragma("unroll") for (int i = 0; i < 32; ++i) {                                                                \
+      asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(win[i % W]) : "n"((W - 1 < 31 - i) ? W - 1 : 31 - i));           \
+      const u32x4 f = win[i % W];                                                                                   \
+      if (i < 2) {                                                                                                  \
+        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};         \
+        sacc[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f), qf[0], z, 0, 0, 0);    \
+      } else if (i < 16) {                                                                                          \
+        sacc[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f), qf[(i >> 1) & 7], sacc[i & 1], 0, 0, 0); \
+      } else {                                                                                                      \
+        oacc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f), pf[((i - 16) >> 3) & 1][(i >> 2) & 1], oacc[i & 3], 0, 0, 0); \
+      }                                                                                                             \
+      if (i + W < 32) FA_PP_READ(i + W, win[i % W]);                                                                \
+      __builtin_amdgcn_sched_barrier(0);                                                                            \
+    }                                                                                                               \
+  } while (0)
+#define FA_PP_WAIT_VM(N)                                                             \
+  do {                                                                               \
+    if ((N) >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                   \
+    else if ((N) >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");              \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            \
+  } while (0)
+
+  // ---- prologue: K(0 .. 2 + g), V(0 .. 1 + g); everything landed and visible before the first section -------------------------
+  for (int t = 0; t <= 2 + grp; ++t)
+    if (t < ntiles) stage_k(t);
+  for (int t = 0; t <= 1 + grp; ++t)
+    if (t < ntiles) stage_v(t);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (grp) __builtin_amdgcn_s_barrier();               // group 1 runs one slot behind group 0
+  __builtin_amdgcn_sched_barrier(0);
+
+  int n_prev = 0;                                       // DMA pieces this wave issued in its previous softmax slot
+  for (int x = 0;; ++x) {
+    // ---- MFMA(x): QK(x), PV(x - 1) -----------------------------------------------------------------------------------------
+    // ONE instruction stream for every active slot (three specialised variants made the register allocator keep O in two
+    // register sets and spill): at x = 0 the PV half multiplies the all-zero P of "tile -1" with V(0) (adds nothing), at
+    // x = wtiles the QK half scores a tile this wave never looks at (whatever the ring slot holds: no softmax follows).
+    if (x <= wtiles && wtiles > 0) {
+      const uint32_t vb = v_ring_lds + (max(x - 1, 0) & (NST - 1)) * TILE, kb = k_ring_lds + (x & (NST - 1)) * TILE;
+      uint32_t k_addr[KS], v_addr[4];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) k_addr[ks] = kb + k_lane[ks];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v_addr[c] = vb + v_lane[c];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // nothing of the compiler's (scalar loads) may sit in the counter the section counts on
+      __builtin_amdgcn_sched_barrier(0);
+      FA_PP_SECTION();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (x == ntiles) break;
+    FA_PP_WAIT_VM(n_prev);                              // the pieces of the slot before the last one have landed
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- softmax(x) ------------------------------------------------------------------------------------------------------------
+    if (x < wtiles) {
+      const int key0 = x * 64;
+      const bool need_mask = (key0 + 64 > sq.kv_len) || (CAUSAL && (key0 + 63 > past + q0 + wave * 32));
+      if (need_mask) {
+        asm volatile("" ::: "memory");                  // a real branch (see flash_attn_kernel)
+        const int lim = CAUSAL ? min(sq.kv_len - 1, past + qrow) : (sq.kv_len - 1);
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = key0 + sub * 32 + 16 * hh + r;
+            if (key > lim) sacc[sub][r] = -INFINITY;
+          }
+      }
+      float mx = fmaxf(sacc[0][0], sacc[1][0]);
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = __builtin_fmaxf(__builtin_fmaxf(mx, sacc[0][r]), sacc[1][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_tile = mx * scale_log2e;
+      if (__builtin_amdgcn_ballot_w64(m_tile > m_run + RESCALE_THR) != 0) {
+        const float m_new = fmaxf(m_run, m_tile);
+        const float alpha = (m_new == -INFINITY) ? 1.f : fast_exp2(m_run - m_new);
+        m_run = m_new;
+        l_run *= alpha;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+      }
+      const float m_safe = (m_run == -INFINITY) ? 0.f : m_run;
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      const f32x2 sc2 = {scale_log2e, scale_log2e}, ms2 = {P_BIAS - m_safe, P_BIAS - m_safe};
+      f32x2 psum2 = {0.f, 0.f};
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2 a = {sacc[sub][r], sacc[sub][r + 1]};
+          const f32x2 y = __builtin_elementwise_fma(a, sc2, ms2);
+          f32x2 e;
+          e.x = fast_exp2(y.x);
+          e.y = fast_exp2(y.y);
+          psum2 += e;
+          sacc[sub][r] = e.x;
+          sacc[sub][r + 1] = e.y;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          u32x4 w;
+          w.x = pack_f16x2(sacc[sub][8 * j + 0], sacc[sub][8 * j + 1]);
+          w.y = pack_f16x2(sacc[sub][8 * j + 2], sacc[sub][8 * j + 3]);
+          w.z = pack_f16x2(sacc[sub][8 * j + 4], sacc[sub][8 * j + 5]);
+          w.w = pack_f16x2(sacc[sub][8 * j + 6], sacc[sub][8 * j + 7]);
+          pf[sub][j] = __builtin_bit_cast(f16x8, w);
+        }
+      }
+      l_run += psum2.x + psum2.y;
+    }
+    // ---- this wave's DMA pieces of K(x + 3 + g), V(x + 2 + g) -----------------------------------------------------------------------
+    n_prev = 0;
+    if (x + 3 + grp < ntiles) {
+      stage_k(x + 3 + grp);
+      n_prev += PPW;
+    }
+    if (x + 2 + grp < ntiles) {
+      stage_v(x + 2 + grp);
+      n_prev += PPW;
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef FA_PP_SECTION
+#undef FA_PP_READ
+#undef FA_PP_WAIT_VM
+  if (!grp) __builtin_amdgcn_s_barrier();              // pairs with group 1's last slot
+
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = (l_tot > 0.f) ? 1.f / l_tot : 0.f;
   if (qrow < sq.q_len) {
@@ -968,6 +1247,13 @@ __global__ __launch_bounds__(256) void attn_temporal8_kernel(const bf16_t* __res
 
 }  // namespace
 
+static int g_flash_pp_min_rows = VT_FLASH_PP_MIN_ROWS;
+int vt_flash_attn_pp_min_rows(int rows) {
+  const int prev = g_flash_pp_min_rows;
+  if (rows > 0) g_flash_pp_min_rows = rows;
+  return prev;
+}
+
 int vt_flash_attn_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf16_t* Vt, const int* tile_table,
                          const VtAttnSeq* seqs, int nseq, int max_q_len, bf16_t* O, int ldo, int heads, int HD,
                          int causal, float scale, hipStream_t s) {
@@ -999,6 +1285,39 @@ int vt_flash_attn_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf16_
     dim3 grid(heads, cdiv(max_q_len, 32 * NW), nseq), block(64 * NW);                                          \
     hipLaunchKernelGGL(kern, grid, block, smem, s, Q, ldq, Kt, Vt, tile_table, seqs, O, ldo, heads, sl2);      \
   } while (0)
+  // long prefills at head_dim 128: the 8-wave ping-pong kernel (256-row blocks, one per CU)
+  bool use_pp = HD == 128 && max_q_len >= g_flash_pp_min_rows;
+#ifdef VT_ABLATIONS
+  static const int pp_env = getenv("VT_FLASH_PP") ? atoi(getenv("VT_FLASH_PP")) : -1;     // 0: never, 1: whenever HD == 128, W: window depth
+  static const int pp_w = getenv("VT_FLASH_PP_W") ? atoi(getenv("VT_FLASH_PP_W")) : 8;
+  if (pp_env == 0) use_pp = false;
+  if (pp_env == 1) use_pp = HD == 128;
+#else
+  const int pp_w = 8;
+#endif
+  if (use_pp) {
+#define VT_FA_PP(CV, WV)                                                                                       \
+  do {                                                                                                         \
+    auto kern = flash_attn_pp_kernel<CV, WV>;                                                                  \
+    const int smem = 8 * 64 * 128 * 2;                                                                         \
+    static bool done = false;                                                                                  \
+    if (!done) {                                                                                               \
+      VT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));        \
+      done = true;                                                                                             \
+    }                                                                                                          \
+    dim3 grid(heads, cdiv(max_q_len, 256), nseq), block(512);                                                  \
+    hipLaunchKernelGGL(kern, grid, block, smem, s, Q, ldq, Kt, Vt, tile_table, seqs, O, ldo, heads, sl2);      \
+  } while (0)
+#ifdef VT_ABLATIONS
+    if (pp_w == 4) { if (causal) VT_FA_PP(true, 4); else VT_FA_PP(false, 4); }
+    else if (pp_w == 12) { if (causal) VT_FA_PP(true, 12); else VT_FA_PP(false, 12); }
+    else
+#endif
+    { if (causal) VT_FA_PP(true, 8); else VT_FA_PP(false, 8); }
+#undef VT_FA_PP
+    VT_LAUNCH_CHECK();
+    return VT_OK;
+  }
   if (HD == 64) {
     if (causal) VT_FA(64, true, 4, 2); else VT_FA(64, false, 4, 2);
 #ifdef VT_ABLATIONS
