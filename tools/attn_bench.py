@@ -45,9 +45,14 @@ def run(S, heads, hd, nseq, causal):
                       "tflops": round(flops / ms / 1e9, 1), "kv_tiles_ms": round(ms_kv, 4)}), flush=True)
 
 
+if __name__ == "__main__" and os.environ.get("ATTN_BENCH_ONLY_C3"):
+    _lib.load(ablations=True)
+    run(5120, 32, 128, 1, True)
+    sys.exit(0)
 if __name__ == "__main__":
-    _lib.load(ablations=bool(os.environ.get("VT_FLASH_ABL") or os.environ.get("VT_FLASH_QBLK256")))   # the switches exist only in the test library
+    _lib.load(ablations=any(os.environ.get(k) for k in ("VT_FLASH_ABL", "VT_FLASH_QBLK256", "VT_FLASH_PP", "VT_FLASH_PP_W", "VT_FLASH_PP_ABL")))   # the switches exist only in the test library
     run(5120, 32, 128, 1, True)
     run(1088, 32, 128, 1, True)
     run(577, 16, 64, 8, False)
     run(2048, 32, 128, 4, True)
+    run(5120, 32, 128, 8, True)         # C4: eight clips packed into one pass

@@ -621,6 +621,85 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmP8 p) {
 // the loads and masked for the stores, the bias is fetched once): with a load / wait / store round per fragment row the
 // read-modify-write of C cost 12 % of a one-round o_proj launch (5120 x 4096 x 4096: 1245 -> 1292 TFLOP/s, 1381 with a bf16 store).
 // The store-only epilogues keep the plain skip-past-the-edge form (the same restructuring measured 8 % SLOWER on them at K = 1024).
+// LDS-staged store epilogue (bf16 outputs of the 256 / 320-row tiles): the direct form above it writes, per store instruction, 8 bytes
+// per lane = 32 contiguous bytes in each of 16 rows -- 64 instructions per wave whose cost is per INSTRUCTION and per touched line, not
+// per byte (tools/vit_gemm_diag.py: 28 us of a 46 us K = 1024 launch do not depend on K). Here every wave parks its 128-column rows
+// as bf16 in the LDS the main loop no longer needs (wave-private region, 16-byte chunks XOR-swizzled by the row: conflict-free for
+// the 8-byte fragment writes and for the 16-byte row reads), reads them back row-contiguous and stores 16 bytes per lane: one
+// instruction = 4 rows x 256 contiguous bytes (whole 128-byte lines), half as many instructions.
+template <int EPI, int MT>
+__device__ __forceinline__ void w4_epilogue_lds(const GemmP8& p, f32x4 (&acc)[MT][8], int bm0, int bn0, int wr, int wc, int lane, char* smem,
+                                                int wave) {
+  static_assert(EPI == VT_EPI_BF16 || EPI == VT_EPI_BF16_GELU || EPI == VT_EPI_BF16_QGELU || EPI == VT_EPI_BF16_RELU || EPI == VT_EPI_SWIGLU_BF16, "bf16 store epilogues");
+  constexpr bool SW = EPI == VT_EPI_SWIGLU_BF16;
+  constexpr int RC = (MT == 8) ? 8 : 5;              // fragment rows per pass (MT = 10: two passes of 80 rows)
+  constexpr int ROWB = SW ? 128 : 256;               // bytes per parked row (64 | 128 bf16 columns)
+  constexpr int CH = ROWB / 16;                      // 16-byte chunks per row
+  constexpr int RPI = 64 / CH;                       // rows per read / store instruction
+  char* const my = smem + wave * (RC * 16 * ROWB);
+  const int r16 = lane & 15, cg = lane >> 4;
+  bf16_t* const C = (bf16_t*)p.C;
+  const int ncol0 = SW ? ((bn0 >> 1) + wc * 64) : (bn0 + wc * 128);   // first output column of this wave
+  const int nout = SW ? (p.N >> 1) : p.N;
+  f32x4 b4[8];
+  if constexpr (!SW) {
+#pragma unroll
+    for (int ni = 0; ni < 8; ++ni)
+      b4[ni] = p.bias ? *(const f32x4*)(p.bias + min(bn0 + wc * 128 + ni * 16 + (cg << 2), p.N - 4)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  __builtin_amdgcn_s_barrier();                      // every wave is done with the main loop's LDS image
+#pragma unroll
+  for (int c0 = 0; c0 < MT; c0 += RC) {
+#pragma unroll
+    for (int mi = c0; mi < c0 + RC; ++mi) {
+      const int row = (mi - c0) * 16 + r16;
+      if constexpr (SW) {
+#pragma unroll
+        for (int nj = 0; nj < 4; ++nj) {
+          const f32x4 g = acc[mi][2 * nj], u2 = acc[mi][2 * nj + 1];
+          u32x2 o;
+          o.x = pack_bf16x2(silu8(g[0]) * u2[0], silu8(g[1]) * u2[1]);
+          o.y = pack_bf16x2(silu8(g[2]) * u2[2], silu8(g[3]) * u2[3]);
+          *(u32x2*)(my + row * ROWB + (((nj * 2 + (cg >> 1)) ^ (row & (CH - 1))) << 4) + (cg & 1) * 8) = o;
+        }
+      } else {
+#pragma unroll
+        for (int ni = 0; ni < 8; ++ni) {
+          f32x4 v = acc[mi][ni] + b4[ni];
+          if constexpr (EPI == VT_EPI_BF16_GELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = gelu_erf8(v[r]);
+          } else if constexpr (EPI == VT_EPI_BF16_QGELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = quick_gelu8(v[r]);
+          } else if constexpr (EPI == VT_EPI_BF16_RELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+          }
+          u32x2 o;
+          o.x = pack_bf16x2(v[0], v[1]);
+          o.y = pack_bf16x2(v[2], v[3]);
+          *(u32x2*)(my + row * ROWB + (((ni * 2 + (cg >> 1)) ^ (row & (CH - 1))) << 4) + (cg & 1) * 8) = o;
+        }
+      }
+    }
+    // LDS operations of one wave complete in order: the reads below see the writes above without a block barrier -- but the COMPILER must
+    // not move them across each other (it may take the 8-byte stores and the 16-byte loads for non-aliasing)
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+    const int m_base = bm0 + wr * (MT * 16) + c0 * 16;
+#pragma unroll
+    for (int j = 0; j < RC * 16 / RPI; ++j) {
+      const int row = j * RPI + lane / CH, ck = lane % CH;
+      const u32x4 d = *(const u32x4*)(my + row * ROWB + ((ck ^ (row & (CH - 1))) << 4));
+      const int m = m_base + row, n = ncol0 + ck * 8;
+      if (m < p.M && n < nout) *(u32x4*)(C + (size_t)m * p.ldc + n) = d;
+    }
+    __builtin_amdgcn_wave_barrier();                 // (the next pass overwrites the region)
+    asm volatile("" ::: "memory");
+  }
+}
+
 template <int EPI, int MT, int NI = 8>
 __device__ __forceinline__ void w4_epilogue(const GemmP8& p, f32x4 (&acc)[MT][NI], int bm0, int bn0, int wr, int wc, int lane) {
   constexpr int WN = NI * 16;   // columns per wave
@@ -881,13 +960,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #undef W4S_MFMA
 #undef W4S_DMA
 #undef W4S_DMA_X
-  w4_epilogue<EPI, MT>(p, acc, bm0, bn0, wr, wc, lane);
+  constexpr bool bf16_store = EPI == VT_EPI_BF16 || EPI == VT_EPI_BF16_GELU || EPI == VT_EPI_BF16_QGELU || EPI == VT_EPI_BF16_RELU || EPI == VT_EPI_SWIGLU_BF16;
+  if constexpr (ABL & 32) {                          // timing ablation: no epilogue stores at all
+    float t = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 8; ++ni) t += acc[mi][ni][0] + acc[mi][ni][3];
+    if (t == 1.2345e-30f) *(float*)p.C = t;
+  } else if constexpr (bf16_store && !(ABL & 64)) {
+    w4_epilogue_lds<EPI, MT>(p, acc, bm0, bn0, wr, wc, lane, smem, wave);      // (launch_w4 checked alignment and N % 8)
+  } else {
+    w4_epilogue<EPI, MT>(p, acc, bm0, bn0, wr, wc, lane);
+  }
 }
 
 template <int EPI, int MT = 8, int ABL = 0, int AUX_A = 0, int AUX_B = 0>
 int launch_w4(const GemmP8& p, hipStream_t s) {
   constexpr int BM = MT * 32;
   constexpr int smem = 2 * (BM * 128 + 256 * 128);  // 128 KiB | 144 KiB
+  constexpr bool bf16_store = EPI == VT_EPI_BF16 || EPI == VT_EPI_BF16_GELU || EPI == VT_EPI_BF16_QGELU || EPI == VT_EPI_BF16_RELU || EPI == VT_EPI_SWIGLU_BF16;
+  if constexpr (bf16_store && !(ABL & (32 | 64))) {
+    // the LDS-staged store epilogue writes 16-byte row chunks: rows 16-byte aligned and whole 8-column chunks inside the matrix,
+    // otherwise the variant with the direct epilogue (which masks 4-column groups)
+    const int nout = (EPI == VT_EPI_SWIGLU_BF16) ? (p.N >> 1) : p.N;
+    if ((nout & 7) != 0 || (p.ldc & 7) != 0 || (((size_t)p.C) & 15) != 0) return launch_w4<EPI, MT, ABL | 64, AUX_A, AUX_B>(p, s);
+  }
   auto kern = gemm_w4_kernel<EPI, MT, ABL, AUX_A, AUX_B>;
   static bool done = false;
   if (!done) {
@@ -1440,6 +1538,18 @@ int vt_gemm_p8_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* 
       default: vt_set_error("vt_gemm(w4r): unknown epilogue %d", epi & 0xff); return VT_ERR_ARG;
     }
   }
+#ifdef VT_ABLATIONS
+  static const int w4_direct = getenv("VT_W4_EPI_DIRECT") ? atoi(getenv("VT_W4_EPI_DIRECT")) : 0;   // A/B: the direct store epilogue
+  if (w4_direct && (epi & 0x4000)) {
+    const bool t320 = (epi & 0x8000) != 0;
+    switch (epi & 0xff) {
+      case VT_EPI_BF16: return t320 ? launch_w4<VT_EPI_BF16, 10, 64>(p, s) : launch_w4<VT_EPI_BF16, 8, 64>(p, s);
+      case VT_EPI_BF16_GELU: return t320 ? launch_w4<VT_EPI_BF16_GELU, 10, 64>(p, s) : launch_w4<VT_EPI_BF16_GELU, 8, 64>(p, s);
+      case VT_EPI_SWIGLU_BF16: return t320 ? launch_w4<VT_EPI_SWIGLU_BF16, 10, 64>(p, s) : launch_w4<VT_EPI_SWIGLU_BF16, 8, 64>(p, s);
+      default: break;
+    }
+  }
+#endif
   if ((epi & 0x4000) && (epi & 0x8000)) {   // 4-wave kernel, 320-row tile (160x128 per wave)
     VT_REQUIRE(!nf, "vt_gemm(w4): no norm fold in the 4-wave kernel");
     switch (epi & 0xff) {
@@ -1467,6 +1577,8 @@ int vt_gemm_p8_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* 
           case 8: return launch_w4<VT_EPI_BF16, 8, 8>(p, s);
           case 15: return launch_w4<VT_EPI_BF16, 8, 15>(p, s);
           case 16: return launch_w4<VT_EPI_BF16, 8, 16>(p, s);
+          case 32: return launch_w4<VT_EPI_BF16, 8, 32>(p, s);     // no epilogue stores
+          case 64: return launch_w4<VT_EPI_BF16, 8, 64>(p, s);     // the direct (8 bytes per lane) store epilogue
           default: break;
         }
 #endif
