@@ -106,11 +106,6 @@ int vt_rmsnorm(const float* x, const int* idx, const float* w, uint16_t* y, int 
 int vt_flash_attn(const uint16_t* Q, int ldq, const uint16_t* k_tiles, const uint16_t* vt_tiles, const int* tile_table,
                   const int* seq_desc, int nseq, int max_q_len, uint16_t* O, int ldo, int heads, int head_dim,
                   int causal, float scale, void* stream);
-/* Dispatch threshold of vt_flash_attn at head_dim 128: prefills with max_q_len >= rows run the 8-wave ping-pong kernel (256-row
- * blocks, one per CU: built for long sequences), shorter ones the 4-wave kernel (128-row blocks). rows > 0 sets it (process-wide
- * tuning knob, default 2048; the tests use it to drive both kernels over the same shapes), rows <= 0 only queries; returns the
- * previous value. */
-int vt_flash_attn_set_pp_min_rows(int rows);
 /* Residual GEMM C[M,N] (fp32) += A[M,K] W[N,K]^T + bias with an optional split-K workspace: when the 256x256 tile grid would
  * cover at most half of the chip (M ~ 1000 rows at N = 4096, the ViT's N = 1024 projections) the K loop is split over up to 8
  * workgroups per tile, fp32 partial products go to `partials` and a second kernel adds them in split order (deterministic).

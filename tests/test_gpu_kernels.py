@@ -571,13 +571,11 @@ def test_cross_entropy_matches_torch(dev, rows, V):
 
 @pytest.mark.parametrize("causal,lens,pasts", [(True, [700, 300, 64, 1], [0, 0, 0, 0]), (False, [577, 130], [0, 0]),
                                                 (True, [257, 40], [100, 1000]), (True, [2304], [0])])
-def test_flash_attention_ping_pong_kernel_matches_four_wave_kernel(dev, causal, lens, pasts):
-    """flash_attn_pp_kernel (8 waves, 256-row blocks, two wave groups half a tile apart; default for >= 2048 query rows at head_dim
-    128) forced onto small / ragged / multi-sequence / chunked (past > 0) problems through vt_flash_attn_set_pp_min_rows: waves past
-    the end of a sequence, blocks with one tile, causal waves that finish before their block does. Against fp64 attention on the
-    same bf16 q / k / v and against the four-wave kernel (same arithmetic, other schedule: equal up to the order of the fp32 sums)."""
-    from vitron_amd import _lib, ops
-    lib = _lib.load()
+def test_flash_attention_ragged_multi_sequence_chunked_vs_fp64(dev, causal, lens, pasts):
+    """The flash kernel at head_dim 128 on ragged / multi-sequence / chunked (past > 0) / long problems over a shuffled page table
+    (sequences of 1 and of 2304 rows, blocks with one tile, a chunk of 40 rows behind 1000 cached keys) against fp64 attention on
+    the same bf16 q / k / v. (Written for the 8-wave ping-pong variant of round 3, which measured slower and was removed: DESIGN.md 3.1.)"""
+    from vitron_amd import ops
     heads, hd = 3, 128
     D = heads * hd
     scale = 1.0 / math.sqrt(hd)
@@ -604,13 +602,7 @@ def test_flash_attention_ping_pong_kernel_matches_four_wave_kernel(dev, causal, 
         q_rows.append(x[pasts[i]:, :D])
     qcat = torch.cat(q_rows, 0).contiguous()
     desc = torch.tensor(desc_new, dtype=torch.int32, device=dev)
-    prev = lib.vt_flash_attn_set_pp_min_rows(1)
-    try:
-        got = ops.flash_attn(qcat, kt, vt, table_t, desc, max(lens), heads, hd, causal, scale)
-        lib.vt_flash_attn_set_pp_min_rows(1 << 30)
-        old = ops.flash_attn(qcat, kt, vt, table_t, desc, max(lens), heads, hd, causal, scale)
-    finally:
-        lib.vt_flash_attn_set_pp_min_rows(prev)
+    got = ops.flash_attn(qcat, kt, vt, table_t, desc, max(lens), heads, hd, causal, scale)
     torch.cuda.synchronize()
     assert torch.isfinite(got.float()).all()
     r0 = 0
@@ -624,5 +616,4 @@ def test_flash_attention_ping_pong_kernel_matches_four_wave_kernel(dev, causal, 
             s = s.masked_fill(mask[None], float("-inf"))
         ref = torch.einsum("hqk,khd->qhd", torch.softmax(s, -1), vv).reshape(q, D).float()
         assert rel_l2(got[r0:r0 + q].float(), bf16r(ref)) <= 3e-3, (i, rel_l2(got[r0:r0 + q].float(), bf16r(ref)))
-        assert rel_l2(got[r0:r0 + q].float(), old[r0:r0 + q].float()) <= 2e-3
         r0 += q

@@ -50,7 +50,7 @@ if __name__ == "__main__" and os.environ.get("ATTN_BENCH_ONLY_C3"):
     run(5120, 32, 128, 1, True)
     sys.exit(0)
 if __name__ == "__main__":
-    _lib.load(ablations=any(os.environ.get(k) for k in ("VT_FLASH_ABL", "VT_FLASH_QBLK256", "VT_FLASH_PP", "VT_FLASH_PP_W", "VT_FLASH_PP_ABL")))   # the switches exist only in the test library
+    _lib.load(ablations=any(os.environ.get(k) for k in ("VT_FLASH_ABL", "VT_FLASH_QBLK256")))   # the switches exist only in the test library
     run(5120, 32, 128, 1, True)
     run(1088, 32, 128, 1, True)
     run(577, 16, 64, 8, False)

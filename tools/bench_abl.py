@@ -1,5 +1,5 @@
 """bench.py on the -DVT_ABLATIONS build of the library (libvitron_hip_abl.so), so that the environment switches of the A/B variants
-(VT_W4_EPI_DIRECT, VT_FLASH_PP, ...) apply to the whole benchmark step: python tools/bench_abl.py <bench.py arguments>.
+(VT_W4_EPI_DIRECT, VT_FLASH_ABL, ...) apply to the whole benchmark step: python tools/bench_abl.py <bench.py arguments>.
 Measurement helper; the product benchmark is bench.py on libvitron_hip.so."""
 import os
 import runpy

@@ -70,7 +70,6 @@ SIGNATURES = {
     "vt_layernorm": (_i, [vp, vp, _i, _i, vp, vp, vp, _i, _i, _f, vp]),
     "vt_rmsnorm": (_i, [vp, vp, vp, vp, _i, _i, _f, vp]),
     "vt_flash_attn": (_i, [vp, _i, vp, vp, vp, vp, _i, _i, vp, _i, _i, _i, _i, _f, vp]),
-    "vt_flash_attn_set_pp_min_rows": (_i, [_i]),
     "vt_attn_decode_scratch_bytes": (_sz, [_i, _i, _i, _i]),
     "vt_attn_decode": (_i, [vp, _i, vp, vp, vp, vp, _i, vp, _i, _i, _i, _f, _i, vp, _sz, vp]),
     "vt_gemm_plan_query": (_i, [_i, _i, _i, _i, vp, vp]),

@@ -149,8 +149,6 @@ int vt_flash_attn(const uint16_t* Q, int ldq, const uint16_t* k_tiles, const uin
                               ldo, heads, head_dim, causal, scale, S(stream));
 }
 
-int vt_flash_attn_set_pp_min_rows(int rows) { return vt_flash_attn_pp_min_rows(rows); }
-
 size_t vt_attn_decode_scratch_bytes(int nseq, int heads, int head_dim, int max_kv_len);  // defined in vt_attn.hip (C++ linkage there)
 int vt_attn_decode(const uint16_t* Q, int ldq, const uint16_t* k_tiles, const uint16_t* vt_tiles, const int* tile_table,
                    const int* seq_desc, int nseq, uint16_t* O, int ldo, int heads, int head_dim, float scale,

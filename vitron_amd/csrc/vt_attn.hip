@@ -39,9 +39,7 @@ __device__ __forceinline__ int k_swz(int key) {
 }
 __device__ __forceinline__ int v_swz(int d) { return (d >> 1) & 7; }
 
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
 #define RESCALE_THR 8.0f
-#define VT_FLASH_PP_MIN_ROWS 2048   // prefills at least this long (head_dim 128) run flash_attn_pp_kernel
 // The softmax weights feed the P.V MFMA as fp16 (11 mantissa bits; V^T pages hold fp16, see vt_common.h). They are computed as
 // 2^(s - m_run + P_BIAS): with the deferred rescale P <= 2^(RESCALE_THR + P_BIAS) = 2^15 < 65504, and the smallest NORMAL fp16
 // (2^-14) sits 2^-21 below the running maximum's weight instead of 2^-14, so that the long tail of a peaked row is not lost to
@@ -293,369 +291,6 @@ __global__ __launch_bounds__(64 * NWAVES, (NWAVES == 8) ? 2 : 2) void flash_attn
 #undef FA_TILE_SYNC
 
   // ---- epilogue ------------------------------------------------------------------------------------------------
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = (l_tot > 0.f) ? 1.f / l_tot : 0.f;
-  if (qrow < sq.q_len) {
-    bf16_t* op = O + (size_t)(sq.q_row0 + qrow) * ldo + head * HD + 4 * hh;
-#pragma unroll
-    for (int db = 0; db < DB; ++db)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        u32x2 o;
-        o.x = pack_bf16x2(oacc[db][4 * g + 0] * inv, oacc[db][4 * g + 1] * inv);
-        o.y = pack_bf16x2(oacc[db][4 * g + 2] * inv, oacc[db][4 * g + 3] * inv);
-        *(u32x2*)(op + db * 32 + 8 * g) = o;
-      }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// flash_attn_pp_kernel<CAUSAL>: the long-prefill attention (head_dim 128, >= 2048 query rows): 8 waves, 256 query rows per block, the
-// two waves of a SIMD alternate between a COMPUTE slot (MFMAs on operands that are already in registers, the softmax arithmetic
-// of the same wave in the gaps between them) and a LOAD slot (LDS -> registers, LDS-DMA of tiles to come), four slots per 64-key tile:
-//
-//     slot          4j               4j+1             4j+2              4j+3
-//     waves 0-3     L1: K(j) -> reg  C1: QK(j)        L2: V(j-1) -> reg C2: PV(j-1) || softmax(j)
-//     waves 4-7     C2(j-1)          L1(j)            C1(j)             L2(j)                          (one slot behind)
-//
-// Same arithmetic as flash_attn_kernel (all-swapped S^T = K.Q^T / O^T = V^T.P^T, permuted K rows, fp16 P and V^T, deferred rescale).
-// What the schedule is built on (measured on this part):
-//   * flash_attn_kernel's MFMA, softmax and "skeleton" times ADD UP (135 + 60 + 95 us at S = 5120): its two waves per SIMD fall into
-//     the same phase, and every fragment read is followed by its wait;
-//   * a first ping-pong version -- MFMA section of one wave beside the WHOLE softmax of its SIMD partner -- did not overlap either:
-//     sections alone 149 us, softmax alone 117 us, together 324 us. The matrix pipe and the VALU of one SIMD overlap for instructions
-//     of the SAME wave (a v_mfma_f32_32x32x16 occupies the pipe for 32 cycles, ~5 other instructions of that wave issue meanwhile),
-//     hardly for two waves; what a partner wave can do for free beside a compute slot is LDS and DMA traffic.
-// Hence: the 16 K (V^T) fragments of a tile are read into a 64-register block in the wave's load slot (the block is time-shared by K
-// and V^T), the compute slots issue nothing but MFMAs + VALU, the exponentials / row sums / fp16 packing of tile j run between the
-// PV MFMAs of tile j - 1 (two P sets), and the O rescale of a row-max jump is applied after those MFMAs (P(j-1) still belongs to the old
-// maximum). LDS: rings of 3 K + 3 V^T tiles (96 KiB, one block per CU); a wave stages its pieces of V(j+1) in L1(j) and of K(j+2) in
-// L2(j) and waits for everything older at the end of L2(j), so that each tile has >= 4 slots of flight and every wave's wait for it
-// lies behind a barrier before the first read. A wave finishes its fragment reads before the barrier that ends its load slot.
-// Causal: a wave whose rows end before tile j skips the slots' work but keeps staging and meeting the barriers. One instruction
-// stream serves every active slot: at j = 0 the PV half multiplies an all-zero P with V(0), at a wave's last iteration QK scores a
-// tile that is never looked at.
-// ABL (timing ablations, test library only; garbage results): 1 = no softmax arithmetic, 2 = no LDS-DMA in the loop, 4 = no MFMAs.
-// ------------------------------------------------------------------------------------------------------------------
-template <bool CAUSAL, int ABL = 0>
-__global__ __launch_bounds__(512, 2) void flash_attn_pp_kernel(const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ Kt,
-                                                              const bf16_t* __restrict__ Vt, const int* __restrict__ tile_table,
-                                                              const VtAttnSeq* __restrict__ seqs, bf16_t* __restrict__ O, int ldo,
-                                                              int heads, float scale_log2e) {
-  constexpr int HD = 128, KS = 8, DB = 4, KROW = 256, TILE = 64 * HD * 2, NST = 3, QBLK = 256, PPW = 2;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const kring = smem;
-  char* const vring = smem + NST * TILE;
-
-  const VtAttnSeq sq = seqs[blockIdx.z];
-  const int nqb = (sq.q_len + QBLK - 1) / QBLK;
-  const int qb = nqb - 1 - (int)blockIdx.y;            // heavy (late) causal blocks first, as in flash_attn_kernel
-  if (qb < 0) return;
-  const int head = blockIdx.x;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int grp = wave >> 2;
-  const int ql = lane & 31, hh = lane >> 5;
-  const int past = sq.kv_len - sq.q_len;
-  const int q0 = qb * QBLK;
-  const int qrow = q0 + wave * 32 + ql;
-  const int qrow_c = min(qrow, sq.q_len - 1);
-
-  int ntiles = (sq.kv_len + 63) >> 6;                  // tiles the BLOCK walks
-  if (CAUSAL) ntiles = min(ntiles, ((past + min(q0 + QBLK - 1, sq.q_len - 1)) >> 6) + 1);
-  int wtiles = ntiles;                                  // tiles THIS WAVE has work in
-  if (CAUSAL) wtiles = min(ntiles, ((past + min(q0 + wave * 32 + 31, sq.q_len - 1)) >> 6) + 1);
-  if (q0 + wave * 32 >= sq.q_len) wtiles = 0;          // a wave past the end of the sequence only stages and meets barriers
-
-  bf16x8 qf[KS];
-  {
-    const bf16_t* qp = Q + (size_t)(sq.q_row0 + qrow_c) * ldq + head * HD + hh * 8;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
-  }
-  // LDS-DMA source offsets of this wave's two 1-KiB pieces of a K tile / a V^T tile (swizzle on the source side)
-  int k_src_off[PPW], v_src_off[PPW];
-#pragma unroll
-  for (int i = 0; i < PPW; ++i) {
-    const int byte = (wave * PPW + i) * 1024 + lane * 16;
-    {
-      const int row = byte / KROW, c = (byte % KROW) >> 4;
-      k_src_off[i] = row * HD + ((c ^ k_swz<HD>(row)) << 3);
-    }
-    {
-      const int row = byte >> 7, c = (byte & 127) >> 4;
-      v_src_off[i] = row * 64 + ((c ^ v_swz(row)) << 3);
-    }
-  }
-  const size_t head_off = (size_t)head * 64 * HD;
-  const size_t tile_stride = (size_t)heads * 64 * HD;
-  const int* table = tile_table + sq.table_off;
-  auto stage_k = [&](int t) {
-    const size_t toff = (size_t)table[t] * tile_stride + head_off;
-    char* base = kring + (t % NST) * TILE;
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) glds16(Kt + toff + k_src_off[i], base + (wave * PPW + i) * 1024);
-  };
-  auto stage_v = [&](int t) {
-    const size_t toff = (size_t)table[t] * tile_stride + head_off;
-    char* base = vring + (t % NST) * TILE;
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) glds16(Vt + toff + v_src_off[i], base + (wave * PPW + i) * 1024);
-  };
-
-  // fragment read offsets (identical to flash_attn_kernel)
-  const int pi = 16 * ((ql >> 2) & 1) + (ql & 3) + 4 * (ql >> 3);
-  const int k_sw0 = k_swz<HD>(pi);
-  const int v_sw = v_swz(ql);
-  const uint32_t k_ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)kring;
-  const uint32_t v_ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)vring;
-  // per-lane LDS byte addresses inside ring slot 0, as base + swizzled chunk: the 8 (4) chunk terms are recomputed in the load slots
-  // (two VALU instructions per read, where the VALU is idle) instead of living in 12 registers through the compute slots
-  const uint32_t k_lane0 = k_ring_lds + pi * KROW, v_lane0 = v_ring_lds + ql * 128;
-  const uint32_t k_x = hh ^ k_sw0, v_x = (2 * hh) ^ v_sw;      // (ks * 2 + hh) ^ k_sw0 == (ks * 2) ^ k_x;  (sub * 4 + 2 hh + j) ^ v_sw == (sub * 4 + j) ^ v_x
-
-  f32x16 oacc[DB];
-#pragma unroll
-  for (int db = 0; db < DB; ++db)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[db][r] = 0.f;
-  f32x16 sacc[2];
-  f16x8 pf[2][2];                                       // P of the tile whose PV product is next
-#pragma unroll
-  for (int i = 0; i < 4; ++i) pf[i >> 1][i & 1] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
-  float m_run = -INFINITY, l_run = 0.f;
-  u32x4 kv[16];                                         // the fragment block: K(j) between L1 and C1, V^T(j-1) between L2 and C2
-
-  // The reads are asm statements (left to the compiler every read sinks next to its use, into the compute slot); the one wait at the end
-  // of the load slot names all 16 destinations, which is what orders the MFMAs (builtins: the compiler pads their hazards) behind it.
-#define FA_PP_RD(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
-#define FA_PP_WAIT_KV()                                                                                             \
-  asm volatile("s_waitcnt lgkmcnt(0)"                                                                               \
-               : "+v"(kv[0]), "+v"(kv[1]), "+v"(kv[2]), "+v"(kv[3]), "+v"(kv[4]), "+v"(kv[5]), "+v"(kv[6]), "+v"(kv[7]), "+v"(kv[8]), \
-                 "+v"(kv[9]), "+v"(kv[10]), "+v"(kv[11]), "+v"(kv[12]), "+v"(kv[13]), "+v"(kv[14]), "+v"(kv[15]))
-#define FA_PP_WAIT_VM(N)                                                             \
-  do {                                                                               \
-    if ((N) >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                   \
-    else if ((N) >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");              \
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            \
-  } while (0)
-#define FA_PP_SLOT_END()                 \
-  do {                                   \
-    __builtin_amdgcn_sched_barrier(0);   \
-    __builtin_amdgcn_s_barrier();        \
-    __builtin_amdgcn_sched_barrier(0);   \
-  } while (0)
-
-  // ---- prologue: K(0), K(1), V(0) landed and visible before the first slot ------------------------------------------------------
-  if (0 < ntiles) stage_k(0);
-  if (1 < ntiles) stage_k(1);
-  if (0 < ntiles) stage_v(0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  if (grp) __builtin_amdgcn_s_barrier();               // waves 4-7 run one slot behind waves 0-3
-  __builtin_amdgcn_sched_barrier(0);
-
-  // Three loops instead of one body with `if (active)` around every slot: values that are produced in one slot and consumed in the next
-  // (the fragment block, S) would otherwise pass through the merge points behind those ifs, become loop-carried and cost ~100 copies
-  // per tile and 40 spilled registers.
-  //   j < wtiles            full iteration
-  //   j == wtiles (> 0)     the wave's last product: V^T(j-1) -> registers, PV(j-1)
-  //   after that            staging and barriers only
-#define FA_PP_STAGE_V(J, N)                        \
-  if (!(ABL & 2) && (J) + 1 < ntiles) {            \
-    stage_v((J) + 1);                              \
-    (N) += PPW;                                    \
-  }
-#define FA_PP_STAGE_K(J, N)                        \
-  if (!(ABL & 2) && (J) + 2 < ntiles) {            \
-    stage_k((J) + 2);                              \
-    (N) += PPW;                                    \
-  }
-#define FA_PP_PV_ONLY()                                                                                             \
-  _Pragma("unroll") for (int i = 0; i < 16; ++i)                                                                    \
-    oacc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, kv[i]), pf[i >> 3][(i >> 2) & 1], oacc[i & 3], 0, 0, 0)
-  int j = 0;
-  for (; j < wtiles; ++j) {
-    // ---- L1(j): K(j) -> registers; this wave's pieces of V(j+1) ------------------------------------------------------------------
-    int n_new = 0;
-    if (!(ABL & 4)) {
-      const uint32_t kb = (j % NST) * TILE;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) FA_PP_RD(kv[i], k_lane0 + kb + ((((i >> 1) * 2) ^ k_x) << 4), (i & 1) * (32 * KROW));
-    }
-    FA_PP_STAGE_V(j, n_new)
-    if (!(ABL & 4)) FA_PP_WAIT_KV();
-    FA_PP_SLOT_END();
-    // ---- C1(j): S(j)^T = K(j) . Q^T -------------------------------------------------------------------------------------------------
-    if (!(ABL & 4)) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        if (i < 2) {
-          const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          sacc[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kv[i]), qf[0], z, 0, 0, 0);
-        } else {
-          sacc[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kv[i]), qf[i >> 1], sacc[i & 1], 0, 0, 0);
-        }
-      }
-    }
-    FA_PP_SLOT_END();
-    // ---- L2(j): V^T(j-1) -> registers; this wave's pieces of K(j+2); everything older than this iteration's pieces has landed -------
-    if (!(ABL & 4)) {
-      const uint32_t vb = (max(j - 1, 0) % NST) * TILE;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) FA_PP_RD(kv[i], v_lane0 + vb + (((((i >> 3) * 4) + ((i >> 2) & 1)) ^ v_x) << 4), (i & 3) * (32 * 128));
-    }
-    FA_PP_STAGE_K(j, n_new)
-    FA_PP_WAIT_VM(n_new);
-    if (!(ABL & 4)) FA_PP_WAIT_KV();
-    FA_PP_SLOT_END();
-    // ---- C2(j): O^T += V^T(j-1) . P(j-1)^T  ||  softmax of S(j) -> P(j) ------------------------------------------------------------
-    if (ABL & 4) {
-    } else if (ABL & 1) {
-      FA_PP_PV_ONLY();
-    } else {
-      const int key0 = j * 64;
-      const bool need_mask = (key0 + 64 > sq.kv_len) || (CAUSAL && (key0 + 63 > past + q0 + wave * 32));
-      if (need_mask) {
-        asm volatile("" ::: "memory");                  // a real branch (see flash_attn_kernel)
-        const int lim = CAUSAL ? min(sq.kv_len - 1, past + qrow) : (sq.kv_len - 1);
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int key = key0 + sub * 32 + 16 * hh + r;
-            if (key > lim) sacc[sub][r] = -INFINITY;
-          }
-      }
-      // row maximum: four independent chains (one wave has the VALU to itself here, so a 16-deep dependent chain is all latency)
-      float mq[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        mq[q] = __builtin_fmaxf(__builtin_fmaxf(sacc[0][4 * q], sacc[1][4 * q]), sacc[0][4 * q + 1]);
-        mq[q] = __builtin_fmaxf(__builtin_fmaxf(mq[q], sacc[1][4 * q + 1]), sacc[0][4 * q + 2]);
-        mq[q] = __builtin_fmaxf(__builtin_fmaxf(mq[q], sacc[1][4 * q + 2]), sacc[0][4 * q + 3]);
-        mq[q] = __builtin_fmaxf(mq[q], sacc[1][4 * q + 3]);
-      }
-      float mx = __builtin_fmaxf(__builtin_fmaxf(mq[0], mq[1]), __builtin_fmaxf(mq[2], mq[3]));
-      if (ABL & 32) mx = 1.0f; else
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_tile = mx * scale_log2e;
-      float alpha = 1.f;
-      const bool resc = (ABL & 32) ? (j == 0) : (__builtin_amdgcn_ballot_w64(m_tile > m_run + RESCALE_THR) != 0);
-      if (resc) {                                       // the O rescale itself waits until PV(j-1) is in: P(j-1) belongs to the old maximum
-        const float m_new = fmaxf(m_run, m_tile);
-        alpha = (m_new == -INFINITY) ? 1.f : fast_exp2(m_run - m_new);
-        m_run = m_new;
-        l_run *= alpha;
-      }
-      const float m_safe = (m_run == -INFINITY) ? 0.f : m_run;
-      const f32x2_t sc2 = {scale_log2e, scale_log2e}, ms2 = {P_BIAS - m_safe, P_BIAS - m_safe};
-      // PV MFMA i of tile j - 1, then one step of the softmax of S(j), software-pipelined so that nothing in a step depends on anything
-      // else in it (this wave has the VALU to itself: a dependent chain costs its full latency, ~50 cycles per step against 32 for the
-      // MFMA): scale-and-shift of score pair i + 1, the two exponentials of pair i, the row-sum add of pair i - 1 (two alternating
-      // partial sums), and after every fourth pair the fp16 pack of the eight weights that were complete one step earlier. Pair i =
-      // scores 2 (i % 8), 2 (i % 8) + 1 of key half i / 8. MFMAs and VALU do not depend on each other, so instruction selection is
-      // free to emit all MFMAs first (it did): the empty asm after every step takes the accumulators, S, the pending pair and the sums
-      // through a volatile statement, which keeps step i + 1 behind step i.
-      f16x8 pn[2][2];
-      f32x2_t ps0 = {0.f, 0.f}, ps1 = {0.f, 0.f};
-      f32x2_t yv = __builtin_elementwise_fma((f32x2_t){sacc[0][0], sacc[0][1]}, sc2, ms2);
-      __builtin_amdgcn_sched_barrier(0);
-#define FA_PP_PACK(G)                                                                                         \
-  do {                                                                                                        \
-    u32x4 w_;                                                                                                 \
-    w_.x = pack_f16x2(sacc[(G) >> 1][8 * ((G) & 1) + 0], sacc[(G) >> 1][8 * ((G) & 1) + 1]);                  \
-    w_.y = pack_f16x2(sacc[(G) >> 1][8 * ((G) & 1) + 2], sacc[(G) >> 1][8 * ((G) & 1) + 3]);                  \
-    w_.z = pack_f16x2(sacc[(G) >> 1][8 * ((G) & 1) + 4], sacc[(G) >> 1][8 * ((G) & 1) + 5]);                  \
-    w_.w = pack_f16x2(sacc[(G) >> 1][8 * ((G) & 1) + 6], sacc[(G) >> 1][8 * ((G) & 1) + 7]);                  \
-    pn[(G) >> 1][(G) & 1] = __builtin_bit_cast(f16x8, w_);                                                    \
-  } while (0)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        oacc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, kv[i]), pf[i >> 3][(i >> 2) & 1], oacc[i & 3], 0, 0, 0);
-        const int sub = i >> 3, r = 2 * (i & 7);
-        f32x2_t yn = yv;
-        if (i < 15) {
-          if (ABL & 16) {
-            yn.x = __builtin_fmaf(sacc[(i + 1) >> 3][2 * ((i + 1) & 7)], scale_log2e, ms2.x);
-            yn.y = __builtin_fmaf(sacc[(i + 1) >> 3][2 * ((i + 1) & 7) + 1], scale_log2e, ms2.x);
-          } else {
-            yn = __builtin_elementwise_fma((f32x2_t){sacc[(i + 1) >> 3][2 * ((i + 1) & 7)], sacc[(i + 1) >> 3][2 * ((i + 1) & 7) + 1]}, sc2, ms2);
-          }
-        }
-        const float e0 = (ABL & 8) ? yv.x : fast_exp2(yv.x), e1 = (ABL & 8) ? yv.y : fast_exp2(yv.y);
-        if (i > 0) {
-          const f32x2_t ep = {sacc[(i - 1) >> 3][2 * ((i - 1) & 7)], sacc[(i - 1) >> 3][2 * ((i - 1) & 7) + 1]};
-          if (i & 1) ps1 += ep; else ps0 += ep;
-        }
-        if (i > 0 && (i & 3) == 0 && !(ABL & 64)) FA_PP_PACK((i >> 2) - 1);
-        sacc[sub][r] = e0;
-        sacc[sub][r + 1] = e1;
-        yv = yn;
-        asm volatile("" : "+v"(oacc[0]), "+v"(oacc[1]), "+v"(oacc[2]), "+v"(oacc[3]), "+v"(sacc[0]), "+v"(sacc[1]), "+v"(yv), "+v"(ps0), "+v"(ps1));
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      ps0 += (f32x2_t){sacc[1][14], sacc[1][15]};
-      if (ABL & 64) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) pn[g >> 1][g & 1] = pf[g >> 1][g & 1];
-      } else {
-        FA_PP_PACK(3);
-      }
-#undef FA_PP_PACK
-      const f32x2_t psum2 = ps0 + ps1;
-      if (resc) {
-#pragma unroll
-        for (int db = 0; db < DB; ++db)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
-      }
-      l_run += psum2.x + psum2.y;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) pf[i >> 1][i & 1] = pn[i >> 1][i & 1];
-    }
-    FA_PP_SLOT_END();          // (j < wtiles <= ntiles: never the block's last iteration)
-  }
-  if (wtiles > 0) {            // j == wtiles: the last PV product of this wave
-    int n_new = 0;
-    FA_PP_STAGE_V(j, n_new)
-    FA_PP_SLOT_END();
-    FA_PP_SLOT_END();
-    if (!(ABL & 4)) {
-      const uint32_t vb = ((j - 1) % NST) * TILE;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) FA_PP_RD(kv[i], v_lane0 + vb + (((((i >> 3) * 4) + ((i >> 2) & 1)) ^ v_x) << 4), (i & 3) * (32 * 128));
-    }
-    FA_PP_STAGE_K(j, n_new)
-    FA_PP_WAIT_VM(n_new);
-    if (!(ABL & 4)) {
-      FA_PP_WAIT_KV();
-    }
-    FA_PP_SLOT_END();
-    if (!(ABL & 4)) FA_PP_PV_ONLY();
-    if (j < ntiles) FA_PP_SLOT_END();
-    ++j;
-  }
-  for (; j <= ntiles; ++j) {   // nothing left to compute: keep staging for the waves that still work, and keep meeting the barriers
-    int n_new = 0;
-    FA_PP_STAGE_V(j, n_new)
-    FA_PP_SLOT_END();
-    FA_PP_SLOT_END();
-    FA_PP_STAGE_K(j, n_new)
-    FA_PP_WAIT_VM(n_new);
-    FA_PP_SLOT_END();
-    if (j < ntiles) FA_PP_SLOT_END();
-  }
-#undef FA_PP_PV_ONLY
-#undef FA_PP_STAGE_K
-#undef FA_PP_STAGE_V
-#undef FA_PP_SLOT_END
-#undef FA_PP_WAIT_VM
-#undef FA_PP_WAIT_KV
-#undef FA_PP_RD
-  // barrier counts: both halves run 4 (ntiles + 1) - 1 slot ends; waves 4-7 met one more at the start
-  if (!grp) __builtin_amdgcn_s_barrier();
-
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = (l_tot > 0.f) ? 1.f / l_tot : 0.f;
   if (qrow < sq.q_len) {
@@ -1333,13 +968,6 @@ __global__ __launch_bounds__(256) void attn_temporal8_kernel(const bf16_t* __res
 
 }  // namespace
 
-static int g_flash_pp_min_rows = VT_FLASH_PP_MIN_ROWS;
-int vt_flash_attn_pp_min_rows(int rows) {
-  const int prev = g_flash_pp_min_rows;
-  if (rows > 0) g_flash_pp_min_rows = rows;
-  return prev;
-}
-
 int vt_flash_attn_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf16_t* Vt, const int* tile_table,
                          const VtAttnSeq* seqs, int nseq, int max_q_len, bf16_t* O, int ldo, int heads, int HD,
                          int causal, float scale, hipStream_t s) {
@@ -1371,46 +999,6 @@ int vt_flash_attn_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf16_
     dim3 grid(heads, cdiv(max_q_len, 32 * NW), nseq), block(64 * NW);                                          \
     hipLaunchKernelGGL(kern, grid, block, smem, s, Q, ldq, Kt, Vt, tile_table, seqs, O, ldo, heads, sl2);      \
   } while (0)
-  // long prefills at head_dim 128: the 8-wave ping-pong kernel (256-row blocks, one per CU)
-  bool use_pp = HD == 128 && max_q_len >= g_flash_pp_min_rows;
-#ifdef VT_ABLATIONS
-  static const int pp_env = getenv("VT_FLASH_PP") ? atoi(getenv("VT_FLASH_PP")) : -1;     // 0: never, 1: whenever HD == 128
-  static const int pp_abl = getenv("VT_FLASH_PP_ABL") ? atoi(getenv("VT_FLASH_PP_ABL")) : 0;
-  if (pp_env == 0) use_pp = false;
-  if (pp_env == 1) use_pp = HD == 128;
-#endif
-  if (use_pp) {
-#define VT_FA_PP(CV, ...)                                                                                      \
-  do {                                                                                                         \
-    auto kern = flash_attn_pp_kernel<CV __VA_OPT__(,) __VA_ARGS__>;                                            \
-    const int smem = 6 * 64 * 128 * 2;                                                                         \
-    static bool done = false;                                                                                  \
-    if (!done) {                                                                                               \
-      VT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));        \
-      done = true;                                                                                             \
-    }                                                                                                          \
-    dim3 grid(heads, cdiv(max_q_len, 256), nseq), block(512);                                                  \
-    hipLaunchKernelGGL(kern, grid, block, smem, s, Q, ldq, Kt, Vt, tile_table, seqs, O, ldo, heads, sl2);      \
-  } while (0)
-#ifdef VT_ABLATIONS
-    if (causal && pp_abl == 1) VT_FA_PP(true, 1);
-    else if (causal && pp_abl == 2) VT_FA_PP(true, 2);
-    else if (causal && pp_abl == 4) VT_FA_PP(true, 4);
-    else if (causal && pp_abl == 3) VT_FA_PP(true, 3);
-    else if (causal && pp_abl == 6) VT_FA_PP(true, 6);
-    else if (causal && pp_abl == 7) VT_FA_PP(true, 7);
-    else if (causal && pp_abl == 8) VT_FA_PP(true, 8);
-    else if (causal && pp_abl == 16) VT_FA_PP(true, 16);
-    else if (causal && pp_abl == 32) VT_FA_PP(true, 32);
-    else if (causal && pp_abl == 64) VT_FA_PP(true, 64);
-    else if (causal && pp_abl == 120) VT_FA_PP(true, 120);
-    else
-#endif
-    { if (causal) VT_FA_PP(true); else VT_FA_PP(false); }
-#undef VT_FA_PP
-    VT_LAUNCH_CHECK();
-    return VT_OK;
-  }
   if (HD == 64) {
     if (causal) VT_FA(64, true, 4, 2); else VT_FA(64, false, 4, 2);
 #ifdef VT_ABLATIONS

@@ -112,7 +112,6 @@ int vt_vit_attn_meta_launch(int* seq_desc, int* tile_table, int F, int N, hipStr
 int vt_flash_attn_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf16_t* Vt, const int* tile_table,
                          const VtAttnSeq* seqs, int nseq, int max_q_len, bf16_t* O, int ldo, int heads, int HD,
                          int causal, float scale, hipStream_t s);
-int vt_flash_attn_pp_min_rows(int rows);   // threshold (query rows) above which head_dim-128 attention runs the ping-pong kernel; returns the previous value
 int vt_kv_tiles_launch(bf16_t* qkv, int ldqkv, int q_col0, int k_col0, int v_col0, bf16_t* Kt, bf16_t* Vt,
                        const int* tile_table, const VtAttnSeq* seqs, int nseq, int max_new_tiles, int heads, int HD,
                        const float* rope_cos, const float* rope_sin, const int* positions, hipStream_t s);
