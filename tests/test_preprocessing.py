@@ -57,3 +57,23 @@ def test_video_preprocess_matches_oracle(shape, size, flip):
     pv = LanguageBindVideoProcessor(image_size=size, num_frames=8, flip=flip)(fr)["pixel_values"]
     assert pv.shape == (1, 3, 8, size, size)
     assert float((pv[0].float().cpu() - ref).abs().max()) <= 2e-2
+
+
+@pytest.mark.skipif(not __import__("os").path.isdir("/root/reference/examples"), reason="needs the reference's example JPEGs (build container)")
+def test_oracle_preprocess_on_the_references_example_images_is_frozen():
+    """tests/golden/preproc_real.json (make_golden_preproc.py): the oracle's restatement of the reference's image / video transforms on
+    three of the reference's own COCO examples -- resized size, crop offsets, per-channel statistics, 64 probe pixels, checksums. Pins
+    the F.interpolate call, the size / crop arithmetic and the normalisation against drift; the size / crop RULES stay a restatement of
+    torchvision / pytorchvideo (absent offline). Inputs stay in /root/reference: the test is skipped where that tree is absent."""
+    import json
+    import os
+
+    from tests.golden import make_golden_preproc as mk
+    with open(os.path.join(os.path.dirname(__file__), "golden", "preproc_real.json")) as f:
+        gold = json.load(f)
+    for c in gold["cases"]:
+        got = mk.describe(os.path.join(mk.REF_EXAMPLES, c["file"]), c["size"])
+        assert got["input_hw"] == c["input_hw"] and got["resized_hw"] == c["resized_hw"] and got["crop_top_left"] == c["crop_top_left"]
+        assert np.allclose(got["probe_values"], c["probe_values"], atol=2e-5) and np.allclose(got["video_probe_values"], c["video_probe_values"], atol=2e-5)
+        assert abs(got["checksum"] - c["checksum"]) <= 1e-6 * c["checksum"] and abs(got["video_checksum"] - c["video_checksum"]) <= 1e-6 * c["video_checksum"]
+        assert np.allclose(got["mean"], c["mean"], atol=1e-5) and np.allclose(got["std"], c["std"], atol=1e-5)
