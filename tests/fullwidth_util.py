@@ -62,3 +62,19 @@ def topk_agreement(logits, g, tag):
     top1 = float((got[:, 0] == ref[:, 0]).double().mean())
     overlap = float(torch.tensor([len(set(a.tolist()) & set(b.tolist())) / 5.0 for a, b in zip(got, ref)]).mean())
     return top1, overlap
+
+
+_ORACLE_CACHE = {}
+
+
+def oracle_llama(name, emulate):
+    """(logits [S, V], final hidden [S, H]) of the oracle on llama_case(name), fp32 or bf16-storage emulation -- computed once per test
+    session: the prefill and the decode parity tests compare against the same two passes (each ~1 min of host time at the 7B width)."""
+    from oracle import vitron_oracle as O
+    key = (name, bool(emulate))
+    if key not in _ORACLE_CACHE:
+        cfg, sd, x = llama_case(name)
+        with torch.no_grad():
+            lg, _, h = O.llama_forward({k: v.float() for k, v in sd.items()}, cfg, x.unsqueeze(0), emulate_bf16=bool(emulate), return_hidden=True)
+        _ORACLE_CACHE[key] = (lg[0], h[0])
+    return _ORACLE_CACHE[key]

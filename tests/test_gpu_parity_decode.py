@@ -84,10 +84,7 @@ def test_decode_steps_at_7b_width_vs_oracle_and_reference(dev, name):
     # the same rows out of ONE prefill over the whole sequence (tile GEMMs, separate norms, flash attention)
     seq2 = SequenceState()
     pre = llama_forward(llama, kv, [seq2], xd, [S], logit_rows=list(range(P, S))).float().cpu()
-    with torch.no_grad():
-        l32, _ = O.llama_forward(f32(sd), cfg, x.unsqueeze(0))
-        lem, _ = O.llama_forward(f32(sd), cfg, x.unsqueeze(0), emulate_bf16=True)
-    l32, lem = l32[0, P:], lem[0, P:]
+    l32, lem = FW.oracle_llama(name, False)[0][P:], FW.oracle_llama(name, True)[0][P:]      # (shared with the prefill parity test)
     d_f32, d_emu, emu_f32, pre_f32 = FW.rel(got, l32), FW.rel(got, lem), FW.rel(lem, l32), FW.rel(pre, l32)
     per_step = [FW.rel(got[t], l32[t]) for t in range(N_STEPS)]
     # the REFERENCE's stored outputs for these rows: projections on the fixed directions, top-5 ids, the whole last row

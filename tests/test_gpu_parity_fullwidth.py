@@ -71,9 +71,8 @@ def test_decoder_prefill_at_7b_width_vs_oracle_and_reference(dev, name):
     seq = SequenceState()
     logits, hidden = llama_forward(llama, kv, [seq], x.to(dev).bfloat16(), [S], logit_rows=list(range(S)), return_hidden=True)
     logits, hidden = logits.float().cpu(), hidden.float().cpu()
-    with torch.no_grad():
-        l32, _, h32 = O.llama_forward(f32(sd), cfg, x.unsqueeze(0), return_hidden=True)
-        lem, _, hem = O.llama_forward(f32(sd), cfg, x.unsqueeze(0), emulate_bf16=True, return_hidden=True)
+    (l32, h32), (lem, hem) = FW.oracle_llama(name, False), FW.oracle_llama(name, True)
+    l32, h32, lem, hem = l32.unsqueeze(0), h32.unsqueeze(0), lem.unsqueeze(0), hem.unsqueeze(0)
     d_emu, d_f32, emu_f32 = FW.rel(logits, lem[0]), FW.rel(logits, l32[0]), FW.rel(lem[0], l32[0])
     h_emu, h_f32, hemu_f32 = FW.rel(hidden, hem[0]), FW.rel(hidden, h32[0]), FW.rel(hem[0], h32[0])
     ref_proj, ref_rows = FW.vs_pin(logits, g, f"llama_{name}_logits")
