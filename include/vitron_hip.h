@@ -55,6 +55,7 @@ enum {
   VT_GEMM_CFG_256x256_W4 = 13, /* 256x256 tile, 4 waves x (128x128), one wave per SIMD, K step placed by hand (plain-store epilogues) */
   VT_GEMM_CFG_320x256_W4 = 14, /* the same kernel on 320-row tiles (160x128 per wave): rows that fill whole rounds only this way */
   VT_GEMM_CFG_160x128_W4 = 15, /* four waves of 80x64 on a 160x128 tile, four-deep LDS ring: N = 1024 projections (K % 256 == 0) */
+  VT_GEMM_CFG_224x256_W4 = 16, /* the four-wave kernel on 224-row tiles (112x128 per wave): row counts a little over a multiple of 224 (1088, 4616) */
 };
 enum { VT_DTYPE_BF16 = 0, VT_DTYPE_F32 = 1 };
 enum { VT_ACT_GELU = 0, VT_ACT_QUICK_GELU = 1 };

@@ -507,13 +507,13 @@ def test_sample_top_k_keep_set(dev, V):
 @pytest.mark.gpu
 @pytest.mark.parametrize("M,N,K", [(300, 384, 256), (577, 1024, 640 + 128), (1000, 544, 1024), (512, 512, 384), (2048, 1024, 2048), (650, 256, 512)])
 def test_gemm_four_wave_kernel(dev, M, N, K):
-    """cfg 13 / 14: 256x256 (320x256) tile, four waves of 128x128 (160x128), accumulators pinned to the accumulator file, hand-placed
-    K step (ragged M / N, short and long K loops, every epilogue, repeated launches bit-identical)."""
+    """cfg 13 / 14 / 16: 256x256 (320x256, 224x256) tile, four waves of 128x128 (160x128, 112x128), accumulators pinned to the accumulator
+    file, hand-placed K step (ragged M / N, short and long K loops, every epilogue, repeated launches bit-identical)."""
     from vitron_amd import _lib, ops
     a, w, b = randn((M, K), 41), randn((N, K), 42, 0.05), randn((N,), 43)
     resid = randn((M, N), 44)
     ad, wd = a.to(dev).bfloat16(), w.to(dev).bfloat16()
-    for cfg in (_lib.CFG_256x256_W4, _lib.CFG_320x256_W4):
+    for cfg in (_lib.CFG_256x256_W4, _lib.CFG_320x256_W4, _lib.CFG_224x256_W4):
         for epi in (ops.EPI_BF16, ops.EPI_BF16_GELU, ops.EPI_BF16_QGELU, ops.EPI_BF16_RELU):
             assert rel_l2(ops.gemm(ad, wd, b.to(dev), epi, cfg=cfg).float(), _gemm_ref(a, w, b, epi)) <= TOL, (cfg, epi)
         assert rel_l2(ops.gemm(ad, wd, None, ops.EPI_SWIGLU_BF16, cfg=cfg).float(), _gemm_ref(a, w, None, ops.EPI_SWIGLU_BF16)) <= TOL

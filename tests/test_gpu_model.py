@@ -5,7 +5,8 @@ extractor) on the MI355X against (a) the golden vectors produced by the REFERENC
 Tolerances (rel-L2), and why:
   TOL = 1e-3        north_star's bar. Holds per kernel (tests/test_gpu_kernels.py) and for SHALLOW chains against the
                     emulating oracle (projector, region extractor, one ViT layer, text-only decoder prefill).
-  TOL_DEEP = 3e-2   deep chains (ViT -> projector -> splice -> decoder). bf16 storage of GEMM operands (eps 2^-8) puts
+  TOL_DEEP = 2.6e-2 deep chains (ViT -> projector -> splice -> decoder); = 1.5 x the worst measured (round 3, [parity-tiny] lines in
+                    profiles/r3_parity_lines.txt: 1.73e-2 vs the reference, 1.58e-2 vs the emulation). bf16 storage of GEMM operands (eps 2^-8) puts
                     even the emulating oracle ~1.5e-2 away from the fp32 reference on these test weights, and tiny fp32
                     summation-order differences flip bf16 roundings, so HIP-vs-emulation drifts to the same noise floor.
                     What IS asserted for deep chains: the HIP result is no farther from the REFERENCE's fp32 output than
@@ -27,7 +28,7 @@ pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(__file__), "golden")
 TOL = 1e-3
 TOL_FP32 = 2e-2
-TOL_DEEP = 3e-2
+TOL_DEEP = 2.6e-2
 TOL_SHALLOW = 3e-3
 
 
@@ -318,7 +319,7 @@ def test_decode_step_folded_rmsnorm_vs_oracle(dev):
         for b, n in enumerate(lens0):
             row = n - 1 + t
             ref, dev_full, g_ = refs[b][row], full[b][row].cpu(), got[t][b].cpu()
-            assert rel_l2(g_, ref) <= TOL_DEEP, (t, b, rel_l2(g_, ref))
+            assert rel_l2(g_, ref) <= 3e-2, (t, b, rel_l2(g_, ref))            # single rows after 32 layers; worst measured 2.56e-2
             assert rel_l2(g_, ref) <= 1.5 * rel_l2(dev_full, ref) + 2e-3, (t, b)       # folding costs no accuracy
             assert rel_l2(g_, dev_full) <= 2e-2, (t, b, rel_l2(g_, dev_full))   # two independent bf16 paths, each <= ~1e-2 from fp32
 
@@ -631,7 +632,7 @@ def test_prefill_folded_rmsnorm_vs_oracle(dev):
         ef, es = rel_l2(got["1"], ref), rel_l2(got["0"], ref)
         assert not torch.equal(got["1"], got["0"])                    # the switch really selects two different paths
         print(f"[parity-tiny] prefill_norm_fold_h{H}: folded_vs_fp32 {ef:.3e} separate_vs_fp32 {es:.3e}", flush=True)
-        assert ef <= TOL_DEEP and es <= TOL_DEEP, (H, ef, es)
+        assert ef <= 3e-2 and es <= 3e-2, (H, ef, es)                 # measured 2.0e-2 at H = 1024 (32 layers), x 1.5
         assert ef <= 1.25 * es + 1e-3, (H, ef, es)                    # no farther from fp32 than the separate-norm path
         worst = max(rel_l2(got["1"][r], ref[r]) for r in range(rows))
         assert worst <= 2 * TOL_DEEP, (H, worst)                      # no single row off (a wrong row factor would be O(1))

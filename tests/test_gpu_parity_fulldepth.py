@@ -68,6 +68,8 @@ def test_c3_full_depth_vs_reference():
     if out:
         with open(out.replace(".json", "_fulldepth.json"), "w") as f:
             json.dump(rep, f, indent=1)
-    assert e_rows <= 1e-2, e_rows                 # 23 ViT layers + projector in bf16 storage vs fp32
-    assert last <= 5e-2 and l_rows <= 5e-2 and h_rows <= 5e-2, (last, l_rows, h_rows)
-    assert top5 >= 0.8 and top1 >= 0.8, (top1, top5)
+    # bounds = round-3 measurements x 1.5 (profiles/r3_parity_fulldepth.json: embeddings 4.2e-3, logits 1.11e-2, hidden 1.12e-2,
+    # last position 1.01e-2, top-1 0.969, top-5 overlap 0.976 -- the whole residual is bf16 storage of 55 layers vs fp32)
+    assert e_rows <= 6.5e-3 and e_proj <= 6.5e-3, (e_rows, e_proj)
+    assert last <= 1.6e-2 and l_rows <= 1.7e-2 and h_rows <= 1.7e-2 and l_proj <= 1.8e-2 and h_proj <= 1.8e-2, (last, l_rows, h_rows, l_proj, h_proj)
+    assert top5 >= 0.95 and top1 >= 0.95 and last_top1, (top1, top5, last_top1)

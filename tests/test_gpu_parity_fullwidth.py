@@ -35,7 +35,7 @@ from tests.golden import cases
 pytestmark = pytest.mark.gpu
 
 FW_TOL_EMU = 2e-3            # HIP vs emulating oracle, whole tensors
-FW_TOL_EMU_DECODER = 1e-2    # decoder layers: independent bf16 rounding of the softmax weights (see above); measured 5.9e-3 / 7.7e-3
+FW_TOL_EMU_DECODER = 8.6e-3  # decoder layers: rounding flips of the bf16 chains (see above); measured 4.1e-3 (1 layer) / 5.7e-3 (2 layers), x 1.5
 REPORT = {}
 
 

@@ -447,14 +447,16 @@ def test_gemm_planner_fills_whole_rounds_of_the_chip():
     assert ops.gemm_plan(4608, 4096, 1024, ops.EPI_BF16_GELU) == (W4_320, 0)
     # a VALU-heavy epilogue on a whole-round grid of 256-row tiles stays on the ping-pong kernel
     assert ops.gemm_plan(4096, 4096, 1024, ops.EPI_BF16_QGELU) == (P4, 0)
-    # ViT qkv (4616 x 3072): 228 tiles of 256 rows in one round beat 180 taller ones
-    assert ops.gemm_plan(4616, 3072, 1024, ops.EPI_BF16) == (W4, 0)
+    # ViT qkv (4616 x 3072): one round either way -- 252 tiles of 224 rows (4704 padded rows) beat 228 of 256 (4864) and 180 taller ones
+    W4_224 = _lib.CFG_224x256_W4
+    assert ops.gemm_plan(4616, 3072, 1024, ops.EPI_BF16) == (W4_224, 0)
     # a single-image prompt (1088 rows) covers a quarter of the chip with big tiles, and the ViT's N = 1024 projections need 584
     # tiles of 64x128 for 512 slots: 160x128 tiles on the four-deep ring (224 / 232 workgroups, one round)
     W4R = _lib.CFG_160x128_W4
     assert ops.gemm_plan(1088, 4096, 4096, ops.EPI_F32_RESID) == (W4R, 0)
     assert ops.gemm_plan(4616, 1024, 4096, ops.EPI_F32_RESID) == (W4R, 0)
-    assert ops.gemm_plan(1088, 12288, 4096, ops.EPI_BF16) == (W4, 0)                    # 240 big tiles: one round
+    assert ops.gemm_plan(1088, 12288, 4096, ops.EPI_BF16) == (W4_224, 0)                # 240 big tiles, one round: 5 x 224 rows pad 1088 to 1120, not 1280
+    assert ops.gemm_plan(1088, 22016, 4096, ops.EPI_SWIGLU_BF16) == (W4_224, 0)         # 430 tiles, two rounds, each 7/8 as long
     assert ops.gemm_plan(1088, 4096, 4096 + 128, ops.EPI_F32_RESID)[0] in small         # the ring walks K in steps of 256
     # K not a multiple of 128 (no big-tile kernel) and the weight-streaming range
     assert ops.gemm_plan(4096, 4096, 4096 + 64, ops.EPI_BF16)[0] in small

@@ -70,7 +70,7 @@ def main():
     rep["qkv_gemm"] = dict(vs_emu=rel(g_qkv.float().cpu(), qkv), emu_vs_fp32=rel(qkv, qkv32))
     npages = (S + 63) // 64
     kt = torch.zeros(npages * heads * 64 * hd, dtype=torch.bfloat16, device=dev)
-    vt = torch.zeros_like(kt)
+    vt = torch.zeros(npages * heads * 64 * hd, dtype=torch.float16, device=dev)       # V^T pages hold fp16
     table = torch.arange(npages, dtype=torch.int32, device=dev)
     desc = torch.tensor([[0, S, S, 0]], dtype=torch.int32, device=dev)
     pos = torch.arange(S, dtype=torch.int32, device=dev)
@@ -88,7 +88,7 @@ def main():
     v_p = torch.zeros((heads, npages * 64, hd))
     v_p[:, :S] = v
     kt2.copy_(d(kr_p.view(heads, npages, 64, hd).permute(1, 0, 2, 3)))
-    vt2.copy_(d(v_p.view(heads, npages, 64, hd).permute(1, 0, 3, 2)))
+    vt2.copy_(d(v_p.view(heads, npages, 64, hd).permute(1, 0, 3, 2), torch.float16))       # exact: v is bf16-rounded, |v| << 65504
     qin = torch.zeros((S, 3 * H))
     qin[:, :H] = qr.transpose(0, 1).reshape(S, H)
     att = ops.flash_attn(d(qin), kt2.view(-1), vt2.view(-1), table, desc, S, heads, hd, True, 1.0 / math.sqrt(hd))

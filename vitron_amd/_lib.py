@@ -19,6 +19,7 @@ CFG_AUTO, CFG_SKINNY, CFG_128x128, CFG_256x128, CFG_256x256, CFG_64x128, CFG_256
 CFG_256x256_W4 = 13
 CFG_320x256_W4 = 14
 CFG_160x128_W4 = 15
+CFG_224x256_W4 = 16
 DTYPE_BF16, DTYPE_F32 = 0, 1
 ACT_GELU, ACT_QUICK_GELU = 0, 1
 PAGE_TOKENS = 64

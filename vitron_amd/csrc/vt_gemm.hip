@@ -752,6 +752,8 @@ int vt_gemm_pick_cfg(int M, int N, int K) {
 //   small tiles     ceil(tiles64x128 / 512) x 0.4545        two workgroups per CU at ~0.55 of the big tiles' rate (remainders of 512 /
 //                                                            1024 rows x 4096: 0.40 / 0.39 of a big round measured; 2560 x 4096 x 4096: 827
 //                                                            TFLOP/s on small tiles vs 1005 on 160 big tiles)
+//   224-row tiles   ceil(tiles224 / 256) x 0.875 x 1.02     four-wave kernel, 112x128 per wave (round 3): 1088 rows are 5 tile rows of 224 (1120) instead
+//                                                            of 5 of 256 (1280)
 //   160x128 tiles   ceil(tiles160 / 256) x 0.42             four-wave kernel on a four-deep LDS ring (K % 256 == 0): one workgroup per CU, a
 //                                                            round of them costs 0.41 of a big round (4616 x 1024 x 4096: 41 us, 935 TFLOP/s
 //                                                            against 692 on 64x128 tiles; 1088 x 4096 x 4096: 906 vs 637)
@@ -786,6 +788,14 @@ static double vt_gemm_plan_cost(int M, int N, int K, int epi, const VtGemmNormFu
     if (c320 < best) {
       best = c320;
       *plan = VtGemmPlan{VT_GEMM_CFG_320x256_W4, 0};
+    }
+    // 224-row tiles (112x128 per wave): a round of them costs 7/8 of a 256-row round; wins where 256-row tiles pad the last tile row
+    // heavily and the tile COUNT stays inside the same number of rounds (1088 rows: 5 tile rows either way; 4616 x 3072: 252 vs 228 tiles)
+    const long t224 = cdiv(M, 224) * (long)tiles_n;
+    const double c224 = (double)((t224 + 255) / 256) * 0.875 * 1.02;
+    if (t224 >= 128 && c224 < best) {   // (under half a round the small tiles' finer grid is as good: not measured, left alone)
+      best = c224;
+      *plan = VtGemmPlan{VT_GEMM_CFG_224x256_W4, 0};
     }
     // (a grid under half a round with a short K loop stays on small tiles: 577 x 3072 x 1024, 96 tiles, 281 vs 339 TFLOP/s)
     const long t160 = cdiv(M, 160) * (long)cdiv(N, 128);
@@ -925,6 +935,7 @@ int vt_gemm_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, 
   if (cfg == VT_GEMM_CFG_256x256_P4) return vt_gemm_p8_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, epi | 0x1000, s, nf);
   if (cfg == VT_GEMM_CFG_256x256_W4) return vt_gemm_p8_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, epi | 0x4000, s, nf);
   if (cfg == VT_GEMM_CFG_320x256_W4) return vt_gemm_p8_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, epi | 0xc000, s, nf);
+  if (cfg == VT_GEMM_CFG_224x256_W4) return vt_gemm_p8_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, epi | 0x24000, s, nf);
   if (cfg == VT_GEMM_CFG_160x128_W4) return vt_gemm_p8_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, epi | 0x10000, s, nf);
   if (cfg == VT_GEMM_CFG_256x256_RP) return vt_gemm_rp_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, epi, s);
   switch (epi) {

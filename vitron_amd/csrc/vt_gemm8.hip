@@ -632,7 +632,7 @@ __device__ __forceinline__ void w4_epilogue_lds(const GemmP8& p, f32x4 (&acc)[MT
                                                 int wave) {
   static_assert(EPI == VT_EPI_BF16 || EPI == VT_EPI_BF16_GELU || EPI == VT_EPI_BF16_QGELU || EPI == VT_EPI_BF16_RELU || EPI == VT_EPI_SWIGLU_BF16, "bf16 store epilogues");
   constexpr bool SW = EPI == VT_EPI_SWIGLU_BF16;
-  constexpr int RC = (MT == 8) ? 8 : 5;              // fragment rows per pass (MT = 10: two passes of 80 rows)
+  constexpr int RC = (MT <= 8) ? MT : 5;             // fragment rows per pass (MT = 10: two passes of 80 rows)
   constexpr int ROWB = SW ? 128 : 256;               // bytes per parked row (64 | 128 bf16 columns)
   constexpr int CH = ROWB / 16;                      // 16-byte chunks per row
   constexpr int RPI = 64 / CH;                       // rows per read / store instruction
@@ -821,7 +821,7 @@ __host__ __device__ __forceinline__ constexpr int w4_vmcnt_imm(int n) { return (
 
 template <int EPI, int MT = 8, int ABL = 0, int AUX_A = 0, int AUX_B = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_w4_kernel(GemmP8 p) {
-  static_assert(MT == 8 || MT == 10, "wave tile height: 128 or 160 rows");
+  static_assert(MT == 7 || MT == 8 || MT == 10, "wave tile height: 112, 128 or 160 rows");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BM = MT * 32;                       // tile rows
   constexpr int A_BYTES = BM * 128, B_BYTES = 256 * 128, BUFB = A_BYTES + B_BYTES;   // one K step in LDS: A rows, then B rows
@@ -906,10 +906,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // The memory / synchronisation instruction that follows MFMA n of a K step living in LDS buffer B (gap table of the header; the
   // positions for MT = 10 are the same pattern stretched: 18 slots in the first section, 8 early + 2 late A pieces).
   constexpr int S1_N = NPB + MT;                    // slots of section 1: DMA B / read A alternating, then the extra A reads
-  constexpr int LG2 = 21 + 2 * S1_N + 2, BAR2 = LG2 + 1;                    // 55, 56  | 59, 60
-  constexpr int NE = MT == 8 ? 3 : 8;               // A pieces issued before the k-half boundary
-  constexpr int VM3 = BAR2 + 2 * NE, BAR3 = VM3 + 1;                        // 62, 63  | 76, 77
-  constexpr int VM4 = MT == 8 ? 92 : 100, BAR4 = VM4 + 1;                   // 92, 93  | 100, 101
+  constexpr int LG2 = 21 + 2 * S1_N + (MT == 7 ? 0 : 2), BAR2 = LG2 + 1;    // 55, 56  | 59, 60  | MT = 7: 51, 52 (the k-half is 56 MFMAs)
+  constexpr int NE = MT == 7 ? 1 : MT == 8 ? 3 : 8; // A pieces issued before the k-half boundary
+  constexpr int VM3 = BAR2 + 2 * NE, BAR3 = VM3 + 1;                        // 62, 63  | 76, 77  | 54, 55
+  constexpr int VM4 = MT == 7 ? 84 : MT == 8 ? 92 : 100, BAR4 = VM4 + 1;    // 92, 93  | 100, 101 | 84, 85
+  static_assert(BAR3 < H && BAR4 + 2 * MT < NM && H + 4 * (NPA - NE - 1) + 1 < VM4, "gap table");
 #define W4S_IX(x, m) ((((x) % (m)) + (m)) % (m))   /* keeps the indices of the untaken branches inside their arrays */
 #define W4S_GAP(n, B, KB)                                                                                        \
   do {                                                                                                           \
@@ -920,12 +921,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       if ((n) & 1) {                                                                                             \
         if ((((n) - 21) >> 1) >= 16) { if (!(ABL & 4)) W4S_RDA(1, B, 1, W4S_IX((((n) - 21) >> 1) - 8, MT)); }         \
         else if (((n) & 3) == 1) { if (!(ABL & 1)) W4S_DMA(B, W4S_IX(((n) - 21) >> 2, 8), KB); }                      \
-        else { if (!(ABL & 4)) W4S_RDA(1, B, 1, W4S_IX(((n) - 23) >> 2, 8)); }                                        \
+        else { if (!(ABL & 4) && (((n) - 23) >> 2) < MT) W4S_RDA(1, B, 1, W4S_IX(((n) - 23) >> 2, MT)); }             \
       }                                                                                                          \
     }                                                                                                            \
     else if ((n) > BAR2 && (n) < VM3) { if (((n) - BAR2) & 1) { if (!(ABL & 1)) W4S_DMA(B, NPB + W4S_IX(((n) - BAR2) >> 1, NE), KB); } } \
     else if ((n) == VM3) { if (!(ABL & 9)) __builtin_amdgcn_s_waitcnt(w4_vmcnt_imm(NPA + NPB + NE)); }           \
-    else if ((n) >= H && (n) <= H + 17) {                                                                        \
+    else if ((n) >= H && (n) < VM4) {                                                                            \
       if (!(((n) - H) & 1)) { if ((n) <= H + 14 && !(ABL & 4)) W4S_RDB(0, (B) ^ 1, 0, W4S_IX(((n) - H) >> 1, 8)); }   \
       else if ((((n) - H) & 3) == 1 && (((n) - H) >> 2) < NPA - NE) { if (!(ABL & 1)) W4S_DMA(B, NPB + NE + W4S_IX(((n) - H) >> 2, NPA - NE), KB); } \
     }                                                                                                            \
@@ -939,7 +940,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define W4S_KSTEP(B, T)   /* spelled out: the optimiser does not unroll a loop around asm statements */           \
   do {                                                                                                           \
     const int _kb = min((T) + 2, nt - 1) * 128;    /* past the end of K: re-fetch the last K step, harmless */    \
-    W4S_32(0, B, _kb) W4S_32(32, B, _kb) W4S_32(64, B, _kb) W4S_32(96, B, _kb)                                    \
+    W4S_32(0, B, _kb) W4S_32(32, B, _kb) W4S_32(64, B, _kb) W4S_8(96, B, _kb) W4S_8(104, B, _kb)                  \
+    if constexpr (NM > 112) { W4S_8(112, B, _kb) W4S_8(120, B, _kb) }                                            \
     if constexpr (NM > 128) { W4S_32(128, B, _kb) }                                                              \
   } while (0)
   for (int t = 0; t < nt; t += 2) {
@@ -1550,6 +1552,19 @@ int vt_gemm_p8_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* 
     }
   }
 #endif
+  if ((epi & 0x4000) && (epi & 0x20000)) {   // 4-wave kernel, 224-row tile (112x128 per wave)
+    VT_REQUIRE(!nf, "vt_gemm(w4): no norm fold in the 4-wave kernel");
+    switch (epi & 0xff) {
+      case VT_EPI_BF16: return launch_w4<VT_EPI_BF16, 7>(p, s);
+      case VT_EPI_BF16_GELU: return launch_w4<VT_EPI_BF16_GELU, 7>(p, s);
+      case VT_EPI_BF16_QGELU: return launch_w4<VT_EPI_BF16_QGELU, 7>(p, s);
+      case VT_EPI_BF16_RELU: return launch_w4<VT_EPI_BF16_RELU, 7>(p, s);
+      case VT_EPI_F32_RESID: return launch_w4<VT_EPI_F32_RESID, 7>(p, s);
+      case VT_EPI_F32: return launch_w4<VT_EPI_F32, 7>(p, s);
+      case VT_EPI_SWIGLU_BF16: return launch_w4<VT_EPI_SWIGLU_BF16, 7>(p, s);
+      default: vt_set_error("vt_gemm(w4, 224-row tile): epilogue %d not instantiated", epi & 0xff); return VT_ERR_ARG;
+    }
+  }
   if ((epi & 0x4000) && (epi & 0x8000)) {   // 4-wave kernel, 320-row tile (160x128 per wave)
     VT_REQUIRE(!nf, "vt_gemm(w4): no norm fold in the 4-wave kernel");
     switch (epi & 0xff) {
