@@ -35,12 +35,15 @@ def main():
         c2()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(5):
+    reps = 20 if steps <= 0 else 5
+    for _ in range(reps):
         c2()
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / 5
+    dt = (time.perf_counter() - t0) / reps
     S = 576 + 512
     print(json.dumps({"config": "C2 336px image + 512 tokens prefill", "S": S, "ms": dt * 1e3, "tokens_per_s": S / dt}), flush=True)
+    if steps <= 0:      # C2 only (python tools/decode_bench.py 0): the per-kernel profile of the single-image prefill
+        return
 
     # ---- C5 ----
     B = 4
