@@ -743,8 +743,10 @@ int vt_gemm_pick_cfg(int M, int N, int K) {
 //                                                            tools/gemm_ab.cpp, round 2: qkv 1408 vs 1331 TFLOP/s on the 4-phase
 //                                                            ping-pong kernel, gate/up SwiGLU 1415 vs 1363, down_proj 1412 vs 1380,
 //                                                            ViT qkv 876 vs 840); the ping-pong kernel where the epilogue is VALU-heavy
-//                                                            (erf-GELU 366 vs 488 on the four-wave kernel's single wave per SIMD,
-//                                                            quick-GELU 586 vs 601) or carries a folded RMSNorm
+//                                                            (round 2: erf-GELU 366 vs 488 on the four-wave kernel's single wave per
+//                                                            SIMD; with round 3's LDS-staged store epilogue the two are within 3 %:
+//                                                            4096 x 4096 x 1024 erf-GELU 805 vs 819, quick-GELU 785 vs 813 TFLOP/s,
+//                                                            profiles/r3_gemm_gelu_ab.jsonl) or carries a folded RMSNorm
 //   320-row tiles   ceil(tiles320 / 256) x 1.25 x 1.04      four-wave kernel, 160x128 per wave: 5120 x 4096 is ONE round of 256 tiles
 //                                                            instead of 1.25 (o_proj 1245 vs 1075 TFLOP/s for whole rounds + small-tile
 //                                                            remainder, down_proj 1341 vs 1173, projector 4608x4096x4096 1329 vs 1131);

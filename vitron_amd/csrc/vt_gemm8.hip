@@ -701,7 +701,7 @@ __device__ __forceinline__ void w4_epilogue_lds(const GemmP8& p, f32x4 (&acc)[MT
 }
 
 template <int EPI, int MT, int NI = 8>
-__device__ __forceinline__ void w4_epilogue(const GemmP8& p, f32x4 (&acc)[MT][NI], int bm0, int bn0, int wr, int wc, int lane) {
+__device__ __forceinline__ void w4_epilogue(const GemmP8& p, f32x4 (&acc)[MT][NI], int bm0, int bn0, int wr, int wc, int lane, int split = 0) {
   constexpr int WN = NI * 16;   // columns per wave
   if constexpr (EPI == VT_EPI_F32_RESID) {
     const int row0 = bm0 + wr * (MT * 16) + (lane & 15);
@@ -756,7 +756,7 @@ __device__ __forceinline__ void w4_epilogue(const GemmP8& p, f32x4 (&acc)[MT][NI
           const int n = bn0 + wc * WN + ni * 16 + ((lane >> 4) << 2);
           if (n >= p.N) continue;
           f32x4 v = acc[mi][ni];
-          if (p.bias) v += *(const f32x4*)(p.bias + n);
+          if (p.bias && split == 0) v += *(const f32x4*)(p.bias + n);   // split-K: the bias goes in once
           if constexpr (EPI == VT_EPI_BF16_GELU) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = gelu_erf8(v[r]);
@@ -768,7 +768,7 @@ __device__ __forceinline__ void w4_epilogue(const GemmP8& p, f32x4 (&acc)[MT][NI
             for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
           }
           if constexpr (EPI == VT_EPI_F32) {
-            *(f32x4*)((float*)p.C + (size_t)m * p.ldc + n) = v;
+            *(f32x4*)((float*)p.C + (size_t)split * p.slab + (size_t)m * p.ldc + n) = v;
           } else {
             u32x2 o;
             o.x = pack_bf16x2(v[0], v[1]);
@@ -833,7 +833,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + 255) / 256;
   const int nwg = tiles_m * tiles_n;
-  const int sid = xcd_remap((int)blockIdx.x, nwg);
+  // two-pass split-K (EPI == F32 only, as in the ping-pong kernel): split s of every tile writes its partial product to slab s
+  const int ksplit = (EPI == VT_EPI_F32) ? p.ksplit : 1;
+  const int split = (ksplit > 1) ? (int)blockIdx.x / nwg : 0;
+  const int sid = xcd_remap((int)blockIdx.x - split * nwg, nwg);
+  const int ku = p.K >> 7;   // K in units of 128 (two K steps), balanced over the splits
+  const int u_begin = (int)((long)ku * split / ksplit), u_end = (int)((long)ku * (split + 1) / ksplit);
   constexpr int GROUP_M = 8;
   const int per_group = GROUP_M * tiles_n;
   const int first_m = (sid / per_group) * GROUP_M;
@@ -843,8 +848,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int bm0 = tm * BM, bn0 = tn * 256;
 
   // DMA sources. Pieces 0..7 of a K step are this wave's share of B (rows (8 wave + j) * 8 ..), pieces 8.. its share of A.
-  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (size_t)bm0 * p.lda), 0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (size_t)bn0 * p.ldw), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (size_t)bm0 * p.lda + u_begin * 128), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (size_t)bn0 * p.ldw + u_begin * 128), 0, 0x7fffffff, 0x00020000);
   const int lrow = lane >> 3, lchk = lane & 7;
   int voff[18];   // NP entries used; sized by a literal: with a size that depends on MT, clang's HOST pass silently drops the kernel stub
 #pragma unroll
@@ -886,7 +891,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define W4S_RDA(SET, BUF, KK, I) fa[SET][I] = *(const bf16x8*)(smem + (BUF) * BUFB + a_base + fo[KK] + (I) * 2048)
 #define W4S_LGKM0() __builtin_amdgcn_s_waitcnt(0xc07f)
 
-  const int nt = p.K >> 6;                         // K % 128 == 0, checked by the launcher
+  const int nt = (u_end - u_begin) * 2;            // K steps of this workgroup's K range (K % 128 == 0, checked by the launcher)
   const int kb1 = min(1, nt - 1) * 128;
 #pragma unroll
   for (int i = 0; i < NP; ++i) W4S_DMA(0, i, 0);
@@ -973,7 +978,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   } else if constexpr (bf16_store && !(ABL & 64)) {
     w4_epilogue_lds<EPI, MT>(p, acc, bm0, bn0, wr, wc, lane, smem, wave);      // (launch_w4 checked alignment and N % 8)
   } else {
-    w4_epilogue<EPI, MT>(p, acc, bm0, bn0, wr, wc, lane);
+    w4_epilogue<EPI, MT>(p, acc, bm0, bn0, wr, wc, lane, split);
   }
 }
 
@@ -994,7 +999,7 @@ int launch_w4(const GemmP8& p, hipStream_t s) {
     VT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     done = true;
   }
-  hipLaunchKernelGGL(kern, dim3(cdiv(p.M, BM) * cdiv(p.N, 256)), dim3(256), smem, s, p);
+  hipLaunchKernelGGL(kern, dim3(cdiv(p.M, BM) * cdiv(p.N, 256) * (EPI == VT_EPI_F32 ? std::max(p.ksplit, 1) : 1)), dim3(256), smem, s, p);
   VT_LAUNCH_CHECK();
   return VT_OK;
 }
@@ -1445,7 +1450,9 @@ int vt_gemm_p4_splitk_resid_launch(const bf16_t* A, int lda, const bf16_t* W, in
   VT_REQUIRE(vt_gemm_p8_supported(M, N, K) && (N % 4) == 0, "vt_gemm(split-K): unsupported shape (N=%d K=%d)", N, K);
   VT_REQUIRE(ksplit >= 2 && (K >> 7) / ksplit >= 2 && partials, "vt_gemm(split-K): ksplit=%d leaves < 256 of K per split, or no workspace", ksplit);
   GemmP8 p{A, W, partials, bias, M, N, K, lda, ldw, N, ksplit, (size_t)M * N, VtGemmNormFuse{}};   // the fold happens in the reduce pass
-  VT_TRY((launch_p8<VT_EPI_F32, 0, true>(p, s)));
+  // pass 1 on the four-wave kernel (round 3; was the ping-pong kernel), on the tile height that pads fewer rows
+  if ((long)cdiv(M, 224) * 224 < (long)cdiv(M, 256) * 256) VT_TRY((launch_w4<VT_EPI_F32, 7>(p, s)));
+  else VT_TRY((launch_w4<VT_EPI_F32, 8>(p, s)));
   const long total = (long)M * (N >> 2);
   const int blocks = (int)std::min<long>((total + 255) / 256, 2048);
   VtGemmNormFuse rnf;
