@@ -2,8 +2,8 @@
 
     python tools/cfg_ab.py "1088,12288,4096,BF16;1088,22016,4096,SWIGLU_BF16" 0,13,16 [iters]
 
-Per shape: us per launch for every cfg id (0 = the dispatcher's choice), weights rotated over 4 copies so that no launch streams its
-weights from the Infinity Cache, interleaved in rounds (cfg a, cfg b, .. repeated) so that clock drift hits all of them alike; the
+Per shape: us per launch for every cfg id (0 = the dispatcher's choice), weights rotated over enough copies (>= 4, >= 600 MB in total)
+that no launch streams its weights from the 256 MB Infinity Cache, interleaved in rounds (cfg a, cfg b, .. repeated) so that clock drift hits all of them alike; the
 bf16 / fp32 outputs of every cfg are compared bit for bit with the first one's (same fragments, same accumulation order)."""
 import json
 import os
@@ -25,7 +25,8 @@ def main():
         M, N, K = int(M), int(N), int(K)
         epi = getattr(ops, "EPI_" + epi_name)
         a = torch.randn((M, K), device=dev).bfloat16()
-        ws = [(torch.randn((N, K), device=dev) * 0.02).bfloat16() for _ in range(4)]
+        nw = max(4, -(-600_000_000 // (N * K * 2)))
+        ws = [(torch.randn((N, K), device=dev) * 0.02).bfloat16() for _ in range(nw)]
         resid = torch.randn((M, N), device=dev) if epi_name == "F32_RESID" else None
         outs, us = {}, {c: 0.0 for c in cfgs}
         for c in cfgs:
@@ -37,11 +38,11 @@ def main():
         for _ in range(rounds):
             for c in cfgs:
                 for i in range(3):
-                    ops.gemm(a, ws[i % 4], None, epi, out=out, cfg=c)
+                    ops.gemm(a, ws[i % nw], None, epi, out=out, cfg=c)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for i in range(iters):
-                    ops.gemm(a, ws[i % 4], None, epi, out=out, cfg=c)
+                    ops.gemm(a, ws[i % nw], None, epi, out=out, cfg=c)
                 e1.record()
                 torch.cuda.synchronize()
                 us[c] += e0.elapsed_time(e1) / iters * 1e3 / rounds
