@@ -43,7 +43,7 @@ REPORT = {}
 def dev():
     from vitron_amd import _lib
     _lib.load()
-    torch.set_num_threads(os.cpu_count() or 8)
+    torch.set_num_threads(min(32, os.cpu_count() or 8))      # PyTorch's CPU GEMMs are slower on all 256 hardware threads of the GPU box than on 16-32
     return torch.device("cuda:0")
 
 

@@ -25,7 +25,7 @@ def main():
     S = int(sys.argv[1]) if len(sys.argv) > 1 else 1088
     _lib.load()
     dev = torch.device("cuda:0")
-    torch.set_num_threads(os.cpu_count() or 8)
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
     cfg = dict(synth.VICUNA_7B, num_hidden_layers=1)
     sd = synth.llama_state(cfg, synth.make_generator(7), w_std=0.02)
     w = {k: v.float() for k, v in sd.items()}
