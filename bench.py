@@ -73,7 +73,7 @@ def pmc_traffic_per_launch():
 def committed_c4_n1():
     """tokens/s of config.c4 at N = 1 from the newest committed bench line (profiles/r<N>_bench.json): the denominator of the
     strong-scaling ratio SURVEY.md 8(e) asks for, so that a multi-GPU line carries it next to the weak-scaling headline."""
-    for r in (3, 2):
+    for r in range(9, 1, -1):   # newest round first
         path = os.path.join(ROOT, "profiles", f"r{r}_bench.json")
         if os.path.exists(path):
             try:
