@@ -55,7 +55,7 @@ def pmc_traffic_per_launch():
     /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950 (128-B requests tallied at 64 B); the counters sit on the L2's
     fabric side, so Infinity-Cache hits are included. PMC counters cannot be collected inside this process: the value is a
     committed measurement, labelled as such on the JSON line; (None, None, None) when no file is there."""
-    path = next((p_ for p_ in (os.path.join(ROOT, "profiles", f"r{r}_pmc_traffic.json") for r in (3, 2)) if os.path.exists(p_)), None)
+    path = next((p_ for p_ in (os.path.join(ROOT, "profiles", f"r{r}_pmc_traffic.json") for r in range(9, 1, -1)) if os.path.exists(p_)), None)
     if path is None:
         return None, None, None
     with open(path) as f:
