@@ -31,6 +31,7 @@ def dev():
 
 LLM_SHAPES = [(5120, 12288, 4096, "BF16"), (5120, 4096, 4096, "F32_RESID"), (5120, 22016, 4096, "SWIGLU_BF16"),
               (5120, 4096, 11008, "F32_RESID"), (1088, 12288, 4096, "BF16"), (4616, 4096, 1024, "BF16_GELU"),
+              (1088, 22016, 4096, "SWIGLU_BF16"), (4616, 3072, 1024, "BF16"), (2436, 22016, 4096, "SWIGLU_BF16"),   # 224-row tiles, ragged last tile row
               (4, 12288, 4096, "BF16"), (4, 4096, 11008, "F32_RESID"), (4, 32000, 4096, "F32")]
 
 
