@@ -238,7 +238,60 @@ def test_flash_attention_fresh(dev, hd, heads, lens, causal):
         k = x[:, D:2 * D].view(L, heads, hd).transpose(0, 1)
         v = x[:, 2 * D:].view(L, heads, hd).transpose(0, 1)
         ref = _attn_ref(q, k, v, scale, causal, 0).transpose(0, 1).reshape(L, D)
-        assert rel_l2(out[r0:r0 + L].float(), bf16r(ref)) <= 3e-3  # P is rounded to bf16 inside the kernel
+        assert rel_l2(out[r0:r0 + L].float(), bf16r(ref)) <= 3e-3  # P is rounded to fp16 (round 2: bf16) inside the kernel, the output to bf16
+
+
+def test_flash_attention_fp16_range_edges(dev):
+    """Round 3 stores V^T pages and the softmax weights in fp16. Edges of that choice: (1) bf16 projections beyond
+    fp16's range saturate at +-65504 in the page (never inf), and the attention output is the reference's on the clamped values;
+    (2) rows whose scores span +-60 (peaked rows, long tails far below 2^-24 of the maximum) stay finite and accurate -- the exponent
+    bias keeps what matters in fp16's normal range; (3) a row whose running maximum jumps by far more than the deferred-rescale
+    threshold from tile to tile (keys sorted ascending in score) is rescaled correctly."""
+    from vitron_amd import ops
+    hd, heads, L = 128, 2, 300
+    D = heads * hd
+    scale = 1.0 / math.sqrt(hd)
+    g = torch.Generator().manual_seed(5)
+    # (1) huge V
+    qkv = torch.randn((L, 3 * D), generator=g)
+    qkv[:, 2 * D:] *= 3.0e4
+    qkv[7, 2 * D + 5], qkv[100, 2 * D + 130], qkv[299, 3 * D - 1] = 1.0e5, -2.0e5, 7.0e4
+    qd = qkv.to(dev).bfloat16()
+    kt, vt, table, desc = _build_tiles(dev, qd, [(0, L, L)], heads, hd)
+    ops.kv_tiles(qd, 0, D, 2 * D, kt, vt, table, desc, (L + 63) // 64, heads, hd)
+    pages = vt.view(torch.float16).view(-1, heads, hd, 64).float()
+    assert torch.isfinite(pages).all() and float(pages.abs().max()) == 65504.0
+    assert float(pages[0, 0, 5, 7]) == 65504.0 and float(pages[100 // 64, 1, 2, 100 % 64]) == -65504.0
+    out = ops.flash_attn(qd, kt, vt, table, desc, L, heads, hd, True, scale).float().cpu()
+    x = bf16r(qkv)
+    q = x[:, :D].view(L, heads, hd).transpose(0, 1)
+    k = x[:, D:2 * D].view(L, heads, hd).transpose(0, 1)
+    v = x[:, 2 * D:].clamp(-65504.0, 65504.0).view(L, heads, hd).transpose(0, 1)
+    ref = _attn_ref(q, k, v, scale, True, 0).transpose(0, 1).reshape(L, D)
+    assert torch.isfinite(out).all() and rel_l2(out, bf16r(ref)) <= 3e-3
+    # (2) wide score range, (3) ascending maxima
+    for variant in ("wide", "ascending"):
+        qkv = torch.randn((L, 3 * D), generator=g)
+        if variant == "wide":
+            qkv[:, :2 * D] *= 3.0                   # logits ~ N(0, 9^2): spans beyond +-30 in most rows
+        else:                                       # k_j = a_j u, q_i = b_i u (+ noise): the score grows with the key index, so the
+            u = torch.sign(torch.randn((1, D), generator=g))       # running maximum of a row jumps at every tile it visits
+            qkv[:, D:2 * D] = torch.linspace(-3.0, 3.0, L).view(L, 1) * u + 0.05 * qkv[:, D:2 * D]
+            qkv[:, :D] = (1.0 + torch.rand((L, 1), generator=g)) * u + 0.05 * qkv[:, :D]
+        qd = qkv.to(dev).bfloat16()
+        kt, vt, table, desc = _build_tiles(dev, qd, [(0, L, L)], heads, hd)
+        ops.kv_tiles(qd, 0, D, 2 * D, kt, vt, table, desc, (L + 63) // 64, heads, hd)
+        out = ops.flash_attn(qd, kt, vt, table, desc, L, heads, hd, True, scale).float().cpu()
+        x = bf16r(qkv)
+        q = x[:, :D].view(L, heads, hd).transpose(0, 1)
+        k = x[:, D:2 * D].view(L, heads, hd).transpose(0, 1)
+        v = x[:, 2 * D:].view(L, heads, hd).transpose(0, 1)
+        logits = (q.double() @ k.double().transpose(1, 2)) * scale
+        assert float(logits.max() - logits.min()) > 60.0, (variant, float(logits.max() - logits.min()))
+        ref = _attn_ref(q, k, v, scale, True, 0).transpose(0, 1).reshape(L, D)
+        err = rel_l2(out, bf16r(ref))
+        print(f"[flash-fp16-edges] {variant}: rel_l2 {err:.3e}", flush=True)
+        assert torch.isfinite(out).all() and err <= 1.1e-3, (variant, err)      # measured 3.6e-4 / 7.1e-4
 
 
 def test_attention_with_past_rope_and_decode(dev):
