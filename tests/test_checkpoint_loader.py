@@ -118,7 +118,7 @@ def test_load_pretrained_model_matches_direct_construction(tmp_path):
     images = [im.to(dev).bfloat16() for im in case["images"]]
     a = model(input_ids=ids, images=images, regions=case["regions"], use_cache=False).logits
     b = ref(input_ids=ids, images=images, regions=case["regions"], use_cache=False).logits
-    assert rel_l2(a, b) <= 2e-2   # merged weights are re-rounded to bf16 on both paths, in a different order
+    assert rel_l2(a, b) <= 2e-3   # merged weights are re-rounded to bf16 on both paths, in a different order (measured: identical)
     assert float((a.argmax(-1) == b.argmax(-1)).float().mean()) >= 0.9
 
 

@@ -120,7 +120,7 @@ def test_attention_full_size_properties(dev):
         sc = torch.einsum("hd,khd->hk", q[r].double(), got_k[:r + 1].double()) * scale          # the keys the kernel really holds
         p = torch.softmax(sc, -1)
         ref = torch.einsum("hk,khd->hd", p, v[:r + 1].double()).reshape(D)
-        assert rel_l2(out[r].float(), bf16r(ref.float())) <= 4e-3, r
+        assert rel_l2(out[r].float(), bf16r(ref.float())) <= 1.4e-3, r                      # measured 9.0e-4 (fp16 softmax weights)
     # softmax rows sum to one: with V == const (per head-dim channel) the output is that constant
     const = torch.linspace(-2, 2, D, device=dev).bfloat16()
     x2 = qkv.clone()
@@ -262,7 +262,7 @@ def test_image_tower_full_size_batch_independence(dev, model7b):
     f2 = model7b.encode_images(imgs[perm])[0]
     assert torch.equal(f2.view(torch.int16), f[perm].view(torch.int16))
     f1 = model7b.encode_images(imgs[1:2])[0]
-    assert rel_l2(f1.float(), f[1:2].float()) <= 1e-2     # a different M picks different GEMM tiles / split-K: same maths, bf16 noise over 23 layers
+    assert rel_l2(f1.float(), f[1:2].float()) <= 8e-3     # a different M picks different GEMM tiles / split-K: same maths, bf16 noise over 23 layers
 
 
 def test_bench_distributed_path_on_one_gpu(dev):

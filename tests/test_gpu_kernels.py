@@ -238,7 +238,7 @@ def test_flash_attention_fresh(dev, hd, heads, lens, causal):
         k = x[:, D:2 * D].view(L, heads, hd).transpose(0, 1)
         v = x[:, 2 * D:].view(L, heads, hd).transpose(0, 1)
         ref = _attn_ref(q, k, v, scale, causal, 0).transpose(0, 1).reshape(L, D)
-        assert rel_l2(out[r0:r0 + L].float(), bf16r(ref)) <= 3e-3  # P is rounded to fp16 (round 2: bf16) inside the kernel, the output to bf16
+        assert rel_l2(out[r0:r0 + L].float(), bf16r(ref)) <= 1.3e-3  # P is rounded to fp16 (round 2: bf16, 3e-3) inside the kernel, the output to bf16; measured 8.4e-4
 
 
 def test_flash_attention_fp16_range_edges(dev):
@@ -268,7 +268,7 @@ def test_flash_attention_fp16_range_edges(dev):
     k = x[:, D:2 * D].view(L, heads, hd).transpose(0, 1)
     v = x[:, 2 * D:].clamp(-65504.0, 65504.0).view(L, heads, hd).transpose(0, 1)
     ref = _attn_ref(q, k, v, scale, True, 0).transpose(0, 1).reshape(L, D)
-    assert torch.isfinite(out).all() and rel_l2(out, bf16r(ref)) <= 3e-3
+    assert torch.isfinite(out).all() and rel_l2(out, bf16r(ref)) <= 1.3e-3          # measured 6.5e-4
     # (2) wide score range, (3) ascending maxima
     for variant in ("wide", "ascending"):
         qkv = torch.randn((L, 3 * D), generator=g)
@@ -326,7 +326,7 @@ def test_attention_with_past_rope_and_decode(dev):
             out = ops.attn_decode(x, kt, vt, table, desc, heads, hd, scale, done + chunk)
         else:
             out = ops.flash_attn(x, kt, vt, table, desc, chunk, heads, hd, True, scale)
-        assert rel_l2(out.float(), bf16r(ref[done:done + chunk])) <= 3e-3, (done, chunk)
+        assert rel_l2(out.float(), bf16r(ref[done:done + chunk])) <= 1.3e-3, (done, chunk)
         done += chunk
 
 
@@ -378,7 +378,7 @@ def test_attn_decode_fused_matches_unfused(dev, hd):
         torch.cuda.synchronize()
         assert torch.equal(xb, x), "fused kernel must not modify qkv"
         assert torch.isfinite(got.float()).all()
-        assert rel_l2(got.float(), ref.float()) <= 2e-3, (trial, rel_l2(got.float(), ref.float()))
+        assert rel_l2(got.float(), ref.float()) <= 1e-6, (trial, rel_l2(got.float(), ref.float()))   # same arithmetic in the same order: measured 4.5e-8
         # every page of every sequence: identical bits (incl. zero padding of a freshly started page)
         used = torch.zeros(npages, dtype=torch.bool)
         used[tables] = True
@@ -508,7 +508,7 @@ def test_gemm_row_scale(dev, M, N, K, epi_name, cfg):
     else:
         acc = acc + bias
         ref = torch.nn.functional.gelu(acc) if epi_name == "BF16_GELU" else acc
-    assert rel_l2(out, ref) <= (1e-5 if epi_name == "F32" else 3e-3), rel_l2(out, ref)
+    assert rel_l2(out, ref) <= (1e-5 if epi_name == "F32" else 2.5e-3), rel_l2(out, ref)      # one bf16 store: measured 1.67e-3
     plain = ops.gemm(a.to(dev), w.to(dev), None if bias is None else bias.to(dev), epi, cfg=cfg,
                      row_scale=torch.ones(M, device=dev)).float().cpu()
     base = ops.gemm(a.to(dev), w.to(dev), None if bias is None else bias.to(dev), epi, cfg=(cfg if M > 64 else 5)).float().cpu()
@@ -668,5 +668,5 @@ def test_flash_attention_ragged_multi_sequence_chunked_vs_fp64(dev, causal, lens
             mask = torch.arange(p + q)[None, :] > (p + torch.arange(q))[:, None]
             s = s.masked_fill(mask[None], float("-inf"))
         ref = torch.einsum("hqk,khd->qhd", torch.softmax(s, -1), vv).reshape(q, D).float()
-        assert rel_l2(got[r0:r0 + q].float(), bf16r(ref)) <= 3e-3, (i, rel_l2(got[r0:r0 + q].float(), bf16r(ref)))
+        assert rel_l2(got[r0:r0 + q].float(), bf16r(ref)) <= 1.3e-3, (i, rel_l2(got[r0:r0 + q].float(), bf16r(ref)))
         r0 += q

@@ -5,6 +5,8 @@ extractor) on the MI355X against (a) the golden vectors produced by the REFERENC
 Tolerances (rel-L2), and why:
   TOL = 1e-3        north_star's bar. Holds per kernel (tests/test_gpu_kernels.py) and for SHALLOW chains against the
                     emulating oracle (projector, region extractor, one ViT layer, text-only decoder prefill).
+  TOL_FP32 = 4.7e-3 shallow chains (towers up to three layers, projector, region extractor) against the REFERENCE's fp32 goldens: 1.5 x the
+                    worst measured (3.1e-3; the emulation's own distance from fp32 is the same size).
   TOL_DEEP = 2.6e-2 deep chains (ViT -> projector -> splice -> decoder); = 1.5 x the worst measured (round 3, [parity-tiny] lines in
                     profiles/r3_parity_lines.txt: 1.73e-2 vs the reference, 1.58e-2 vs the emulation). bf16 storage of GEMM operands (eps 2^-8) puts
                     even the emulating oracle ~1.5e-2 away from the fp32 reference on these test weights, and tiny fp32
@@ -27,7 +29,7 @@ from vitron_amd import synth
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(__file__), "golden")
 TOL = 1e-3
-TOL_FP32 = 2e-2
+TOL_FP32 = 4.7e-3
 TOL_DEEP = 2.6e-2
 TOL_SHALLOW = 3e-3
 
@@ -84,7 +86,7 @@ def test_vit_tower(dev, name, cfg, shape):
         nl = vit.run_layers
         emu = O.vit_forward(f32(sd), cfg, x, nl, emulate_bf16=True)
         ref = torch.as_tensor(g[f"{name}_hidden_{nl}"])
-        assert rel_l2(hidden, emu) <= (TOL if nl <= 1 else 5e-3), (sel, "vs emulating oracle")
+        assert rel_l2(hidden, emu) <= (TOL if nl <= 1 else 3.8e-3), (sel, "vs emulating oracle")      # measured 2.5e-3 at depth 3
         assert rel_l2(hidden, ref) <= TOL_FP32 and no_worse_than_emulation(hidden, emu, ref), (sel, "vs reference fp32")
         assert rel_l2(feats.float().reshape(-1, 16, 128), O.bf16_round(emu[:, 1:])) <= (TOL if nl <= 1 else 5e-3)
         assert feats.shape == ((2, 4, 16, 128) if name == "video" else (3, 16, 128))
@@ -106,7 +108,7 @@ def test_vit_tower_second_shape(dev, name):
         nl = vit.run_layers
         emu = O.vit_forward(f32(sd), cfg, x, nl, emulate_bf16=True)
         ref = torch.as_tensor(g[f"{name}_hidden_{nl}"])
-        assert rel_l2(hidden, emu) <= (TOL if nl <= 1 else 5e-3), (sel, "vs emulating oracle")
+        assert rel_l2(hidden, emu) <= (TOL if nl <= 1 else 3.8e-3), (sel, "vs emulating oracle")      # measured 2.5e-3 at depth 3
         assert rel_l2(hidden, ref) <= TOL_FP32 and no_worse_than_emulation(hidden, emu, ref), (sel, "vs reference fp32")
         assert feats.shape == ((1, 8, 25, 128) if name == "video_b" else (2, 25, 128))
 
@@ -159,7 +161,7 @@ def test_f1_branches_clip_tower_and_mlp3x_projector(dev, tmp_path):
         ref = torch.as_tensor(g[f"clip_{feat}"])
         assert tuple(out.shape) == ref.shape and out.dtype == torch.bfloat16
         want = emu if feat == "cls_patch" else emu[:, 1:]
-        assert rel_l2(out.float(), O.bf16_round(want)) <= 5e-3, feat
+        assert rel_l2(out.float(), O.bf16_round(want)) <= TOL, feat
         assert rel_l2(out.float(), ref) <= TOL_FP32 and no_worse_than_emulation(out.float().cpu(), O.bf16_round(want), ref), feat
         lst = t([x[0].to(dev).bfloat16(), x[2].to(dev).bfloat16()])             # list input: one [1, P, D] tensor per image (:41-47)
         assert rel_l2(lst[1].float(), torch.as_tensor(g[f"clip_{feat}_list1"])) <= TOL_FP32 and lst[0].shape[0] == 1
@@ -277,7 +279,7 @@ def test_decode_matches_prefill(dev, model):
     b = llama_forward(llama, kv, [s], emb[70:149], [79], logit_rows=list(range(79)))   # chunked prefill with past
     c = llama_forward(llama, kv, [s], emb[149:150], [1])                                 # single-token decode
     got = torch.cat([a, b, c], 0)
-    assert rel_l2(got, full) <= 5e-3   # chunking changes where P is rounded to bf16 inside the attention kernels
+    assert rel_l2(got, full) <= 3.9e-3   # chunking changes where the running maximum stands when P is rounded inside the attention kernels; measured 2.6e-3
     assert torch.equal(got.argmax(-1), full.argmax(-1)) or rel_l2(got, full) <= 5e-4
 
 
@@ -321,7 +323,7 @@ def test_decode_step_folded_rmsnorm_vs_oracle(dev):
             ref, dev_full, g_ = refs[b][row], full[b][row].cpu(), got[t][b].cpu()
             assert rel_l2(g_, ref) <= 3e-2, (t, b, rel_l2(g_, ref))            # single rows after 32 layers; worst measured 2.56e-2
             assert rel_l2(g_, ref) <= 1.5 * rel_l2(dev_full, ref) + 2e-3, (t, b)       # folding costs no accuracy
-            assert rel_l2(g_, dev_full) <= 2e-2, (t, b, rel_l2(g_, dev_full))   # two independent bf16 paths, each <= ~1e-2 from fp32
+            assert rel_l2(g_, dev_full) <= 1.6e-2, (t, b, rel_l2(g_, dev_full))   # two independent bf16 paths, each <= ~1e-2 from fp32; measured 1.03e-2
 
 
 @pytest.mark.gpu
@@ -598,7 +600,7 @@ def test_generate_stops_on_eos_with_speculative_step_rolled_back(dev):
     m.config.kv_prefix_reuse = False
     o3, lg3 = m.generate(p2, do_sample=False, max_new_tokens=3, eos_token_id=-1, return_logits=True)
     for a, b in zip(lg2, lg3):
-        assert rel_l2(a.float(), b.float()) <= 5e-3
+        assert rel_l2(a.float(), b.float()) <= 3.9e-3          # measured 2.6e-3
     assert torch.equal(o2, o3) or rel_l2(lg2[-1].float(), lg3[-1].float()) <= 5e-4
 
 
@@ -635,7 +637,7 @@ def test_prefill_folded_rmsnorm_vs_oracle(dev):
         assert ef <= 3e-2 and es <= 3e-2, (H, ef, es)                 # measured 2.0e-2 at H = 1024 (32 layers), x 1.5
         assert ef <= 1.25 * es + 1e-3, (H, ef, es)                    # no farther from fp32 than the separate-norm path
         worst = max(rel_l2(got["1"][r], ref[r]) for r in range(rows))
-        assert worst <= 2 * TOL_DEEP, (H, worst)                      # no single row off (a wrong row factor would be O(1))
+        assert worst <= 4.9e-2, (H, worst)                            # no single row off (a wrong row factor would be O(1)); measured 3.2e-2
 
 
 @pytest.mark.gpu
@@ -685,7 +687,7 @@ def test_multimodal_glue_random_layouts_vs_reference(dev, model):
             assert np.array_equal(np.array(model._last_splice[0], dtype=np.int32), ref_m), name
             got = embeds.double().cpu() @ proj
             assert got.shape == ref_p.shape, name
-            assert rel_l2(got.float(), ref_p.float()) <= 1e-2, (name, rel_l2(got.float(), ref_p.float()))
+            assert rel_l2(got.float(), ref_p.float()) <= 7.4e-3, (name, rel_l2(got.float(), ref_p.float()))   # measured 4.9e-3
             # a misplaced row would show as an O(1) error in that row: bound the worst row against the scale of the case
             assert float((got - ref_p).abs().max()) <= 0.05 * float(ref_p.abs().max()), name
     finally:
