@@ -1,5 +1,5 @@
 """Error-localisation report for the end-to-end path on the GPU box (not a test): per-stage / per-row rel-L2 of the
-HIP path vs the emulating oracle and vs the reference-generated goldens. python tools/gpu_diag.py > gpurun_out/diag.txt"""
+HIP path vs the emulating oracle and vs the reference-generated goldens. python tests/gpu_diag.py > gpurun_out/diag.txt; under tests/ because it calls the oracle"""
 import os
 import sys
 

@@ -2,7 +2,9 @@
 bench init), S rows, every operator run ON THE ORACLE'S OWN INTERMEDIATES (teacher forcing), so each line is the deviation that
 ONE operator adds on identical inputs: rel-L2 vs the emulation (same bf16 storage points) and vs fp32.
 
-    python tools/parity_ops_fullwidth.py [S=1088]
+    python tests/parity_ops_fullwidth.py [S=1088]        (report; tests/test_gpu_parity_ops.py asserts the same numbers)
+
+Lives under tests/ because it calls the oracle (test infrastructure): nothing outside tests/, smoke() and bench.py's cpu_baseline does.
 """
 import json
 import math
@@ -21,8 +23,8 @@ def rel(a, b):
     return FW.rel(a, b)
 
 
-def main():
-    S = int(sys.argv[1]) if len(sys.argv) > 1 else 1088
+def measure(S=1088):
+    """{operator: {vs_emu, emu_vs_fp32, ..}} for one 7B-width decoder layer on S rows."""
     _lib.load()
     dev = torch.device("cuda:0")
     torch.set_num_threads(min(32, os.cpu_count() or 8))
@@ -111,6 +113,11 @@ def main():
     kvc = PagedKVCache(llama, npages + 1)
     _, hid = llama_forward(llama, kvc, [SequenceState()], d(x0), [S], logit_rows=[S - 1], return_hidden=True)
     rep["whole_layer_hidden"] = dict(vs_emu=rel(hid.cpu(), x2))
+    return rep
+
+
+def main():
+    rep = measure(int(sys.argv[1]) if len(sys.argv) > 1 else 1088)
     for k_, v_ in rep.items():
         print(f"{k_:20s} " + json.dumps({a_: round(b_, 7) for a_, b_ in v_.items()}), flush=True)
 

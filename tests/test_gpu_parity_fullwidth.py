@@ -10,16 +10,16 @@ The float contract these tests state and measure:
   * HIP is no farther from fp32 (oracle == reference to 2e-5, tests/test_oracle_fullwidth.py) than the oracle's emulation of the
     kernels' bf16 storage points is (x 1.25 + 2e-4) -- measured: equal to three digits everywhere;
   * HIP is within FW_TOL_EMU = 2e-3 of that emulation wherever no softmax weight is rounded (projector, region: 1e-4 .. 2e-4) and
-    for the ViT layers (1.3e-3 after two layers), and within FW_TOL_EMU_DECODER = 1e-2 for decoder layers at H = 4096: every operator
-    of a decoder layer run on the emulation's own inputs deviates from it by <= 6e-5 EXCEPT flash attention (2.0e-3,
-    tools/parity_ops_fullwidth.py -> profiles/r2_parity_ops_fullwidth.txt): the kernel rounds P to bf16 relative to its running
-    row maximum, the emulation relative to the final one, so the two draw independent 2^-9 rounding errors on the few softmax weights
-    that dominate a row at this init, and o_proj / RMSNorm / the MLP amplify that to 5..8e-3 on the layer output -- the same size
-    as the emulation's own distance from fp32 (1.0..1.3e-2), in an independent direction.
+    for the ViT layers (1.3e-3 after two layers), and within FW_TOL_EMU_DECODER = 8.6e-3 for decoder layers at H = 4096 (measured 4.1e-3 /
+    5.7e-3). Every operator of a decoder layer run on the emulation's own inputs is within 1e-3 of it (tests/test_gpu_parity_ops.py:
+    <= 5.2e-5, flash attention 6.7e-4 since round 3 packs the softmax weights to fp16 -- round 2, bf16 P against the running maximum:
+    2.0e-3); what a whole layer adds on top (3.3e-3) is rounding FLIPS: a 1e-7 difference in an fp32 sum moves the next bf16 store by a
+    whole ulp, and o_proj / RMSNorm / the MLP amplify it -- the same size as a fraction of the emulation's own distance from fp32
+    (1.0..1.3e-2), in an independent direction.
 north_star's 1e-3 against an fp32 reference is below what ONE bf16 store leaves (2^-9 relative per element, ~1.7e-3 rel-L2): it is
 met per operator against the emulation and reported -- not asserted -- for the chains.
 Integer outputs (region cell masks and counts) are bit-exact against the reference. Measured numbers are printed (pytest -s) and
-collected by tools/parity_report.py into profiles/.
+written to $VT_PARITY_REPORT (-> profiles/r3_parity_fullwidth.json).
 """
 import json
 import os
