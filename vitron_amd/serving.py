@@ -130,14 +130,22 @@ class ServingEngine:
             raise
         rest = reqs[len(admitted):]
         flats = [r.flat for r in admitted]
-        if self.batch_prefill and len(admitted) > 1:
-            logits = llama_forward(llama, m.kv, [r.seq for r in admitted], torch.cat(flats, 0), [f.shape[0] for f in flats])
-            nxt = self._pick(logits)
-            for i, r in enumerate(admitted):
-                r.last = nxt[i:i + 1]
-        else:
-            for r, f in zip(admitted, flats):
-                r.last = self._pick(llama_forward(llama, m.kv, [r.seq], f, [f.shape[0]]))
+        try:
+            if self.batch_prefill and len(admitted) > 1:
+                logits = llama_forward(llama, m.kv, [r.seq for r in admitted], torch.cat(flats, 0), [f.shape[0] for f in flats])
+                nxt = self._pick(logits)
+                for i, r in enumerate(admitted):
+                    r.last = nxt[i:i + 1]
+            else:
+                for r, f in zip(admitted, flats):
+                    r.last = self._pick(llama_forward(llama, m.kv, [r.seq], f, [f.shape[0]]))
+        except Exception:                                   # a failed prefill gives its pages back and leaves every candidate queued
+            for r in admitted:
+                m.kv.release(r.seq.pages)
+                r.seq.pages, r.seq.length, r.last = [], 0, None
+            for r in reversed(reqs):
+                self.waiting.appendleft(r)
+            raise
         for r in admitted:
             r.flat = None                                   # the rows are in the cache now
         self.active += admitted
