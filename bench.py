@@ -70,6 +70,23 @@ def pmc_traffic_per_launch():
     return (tot / n if n else None), d.get("_measured_on", "unknown build"), os.path.relpath(path, ROOT)
 
 
+def pmc_traffic_decode_per_launch():
+    """The same for the weight-streaming GEMM of the decode flow (profiles/r<N>_pmc_traffic_decode.json: separate --pmc FETCH_SIZE /
+    WRITE_SIZE passes over tools/decode_bench.py 64): mean HBM-side bytes per gemm_skinny_dma_kernel launch."""
+    path = next((p_ for p_ in (os.path.join(ROOT, "profiles", f"r{r}_pmc_traffic_decode.json") for r in range(9, 0, -1)) if os.path.exists(p_)), None)
+    if path is None:
+        return None, None
+    with open(path) as f:
+        d = json.load(f)
+    tot, n = 0.0, 0
+    for k, v in d.items():
+        if k.startswith("gemm_skinny") and isinstance(v, dict) and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            l = v["FETCH_SIZE"]["launches"]
+            tot += l * (2.0 * v["FETCH_SIZE"]["mean_per_launch"] + v["WRITE_SIZE"]["mean_per_launch"]) * 1024.0
+            n += l
+    return (tot / n if n else None), os.path.relpath(path, ROOT)
+
+
 def committed_c4_n1():
     """tokens/s of config.c4 at N = 1 from the newest committed bench line (profiles/r<N>_bench.json): the denominator of the
     strong-scaling ratio SURVEY.md 8(e) asks for, so that a multi-GPU line carries it next to the weak-scaling headline."""
@@ -315,6 +332,8 @@ def c5_report(model, llama, dev, steps, seed):
                          "frac": (gs["work"] / (gs["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if gs["ms"] > 0 else 0.0,
                          "avg_launch_ms": gs["ms"] / max(gs["launches"], 1), "launches_per_step": gs["launches"] / max(n_dec, 1),
                          "algorithmic_mbytes_per_launch": gs["work"] / max(gs["launches"], 1) / 1e6,
+                         "traffic": pmc_traffic_decode_per_launch()[0],
+                         "traffic_note": f"mean bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, KiB) from the committed rocprofv3 --pmc passes {pmc_traffic_decode_per_launch()[1]}; not collected live",
                          "note": f"HIP-event pairs around the launches of a separate {psteps}-token generate() (incl. the region path's three weight-streaming GEMMs)"},
             "whole_step_gbytes": (wbytes + kv_bytes) / 1e9, "whole_step_GBps": (wbytes + kv_bytes) / dec / 1e9,
             "whole_step_frac_of_hbm_peak": (wbytes + kv_bytes) / dec / 1e9 / HBM_PEAK_GBS,
