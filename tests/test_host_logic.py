@@ -507,3 +507,100 @@ def test_tower_and_projector_factories_pick_the_reference_branches(tmp_path):
     c.mm_projector_type = "mlp_gelu"
     with pytest.raises(ValueError):
         build_vision_projector(c)
+
+
+def test_serving_admission_host_logic_with_a_stub_model(monkeypatch):
+    """vitron_amd.serving.ServingEngine._admit / step, host side only (stub model + stub page pool, the decoder pass patched out): an idle
+    engine sizes the pool for the WHOLE candidate batch; a request that does not fit while others are live waits at the head of the
+    queue with its spliced rows kept (embedded once); a failure while the pool would have to grow -- or inside the prefill -- gives every
+    page back and leaves every candidate queued."""
+    import types
+
+    import torch
+
+    from vitron_amd import serving
+
+    class Pool:
+        def __init__(self, n):
+            self.num_pages, self.free = n, list(range(n))
+
+        def alloc(self, k):
+            assert k <= len(self.free)
+            out, self.free = self.free[:k], self.free[k:]
+            return out
+
+        def release(self, pages):
+            self.free += list(pages)
+
+    class Model:
+        device = torch.device("cpu")
+        config = types.SimpleNamespace(eos_token_id=2, vis_cache_entries=4)
+
+        def __init__(self):
+            self.kv, self.embeds, self.grow_fails = None, 0, False
+
+        def get_model(self):
+            return types.SimpleNamespace(llama=None, embed_tokens=lambda ids: torch.zeros((1, ids.shape[1], 8)))
+
+        def prepare_inputs_labels_for_multimodal(self, ids, *a, **k):
+            self.embeds += 1
+            return (None, None, None, None, None, None)
+
+        def _ensure_kv(self, n):
+            if self.grow_fails:
+                raise RuntimeError("pages in use")
+            if self.kv is None or self.kv.num_pages < n:
+                self.kv = Pool(n)
+
+        def reset_prefix_cache(self):
+            pass
+
+    calls = {"n": 0, "fail": False}
+
+    def fake_forward(llama, kv, seqs, flat, lens, *a, **k):
+        calls["n"] += 1
+        if calls["fail"]:
+            raise RuntimeError("device error")
+        for s, n in zip(seqs, lens):
+            s.length += n
+        return torch.zeros((len(seqs), 16))
+
+    monkeypatch.setattr(serving, "llama_forward", fake_forward)
+    monkeypatch.setattr(serving.ops, "argmax", lambda lg: torch.zeros((lg.shape[0],), dtype=torch.int32))
+    m = Model()
+    eng = serving.ServingEngine(m, max_batch=4)
+    ids = lambda n: torch.ones((1, n), dtype=torch.long)             # noqa: E731
+    need = lambda n, new: (n + new + 63) // 64 + 1                    # noqa: E731
+    a, b = eng.submit(ids(100), max_new_tokens=28), eng.submit(ids(300), max_new_tokens=84)
+    rest = eng._admit([eng.waiting.popleft(), eng.waiting.popleft()])
+    assert rest == [] and len(eng.active) == 2 and m.kv.num_pages == need(100, 28) + need(300, 84) and not m.kv.free   # sized for the batch
+    assert m.embeds == 2
+    # a third request while the two are live: no page is free -> it waits (rows kept), nothing raised, nothing re-embedded on the retry
+    c = eng.submit(ids(50), max_new_tokens=14)
+    r = eng.waiting.popleft()
+    assert eng._admit([r]) == [r] and r.flat is not None and r.need == need(50, 14) and m.embeds == 3
+    assert eng._admit([r]) == [r] and m.embeds == 3
+    # the first request retires: its pages come back, the waiting one fits now
+    eng._retire(eng.active[0])
+    eng.active = eng.active[1:]
+    assert eng._admit([r]) == [] and r.flat is None and len(r.seq.pages) == need(50, 14) and r in eng.active
+    # idle engine, the pool has to grow but cannot (pages held elsewhere): candidates stay queued, no page leaked
+    for q in list(eng.active):
+        eng._retire(q)
+    eng.active = []
+    free_before = len(m.kv.free)
+    m.grow_fails = True
+    big = eng.submit(ids(4000), max_new_tokens=96)
+    cand = [eng.waiting.popleft()]
+    with pytest.raises(RuntimeError):
+        eng._admit(cand)
+    assert list(eng.waiting) == cand and len(m.kv.free) == free_before and cand[0].seq.pages == []
+    # a prefill that fails on the device: pages back, candidates queued again
+    m.grow_fails, calls["fail"] = False, True
+    cand = [eng.waiting.popleft()]
+    with pytest.raises(RuntimeError):
+        eng._admit(cand)
+    assert list(eng.waiting) == cand and cand[0].seq.pages == [] and len(m.kv.free) == m.kv.num_pages and not eng.active
+    calls["fail"] = False
+    assert eng._admit([eng.waiting.popleft()]) == [] and len(eng.active) == 1
+    assert (a, b, c, big) == (0, 1, 2, 3)
