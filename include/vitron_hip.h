@@ -9,7 +9,15 @@
  *   - plain C, no torch types; every tensor is a raw DEVICE pointer owned by the caller (PyTorch's caching
  *     allocator in practice) and valid for the duration of the call. The library never allocates or frees
  *     tensor memory: scratch comes in as (workspace, workspace_bytes); query the size with *_workspace_bytes.
- *   - bf16 tensors are uint16_t* (raw bits), row-major. Linear weights keep torch's [out][in] layout.
+ *   - 16-bit tensors are uint16_t* (raw bits), row-major. Linear weights keep torch's [out][in] layout.
+ *   - OPERAND FORMAT. The same sources are built twice with the same ABI: libvitron_hip.so computes with bf16 operands
+ *     (BASELINE.json's dtype) and libvitron_hip_f16.so with IEEE fp16 operands -- the reference's own inference dtype
+ *     (vitron/model/builder.py:47 torch_dtype=float16; towers :153,161). vt_operand_format() says which one a handle is.
+ *     Wherever this header says "bf16" for a tensor (weights, activations, embeddings, K pages, pixel input, outputs) read
+ *     "the library's operand format"; the historical names (vt_gemm_bf16, VT_EPI_BF16, VT_DTYPE_BF16) are kept for both.
+ *     Everything else is identical in the two libraries: fp32 residual stream / accumulation / softmax statistics / biases,
+ *     fp16 V^T pages and softmax weights. The fp16 library saturates operand stores at +-65504 (the reference would
+ *     produce inf); bf16 weights of magnitude below 2^-14 lose mantissa bits when repacked to fp16 (absolute error <= 2^-25).
  *   - every function is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream),
  *     re-entrant, and returns 0 on success or a negative vt_status; vt_last_error() gives the message of the
  *     calling thread's last failure. Nothing throws, nothing synchronises the device.
@@ -57,12 +65,15 @@ enum {
   VT_GEMM_CFG_160x128_W4 = 15, /* four waves of 80x64 on a 160x128 tile, four-deep LDS ring: N = 1024 projections (K % 256 == 0) */
   VT_GEMM_CFG_224x256_W4 = 16, /* the four-wave kernel on 224-row tiles (112x128 per wave): row counts a little over a multiple of 224 (1088, 4616) */
 };
-enum { VT_DTYPE_BF16 = 0, VT_DTYPE_F32 = 1 };
+enum { VT_DTYPE_BF16 = 0, VT_DTYPE_OP16 = 0 /* the 16-bit operand format of the library */, VT_DTYPE_F32 = 1 };
 enum { VT_ACT_GELU = 0, VT_ACT_QUICK_GELU = 1 };
 
 #define VT_PAGE_TOKENS 64 /* tokens per KV-cache page == keys per attention tile */
 
 int vt_version(void);
+/* operand format of THIS library (see Conventions): every uint16_t tensor argument carries these bits */
+enum { VT_OPERAND_BF16 = 0, VT_OPERAND_FP16 = 1 };
+int vt_operand_format(void);
 /* copies the calling thread's last error message (NUL terminated) into buf; returns its length */
 int vt_last_error(char* buf, size_t buf_len);
 
@@ -201,7 +212,9 @@ int vt_projector_forward(const uint16_t* x, int M, int Din, const uint16_t* w1, 
  *   feats   bf16 [B][G*G][D]      patch features of the image tower (pre-projector)
  *   slices  int32 [B][4]          {row_start,row_stop,col_start,col_stop} = Python slice(int(x1),int(x2)) /
  *                                  slice(int(y1),int(y2)) resolved against image_size on the host (x -> rows, :83)
- *   coords  bf16 [B][8]           raw box {x1,y1,x2,y2,0,0,0,0} (LocationEncoder input, :126)
+ *   coords  fp32 [B][4]           raw box {x1,y1,x2,y2} (LocationEncoder input, :126; fp32 so that canvas coordinates above 256,
+ *                                  which bf16 cannot hold, reach the K = 4 layer unrounded -- the reference casts them to the
+ *                                  model dtype, where fp16 holds integers to 2048)
  *   mlp_w[2]/mlp_b[2]             first two layers of region_linear (D->H, H->H, ReLU after each; layer.py:17-20)
  *   loc_w0 / loc_b0               LocationEncoder layer 0, bf16 [H/2][8] (zero padded from [H/2][4]) / fp32 [H/2]
  *   final_w / final_b             [H][H + H/2] = [ region_linear.layers.2.weight | loc_encoder.2.weight ] and the SUM of their
@@ -220,7 +233,7 @@ typedef struct vt_region_weights {
   const float* final_b;
 } vt_region_weights;
 size_t vt_region_workspace_bytes(int B, int in_dim, int out_dim);
-int vt_region_forward(const vt_region_weights* w, const uint16_t* feats, const int* slices, const uint16_t* coords,
+int vt_region_forward(const vt_region_weights* w, const uint16_t* feats, const int* slices, const float* coords,
                       int B, int G, int image_size, uint16_t* out, int* cell_mask, int* cell_count, void* workspace,
                       size_t workspace_bytes, void* stream);
 

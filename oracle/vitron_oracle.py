@@ -19,12 +19,14 @@ against outputs of the reference's OWN modules run in the build container under 
   - vitron/mm_utils.py                                                   tokenizer_image_token, preprocess_region ...
 and tests/test_oracle_golden.py checks this file against them (fp32, rel-L2 <= 1e-5; integer outputs exact).
 
-Two numeric modes:
-  emulate_bf16=False  pure fp32 on the given (bf16-representable) inputs and weights.
-  emulate_bf16=True   same maths, but values are rounded to bf16 at exactly the points where the HIP path
-                      stores bf16 (GEMM operands: norm outputs, fused-QKV, attention outputs, activations) and the
-                      softmax weights to fp16 where the prefill attention kernel feeds them to its P.V MFMA;
-                      accumulation, softmax, norms and the residual stream stay fp32 like the kernels.
+Numeric modes (the `emulate_bf16` argument of every function; the name predates the fp16 build):
+  emulate_bf16=False   pure fp32 on the given (bf16-representable) inputs and weights.
+  emulate_bf16=True    same maths, but values are rounded to bf16 at exactly the points where the HIP path
+                       stores its 16-bit operands (norm outputs, fused-QKV, attention outputs, activations) and the
+                       softmax weights to fp16 where the prefill attention kernel feeds them to its P.V MFMA;
+                       accumulation, softmax, norms and the residual stream stay fp32 like the kernels.
+  emulate_bf16="fp16"  the same storage points rounded to IEEE fp16 (saturating at +-65504): the emulation of
+                       libvitron_hip_f16.so, the fp16-operand build (vitron_amd/csrc/vt_common.h).
 State dicts use the reference's parameter names.
 """
 from __future__ import annotations
@@ -51,7 +53,16 @@ def fp16_round(x: torch.Tensor) -> torch.Tensor:
     return x.to(torch.float16).to(torch.float32)
 
 
-def _r(x: torch.Tensor, emulate: bool) -> torch.Tensor:
+def fp16_store(x: torch.Tensor) -> torch.Tensor:
+    """An operand store of the fp16 build: round to nearest even, saturate at +-65504 (vt_common.h pack_op2)."""
+    return x.clamp(-65504.0, 65504.0).to(torch.float16).to(torch.float32)
+
+
+def _r(x: torch.Tensor, emulate) -> torch.Tensor:
+    if isinstance(emulate, str):
+        if emulate != "fp16":
+            raise ValueError(f"emulate_bf16 must be False, True or 'fp16', got {emulate!r}")
+        return fp16_store(x)
     return bf16_round(x) if emulate else x
 
 
@@ -80,7 +91,7 @@ def clip_attention(x, sd: SD, prefix: str, heads: int, emulate: bool, round_p: b
     s = q @ k.transpose(-1, -2)
     if emulate and round_p:  # flash kernel: P (relative to the row max) is rounded to fp16 for the PV MFMA, row sum fp32
         p = torch.exp(s - s.amax(-1, keepdim=True))
-        o = (fp16_round(p) @ v) / p.sum(-1, keepdim=True)
+        o = (fp16_round(p) @ fp16_store(v)) / p.sum(-1, keepdim=True)   # V^T pages hold fp16, saturating at +-65504 (vt_common.h)
     else:
         o = torch.softmax(s, dim=-1) @ v
     o = o.transpose(1, 2).reshape(B, N, D)
@@ -381,7 +392,10 @@ def llama_forward(sd: SD, cfg: dict, inputs_embeds: torch.Tensor, position_ids: 
         s = q @ k.transpose(-1, -2) / math.sqrt(hd) + mask
         if emulate_bf16:
             pr = torch.exp(s - s.amax(-1, keepdim=True))
-            o = (fp16_round(pr) @ v) / pr.sum(-1, keepdim=True)   # P in fp16 for the PV MFMA; V (bf16 values) is exact in fp16
+            # P in fp16 for the PV MFMA; the V^T pages hold the fp16 image of V: exact for bf16 values of magnitude 2^-14 .. 65504,
+            # SATURATING beyond (vt_common.h op2_to_f16x2) -- emulated, so that a checkpoint with outlier V activations shows up as a
+            # parity difference against the fp32 mode instead of passing silently
+            o = (fp16_round(pr) @ fp16_store(v)) / pr.sum(-1, keepdim=True)
         else:
             o = torch.softmax(s, dim=-1, dtype=torch.float32) @ v
         o = _r(o.transpose(1, 2).reshape(B, S, H), emulate_bf16)
@@ -446,8 +460,7 @@ def multimodal_prepare(weights: dict, cfgs: dict, input_ids: torch.Tensor, atten
         f = tower_features(weights["image_tower"], cfgs["image"], batch, -2, emulate_bf16)      # encode_images :168-181
         if use_regions:
             rb = [regions[i] for i in image_idx]                                                # :241
-            coords = bf16_round(torch.tensor(rb, dtype=torch.float32)) if emulate_bf16 else None
-            r, _, _ = region_forward(weights["region"], f, rb, region_image_size, emulate_bf16, coords)
+            r, _, _ = region_forward(weights["region"], f, rb, region_image_size, emulate_bf16)   # coordinates stay fp32 (the ABI takes them so)
         pf = projector_forward(weights["projector"], f, emulate_bf16)
         for j, i in enumerate(image_idx):
             feats[i] = pf[j]

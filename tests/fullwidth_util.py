@@ -42,6 +42,12 @@ def region_case(canvas):
     return sd, cases.features((len(boxes), 24 * 24, 1024), cases.FW_SEED + 12), boxes
 
 
+def operand(op):
+    """(torch dtype, oracle emulation flag, oracle rounding function) of an operand build name ('bf16' | 'fp16')."""
+    from oracle import vitron_oracle as O
+    return (torch.bfloat16, True, O.bf16_round) if op == "bf16" else (torch.float16, "fp16", O.fp16_store)
+
+
 def rel(a, b):
     a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
@@ -68,13 +74,15 @@ _ORACLE_CACHE = {}
 
 
 def oracle_llama(name, emulate):
-    """(logits [S, V], final hidden [S, H]) of the oracle on llama_case(name), fp32 or bf16-storage emulation -- computed once per test
-    session: the prefill and the decode parity tests compare against the same two passes (each ~1 min of host time at the 7B width)."""
+    """(logits [S, V], final hidden [S, H]) of the oracle on llama_case(name): fp32 (emulate False), bf16-storage emulation (True) or
+    fp16-storage emulation ("fp16") -- computed once per test session: the prefill and the decode parity tests compare against the
+    same passes (each ~1 min of host time at the 7B width)."""
     from oracle import vitron_oracle as O
-    key = (name, bool(emulate))
+    emulate = emulate if isinstance(emulate, str) else bool(emulate)
+    key = (name, emulate)
     if key not in _ORACLE_CACHE:
         cfg, sd, x = llama_case(name)
         with torch.no_grad():
-            lg, _, h = O.llama_forward({k: v.float() for k, v in sd.items()}, cfg, x.unsqueeze(0), emulate_bf16=bool(emulate), return_hidden=True)
+            lg, _, h = O.llama_forward({k: v.float() for k, v in sd.items()}, cfg, x.unsqueeze(0), emulate_bf16=emulate, return_hidden=True)
         _ORACLE_CACHE[key] = (lg[0], h[0])
     return _ORACLE_CACHE[key]

@@ -101,7 +101,9 @@ def test_load_pretrained_model_matches_direct_construction(tmp_path):
     from tests.util import rel_l2
     ck = _write_checkpoint(str(tmp_path))
     dev = torch.device("cuda:0")
-    tok, model, procs, ctx = load_pretrained_model(ck["ckpt"], ck["base"], "vitron-7b-lora", device="cuda", tokenizer=object())
+    # (bf16 asked for explicitly: like the reference, a checkpoint directory loads as fp16 by default -- tests/test_gpu_fp16.py)
+    tok, model, procs, ctx = load_pretrained_model(ck["ckpt"], ck["base"], "vitron-7b-lora", device="cuda", tokenizer=object(),
+                                                   torch_dtype=torch.bfloat16)
     assert ctx == 2048 and procs["image"].crop_size == {"height": 56, "width": 56} and procs["video"].num_frames == 4
     # reference construction straight from the merged tensors
     cfg = LlavaConfig(**cases.LLM, mm_hidden_size=cases.MM_HIDDEN, mm_image_tower="x/LanguageBind_Image", mm_video_tower="x/LanguageBind_Video_merge")
@@ -162,7 +164,8 @@ def test_parameter_names_are_the_references_own():
 
 
 @pytest.mark.gpu
-def test_full_checkpoint_written_with_reference_names_loads(tmp_path):
+@pytest.mark.parametrize("dtype", [None, torch.bfloat16], ids=["default_fp16", "bf16"])
+def test_full_checkpoint_written_with_reference_names_loads(tmp_path, dtype):
     """A plain (non-LoRA) checkpoint directory whose pytorch_model.bin carries exactly the reference's state_dict() names
     (tower weights included, as a checkpoint saved with loaded towers has them) goes through load_pretrained_model and gives
     the logits of a model constructed directly from the same tensors."""
@@ -180,17 +183,21 @@ def test_full_checkpoint_written_with_reference_names_loads(tmp_path):
     for d, pre, cfg in ((img, "model.image_tower.image_tower.", cases.VIT_IMAGE), (vid, "model.video_tower.video_tower.", cases.VIT_VIDEO)):
         torch.save({"vision_model." + k[len(pre):]: v for k, v in src.items() if k.startswith(pre)}, os.path.join(d, "pytorch_model.bin"))
         json.dump({"vision_config": dict(cfg)}, open(os.path.join(d, "config.json"), "w"))
-    tok, model, procs, _ = load_pretrained_model(ck, None, "vitron-llava-7b", device="cuda", tokenizer=object())
+    # dtype None: the loader's default for a checkpoint directory = the reference's, fp16 (builder.py:47)
+    tok, model, procs, _ = load_pretrained_model(ck, None, "vitron-llava-7b", device="cuda", tokenizer=object(),
+                                                 **({} if dtype is None else {"torch_dtype": dtype}))
+    dtype = dtype or torch.float16
+    assert model.dtype == dtype
     dev = torch.device("cuda:0")
     direct = LlavaLlamaForCausalLM(LlavaConfig(**cases.LLM, mm_hidden_size=cases.MM_HIDDEN, mm_image_tower="x/LanguageBind_Image",
                                                mm_video_tower="x/LanguageBind_Video_merge"))
     direct.get_image_tower().load_state(cases.VIT_IMAGE, {k[len("model.image_tower.image_tower."):]: v for k, v in src.items() if k.startswith("model.image_tower.")})
     direct.get_video_tower().load_state(cases.VIT_VIDEO, {k[len("model.video_tower.video_tower."):]: v for k, v in src.items() if k.startswith("model.video_tower.")})
     direct.load_state_dict({k: v for k, v in src.items() if not k.startswith(("model.image_tower.", "model.video_tower."))})
-    direct.to(dev)
+    direct.to(dev, dtype=dtype)
     case = cases.glue_cases()["image_region"]
     ids = case["input_ids"].to(dev)
-    images = [im.to(dev).bfloat16() for im in case["images"]]
+    images = [im.to(dev).to(dtype) for im in case["images"]]
     a = model(input_ids=ids, images=images, regions=case["regions"], use_cache=False).logits
     b = direct(input_ids=ids, images=images, regions=case["regions"], use_cache=False).logits
     assert torch.equal(a, b)          # same tensors, same packing: bit-identical

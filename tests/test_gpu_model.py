@@ -125,8 +125,7 @@ def test_projector_and_region(dev, model):
         out, cells, count = model.get_region_extractor().packed.forward(feats.to(dev).bfloat16(), cases.BOXES, return_mask=True)
         assert np.array_equal(cells.cpu().numpy(), g[f"region_{tag}_cells"])        # bit exact vs the REFERENCE
         assert count.cpu().tolist() == g[f"region_{tag}_cells"].sum(-1).tolist()
-        coords = O.bf16_round(torch.tensor(cases.BOXES, dtype=torch.float32))
-        emu, _, _ = O.region_forward(f32(st["region"]), feats, cases.BOXES, 224, True, coords)
+        emu, _, _ = O.region_forward(f32(st["region"]), feats, cases.BOXES, 224, True)      # box coordinates stay fp32 (round 4)
         assert rel_l2(out.float(), emu) <= TOL
         assert rel_l2(out.float(), torch.as_tensor(g[f"region_{tag}_out"])) <= TOL_FP32
 

@@ -33,6 +33,10 @@ pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(__file__), "golden")
 N_STEPS = 8
 TOL_7B_LOGITS = 1.9e-2       # logits vs fp32 at H = 4096, 1-2 layers (measured 1.0-1.3e-2, x 1.5)
+TOL_7B_LOGITS_FP16 = 3.0e-3  # the same in the fp16-operand build (round 4: measured x 1.5, profiles/r4_parity_decode.json): the noise bound of the
+                             # id comparison shrinks with it, so more of the reference's ids are decidable and asserted
+TOL_7B = {"bf16": TOL_7B_LOGITS, "fp16": TOL_7B_LOGITS_FP16}
+OPERANDS = ["bf16", "fp16"]
 TOL_TINY_LOGITS = 1.1e-1     # decode-step logits of the tiny-width chains vs the reference (w_std 0.05 / attn_std 0.12-0.15, DESIGN.md 4: measured
                              # 2.6e-2 .. 7.3e-2 over 12 free-running steps, x 1.5)
 NOISE_TINY = 3e-2            # typical logits error there (the prefill bound of tests/test_gpu_model.py): basis of the id noise bound
@@ -67,24 +71,27 @@ def dev():
 # ---------------------------------------------------------------------------------------------------------------------------------
 # (a) decode kernels at the 7B width vs oracle and reference
 # ---------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("op", OPERANDS)
 @pytest.mark.parametrize("name", list(cases.FW_LLAMA))
-def test_decode_steps_at_7b_width_vs_oracle_and_reference(dev, name):
+def test_decode_steps_at_7b_width_vs_oracle_and_reference(dev, name, op):
     from vitron_amd.engine import PackedLlama, PagedKVCache, SequenceState, llama_forward
+    odt, emu, _ = FW.operand(op)
+    tol = TOL_7B[op]
     g = FW.golden()
     cfg, sd, x = FW.llama_case(name)
     S = x.shape[0]
     P = S - N_STEPS
-    llama = PackedLlama(sd, cfg, dev)
+    llama = PackedLlama(sd, cfg, dev, dtype=odt)
     kv = PagedKVCache(llama, 2 * ((S + 63) // 64 + 1))
     seq = SequenceState()
-    xd = x.to(dev).bfloat16()
+    xd = x.to(dev).to(odt)
     llama_forward(llama, kv, [seq], xd[:P], [P], logit_rows=[])
     steps = [llama_forward(llama, kv, [seq], xd[P + t:P + t + 1], [1]) for t in range(N_STEPS)]   # rows <= 16, q_len 1: the decode kernels
     got = torch.cat(steps, 0).float().cpu()                                                  # logits of rows P .. S-1
     # the same rows out of ONE prefill over the whole sequence (tile GEMMs, separate norms, flash attention)
     seq2 = SequenceState()
     pre = llama_forward(llama, kv, [seq2], xd, [S], logit_rows=list(range(P, S))).float().cpu()
-    l32, lem = FW.oracle_llama(name, False)[0][P:], FW.oracle_llama(name, True)[0][P:]      # (shared with the prefill parity test)
+    l32, lem = FW.oracle_llama(name, False)[0][P:], FW.oracle_llama(name, emu)[0][P:]      # (shared with the prefill parity test)
     d_f32, d_emu, emu_f32, pre_f32 = FW.rel(got, l32), FW.rel(got, lem), FW.rel(lem, l32), FW.rel(pre, l32)
     per_step = [FW.rel(got[t], l32[t]) for t in range(N_STEPS)]
     # the REFERENCE's stored outputs for these rows: projections on the fixed directions, top-5 ids, the whole last row
@@ -96,11 +103,11 @@ def test_decode_steps_at_7b_width_vs_oracle_and_reference(dev, name):
     top1 = float((got.argmax(-1) == ref_top5[:, 0]).double().mean())
     assert int(g[f"{tag}_rowidx"][-1]) == S - 1
     d_last = FW.rel(got[-1], g[f"{tag}_rows"][-1])
-    _note(f"decode_{name}", prefill_rows=P, steps=N_STEPS, vs_fp32=d_f32, vs_emulation=d_emu, emulation_vs_fp32=emu_f32,
+    _note(f"decode_{name}_{op}", prefill_rows=P, steps=N_STEPS, vs_fp32=d_f32, vs_emulation=d_emu, emulation_vs_fp32=emu_f32,
           prefill_kernels_vs_fp32=pre_f32, worst_step_vs_fp32=max(per_step), vs_reference_proj=d_proj, emulation_vs_reference_proj=emu_proj,
           last_row_vs_reference=d_last, top1_vs_reference=top1)
     assert torch.isfinite(got).all()
-    assert d_f32 <= 1.25 * emu_f32 + 2e-4 and max(per_step) <= TOL_7B_LOGITS, (d_f32, emu_f32, per_step)
+    assert d_f32 <= 1.25 * emu_f32 + 2e-4 and max(per_step) <= tol, (d_f32, emu_f32, per_step)
     assert d_last <= 1.25 * emu_f32 + 2e-4, (d_last, emu_f32)                   # the reference's own last logits row
     assert d_proj <= 1.5 * emu_proj + 2e-3, (d_proj, emu_proj)                   # 8 rows x 4 directions: a small sample, looser factor
     assert d_f32 <= 1.25 * pre_f32 + 2e-3, (d_f32, pre_f32)                      # the decode kernels cost no accuracy against the prefill kernels
@@ -109,7 +116,7 @@ def test_decode_steps_at_7b_width_vs_oracle_and_reference(dev, name):
     top2 = l32.topk(2, dim=-1).values
     rms = l32.double().pow(2).mean(-1).sqrt()
     for t in range(N_STEPS):
-        if float(top2[t, 0] - top2[t, 1]) > noise_bound(TOL_7B_LOGITS, float(rms[t])):
+        if float(top2[t, 0] - top2[t, 1]) > noise_bound(tol, float(rms[t])):
             assert int(got[t].argmax()) == int(ref_top5[t, 0]), (t, float(top2[t, 0] - top2[t, 1]))
 
 
@@ -130,22 +137,25 @@ def _check_ids(name, got_ids, ref_ids, margins, bounds, candidates):
     return asserted, exempt
 
 
-def test_greedy_ids_at_7b_width_vs_reference(dev):
+@pytest.mark.parametrize("op", OPERANDS)
+def test_greedy_ids_at_7b_width_vs_reference(dev, op):
     """Prefill 1088 rows, then 8 greedy steps on the device-resident decode state (DecodeState: vt_decode_feed + vt_llama_forward +
     vt_argmax, no host round trip inside a step), teacher-forced on the reference's ids."""
     from vitron_amd import ops
     from vitron_amd.engine import DecodeState, PackedLlama, PagedKVCache, SequenceState, llama_forward
+    odt, _, _ = FW.operand(op)
+    tol = TOL_7B[op]
     g = np.load(os.path.join(G, "greedy.npz"))
     name = "s1088_l2"
     cfg, sd, x = FW.llama_case(name)
     assert synth.checksum(sd) == pytest.approx(float(g[f"llama_{name}_checksum"]), rel=1e-12)
     ref_ids = g[f"llama_{name}_ids"].tolist()
     n = len(ref_ids)
-    llama = PackedLlama(sd, cfg, dev)
+    llama = PackedLlama(sd, cfg, dev, dtype=odt)
     kv = PagedKVCache(llama, (x.shape[0] + n + 63) // 64 + 2)
     # teacher-forced: every step sees the reference's previous id
     seq = SequenceState()
-    logits = llama_forward(llama, kv, [seq], x.to(dev).bfloat16(), [x.shape[0]])
+    logits = llama_forward(llama, kv, [seq], x.to(dev).to(odt), [x.shape[0]])
     st = DecodeState(llama, kv, [seq], n)
     got_ids, rows = [], []
     for t in range(n):
@@ -156,7 +166,7 @@ def test_greedy_ids_at_7b_width_vs_reference(dev):
             logits = st.forward()
     rows = torch.stack(rows)
     margins, rms = g[f"llama_{name}_margin"], g[f"llama_{name}_rms"]
-    bounds = [noise_bound(TOL_7B_LOGITS, float(r)) for r in rms]
+    bounds = [noise_bound(tol, float(r)) for r in rms]
     t5i, t5v = g[f"llama_{name}_top5_ids"], g[f"llama_{name}_top5_vals"]
     cand = [[int(i) for i, v in zip(t5i[t], t5v[t]) if t5v[t][0] - v <= bounds[t]] for t in range(n)]
     asserted, exempt = _check_ids("7b", got_ids, ref_ids, margins, bounds, cand)
@@ -166,7 +176,7 @@ def test_greedy_ids_at_7b_width_vs_reference(dev):
     # free-running greedy through the same state: identical to the teacher-forced run as long as the ids agree
     kv.release(seq.pages)
     seq2 = SequenceState()
-    logits = llama_forward(llama, kv, [seq2], x.to(dev).bfloat16(), [x.shape[0]])
+    logits = llama_forward(llama, kv, [seq2], x.to(dev).to(odt), [x.shape[0]])
     st = DecodeState(llama, kv, [seq2], n)
     free = []
     for t in range(n):
@@ -176,11 +186,12 @@ def test_greedy_ids_at_7b_width_vs_reference(dev):
             st.feed(nxt)
             logits = st.forward()
     agree = next((t for t in range(n) if free[t] != ref_ids[t]), n)
-    _note("greedy_7b", steps=n, asserted=asserted, exempt=exempt, ids=got_ids, reference_ids=ref_ids, free_running_agree_steps=agree,
+    _note(f"greedy_7b_{op}", steps=n, asserted=asserted, exempt=exempt, ids=got_ids, reference_ids=ref_ids, free_running_agree_steps=agree,
           top5_values_vs_reference=d_top5, proj_vs_reference=d_proj, bound=float(np.mean(bounds)))
-    assert asserted >= 3, (asserted, exempt)                       # the reference's margins at this init: 3 of 8 above the 3-sigma bound
+    # the reference's margins at this init: 3 of 8 above the 3-sigma bound of the bf16 build, >= 6 of 8 above the fp16 build's
+    assert asserted >= (3 if op == "bf16" else 6), (asserted, exempt)
     assert sum(int(a == b) for a, b in zip(got_ids, ref_ids)) >= 6   # (measured: all 8 equal, teacher-forced and free-running)
-    assert d_top5 <= TOL_7B_LOGITS and d_proj <= 2 * TOL_7B_LOGITS, (d_top5, d_proj)
+    assert d_top5 <= tol and d_proj <= 2 * tol, (d_top5, d_proj)
     assert free[:agree] == got_ids[:agree]
 
 

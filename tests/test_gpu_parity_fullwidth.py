@@ -36,6 +36,12 @@ pytestmark = pytest.mark.gpu
 
 FW_TOL_EMU = 2e-3            # HIP vs emulating oracle, whole tensors
 FW_TOL_EMU_DECODER = 8.6e-3  # decoder layers: rounding flips of the bf16 chains (see above); measured 4.1e-3 (1 layer) / 5.7e-3 (2 layers), x 1.5
+# The fp16-operand build (round 4; libvitron_hip_f16.so, the reference's own inference dtype): one store leaves 2^-12 per element, so
+# the chains are compared with the REFERENCE / plain fp32 at north_star's scale. Bounds = round-4 measurements x 1.5
+# (profiles/r4_parity_fullwidth.json); the bf16 bounds above are unchanged.
+FP16_TOL_VS_FP32_DECODER = 2.4e-3   # logits / hidden of 1-2 decoder layers at H = 4096 vs fp32
+FP16_TOL_VS_FP32_TOWER = 6e-4       # 1-2 ViT-L layers, projector, region extractor vs fp32
+OPERANDS = ["bf16", "fp16"]
 REPORT = {}
 
 
@@ -60,82 +66,95 @@ def _note(name, **kw):
             json.dump(REPORT, f, indent=1)
 
 
+@pytest.mark.parametrize("op", OPERANDS)
 @pytest.mark.parametrize("name", list(cases.FW_LLAMA))
-def test_decoder_prefill_at_7b_width_vs_oracle_and_reference(dev, name):
+def test_decoder_prefill_at_7b_width_vs_oracle_and_reference(dev, name, op):
     from vitron_amd.engine import PackedLlama, PagedKVCache, SequenceState, llama_forward
+    odt, emu, _ = FW.operand(op)
     g = FW.golden()
     cfg, sd, x = FW.llama_case(name)
     S = x.shape[0]
-    llama = PackedLlama(sd, cfg, dev)
+    llama = PackedLlama(sd, cfg, dev, dtype=odt)
     kv = PagedKVCache(llama, (S + 63) // 64 + 1)
     seq = SequenceState()
-    logits, hidden = llama_forward(llama, kv, [seq], x.to(dev).bfloat16(), [S], logit_rows=list(range(S)), return_hidden=True)
+    logits, hidden = llama_forward(llama, kv, [seq], x.to(dev).to(odt), [S], logit_rows=list(range(S)), return_hidden=True)
     logits, hidden = logits.float().cpu(), hidden.float().cpu()
-    (l32, h32), (lem, hem) = FW.oracle_llama(name, False), FW.oracle_llama(name, True)
+    (l32, h32), (lem, hem) = FW.oracle_llama(name, False), FW.oracle_llama(name, emu)
     l32, h32, lem, hem = l32.unsqueeze(0), h32.unsqueeze(0), lem.unsqueeze(0), hem.unsqueeze(0)
     d_emu, d_f32, emu_f32 = FW.rel(logits, lem[0]), FW.rel(logits, l32[0]), FW.rel(lem[0], l32[0])
     h_emu, h_f32, hemu_f32 = FW.rel(hidden, hem[0]), FW.rel(hidden, h32[0]), FW.rel(hem[0], h32[0])
     ref_proj, ref_rows = FW.vs_pin(logits, g, f"llama_{name}_logits")
     top1, top5 = FW.topk_agreement(logits, g, f"llama_{name}_logits")
     top1_emu, top5_emu = FW.topk_agreement(lem[0], g, f"llama_{name}_logits")
-    _note(f"llama_{name}", rows=S, layers=cfg["num_hidden_layers"], logits_vs_emulation=d_emu, logits_vs_fp32=d_f32,
+    _note(f"llama_{name}_{op}", rows=S, layers=cfg["num_hidden_layers"], logits_vs_emulation=d_emu, logits_vs_fp32=d_f32,
           emulation_vs_fp32=emu_f32, hidden_vs_emulation=h_emu, hidden_vs_fp32=h_f32, hidden_emulation_vs_fp32=hemu_f32,
           logits_vs_reference_rows=ref_rows, logits_vs_reference_proj=ref_proj, top1_vs_reference=top1, top5_overlap_vs_reference=top5,
           top1_of_emulation=top1_emu, top5_overlap_of_emulation=top5_emu)
+    if op == "fp16":     # against plain fp32 and the reference's own rows, at north_star's scale
+        assert d_f32 <= FP16_TOL_VS_FP32_DECODER and h_f32 <= FP16_TOL_VS_FP32_DECODER and ref_rows <= FP16_TOL_VS_FP32_DECODER, (d_f32, h_f32, ref_rows)
     assert d_emu <= FW_TOL_EMU_DECODER and h_emu <= FW_TOL_EMU_DECODER, (d_emu, h_emu)
     assert d_f32 <= 1.25 * emu_f32 + 2e-4 and h_f32 <= 1.25 * hemu_f32 + 2e-4, (d_f32, emu_f32, h_f32, hemu_f32)
     assert ref_rows <= 1.25 * emu_f32 + 2e-4, (ref_rows, emu_f32)            # against the reference's own logits rows
     assert top1 >= top1_emu - 0.01 and top5 >= top5_emu - 0.01, (top1, top1_emu, top5, top5_emu)
 
 
+@pytest.mark.parametrize("op", OPERANDS)
 @pytest.mark.parametrize("name", ["video336", "image336"])
-def test_towers_at_vit_l_336_vs_oracle_and_reference(dev, name):
+def test_towers_at_vit_l_336_vs_oracle_and_reference(dev, name, op):
     from vitron_amd.engine import PackedVit
+    odt, emu, rnd = FW.operand(op)
     g = FW.golden()
     cfg, sd, x = FW.vit_case(name)
     for nl in (1, cases.FW_VIT_LAYERS):
-        vit = PackedVit(sd, cfg, dev, select_layer=nl)
-        feats, hidden = vit.forward(x.to(dev).bfloat16(), return_hidden=True)
+        vit = PackedVit(sd, cfg, dev, select_layer=nl, dtype=odt)
+        feats, hidden = vit.forward(x.to(dev).to(odt), return_hidden=True)
         hidden = hidden.float().cpu().reshape(-1, 1024)
         with torch.no_grad():
             h32 = O.vit_forward(f32(sd), cfg, x, num_layers=nl).reshape(-1, 1024)
-            hem = O.vit_forward(f32(sd), cfg, x, num_layers=nl, emulate_bf16=True).reshape(-1, 1024)
+            hem = O.vit_forward(f32(sd), cfg, x, num_layers=nl, emulate_bf16=emu).reshape(-1, 1024)
         d_emu, d_f32, emu_f32 = FW.rel(hidden, hem), FW.rel(hidden, h32), FW.rel(hem, h32)
         ref_proj, ref_rows = FW.vs_pin(hidden, g, f"vit_{name}_hidden_{nl}")
         # feature_select: patch tokens (CLS dropped) of this hidden state, bf16
         N = hidden.shape[0] // (x.shape[0] * (x.shape[2] if x.dim() == 5 else 1))
         patch = hem.reshape(-1, N, 1024)[:, 1:].reshape(-1, 1024)
-        d_feat = FW.rel(feats.float().cpu().reshape(-1, 1024), O.bf16_round(patch))
-        _note(f"vit_{name}_layers{nl}", rows=hidden.shape[0], vs_emulation=d_emu, vs_fp32=d_f32, emulation_vs_fp32=emu_f32,
+        d_feat = FW.rel(feats.float().cpu().reshape(-1, 1024), rnd(patch))
+        _note(f"vit_{name}_layers{nl}_{op}", rows=hidden.shape[0], vs_emulation=d_emu, vs_fp32=d_f32, emulation_vs_fp32=emu_f32,
               vs_reference_rows=ref_rows, vs_reference_proj=ref_proj, features_vs_emulation=d_feat)
         # one WHOLE tower layer stays inside north_star's 1e-3 of the emulation (measured 5.7e-4 video / 4.4e-4 image); two layers 1.24e-3
+        if op == "fp16":
+            assert d_f32 <= FP16_TOL_VS_FP32_TOWER and ref_rows <= FP16_TOL_VS_FP32_TOWER, (nl, d_f32, ref_rows)
         assert d_emu <= (8.6e-4 if nl == 1 else 1.9e-3) and d_feat <= (2.2e-3 if nl == 1 else 3.3e-3), (nl, d_emu, d_feat)
         assert d_f32 <= 1.25 * emu_f32 + 2e-4 and ref_rows <= 1.25 * emu_f32 + 3e-4, (nl, d_f32, ref_rows, emu_f32)
 
 
-def test_projector_and_region_at_full_width_vs_oracle_and_reference(dev):
+@pytest.mark.parametrize("op", OPERANDS)
+def test_projector_and_region_at_full_width_vs_oracle_and_reference(dev, op):
     from vitron_amd.engine import PackedProjector, PackedRegion
+    odt, emu, _ = FW.operand(op)
     g = FW.golden()
     sd, x = FW.projector_case()
-    out = PackedProjector(sd, dev).forward(x.to(dev).bfloat16()).float().cpu()
+    out = PackedProjector(sd, dev, dtype=odt).forward(x.to(dev).to(odt)).float().cpu()
     with torch.no_grad():
-        o32, oem = O.projector_forward(f32(sd), x), O.projector_forward(f32(sd), x, emulate_bf16=True)
+        o32, oem = O.projector_forward(f32(sd), x), O.projector_forward(f32(sd), x, emulate_bf16=emu)
     d_emu, d_f32, emu_f32 = FW.rel(out, oem), FW.rel(out, o32), FW.rel(oem, o32)
     ref_proj, ref_rows = FW.vs_pin(out, g, "projector")
-    _note("projector", rows=x.shape[0], vs_emulation=d_emu, vs_fp32=d_f32, emulation_vs_fp32=emu_f32, vs_reference_rows=ref_rows)
+    _note(f"projector_{op}", rows=x.shape[0], vs_emulation=d_emu, vs_fp32=d_f32, emulation_vs_fp32=emu_f32, vs_reference_rows=ref_rows)
     assert d_emu <= 1e-3 and d_f32 <= 1.25 * emu_f32 + 2e-4 and ref_rows <= 1.25 * emu_f32 + 3e-4, (d_emu, d_f32, ref_rows, emu_f32)
+    if op == "fp16":
+        assert d_f32 <= FP16_TOL_VS_FP32_TOWER and ref_rows <= FP16_TOL_VS_FP32_TOWER, (d_f32, ref_rows)
     for canvas in (224, 336):
         sd, feats, boxes = FW.region_case(canvas)
-        reg = PackedRegion(sd, dev, image_size=canvas)
-        out, cells, count = reg.forward(feats.to(dev).bfloat16(), boxes, return_mask=True)
+        reg = PackedRegion(sd, dev, image_size=canvas, dtype=odt)
+        out, cells, count = reg.forward(feats.to(dev).to(odt), boxes, return_mask=True)
         assert np.array_equal(cells.cpu().numpy(), g[f"region_c{canvas}_cells"])        # bit exact vs the REFERENCE at G = 24
         assert count.cpu().tolist() == g[f"region_c{canvas}_cells"].sum(-1).tolist()
-        coords = O.bf16_round(torch.tensor(boxes, dtype=torch.float32))
-        with torch.no_grad():
-            oem, _, _ = O.region_forward(f32(sd), feats, boxes, canvas, True, coords)
+        with torch.no_grad():        # (box coordinates reach the LocationEncoder in fp32 since round 4: no rounding to emulate)
+            oem, _, _ = O.region_forward(f32(sd), feats, boxes, canvas, emu)
             o32, _, _ = O.region_forward(f32(sd), feats, boxes, canvas)
         got = out[:, 0].float().cpu()
         d_emu, d_f32, emu_f32 = FW.rel(got, oem[:, 0]), FW.rel(got, o32[:, 0]), FW.rel(oem[:, 0], o32[:, 0])
         d_ref = FW.rel(got, g[f"region_c{canvas}_out"])
-        _note(f"region_canvas{canvas}", boxes=len(boxes), vs_emulation=d_emu, vs_fp32=d_f32, emulation_vs_fp32=emu_f32, vs_reference=d_ref)
+        _note(f"region_canvas{canvas}_{op}", boxes=len(boxes), vs_emulation=d_emu, vs_fp32=d_f32, emulation_vs_fp32=emu_f32, vs_reference=d_ref)
         assert d_emu <= FW_TOL_EMU and d_f32 <= 1.25 * emu_f32 + 5e-4 and d_ref <= 1.25 * emu_f32 + 5e-4, (canvas, d_emu, d_f32, d_ref, emu_f32)
+        if op == "fp16":
+            assert d_f32 <= FP16_TOL_VS_FP32_TOWER and d_ref <= FP16_TOL_VS_FP32_TOWER, (canvas, d_f32, d_ref)

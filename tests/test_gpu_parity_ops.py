@@ -14,12 +14,22 @@ MEASURED_X_1_5 = {"rmsnorm": 1e-6, "qkv_gemm": 6.3e-5, "rope_q": 1e-5, "rope_k_p
                   "rmsnorm2": 3e-5, "swiglu_gemm": 7.8e-5, "down_proj_resid": 1.1e-6, "whole_layer_hidden": 5.0e-3}
 
 
-def test_every_decoder_operator_within_1e3_of_the_emulation_at_7b_width():
+# fp16-operand build (libvitron_hip_f16.so): one store leaves 2^-12 per element (2.1e-4 rel-L2) instead of bf16's 2^-9 (1.66e-3),
+# so the operators are also compared with PLAIN fp32 here -- north_star's 1e-3 against an fp32 evaluation, not only against the
+# emulation of the kernel's own storage points. Bounds = first measurement x 1.5 (profiles/r4_parity_ops_fullwidth_fp16.txt).
+MEASURED_X_1_5_FP16 = {"rmsnorm": 1e-6, "qkv_gemm": 6.3e-5, "rope_q": 1e-5, "rope_k_pages": 1e-5, "flash_attn": 1.0e-3, "o_proj_resid": 1e-6,
+                       "rmsnorm2": 3e-5, "swiglu_gemm": 7.8e-5, "down_proj_resid": 1.1e-6, "whole_layer_hidden": 5.0e-3}
+
+
+@pytest.mark.parametrize("operand", ["bf16", "fp16"])
+def test_every_decoder_operator_within_1e3_of_the_emulation_at_7b_width(operand):
     from tests import parity_ops_fullwidth as P
-    rep = P.measure(1088)
-    print("[parity-ops] " + json.dumps({k: {a: round(b, 7) for a, b in v.items()} for k, v in rep.items()}), flush=True)
+    rep = P.measure(1088, operand)
+    print(f"[parity-ops-{operand}] " + json.dumps({k: {a: round(b, 7) for a, b in v.items()} for k, v in rep.items()}), flush=True)
     for name, r in rep.items():
-        bound = MEASURED_X_1_5[name]
+        bound = (MEASURED_X_1_5 if operand == "bf16" else MEASURED_X_1_5_FP16)[name]
+        if operand == "fp16" and "emu_vs_fp32" in r:
+            assert r["emu_vs_fp32"] <= 1e-3, (name, r)        # ONE fp16 store is inside north_star's tolerance against plain fp32
         assert r["vs_emu"] <= bound, (name, r)
         if name != "whole_layer_hidden":
             assert r["vs_emu"] <= TOL_OP, (name, r)

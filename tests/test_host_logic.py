@@ -311,21 +311,45 @@ def test_weight_packing_layouts():
     assert torch.allclose(m["encoder.layers.0.self_attn.q_proj.weight"], base + 8.0 * (b @ a))
 
 
-def test_cabi_library_loads_and_exports_header_symbols():
-    """Every function declared in include/vitron_hip.h is exported by libvitron_hip.so and bound in _lib.SIGNATURES."""
+@pytest.mark.parametrize("operand", ["bf16", "fp16"])
+def test_cabi_library_loads_and_exports_header_symbols(operand):
+    """Every function declared in include/vitron_hip.h is exported by libvitron_hip.so AND by libvitron_hip_f16.so (the same ABI in
+    the two operand formats) and bound in _lib.SIGNATURES."""
     from vitron_amd import _lib
-    lib = _lib.load()
+    lib = _lib.load(operand=operand)
     hdr = open(os.path.join(ROOT, "include", "vitron_hip.h")).read()
     declared = set(re.findall(r"^(?:int|size_t)\s+(vt_\w+)\s*\(", hdr, flags=re.M))
     assert declared, "no declarations parsed"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.vt_version() >= 100
+    assert lib.vt_version() >= 110
+    assert lib.vt_operand_format() == {"bf16": _lib.OPERAND_BF16, "fp16": _lib.OPERAND_FP16}[operand]
     # error convention: bad arguments come back as a negative status + message, nothing throws, no GPU needed
     st = lib.vt_gemm_bf16(None, 8, None, 8, None, 8, None, 4, 4, 8, 0, 0, None, None)
-    assert st == -1 and "null" in _lib.last_error()
+    assert st == -1 and "null" in _lib.last_error(lib)
     assert lib.vt_projector_workspace_bytes(100, 4096) >= 100 * 4096 * 2
+
+
+def test_operand_format_selection_is_by_dtype():
+    """A tensor's dtype picks the library build (bf16 -> libvitron_hip.so, fp16 -> libvitron_hip_f16.so); anything else is refused;
+    the two handles are distinct objects with their own error state."""
+    from vitron_amd import _lib
+    assert _lib.operand_of(torch.bfloat16) == "bf16" and _lib.operand_of(torch.float16) == "fp16" and _lib.operand_of("fp16") == "fp16"
+    assert _lib.operand_of(torch.zeros(1, dtype=torch.float16)) == "fp16"
+    for bad in (torch.float32, torch.int8, "fp8"):
+        with pytest.raises(_lib.VitronHipError):
+            _lib.operand_of(bad)
+    a, b = _lib.lib_for(torch.bfloat16), _lib.lib_for(torch.float16)
+    assert a is not b and a is _lib.load(operand="bf16") and b is _lib.load(operand="fp16")
+    assert _lib.torch_dtype("fp16") == torch.float16 and _lib.torch_dtype("bf16") == torch.bfloat16
+    assert a.vt_projector_workspace_bytes(0, 0) == b.vt_projector_workspace_bytes(0, 0)
+    a.vt_gemm_bf16(None, 8, None, 8, None, 8, None, 4, 4, 8, 0, 0, None, None)          # sets a's message only
+    assert "null" in _lib.last_error(a)
+    from vitron_amd.model.language_model.llava_llama import LlavaConfig, LlavaLlamaForCausalLM, _resolve_dtype
+    assert _resolve_dtype("float16") == torch.float16 and _resolve_dtype("torch.bfloat16") == torch.bfloat16 and _resolve_dtype(None) is None
+    m = LlavaLlamaForCausalLM(LlavaConfig(torch_dtype="float16"))                        # a HF config.json carries the dtype as a string
+    assert m.dtype == torch.float16 and m.half().dtype == torch.float16 and m.to(torch.bfloat16).dtype == torch.bfloat16
 
 
 def test_cabi_argument_validation_without_a_gpu():
@@ -457,6 +481,9 @@ def test_gemm_planner_fills_whole_rounds_of_the_chip():
     assert ops.gemm_plan(4616, 1024, 4096, ops.EPI_F32_RESID) == (W4R, 0)
     assert ops.gemm_plan(1088, 12288, 4096, ops.EPI_BF16) == (W4_224, 0)                # 240 big tiles, one round: 5 x 224 rows pad 1088 to 1120, not 1280
     assert ops.gemm_plan(1088, 22016, 4096, ops.EPI_SWIGLU_BF16) == (W4_224, 0)         # 430 tiles, two rounds, each 7/8 as long
+    # ... and ONLY where they pad fewer rows than 256-row tiles do (the price was measured at 1088 / 4616 rows only): a multiple of 256
+    # stays on the 256-row tile even where the round count would tie (2048 x 8192: 256 tiles of 256 rows, not 320 of 224 with 9 % padding)
+    assert ops.gemm_plan(2048, 8192, 4096, ops.EPI_BF16) == (W4, 0) and ops.gemm_plan(2048, 12288, 4096, ops.EPI_BF16) == (W4, 0)
     assert ops.gemm_plan(1088, 4096, 4096 + 128, ops.EPI_F32_RESID)[0] in small         # the ring walks K in steps of 256
     # K not a multiple of 128 (no big-tile kernel) and the weight-streaming range
     assert ops.gemm_plan(4096, 4096, 4096 + 64, ops.EPI_BF16)[0] in small
@@ -511,9 +538,10 @@ def test_tower_and_projector_factories_pick_the_reference_branches(tmp_path):
 
 def test_serving_admission_host_logic_with_a_stub_model(monkeypatch):
     """vitron_amd.serving.ServingEngine._admit / step, host side only (stub model + stub page pool, the decoder pass patched out): an idle
-    engine sizes the pool for the WHOLE candidate batch; a request that does not fit while others are live waits at the head of the
-    queue with its spliced rows kept (embedded once); a failure while the pool would have to grow -- or inside the prefill -- gives every
-    page back and leaves every candidate queued."""
+    engine sizes the pool for the WHOLE candidate batch (never beyond the constructor's cap); a request that does not fit while others are
+    live waits at the head of the queue with its spliced rows kept (embedded once); a request that fails on its own (encode, prefill, can
+    never fit the pool) leaves the engine with its exception and the ones behind it are served; a device-level failure gives every page
+    back and leaves every candidate queued."""
     import types
 
     import torch
@@ -540,10 +568,15 @@ def test_serving_admission_host_logic_with_a_stub_model(monkeypatch):
             self.kv, self.embeds, self.grow_fails = None, 0, False
 
         def get_model(self):
-            return types.SimpleNamespace(llama=None, embed_tokens=lambda ids: torch.zeros((1, ids.shape[1], 8)))
+            return types.SimpleNamespace(llama=types.SimpleNamespace(embed=torch.zeros((4, 8))),
+                                         embed_tokens=lambda ids: torch.zeros((1, ids.shape[1], 8)))
+
+        bad_embed_len = None
 
         def prepare_inputs_labels_for_multimodal(self, ids, *a, **k):
             self.embeds += 1
+            if ids.shape[1] == self.bad_embed_len:
+                raise ValueError("images were passed but the model has no image tower")
             return (None, None, None, None, None, None)
 
         def _ensure_kv(self, n):
@@ -555,18 +588,21 @@ def test_serving_admission_host_logic_with_a_stub_model(monkeypatch):
         def reset_prefix_cache(self):
             pass
 
-    calls = {"n": 0, "fail": False}
+    calls = {"n": 0, "fail": False, "fail_rows": None}
 
     def fake_forward(llama, kv, seqs, flat, lens, *a, **k):
         calls["n"] += 1
         if calls["fail"]:
-            raise RuntimeError("device error")
+            raise RuntimeError("vt_llama_forward failed (status -2): hipErrorLaunchFailure")
+        if calls["fail_rows"] is not None and calls["fail_rows"] in lens:
+            raise RuntimeError("llama_forward: position 9000 beyond rope table (8192)")
         for s, n in zip(seqs, lens):
             s.length += n
         return torch.zeros((len(seqs), 16))
 
     monkeypatch.setattr(serving, "llama_forward", fake_forward)
     monkeypatch.setattr(serving.ops, "argmax", lambda lg: torch.zeros((lg.shape[0],), dtype=torch.int32))
+    monkeypatch.setattr(serving.ops, "embed_splice", lambda emb, vis, reg, plan: torch.zeros((plan.shape[0], 8)))
     m = Model()
     eng = serving.ServingEngine(m, max_batch=4)
     ids = lambda n: torch.ones((1, n), dtype=torch.long)             # noqa: E731
@@ -584,23 +620,63 @@ def test_serving_admission_host_logic_with_a_stub_model(monkeypatch):
     eng._retire(eng.active[0])
     eng.active = eng.active[1:]
     assert eng._admit([r]) == [] and r.flat is None and len(r.seq.pages) == need(50, 14) and r in eng.active
-    # idle engine, the pool has to grow but cannot (pages held elsewhere): candidates stay queued, no page leaked
+    # idle engine, the pool would have to grow but cannot (allocator says no) and every page of it is free: the request can never be
+    # scheduled -> it FAILS on its own (it used to be re-queued and re-raised on every step, wedging the engine), no page leaked
     for q in list(eng.active):
         eng._retire(q)
     eng.active = []
     free_before = len(m.kv.free)
     m.grow_fails = True
     big = eng.submit(ids(4000), max_new_tokens=96)
-    cand = [eng.waiting.popleft()]
-    with pytest.raises(RuntimeError):
+    small = eng.submit(ids(40), max_new_tokens=8)
+    cand = [eng.waiting.popleft(), eng.waiting.popleft()]
+    assert eng._admit(cand) == [] and big in eng.failed and "KV pages" in str(eng.failed[big].error)
+    assert [r.rid for r in eng.active] == [small] and len(m.kv.free) == free_before - need(40, 8)      # the one behind it is served
+    eng._retire(eng.active[0])
+    eng.active = []
+    m.grow_fails = False
+    # a prefill that fails for ONE request (its own fault: e.g. a prompt beyond the rotary table): that request fails, the other runs
+    calls["fail_rows"] = 77
+    bad, good = eng.submit(ids(77), max_new_tokens=8), eng.submit(ids(60), max_new_tokens=8)
+    assert eng._admit([eng.waiting.popleft(), eng.waiting.popleft()]) == []
+    assert bad in eng.failed and [r.rid for r in eng.active] == [good] and eng.failed[bad].seq.pages == []
+    assert len(m.kv.free) == m.kv.num_pages - need(60, 8)
+    eng._retire(eng.active[0])
+    eng.active = []
+    calls["fail_rows"] = None
+    # a DEVICE error in the prefill (HIP status -2 of the C ABI) is nobody's fault: it propagates, pages back, candidates queued again
+    calls["fail"] = True
+    dev_a, dev_b = eng.submit(ids(50), max_new_tokens=8), eng.submit(ids(51), max_new_tokens=8)
+    cand = [eng.waiting.popleft(), eng.waiting.popleft()]
+    with pytest.raises(RuntimeError, match="status -2"):
         eng._admit(cand)
-    assert list(eng.waiting) == cand and len(m.kv.free) == free_before and cand[0].seq.pages == []
-    # a prefill that fails on the device: pages back, candidates queued again
-    m.grow_fails, calls["fail"] = False, True
-    cand = [eng.waiting.popleft()]
-    with pytest.raises(RuntimeError):
-        eng._admit(cand)
-    assert list(eng.waiting) == cand and cand[0].seq.pages == [] and len(m.kv.free) == m.kv.num_pages and not eng.active
+    assert list(eng.waiting) == cand and all(r.seq.pages == [] for r in cand) and len(m.kv.free) == m.kv.num_pages and not eng.active
     calls["fail"] = False
-    assert eng._admit([eng.waiting.popleft()]) == [] and len(eng.active) == 1
+    assert eng._admit([eng.waiting.popleft(), eng.waiting.popleft()]) == [] and len(eng.active) == 2
+    # an encode that fails for one request (bad image shape): isolated the same way, step() keeps serving
+    for q in list(eng.active):
+        eng._retire(q)
+    eng.active = []
+    m.bad_embed_len = 33
+    e_bad, e_ok = eng.submit(ids(33), max_new_tokens=4), eng.submit(ids(20), max_new_tokens=4)
+    out = eng.step()
+    assert e_bad in eng.failed and isinstance(eng.errors()[e_bad], ValueError) and [rid for rid, _ in out] == [e_ok]
+    assert eng.cancel(e_ok) is False and eng.pending() == 1
+    outs = eng.run()
+    assert e_ok in outs and e_bad not in outs and eng.pending() == 0 and len(m.kv.free) == m.kv.num_pages
+    # a pool CAPPED by the constructor is never rebuilt larger: the prefix that fits is admitted, the rest waits
+    monkeypatch.setattr(serving, "PagedKVCache", lambda llama, n: Pool(n))
+    m2 = Model()
+    eng2 = serving.ServingEngine(m2, max_batch=4, kv_pages=10)
+    r1, r2, r3 = eng2.submit(ids(200), max_new_tokens=56), eng2.submit(ids(200), max_new_tokens=56), eng2.submit(ids(100), max_new_tokens=28)
+    rest = eng2._admit([eng2.waiting.popleft() for _ in range(3)])
+    assert m2.kv.num_pages == 10 and [r.rid for r in eng2.active] == [r1, r2] and [r.rid for r in rest] == [r3]       # 5 + 5 pages fit, 3 more do not
+    huge = eng2.submit(ids(1000), max_new_tokens=8)                                                                    # 17 pages > the cap
+    for q in list(eng2.active):
+        eng2._retire(q)
+    eng2.active = []
+    assert eng2._admit(rest + [eng2.waiting.popleft()]) == [] and huge in eng2.failed and [r.rid for r in eng2.active] == [r3]
+    assert eng2.cancel(12345) is False
+    w = eng2.submit(ids(10), max_new_tokens=2)
+    assert eng2.cancel(w) is True and not eng2.waiting
     assert (a, b, c, big) == (0, 1, 2, 3)

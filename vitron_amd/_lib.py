@@ -1,4 +1,8 @@
-"""ctypes binding of libvitron_hip.so (C ABI: include/vitron_hip.h).
+"""ctypes binding of libvitron_hip.so / libvitron_hip_f16.so (C ABI: include/vitron_hip.h).
+
+The same ABI exists in two operand formats (include/vitron_hip.h "OPERAND FORMAT"): bf16 (libvitron_hip.so, the benchmark's
+dtype) and IEEE fp16 (libvitron_hip_f16.so, the reference's inference dtype, vitron/model/builder.py:47). A tensor's torch
+dtype selects the library: `lib_for(t)`.
 
 There is deliberately NO fallback: if the shared library is missing or fails to load, every operator of
 vitron_amd raises. `load()` builds it with hipcc when the sources are newer than the binary (or the binary is
@@ -12,6 +16,8 @@ from pathlib import Path
 
 PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = PKG_DIR / "libvitron_hip.so"
+LIB_PATHS = {"bf16": LIB_PATH, "fp16": PKG_DIR / "libvitron_hip_f16.so"}
+OPERAND_BF16, OPERAND_FP16 = 0, 1
 
 # ---- enums (mirror include/vitron_hip.h) ---------------------------------------------------------------------
 EPI_BF16, EPI_BF16_GELU, EPI_BF16_QGELU, EPI_BF16_RELU, EPI_F32_RESID, EPI_F32, EPI_SWIGLU_BF16 = range(7)
@@ -66,6 +72,7 @@ _i, _f, _sz = C.c_int, C.c_float, C.c_size_t
 # name -> (restype, argtypes); this table is also what tests check against the header
 SIGNATURES = {
     "vt_version": (_i, []),
+    "vt_operand_format": (_i, []),
     "vt_last_error": (_i, [C.c_char_p, _sz]),
     "vt_gemm_bf16": (_i, [vp, _i, vp, _i, vp, _i, vp, _i, _i, _i, _i, _i, vp, vp]),
     "vt_layernorm": (_i, [vp, vp, _i, _i, vp, vp, vp, _i, _i, _f, vp]),
@@ -100,81 +107,141 @@ SIGNATURES = {
 }
 PROF_CLASSES = ("gemm_tile", "flash_attn", "gemm_skinny", "attn_decode")
 
-_lib = None
+_libs = {}          # operand ("bf16" | "fp16" | "abl") -> CDLL
+_default_operand = os.environ.get("VITRON_AMD_OPERAND", "bf16")
 
 
 class VitronHipError(RuntimeError):
     pass
 
 
-def _needs_build() -> bool:
-    if not LIB_PATH.exists():
+def operand_of(x) -> str:
+    """'bf16' | 'fp16' for a torch dtype, a tensor, or one of those strings (anything else raises)."""
+    import torch
+    if isinstance(x, str):
+        if x in LIB_PATHS:
+            return x
+        raise VitronHipError(f"operand format must be 'bf16' or 'fp16', got {x!r}")
+    dt = x.dtype if isinstance(x, torch.Tensor) else x
+    if dt == torch.bfloat16:
+        return "bf16"
+    if dt == torch.float16:
+        return "fp16"
+    raise VitronHipError(f"vitron_amd computes with bf16 or fp16 operands, got {dt}")
+
+
+def torch_dtype(operand=None):
+    import torch
+    return {"bf16": torch.bfloat16, "fp16": torch.float16}[operand_of(operand or _default_operand)]
+
+
+def default_operand() -> str:
+    return _default_operand
+
+
+def set_default_operand(operand) -> None:
+    """Operand format of objects built without an explicit dtype ('bf16' unless VITRON_AMD_OPERAND says otherwise)."""
+    global _default_operand
+    _default_operand = operand_of(operand)
+
+
+def _needs_build(path: Path) -> bool:
+    if not path.exists():
         return True
     srcs = list((PKG_DIR / "csrc").glob("*.hip")) + list((PKG_DIR / "csrc").glob("*.h")) + \
         list((PKG_DIR.parent / "include").glob("*.h"))
     if not srcs:
         return False
-    return max(p.stat().st_mtime for p in srcs) > LIB_PATH.stat().st_mtime
+    return max(p.stat().st_mtime for p in srcs) > path.stat().st_mtime
 
 
-def load(build_if_needed: bool = True, ablations: bool = False):
-    """Load (building first when stale and hipcc is present) libvitron_hip.so. Raises if unavailable.
+def _bind(lib):
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here == header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+def load(build_if_needed: bool = True, ablations: bool = False, operand=None):
+    """Load (building first when stale and hipcc is present) the library for `operand` ('bf16' default / 'fp16', or a torch
+    dtype / tensor). Raises if unavailable.
     ablations=True (tools/ only, must be the FIRST load of the process): the -DVT_ABLATIONS build of the same sources,
-    libvitron_hip_abl.so, which also carries the timing-ablation kernels and their switches (vitron_amd/build.py)."""
-    global _lib
-    if _lib is not None:
-        return _lib
+    libvitron_hip_abl.so, which also carries the timing-ablation kernels and their switches (vitron_amd/build.py); it then
+    stands in for the bf16 library."""
+    op = operand_of(operand if operand is not None else _default_operand)
+    if op in _libs:
+        return _libs[op]
     if ablations:
         from . import build as _build
         import torch  # noqa: F401  (same runtime-ordering reason as below)
-        lib = C.CDLL(str(_build.build(ablations=True)))
-        for name, (res, args) in SIGNATURES.items():
-            fn = getattr(lib, name)
-            fn.restype = res
-            fn.argtypes = args
-        _lib = lib
-        return lib
-    if build_if_needed and _needs_build() and os.environ.get("VITRON_AMD_NO_BUILD") != "1":
+        _libs["bf16"] = _bind(C.CDLL(str(_build.build(ablations=True))))
+        return _libs["bf16"]
+    path = LIB_PATHS[op]
+    if build_if_needed and _needs_build(path) and os.environ.get("VITRON_AMD_NO_BUILD") != "1":
         from . import build as _build
         try:
-            _build.build()
+            _build.build(operand=op)
         except Exception as e:  # stale binary is still usable; a missing one is fatal below
-            if not LIB_PATH.exists():
-                raise VitronHipError(f"libvitron_hip.so is missing and could not be built: {e}") from e
-    if not LIB_PATH.exists():
-        raise VitronHipError(f"{LIB_PATH} not found: run `python -m vitron_amd.build` (needs hipcc). "
+            if not path.exists():
+                raise VitronHipError(f"{path.name} is missing and could not be built: {e}") from e
+    if not path.exists():
+        raise VitronHipError(f"{path} not found: run `python -m vitron_amd.build` (needs hipcc). "
                              "vitron_amd has no CPU or PyTorch fallback for its operators.")
     # PyTorch bundles its own HIP runtime (torch/lib/libamdhip64.so, same SONAME as /opt/rocm's). It must be the
     # one already mapped when libvitron_hip.so resolves libamdhip64.so.7, or the process ends up with two runtimes
     # ("no ROCm-capable device is detected" at the first launch). Importing torch first guarantees that.
     import torch  # noqa: F401
-    lib = C.CDLL(str(LIB_PATH))
-    for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)  # AttributeError here == header/library mismatch
-        fn.restype = res
-        fn.argtypes = args
-    _lib = lib
+    lib = _bind(C.CDLL(str(path)))
+    want = OPERAND_FP16 if op == "fp16" else OPERAND_BF16
+    if lib.vt_operand_format() != want:
+        raise VitronHipError(f"{path.name} reports operand format {lib.vt_operand_format()}, expected {want} ({op})")
+    _libs[op] = lib
     return lib
 
 
-def last_error() -> str:
+def lib_for(x):
+    """The library whose operand format is the dtype of tensor / dtype `x`."""
+    return load(operand=operand_of(x))
+
+
+def load_any():
+    """A library for operators that touch no 16-bit tensor (arg-max, sampler, cross entropy, planner): whichever is already
+    loaded, else the default one."""
+    for lib in _libs.values():
+        return lib
+    return load()
+
+
+def last_error(lib=None) -> str:
     buf = C.create_string_buffer(512)
-    load().vt_last_error(buf, 512)
+    (lib or load_any()).vt_last_error(buf, 512)
     return buf.value.decode("utf-8", "replace")
 
 
-def check(status: int, what: str = "") -> None:
+def check(status: int, what: str = "", lib=None) -> None:
+    """Raise on a non-zero status. `lib`: the handle the call went through (its thread-local message is the one to read);
+    without it every loaded library is asked."""
     if status != 0:
-        raise VitronHipError(f"{what or 'libvitron_hip'} failed (status {status}): {last_error()}")
+        msgs = [last_error(lib)] if lib is not None else [m for m in (last_error(l) for l in _libs.values()) if m]
+        raise VitronHipError(f"{what or 'libvitron_hip'} failed (status {status}): {' | '.join(msgs)}")
 
 
 def profile_begin() -> None:
-    check(load().vt_profile_begin(), "vt_profile_begin")
+    for lib in _libs.values():
+        check(lib.vt_profile_begin(), "vt_profile_begin", lib)
 
 
 def profile_end() -> dict:
-    """{class: {'launches', 'ms', 'work'}} for the launches since profile_begin (device-side event timing)."""
+    """{class: {'launches', 'ms', 'work'}} for the launches since profile_begin (device-side event timing), summed over the
+    loaded libraries."""
     n = len(PROF_CLASSES)
-    launches, ms, work = (C.c_int * n)(), (C.c_double * n)(), (C.c_double * n)()
-    check(load().vt_profile_end(launches, ms, work), "vt_profile_end")
-    return {PROF_CLASSES[i]: {"launches": launches[i], "ms": ms[i], "work": work[i]} for i in range(n)}
+    out = {c: {"launches": 0, "ms": 0.0, "work": 0.0} for c in PROF_CLASSES}
+    for lib in _libs.values():
+        launches, ms, work = (C.c_int * n)(), (C.c_double * n)(), (C.c_double * n)()
+        check(lib.vt_profile_end(launches, ms, work), "vt_profile_end", lib)
+        for i, c in enumerate(PROF_CLASSES):
+            out[c]["launches"] += launches[i]
+            out[c]["ms"] += ms[i]
+            out[c]["work"] += work[i]
+    return out

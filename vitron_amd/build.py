@@ -19,6 +19,9 @@ PKG_DIR = Path(__file__).resolve().parent
 CSRC = PKG_DIR / "csrc"
 INCLUDE = PKG_DIR.parent / "include"
 LIB_PATH = PKG_DIR / "libvitron_hip.so"
+# the SAME sources compiled with -DVT_OPERAND_F16=1: every GEMM / attention operand in IEEE fp16 instead of bf16 (vt_common.h,
+# include/vitron_hip.h "OPERAND FORMAT"); same ABI, same symbol names. A product library like the one above.
+F16_LIB_PATH = PKG_DIR / "libvitron_hip_f16.so"
 # the SAME sources compiled with -DVT_ABLATIONS: timing-ablation / A-B variants of the GEMM and attention main loops (garbage
 # results by construction) and their environment switches. Only tools/ load it (vitron_amd._lib.load(ablations=True)); the
 # product library above contains none of that code.
@@ -68,18 +71,33 @@ def _build_lock(bdir: Path):
             fcntl.flock(f, fcntl.LOCK_UN)
 
 
-def build(force: bool = False, verbose: bool = False, ablations: bool = False) -> Path:
-    """Compile every HIP source for gfx950 and link libvitron_hip.so (ablations=True: the -DVT_ABLATIONS test library
-    libvitron_hip_abl.so instead). Returns the library path."""
-    bdir = CSRC / ("build_abl" if ablations else "build")
+def build(force: bool = False, verbose: bool = False, ablations: bool = False, operand: str = "bf16") -> Path:
+    """Compile every HIP source for gfx950 and link libvitron_hip.so (operand="fp16": libvitron_hip_f16.so, the fp16-operand
+    build; ablations=True: the -DVT_ABLATIONS test library libvitron_hip_abl.so instead). Returns the library path."""
+    if operand not in ("bf16", "fp16"):
+        raise ValueError(f"operand must be 'bf16' or 'fp16', got {operand!r}")
+    if ablations and operand != "bf16":
+        raise ValueError("the ablation library exists for bf16 operands only")
+    bdir = CSRC / ("build_abl" if ablations else "build_f16" if operand == "fp16" else "build")
     bdir.mkdir(exist_ok=True)
     with _build_lock(bdir):
-        return _build_locked(bdir, force, verbose, ablations)
+        return _build_locked(bdir, force, verbose, ablations, operand)
 
 
-def _build_locked(bdir: Path, force: bool, verbose: bool, ablations: bool = False) -> Path:
-    LIB_PATH = ABL_LIB_PATH if ablations else globals()["LIB_PATH"]
-    extra = ("-DVT_ABLATIONS",) if ablations else ()
+def build_all(force: bool = False, verbose: bool = False):
+    """Both product libraries (bf16 and fp16 operands), compiled concurrently."""
+    with ThreadPoolExecutor(max_workers=2) as ex:
+        futs = [ex.submit(build, force, verbose, False, op) for op in ("bf16", "fp16")]
+        return [f.result() for f in futs]
+
+
+def lib_path(operand: str = "bf16") -> Path:
+    return F16_LIB_PATH if operand == "fp16" else LIB_PATH
+
+
+def _build_locked(bdir: Path, force: bool, verbose: bool, ablations: bool = False, operand: str = "bf16") -> Path:
+    LIB_PATH = ABL_LIB_PATH if ablations else lib_path(operand)
+    extra = ("-DVT_ABLATIONS",) if ablations else ("-DVT_OPERAND_F16=1",) if operand == "fp16" else ()
     hdr_m = _deps_mtime()
     todo = []
     objs = []
@@ -96,7 +114,9 @@ def _build_locked(bdir: Path, force: bool, verbose: bool, ablations: bool = Fals
             list(ex.map(lambda so: _compile_one(so[0], so[1], verbose, extra), todo))
     if todo or not LIB_PATH.exists() or any(o.stat().st_mtime > LIB_PATH.stat().st_mtime for o in objs):
         tmp = LIB_PATH.with_suffix(f".tmp{os.getpid()}.so")
-        cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *map(str, objs), "-o", str(tmp)]
+        # -Bsymbolic: the library's own references bind to its own definitions, so the bf16 and the fp16 build (same symbol names)
+        # can live in one process
+        cmd = [_hipcc(), "-shared", "-fPIC", "-Wl,-Bsymbolic", f"--offload-arch={ARCH}", *map(str, objs), "-o", str(tmp)]
         if verbose:
             print("[vitron_amd.build]", " ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -109,5 +129,8 @@ def _build_locked(bdir: Path, force: bool, verbose: bool, ablations: bool = Fals
 
 
 if __name__ == "__main__":
-    p = build(force="--force" in sys.argv, verbose=True, ablations="--ablations" in sys.argv)
-    print(p)
+    if "--ablations" in sys.argv:
+        print(build(force="--force" in sys.argv, verbose=True, ablations=True))
+    else:
+        for p in build_all(force="--force" in sys.argv, verbose=True):
+            print(p)

@@ -74,7 +74,9 @@ inline hipStream_t S_(void* s) { return (hipStream_t)s; }
 
 extern "C" {
 
-int vt_version(void) { return 100; }
+int vt_version(void) { return 110; }
+
+int vt_operand_format(void) { return VT_OPERAND_F16 ? VT_OPERAND_FP16 : VT_OPERAND_BF16; }
 
 int vt_last_error(char* buf, size_t buf_len) {
   const size_t n = strlen(g_err);
@@ -250,7 +252,7 @@ size_t vt_region_workspace_bytes(int B, int in_dim, int out_dim) {
   return n + 1024;
 }
 
-int vt_region_forward(const vt_region_weights* w, const uint16_t* feats, const int* slices, const uint16_t* coords,
+int vt_region_forward(const vt_region_weights* w, const uint16_t* feats, const int* slices, const float* coords,
                       int B, int G, int image_size, uint16_t* out, int* cell_mask, int* cell_count, void* workspace,
                       size_t workspace_bytes, void* stream) {
   VT_REQUIRE(w && feats && slices && coords && out, "vt_region_forward: null pointer");

@@ -186,7 +186,7 @@ __global__ __launch_bounds__(64 * NWAVES, (NWAVES == 8) ? 2 : 2) void flash_attn
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub) {
         const bf16x8 kf = *(const bf16x8*)(kb + k_row_off[sub] + (chunk << 4));
-        if (!(ABL & 2)) sacc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[sub], 0, 0, 0);
+        if (!(ABL & 2)) sacc[sub] = VT_MFMA_32x32x16(kf, qf[ks], sacc[sub]);
         else sacc[sub][ks] += __builtin_bit_cast(float, (uint32_t)kf[0] << 16);
       }
     }
@@ -300,8 +300,8 @@ __global__ __launch_bounds__(64 * NWAVES, (NWAVES == 8) ? 2 : 2) void flash_attn
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         u32x2 o;
-        o.x = pack_bf16x2(oacc[db][4 * g + 0] * inv, oacc[db][4 * g + 1] * inv);
-        o.y = pack_bf16x2(oacc[db][4 * g + 2] * inv, oacc[db][4 * g + 3] * inv);
+        o.x = pack_op2(oacc[db][4 * g + 0] * inv, oacc[db][4 * g + 1] * inv);
+        o.y = pack_op2(oacc[db][4 * g + 2] * inv, oacc[db][4 * g + 3] * inv);
         *(u32x2*)(op + db * 32 + 8 * g) = o;
       }
   }
@@ -358,16 +358,16 @@ __global__ __launch_bounds__(256) void kv_tiles_kernel(bf16_t* __restrict__ qkv,
         for (int w = 0; w < 4; ++w) {
           const float c0 = cs[2 * w], c1 = cs[2 * w + 1], s0 = sn[2 * w], s1 = sn[2 * w + 1];
           {
-            const float a0 = bf16lo_to_f32(lo[w]), a1 = bf16hi_to_f32(lo[w]);
-            const float b0 = bf16lo_to_f32(hi[w]), b1 = bf16hi_to_f32(hi[w]);
-            klo_o[w] = pack_bf16x2(rope_lo(a0, b0, c0, s0), rope_lo(a1, b1, c1, s1));
-            khi_o[w] = pack_bf16x2(rope_hi(a0, b0, c0, s0), rope_hi(a1, b1, c1, s1));
+            const float a0 = oplo_to_f32(lo[w]), a1 = ophi_to_f32(lo[w]);
+            const float b0 = oplo_to_f32(hi[w]), b1 = ophi_to_f32(hi[w]);
+            klo_o[w] = pack_op2(rope_lo(a0, b0, c0, s0), rope_lo(a1, b1, c1, s1));
+            khi_o[w] = pack_op2(rope_hi(a0, b0, c0, s0), rope_hi(a1, b1, c1, s1));
           }
           {
-            const float a0 = bf16lo_to_f32(qlo[w]), a1 = bf16hi_to_f32(qlo[w]);
-            const float b0 = bf16lo_to_f32(qhi[w]), b1 = bf16hi_to_f32(qhi[w]);
-            qlo_o[w] = pack_bf16x2(rope_lo(a0, b0, c0, s0), rope_lo(a1, b1, c1, s1));
-            qhi_o[w] = pack_bf16x2(rope_hi(a0, b0, c0, s0), rope_hi(a1, b1, c1, s1));
+            const float a0 = oplo_to_f32(qlo[w]), a1 = ophi_to_f32(qlo[w]);
+            const float b0 = oplo_to_f32(qhi[w]), b1 = ophi_to_f32(qhi[w]);
+            qlo_o[w] = pack_op2(rope_lo(a0, b0, c0, s0), rope_lo(a1, b1, c1, s1));
+            qhi_o[w] = pack_op2(rope_hi(a0, b0, c0, s0), rope_hi(a1, b1, c1, s1));
           }
         }
         lo = klo_o;
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256) void kv_tiles_kernel(bf16_t* __restrict__ qkv,
     if (!full && !any_new) continue;
     float vals[8];   // bf16 -> fp16 (exact in fp16's normal range, saturating): the V^T pages hold fp16, see vt_common.h
 #pragma unroll
-    for (int j = 0; j < 8; ++j) vals[j] = vt_clamp_f16(bf16_to_f32(vs[kc * 8 + j][d]));
+    for (int j = 0; j < 8; ++j) vals[j] = vt_clamp_f16(op_to_f32(vs[kc * 8 + j][d]));
     uint16_t* dst = vt + d * 64 + kc * 8;
     u32x4 w;
     w.x = pack_f16x2(vals[0], vals[1]);
@@ -498,8 +498,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
   float qf[8];
 #pragma unroll
   for (int w = 0; w < 4; ++w) {
-    qf[2 * w] = bf16lo_to_f32(qv[w]);
-    qf[2 * w + 1] = bf16hi_to_f32(qv[w]);
+    qf[2 * w] = oplo_to_f32(qv[w]);
+    qf[2 * w + 1] = ophi_to_f32(qv[w]);
   }
   float m_run = -INFINITY, l_run = 0.f, acc[NACC];
 #pragma unroll
@@ -525,8 +525,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
       float part_s = 0.f;
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
-        part_s = fmaf(bf16lo_to_f32(kv[w]), qf[2 * w], part_s);
-        part_s = fmaf(bf16hi_to_f32(kv[w]), qf[2 * w + 1], part_s);
+        part_s = fmaf(oplo_to_f32(kv[w]), qf[2 * w], part_s);
+        part_s = fmaf(ophi_to_f32(kv[w]), qf[2 * w + 1], part_s);
       }
       part[i] = part_s;
     }
@@ -616,7 +616,7 @@ __global__ __launch_bounds__(64) void attn_decode_combine_kernel(const float* __
   const float inv = l > 0.f ? 1.f / l : 0.f;
   bf16_t* op = O + (size_t)seqs[seq].q_row0 * ldo + head * HD;
 #pragma unroll
-  for (int i = 0; i < HD / 64; ++i) op[lane + 64 * i] = f32_to_bf16(o[i] * inv);
+  for (int i = 0; i < HD / 64; ++i) op[lane + 64 * i] = f32_to_op(o[i] * inv);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -696,10 +696,10 @@ __global__ __launch_bounds__(512) void attn_decode_fused_kernel(
     u32x4 o;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
-      const float a0 = bf16lo_to_f32(lo[w]), a1 = bf16hi_to_f32(lo[w]);
-      const float b0 = bf16lo_to_f32(hi[w]), b1 = bf16hi_to_f32(hi[w]);
+      const float a0 = oplo_to_f32(lo[w]), a1 = ophi_to_f32(lo[w]);
+      const float b0 = oplo_to_f32(hi[w]), b1 = ophi_to_f32(hi[w]);
       const float c0 = cs[2 * w], c1 = cs[2 * w + 1], s0 = sn[2 * w], s1 = sn[2 * w + 1];
-      o[w] = upper ? pack_bf16x2(rope_hi(a0, b0, c0, s0), rope_hi(a1, b1, c1, s1)) : pack_bf16x2(rope_lo(a0, b0, c0, s0), rope_lo(a1, b1, c1, s1));
+      o[w] = upper ? pack_op2(rope_hi(a0, b0, c0, s0), rope_hi(a1, b1, c1, s1)) : pack_op2(rope_lo(a0, b0, c0, s0), rope_lo(a1, b1, c1, s1));
     }
     return o;
   };
@@ -721,8 +721,8 @@ __global__ __launch_bounds__(512) void attn_decode_fused_kernel(
   float qf[8];
 #pragma unroll
   for (int w = 0; w < 4; ++w) {
-    qf[2 * w] = bf16lo_to_f32(qv[w]);
-    qf[2 * w + 1] = bf16hi_to_f32(qv[w]);
+    qf[2 * w] = oplo_to_f32(qv[w]);
+    qf[2 * w + 1] = ophi_to_f32(qv[w]);
   }
   __builtin_amdgcn_sched_barrier(0);
 
@@ -738,8 +738,8 @@ __global__ __launch_bounds__(512) void attn_decode_fused_kernel(
       float part_s = 0.f;
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
-        part_s = fmaf(bf16lo_to_f32(kv[w]), qf[2 * w], part_s);
-        part_s = fmaf(bf16hi_to_f32(kv[w]), qf[2 * w + 1], part_s);
+        part_s = fmaf(oplo_to_f32(kv[w]), qf[2 * w], part_s);
+        part_s = fmaf(ophi_to_f32(kv[w]), qf[2 * w + 1], part_s);
       }
       part[i] = part_s;
     }
@@ -750,15 +750,15 @@ __global__ __launch_bounds__(512) void attn_decode_fused_kernel(
       float part_s = 0.f;
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
-        part_s = fmaf(bf16lo_to_f32(kr[w]), qf[2 * w], part_s);
-        part_s = fmaf(bf16hi_to_f32(kr[w]), qf[2 * w + 1], part_s);
+        part_s = fmaf(oplo_to_f32(kr[w]), qf[2 * w], part_s);
+        part_s = fmaf(ophi_to_f32(kr[w]), qf[2 * w + 1], part_s);
       }
       part_s = allreduce_lanes<CH>(part_s);
       if (key_of_lane == r_new) s_mine = part_s;
       if (lane < CH) {
         *(u32x4*)(kt + r_new * HD + lane * 8) = kr;                                       // lane < CH: c == lane
         const u32x4 vn = *(const u32x4*)(qrow + v_col0 + head * HD + lane * 8);       // bf16 from the projection -> fp16 page format
-        *(u32x4*)(&sm_v[lane * 8]) = (u32x4){bf16x2_to_f16x2(vn.x), bf16x2_to_f16x2(vn.y), bf16x2_to_f16x2(vn.z), bf16x2_to_f16x2(vn.w)};
+        *(u32x4*)(&sm_v[lane * 8]) = (u32x4){op2_to_f16x2(vn.x), op2_to_f16x2(vn.y), op2_to_f16x2(vn.z), op2_to_f16x2(vn.w)};
       }
       __builtin_amdgcn_wave_barrier();
       if (!fresh) {
@@ -842,7 +842,7 @@ __global__ __launch_bounds__(512) void attn_decode_fused_kernel(
       l += sm_l[w] * wt;
       o += sm_o[w][threadIdx.x] * wt;
     }
-    O[(size_t)sq.q_row0 * ldo + head * HD + threadIdx.x] = f32_to_bf16(l > 0.f ? o / l : 0.f);
+    O[(size_t)sq.q_row0 * ldo + head * HD + threadIdx.x] = f32_to_op(l > 0.f ? o / l : 0.f);
   }
 }
 
@@ -866,9 +866,9 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(const bf16_t* __rest
   for (int t = 0; t < T; ++t) {
     const size_t row = ((size_t)b * T + t) * N + n;
     const bf16_t* p = qkv + row * (size_t)(3 * D) + head * 64 + lane;
-    q[t] = bf16_to_f32(p[0]);
-    k[t] = bf16_to_f32(p[D]);
-    v[t] = bf16_to_f32(p[2 * D]);
+    q[t] = op_to_f32(p[0]);
+    k[t] = op_to_f32(p[D]);
+    v[t] = op_to_f32(p[2 * D]);
   }
 #pragma unroll
   for (int t1 = 0; t1 < T; ++t1) {
@@ -887,7 +887,7 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(const bf16_t* __rest
       acc += p * v[t2];
     }
     const size_t row = ((size_t)b * T + t1) * N + n;
-    out[row * (size_t)D + head * 64 + lane] = f32_to_bf16(acc / den);
+    out[row * (size_t)D + head * 64 + lane] = f32_to_op(acc / den);
   }
 }
 
@@ -928,8 +928,8 @@ __global__ __launch_bounds__(256) void attn_temporal8_kernel(const bf16_t* __res
     const u32x4 k8 = *(const u32x4*)&sm[wave][1][c][ch * 8];
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
-      sc = fmaf(bf16lo_to_f32(a[w]), bf16lo_to_f32(k8[w]), sc);
-      sc = fmaf(bf16hi_to_f32(a[w]), bf16hi_to_f32(k8[w]), sc);
+      sc = fmaf(oplo_to_f32(a[w]), oplo_to_f32(k8[w]), sc);
+      sc = fmaf(ophi_to_f32(a[w]), ophi_to_f32(k8[w]), sc);
     }
   }
   float mx = sc;
@@ -954,15 +954,15 @@ __global__ __launch_bounds__(256) void attn_temporal8_kernel(const bf16_t* __res
     const u32x4 v8 = *(const u32x4*)&sm[wave][2][t2][c * 8];
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
-      acc[2 * w] = fmaf(pr[t2], bf16lo_to_f32(v8[w]), acc[2 * w]);
-      acc[2 * w + 1] = fmaf(pr[t2], bf16hi_to_f32(v8[w]), acc[2 * w + 1]);
+      acc[2 * w] = fmaf(pr[t2], oplo_to_f32(v8[w]), acc[2 * w]);
+      acc[2 * w + 1] = fmaf(pr[t2], ophi_to_f32(v8[w]), acc[2 * w + 1]);
     }
   }
   u32x4 o;
-  o.x = pack_bf16x2(acc[0], acc[1]);
-  o.y = pack_bf16x2(acc[2], acc[3]);
-  o.z = pack_bf16x2(acc[4], acc[5]);
-  o.w = pack_bf16x2(acc[6], acc[7]);
+  o.x = pack_op2(acc[0], acc[1]);
+  o.y = pack_op2(acc[2], acc[3]);
+  o.z = pack_op2(acc[4], acc[5]);
+  o.w = pack_op2(acc[6], acc[7]);
   *(u32x4*)(out + row * (size_t)D + head * 64 + c * 8) = o;
 }
 

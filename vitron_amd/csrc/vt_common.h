@@ -7,7 +7,18 @@
 #include <stdint.h>
 #include <stddef.h>
 
-typedef uint16_t bf16_t;  // raw bfloat16 bits; all bf16 tensors cross the C-ABI as uint16_t*
+// ---- operand format ---------------------------------------------------------------------------------------------
+// The library is built twice from these sources (vitron_amd/build.py): libvitron_hip.so with bf16 GEMM / attention operands
+// (VT_OPERAND_F16 = 0, BASELINE.json's dtype) and libvitron_hip_f16.so with IEEE fp16 operands (VT_OPERAND_F16 = 1: the reference's
+// own inference dtype, vitron/model/builder.py:47,153,161 -- 11 mantissa bits instead of 8 at the same MFMA rate). "Operand" =
+// every 16-bit tensor that crosses the C ABI or feeds an MFMA: weights, norm outputs, fused QKV, rotated q / K pages, attention
+// output, activations, embeddings. The residual stream, accumulators, softmax statistics and biases are fp32 in both builds; the
+// V^T pages and the softmax weights P are fp16 in both. Kernels only touch operands through the helpers below.
+#ifndef VT_OPERAND_F16
+#define VT_OPERAND_F16 0
+#endif
+typedef uint16_t op16_t;  // raw bits of one operand element (bf16 or fp16 by build); 16-bit tensors cross the C ABI as uint16_t*
+typedef op16_t bf16_t;    // historical spelling, same type
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8;   // 8 bf16 = one MFMA A/B fragment (4 VGPRs)
 typedef __attribute__((ext_vector_type(4))) short bf16x4;
@@ -60,56 +71,85 @@ void vt_set_error(const char* fmt, ...);
     if (_r != VT_OK) return _r; \
   } while (0)
 
-// ---- bf16 <-> f32 (device + host) ---------------------------------------------------------------
-__host__ __device__ __forceinline__ float bf16_to_f32(bf16_t h) {
+// ---- bf16 / fp16 <-> f32 primitives --------------------------------------------------------------------------
+__host__ __device__ __forceinline__ float bf16_bits_to_f32(uint16_t h) {
   union { uint32_t u; float f; } v;
   v.u = ((uint32_t)h) << 16;
   return v.f;
 }
 // round-to-nearest-even, NaN kept quiet
-__host__ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+__host__ __device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
   union { uint32_t u; float f; } v;
   v.f = f;
   uint32_t u = v.u;
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
   u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+  return (uint16_t)(u >> 16);
 }
-// two floats -> packed bf16x2 (lo in bits 0..15): one v_cvt_pk_bf16_f32 (round-to-nearest-even, same as f32_to_bf16)
 typedef __bf16 vt_bf16v2 __attribute__((ext_vector_type(2)));
 typedef float vt_f32v2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  vt_f32v2 v = {lo, hi};
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, vt_bf16v2));
-}
-// raw v_exp_f32 (no denormal-range fix-up): for softmax weights, whose arguments are <= ~8 and whose tiny results may flush
-__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
-__device__ __forceinline__ float bf16lo_to_f32(uint32_t w) { return __uint_as_float(w << 16); }
-__device__ __forceinline__ float bf16hi_to_f32(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
-
-// ---- fp16 helpers: the V^T pages and the softmax weights P of the attention kernels --------------------------------------
-// V is produced in bf16 by the QKV projection (8 mantissa bits) and STORED in the V^T pages as fp16 (11 bits): the conversion is
-// exact for 2^-14 <= |v| <= 65504 (smaller values keep an absolute error <= 2^-25, larger ones saturate at +-65504 -- stated
-// assumption: |V| <= 65504, five orders of magnitude above what a LayerNorm/RMSNorm-fed projection produces). What it buys: the
-// P.V product of the prefill attention runs on v_mfma_f32_32x32x16_f16 with P at 11 mantissa bits instead of bf16's 8.
 typedef _Float16 vt_f16v2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));   // 8 fp16 = one MFMA A/B fragment (4 VGPRs)
-// two floats -> packed fp16x2 (lo in bits 0..15): one v_cvt_pk_f16_f32, round-to-nearest-even
+// two floats -> packed fp16x2 (lo in bits 0..15): one v_cvt_pk_f16_f32, round-to-nearest-even (no saturation: callers that can
+// exceed +-65504 clamp first)
 __device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
   vt_f32v2 v = {lo, hi};
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, vt_f16v2));
 }
 __device__ __forceinline__ float f16lo_to_f32(uint32_t w) { return (float)__builtin_bit_cast(vt_f16v2, w).x; }
 __device__ __forceinline__ float f16hi_to_f32(uint32_t w) { return (float)__builtin_bit_cast(vt_f16v2, w).y; }
-__device__ __forceinline__ float vt_clamp_f16(float x) { return __builtin_fminf(__builtin_fmaxf(x, -65504.f), 65504.f); }
-// packed bf16x2 -> packed fp16x2 (saturating)
-__device__ __forceinline__ uint32_t bf16x2_to_f16x2(uint32_t w) {
-  return pack_f16x2(vt_clamp_f16(bf16lo_to_f32(w)), vt_clamp_f16(bf16hi_to_f32(w)));
-}
-__device__ __forceinline__ uint16_t bf16_to_f16_bits(bf16_t h) {
-  return (uint16_t)(pack_f16x2(vt_clamp_f16(bf16_to_f32(h)), 0.f) & 0xffffu);
-}
+__device__ __forceinline__ float vt_clamp_f16(float x) { return __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f); }   // one v_med3_f32
 __device__ __forceinline__ float f16_bits_to_f32(uint16_t h) { return f16lo_to_f32((uint32_t)h); }
+
+// ---- operand <-> f32: the ONLY places where the two builds differ in their arithmetic -------------------------------------------
+// fp16 stores SATURATE at +-65504 (the reference's fp16 path would produce inf there and NaN one operator later; a finite clamp
+// keeps one outlier from poisoning a row). bf16 has fp32's exponent range and needs no clamp.
+#if VT_OPERAND_F16
+#define VT_OP_NAME "f16"
+__device__ __forceinline__ float op_to_f32(op16_t h) { return f16_bits_to_f32(h); }
+__device__ __forceinline__ op16_t f32_to_op(float f) { return (op16_t)(pack_f16x2(vt_clamp_f16(f), 0.f) & 0xffffu); }
+__device__ __forceinline__ uint32_t pack_op2(float lo, float hi) { return pack_f16x2(vt_clamp_f16(lo), vt_clamp_f16(hi)); }
+__device__ __forceinline__ float oplo_to_f32(uint32_t w) { return f16lo_to_f32(w); }
+__device__ __forceinline__ float ophi_to_f32(uint32_t w) { return f16hi_to_f32(w); }
+// packed operand pair -> packed fp16 pair for the V^T pages: already fp16
+__device__ __forceinline__ uint32_t op2_to_f16x2(uint32_t w) { return w; }
+__device__ __forceinline__ uint16_t op_to_f16_bits(op16_t h) { return h; }
+#else
+#define VT_OP_NAME "bf16"
+__device__ __forceinline__ float op_to_f32(op16_t h) { return bf16_bits_to_f32(h); }
+__device__ __forceinline__ op16_t f32_to_op(float f) { return f32_to_bf16_bits(f); }
+// two floats -> packed bf16x2 (lo in bits 0..15): one v_cvt_pk_bf16_f32 (round-to-nearest-even, same as f32_to_bf16_bits)
+__device__ __forceinline__ uint32_t pack_op2(float lo, float hi) {
+  vt_f32v2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, vt_bf16v2));
+}
+__device__ __forceinline__ float oplo_to_f32(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float ophi_to_f32(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+// V is produced in bf16 by the QKV projection (8 mantissa bits) and STORED in the V^T pages as fp16 (11 bits): the conversion is
+// exact for 2^-14 <= |v| <= 65504 (smaller values keep an absolute error <= 2^-25, larger ones saturate at +-65504 -- stated
+// assumption: |V| <= 65504, five orders of magnitude above what a LayerNorm/RMSNorm-fed projection produces). What it buys: the
+// P.V product of the prefill attention runs on v_mfma_f32_32x32x16_f16 with P at 11 mantissa bits instead of bf16's 8.
+__device__ __forceinline__ uint32_t op2_to_f16x2(uint32_t w) {
+  return pack_f16x2(vt_clamp_f16(oplo_to_f32(w)), vt_clamp_f16(ophi_to_f32(w)));
+}
+__device__ __forceinline__ uint16_t op_to_f16_bits(op16_t h) {
+  return (uint16_t)(pack_f16x2(vt_clamp_f16(op_to_f32(h)), 0.f) & 0xffffu);
+}
+#endif
+// The operand MFMAs. Fragments travel as 4 VGPRs of raw bits (bf16x8 = 8 x 16 bit) in both builds.
+#if VT_OPERAND_F16
+#define VT_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0)
+#define VT_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0)
+#define VT_MFMA_16x16x32_ASM "v_mfma_f32_16x16x32_f16"
+#define VT_MFMA_32x32x16_ASM "v_mfma_f32_32x32x16_f16"
+#else
+#define VT_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#define VT_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#define VT_MFMA_16x16x32_ASM "v_mfma_f32_16x16x32_bf16"
+#define VT_MFMA_32x32x16_ASM "v_mfma_f32_32x32x16_bf16"
+#endif
+// raw v_exp_f32 (no denormal-range fix-up): for softmax weights, whose arguments are <= ~8 and whose tiny results may flush
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 // GELU (exact-erf flavour: nn.GELU(), CLIP 'gelu') for the GEMM epilogues: 0.5 x (1 + erf(x / sqrt 2)) with 1 - erf(|z|) from
 // Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 store that follows): branch-free, one rcp and one exp2 -- the

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bt_kernel(GemmP p
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = VT_MFMA_16x16x32(bfr[ni], af[mi], acc[mi][ni]);
     }
     __syncthreads();
   }
@@ -184,8 +184,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bt_kernel(GemmP p
         const int no = ((bn0 + wn * WTN + ni * 16) >> 1) + ((lane >> 4) << 2);
         const f32x4 g = acc[mi][ni] * rs, u = acc[mi][ni + 1] * rs;
         u32x2 o;
-        o.x = pack_bf16x2(silu(g[0]) * u[0], silu(g[1]) * u[1]);
-        o.y = pack_bf16x2(silu(g[2]) * u[2], silu(g[3]) * u[3]);
+        o.x = pack_op2(silu(g[0]) * u[0], silu(g[1]) * u[1]);
+        o.y = pack_op2(silu(g[2]) * u[2], silu(g[3]) * u[3]);
         *(u32x2*)(crow + no) = o;
       }
     } else {
@@ -216,8 +216,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bt_kernel(GemmP p
             if (out_partials) {
               const f32x4 w4 = *(const f32x4*)(p.nf.out_w + n);
               u32x2 o;
-              o.x = pack_bf16x2(nv[0] * w4[0], nv[1] * w4[1]);
-              o.y = pack_bf16x2(nv[2] * w4[2], nv[3] * w4[3]);
+              o.x = pack_op2(nv[0] * w4[0], nv[1] * w4[1]);
+              o.y = pack_op2(nv[2] * w4[2], nv[3] * w4[3]);
               *(u32x2*)(p.nf.out_xw + (size_t)m * p.nf.ld_xw + n) = o;
               ss += (nv[0] * nv[0] + nv[1] * nv[1]) + (nv[2] * nv[2] + nv[3] * nv[3]);
             }
@@ -225,8 +225,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bt_kernel(GemmP p
             *(f32x4*)((float*)p.C + (size_t)m * p.ldc + n) = v;
           } else {
             u32x2 o;
-            o.x = pack_bf16x2(v[0], v[1]);
-            o.y = pack_bf16x2(v[2], v[3]);
+            o.x = pack_op2(v[0], v[1]);
+            o.y = pack_op2(v[2], v[3]);
             *(u32x2*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
           }
         }
@@ -289,8 +289,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_mfma_kernel(GemmP p) {
 #define SK_MFMA(W_, X_)                                                                                   \
   _Pragma("unroll") for (int u = 0; u < UNR; ++u)                                                         \
     _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                        \
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, W_[u][t]),              \
-                                                       __builtin_bit_cast(bf16x8, X_[u]), acc[t], 0, 0, 0);
+      acc[t] = VT_MFMA_16x16x32(__builtin_bit_cast(bf16x8, W_[u][t]), __builtin_bit_cast(bf16x8, X_[u]), acc[t]);
   SK_LOAD(wa, xa, s0);
   for (int s = s0; s < s1; s += 2 * UNR) {
     SK_LOAD(wb, xb, s + UNR);
@@ -317,7 +316,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_mfma_kernel(GemmP p) {
   }
   if constexpr (EPI == VT_EPI_SWIGLU_BF16) {
     const int q = blockIdx.x * 16 + nn;                      // output column; gate row n_base+nn, up row n_base+16+nn
-    if (n_base + 16 + nn < p.N) ((bf16_t*)p.C)[(size_t)m * p.ldc + q] = f32_to_bf16(silu(v[0]) * v[NT - 1]);
+    if (n_base + 16 + nn < p.N) ((bf16_t*)p.C)[(size_t)m * p.ldc + q] = f32_to_op(silu(v[0]) * v[NT - 1]);
   } else {
     const int n = n_base + nn;
     if (n >= p.N) return;
@@ -331,7 +330,7 @@ __global__ __launch_bounds__(512) void gemm_skinny_mfma_kernel(GemmP p) {
     } else if constexpr (EPI == VT_EPI_F32) {
       ((float*)p.C)[(size_t)m * p.ldc + n] = r;
     } else {
-      ((bf16_t*)p.C)[(size_t)m * p.ldc + n] = f32_to_bf16(r);
+      ((bf16_t*)p.C)[(size_t)m * p.ldc + n] = f32_to_op(r);
     }
   }
 }
@@ -438,8 +437,8 @@ __global__ __launch_bounds__(64 * NWAVE) void gemm_skinny_dma_kernel(GemmP p) {
     if (i + R < n) issue(s0 + i + R, i & (R - 1));
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][0], xf[0], acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][1], xf[1], acc[t], 0, 0, 0);
+      acc[t] = VT_MFMA_16x16x32(wf[t][0], xf[0], acc[t]);
+      acc[t] = VT_MFMA_16x16x32(wf[t][1], xf[1], acc[t]);
     }
   }
 
@@ -469,7 +468,7 @@ __global__ __launch_bounds__(64 * NWAVE) void gemm_skinny_dma_kernel(GemmP p) {
   }
   if constexpr (EPI == VT_EPI_SWIGLU_BF16) {
     const int q = blockIdx.x * 16 + nn;                      // output column; gate row n_base+nn, up row n_base+16+nn
-    if (n_base + 16 + nn < p.N) ((bf16_t*)p.C)[(size_t)m * p.ldc + q] = f32_to_bf16(silu(v[0]) * v[NT - 1]);
+    if (n_base + 16 + nn < p.N) ((bf16_t*)p.C)[(size_t)m * p.ldc + q] = f32_to_op(silu(v[0]) * v[NT - 1]);
   } else {
     const int nc = n_base + nn;
     if constexpr (EPI == VT_EPI_F32_RESID) {
@@ -477,7 +476,7 @@ __global__ __launch_bounds__(64 * NWAVE) void gemm_skinny_dma_kernel(GemmP p) {
         float* c = (float*)p.C + (size_t)m * p.ldc + nc;
         const float x = *c + v[0];
         *c = x;
-        p.nf.out_xw[(size_t)m * p.nf.ld_xw + nc] = f32_to_bf16(x * p.nf.out_w[nc]);
+        p.nf.out_xw[(size_t)m * p.nf.ld_xw + nc] = f32_to_op(x * p.nf.out_w[nc]);
         float ss = x * x;
 #pragma unroll
         for (int off = 1; off < 16; off <<= 1) ss += __shfl_xor(ss, off, 16);
@@ -496,7 +495,7 @@ __global__ __launch_bounds__(64 * NWAVE) void gemm_skinny_dma_kernel(GemmP p) {
     } else if constexpr (EPI == VT_EPI_F32) {
       ((float*)p.C)[(size_t)m * p.ldc + nc] = r;
     } else {
-      ((bf16_t*)p.C)[(size_t)m * p.ldc + nc] = f32_to_bf16(r);
+      ((bf16_t*)p.C)[(size_t)m * p.ldc + nc] = f32_to_op(r);
     }
   }
 }
@@ -612,8 +611,8 @@ __global__ __launch_bounds__(64 * NWAVE) void gemm_skinny_dma32_kernel(GemmP p) 
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int g = 0; g < MT; ++g) {
-        acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][0], xf[g][0], acc[t][g], 0, 0, 0);
-        acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][1], xf[g][1], acc[t][g], 0, 0, 0);
+        acc[t][g] = VT_MFMA_16x16x32(wf[t][0], xf[g][0], acc[t][g]);
+        acc[t][g] = VT_MFMA_16x16x32(wf[t][1], xf[g][1], acc[t][g]);
       }
   }
 
@@ -638,7 +637,7 @@ __global__ __launch_bounds__(64 * NWAVE) void gemm_skinny_dma32_kernel(GemmP p) 
     }
     if constexpr (EPI == VT_EPI_SWIGLU_BF16) {
       const int q = blockIdx.x * 16 + nn;
-      if (n_base + 16 + nn < p.N) ((bf16_t*)p.C)[(size_t)m * p.ldc + q] = f32_to_bf16(silu(v[0]) * v[NT - 1]);
+      if (n_base + 16 + nn < p.N) ((bf16_t*)p.C)[(size_t)m * p.ldc + q] = f32_to_op(silu(v[0]) * v[NT - 1]);
     } else {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
@@ -654,7 +653,7 @@ __global__ __launch_bounds__(64 * NWAVE) void gemm_skinny_dma32_kernel(GemmP p) 
         } else if constexpr (EPI == VT_EPI_F32) {
           ((float*)p.C)[(size_t)m * p.ldc + nc] = r;
         } else {
-          ((bf16_t*)p.C)[(size_t)m * p.ldc + nc] = f32_to_bf16(r);
+          ((bf16_t*)p.C)[(size_t)m * p.ldc + nc] = f32_to_op(r);
         }
       }
     }
@@ -795,7 +794,11 @@ static double vt_gemm_plan_cost(int M, int N, int K, int epi, const VtGemmNormFu
     // heavily and the tile COUNT stays inside the same number of rounds (1088 rows: 5 tile rows either way; 4616 x 3072: 252 vs 228 tiles)
     const long t224 = cdiv(M, 224) * (long)tiles_n;
     const double c224 = (double)((t224 + 255) / 256) * 0.875 * 1.02;
-    if (t224 >= 128 && c224 < best) {   // (under half a round the small tiles' finer grid is as good: not measured, left alone)
+    // Only where it PADS FEWER ROWS than the 256-row tile (1088 -> 1120 vs 1280; 4616 -> 4704 vs 4864): the 0.875 x 1.02 price was
+    // measured on exactly those shapes (profiles/r3_gemm_tile224_ab.jsonl). A multiple of 256 (2048 rows: 160 tiles instead of 128,
+    // 9 % padding) would otherwise switch kernels on an extrapolated model -- unmeasured shapes stay on the 256-row tile.
+    const bool pads_less = (long)cdiv(M, 224) * 224 < (long)cdiv(M, 256) * 256;
+    if (pads_less && t224 >= 128 && c224 < best) {   // (under half a round the small tiles' finer grid is as good: not measured, left alone)
       best = c224;
       *plan = VtGemmPlan{VT_GEMM_CFG_224x256_W4, 0};
     }

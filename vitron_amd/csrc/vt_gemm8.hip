@@ -166,7 +166,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmP8 p) {
     _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                           \
       _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                         \
         _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                       \
-          acc[QM][QN][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[ni][kk], AF[mi][kk], acc[QM][QN][mi][ni], 0, 0, 0); \
+          acc[QM][QN][mi][ni] = VT_MFMA_16x16x32(BF[ni][kk], AF[mi][kk], acc[QM][QN][mi][ni]); \
     __builtin_amdgcn_s_setprio(0);                                                             \
   } while (0)
 #define MFMA_Q(QM, QN, BF) MFMA_QA(QM, QN, BF, af)
@@ -393,8 +393,8 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmP8 p) {
             if (quad_ok) {
               const int sl = e0 & 0x3ffffff;
               u32x2 o;
-              o.x = bf16x2_to_f16x2(pack_bf16x2(t0, t1));   // bf16 like the plain store epilogue, then the V^T pages' fp16 (vt_common.h)
-              o.y = bf16x2_to_f16x2(pack_bf16x2(t2, t3));
+              o.x = op2_to_f16x2(pack_op2(t0, t1));   // bf16 like the plain store epilogue, then the V^T pages' fp16 (vt_common.h)
+              o.y = op2_to_f16x2(pack_op2(t2, t3));
               *(u32x2*)(p.qf.vt_pages + (((size_t)(sl >> 6) * heads + head) * 128 + dim) * 64 + (sl & 63)) = o;
             } else {
               const float tv[4] = {t0, t1, t2, t3};
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmP8 p) {
                 const int mi_row = bm0 + qm * 128 + wr * 64 + mi * 16 + ((lane & 12) | i);
                 if (mi_row < p.M) {
                   const int sl = ei & 0x3ffffff;
-                  p.qf.vt_pages[(((size_t)(sl >> 6) * heads + head) * 128 + dim) * 64 + (sl & 63)] = bf16_to_f16_bits(f32_to_bf16(tv[i]));
+                  p.qf.vt_pages[(((size_t)(sl >> 6) * heads + head) * 128 + dim) * 64 + (sl & 63)] = op_to_f16_bits(f32_to_op(tv[i]));
                 }
               }
             }
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmP8 p) {
 #pragma unroll
           for (int ni = 0; ni < 2; ++ni) {
             const f32x4 v = acc[r >> 2][qn][r & 3][ni];
-            u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            u32x2 o = {pack_op2(v[0], v[1]), pack_op2(v[2], v[3])};
             *(u32x2*)(T + row * LDT + wc * 32 + ni * 16 + ((lane >> 4) << 2)) = o;
           }
         }
@@ -470,17 +470,17 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmP8 p) {
             for (int ni = 0; ni < 2; ++ni) {
               const int col = wc * 32 + ni * 16 + ((lane >> 4) << 2);
               const f32x4 v = acc[r >> 2][qn][r & 3][ni];
-              const uint32_t xo[2] = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};   // the bf16 values parked above
+              const uint32_t xo[2] = {pack_op2(v[0], v[1]), pack_op2(v[2], v[3])};   // the bf16 values parked above
               const uint32_t po[2] = {part[h][ni].x, part[h][ni].y};
               uint32_t ov[2];
 #pragma unroll
               for (int w = 0; w < 2; ++w) {
                 // a = low-half value, b = high-half value of the pair; the shared rope_lo / rope_hi of vt_kv_tiles
-                const float a0 = bf16lo_to_f32(upper ? po[w] : xo[w]), a1 = bf16hi_to_f32(upper ? po[w] : xo[w]);
-                const float b0 = bf16lo_to_f32(upper ? xo[w] : po[w]), b1 = bf16hi_to_f32(upper ? xo[w] : po[w]);
+                const float a0 = oplo_to_f32(upper ? po[w] : xo[w]), a1 = ophi_to_f32(upper ? po[w] : xo[w]);
+                const float b0 = oplo_to_f32(upper ? xo[w] : po[w]), b1 = ophi_to_f32(upper ? xo[w] : po[w]);
                 const float c0 = c4[h][ni][2 * w], c1 = c4[h][ni][2 * w + 1], s0 = s4[h][ni][2 * w], s1 = s4[h][ni][2 * w + 1];
-                ov[w] = upper ? pack_bf16x2(rope_hi(a0, b0, c0, s0), rope_hi(a1, b1, c1, s1))
-                              : pack_bf16x2(rope_lo(a0, b0, c0, s0), rope_lo(a1, b1, c1, s1));
+                ov[w] = upper ? pack_op2(rope_hi(a0, b0, c0, s0), rope_hi(a1, b1, c1, s1))
+                              : pack_op2(rope_lo(a0, b0, c0, s0), rope_lo(a1, b1, c1, s1));
               }
               const u32x2 o = {ov[0], ov[1]};
               *(u32x2*)(dst + col) = o;
@@ -547,8 +547,8 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmP8 p) {
             *(f32x4*)(Cf + (size_t)m * p.ldc + n) = nv;
             if (out_partials) {
               u32x2 o;
-              o.x = pack_bf16x2(nv[0] * w4[qn][ni][0], nv[1] * w4[qn][ni][1]);
-              o.y = pack_bf16x2(nv[2] * w4[qn][ni][2], nv[3] * w4[qn][ni][3]);
+              o.x = pack_op2(nv[0] * w4[qn][ni][0], nv[1] * w4[qn][ni][1]);
+              o.y = pack_op2(nv[2] * w4[qn][ni][2], nv[3] * w4[qn][ni][3]);
               *(u32x2*)(out_xw + (size_t)m * p.nf.ld_xw + n) = o;
               ss += (nv[0] * nv[0] + nv[1] * nv[1]) + (nv[2] * nv[2] + nv[3] * nv[3]);
             }
@@ -580,8 +580,8 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmP8 p) {
             if (nbase + ((lane >> 4) << 2) >= p.N) continue;
             const f32x4 g = acc[qm][qn][mi][0] * rs, u2 = acc[qm][qn][mi][1] * rs;
             u32x2 o;
-            o.x = pack_bf16x2(silu8(g[0]) * u2[0], silu8(g[1]) * u2[1]);
-            o.y = pack_bf16x2(silu8(g[2]) * u2[2], silu8(g[3]) * u2[3]);
+            o.x = pack_op2(silu8(g[0]) * u2[0], silu8(g[1]) * u2[1]);
+            o.y = pack_op2(silu8(g[2]) * u2[2], silu8(g[3]) * u2[3]);
             *(u32x2*)((bf16_t*)p.C + (size_t)m * p.ldc + (nbase >> 1) + ((lane >> 4) << 2)) = o;
           } else {
 #pragma unroll
@@ -604,8 +604,8 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmP8 p) {
                 *(f32x4*)((float*)p.C + (size_t)split * p.slab + (size_t)m * p.ldc + n) = v;
               } else {
                 u32x2 o;
-                o.x = pack_bf16x2(v[0], v[1]);
-                o.y = pack_bf16x2(v[2], v[3]);
+                o.x = pack_op2(v[0], v[1]);
+                o.y = pack_op2(v[2], v[3]);
                 *(u32x2*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
               }
             }
@@ -658,8 +658,8 @@ __device__ __forceinline__ void w4_epilogue_lds(const GemmP8& p, f32x4 (&acc)[MT
         for (int nj = 0; nj < 4; ++nj) {
           const f32x4 g = acc[mi][2 * nj], u2 = acc[mi][2 * nj + 1];
           u32x2 o;
-          o.x = pack_bf16x2(silu8(g[0]) * u2[0], silu8(g[1]) * u2[1]);
-          o.y = pack_bf16x2(silu8(g[2]) * u2[2], silu8(g[3]) * u2[3]);
+          o.x = pack_op2(silu8(g[0]) * u2[0], silu8(g[1]) * u2[1]);
+          o.y = pack_op2(silu8(g[2]) * u2[2], silu8(g[3]) * u2[3]);
           *(u32x2*)(my + row * ROWB + (((nj * 2 + (cg >> 1)) ^ (row & (CH - 1))) << 4) + (cg & 1) * 8) = o;
         }
       } else {
@@ -677,8 +677,8 @@ __device__ __forceinline__ void w4_epilogue_lds(const GemmP8& p, f32x4 (&acc)[MT
             for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
           }
           u32x2 o;
-          o.x = pack_bf16x2(v[0], v[1]);
-          o.y = pack_bf16x2(v[2], v[3]);
+          o.x = pack_op2(v[0], v[1]);
+          o.y = pack_op2(v[2], v[3]);
           *(u32x2*)(my + row * ROWB + (((ni * 2 + (cg >> 1)) ^ (row & (CH - 1))) << 4) + (cg & 1) * 8) = o;
         }
       }
@@ -746,8 +746,8 @@ __device__ __forceinline__ void w4_epilogue(const GemmP8& p, f32x4 (&acc)[MT][NI
           if (nbase + ((lane >> 4) << 2) >= p.N) continue;
           const f32x4 g = acc[mi][2 * nj], u2 = acc[mi][2 * nj + 1];
           u32x2 o;
-          o.x = pack_bf16x2(silu8(g[0]) * u2[0], silu8(g[1]) * u2[1]);
-          o.y = pack_bf16x2(silu8(g[2]) * u2[2], silu8(g[3]) * u2[3]);
+          o.x = pack_op2(silu8(g[0]) * u2[0], silu8(g[1]) * u2[1]);
+          o.y = pack_op2(silu8(g[2]) * u2[2], silu8(g[3]) * u2[3]);
           *(u32x2*)((bf16_t*)p.C + (size_t)m * p.ldc + (nbase >> 1) + ((lane >> 4) << 2)) = o;
         }
       } else {
@@ -771,8 +771,8 @@ __device__ __forceinline__ void w4_epilogue(const GemmP8& p, f32x4 (&acc)[MT][NI
             *(f32x4*)((float*)p.C + (size_t)split * p.slab + (size_t)m * p.ldc + n) = v;
           } else {
             u32x2 o;
-            o.x = pack_bf16x2(v[0], v[1]);
-            o.y = pack_bf16x2(v[2], v[3]);
+            o.x = pack_op2(v[0], v[1]);
+            o.y = pack_op2(v[2], v[3]);
             *(u32x2*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
           }
         }
@@ -881,10 +881,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define W4S_MFMA(N)                                                                                              \
   do {                                                                                                           \
     if ((((N) % H) >> 3) < 8)                                                                                    \
-      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"                                                     \
+      asm volatile(VT_MFMA_16x16x32_ASM " %0, %1, %2, %0"                                                     \
                    : "+a"(acc[(((N) % H) >> 3) & 7][(N) & 7]) : "v"(fb[((N) / H) & 1][(N) & 7]), "v"(fa[((N) / H) & 1][(((N) % H) >> 3) % MT])); \
     else                                                                                                         \
-      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"                                                     \
+      asm volatile(VT_MFMA_16x16x32_ASM " %0, %1, %2, %0"                                                     \
                    : "+v"(acc[(((N) % H) >> 3) % MT][(N) & 7]) : "v"(fb[((N) / H) & 1][(N) & 7]), "v"(fa[((N) / H) & 1][(((N) % H) >> 3) % MT])); \
   } while (0)
 #define W4S_RDB(SET, BUF, KK, I) fb[SET][I] = *(const bf16x8*)(smem + (BUF) * BUFB + b_base + fo[KK] + (I) * 2048)
@@ -1070,7 +1070,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
   bf16x8 fa[2][MT], fb[2][NI];
 #define W4R_MFMA(N)                                                                                              \
-  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"                                                         \
+  asm volatile(VT_MFMA_16x16x32_ASM " %0, %1, %2, %0"                                                         \
                : "+a"(acc[((N) % H) / NI][(N) % NI]) : "v"(fb[((N) / H) & 1][(N) % NI]), "v"(fa[((N) / H) & 1][((N) % H) / NI]))
 #define W4R_RDB(SET, BUF, KK, I) fb[SET][I] = *(const bf16x8*)(smem + (BUF) * BUFB + b_base + fo[KK] + (I) * 2048)
 #define W4R_RDA(SET, BUF, KK, I) fa[SET][I] = *(const bf16x8*)(smem + (BUF) * BUFB + a_base + fo[KK] + (I) * 2048)
@@ -1231,7 +1231,7 @@ __global__ __launch_bounds__(512, 2) void gemm_rp_kernel(GemmP8 p) {
   do {                                                                                    \
     _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                      \
       _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                    \
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FB[ni], FA[mi], acc[mi][ni], 0, 0, 0); \
+        acc[mi][ni] = VT_MFMA_32x32x16(FB[ni], FA[mi], acc[mi][ni]); \
   } while (0)
   // one k-step: reads of the next fragments interleaved 1:1 behind the first MFMAs
 #define RP_STEP(FA_CUR, FB_CUR, FA_NXT, FB_NXT, BUF, KS_NXT)                              \
@@ -1311,8 +1311,8 @@ __global__ __launch_bounds__(512, 2) void gemm_rp_kernel(GemmP8 p) {
           const int nl = 8 * g + 4 * (lane >> 5);
           if (nfrag + nl >= p.N) continue;
           u32x2 o;
-          o.x = pack_bf16x2(silu8(a[4 * g + 0]) * a[4 * g + 8], silu8(a[4 * g + 1]) * a[4 * g + 9]);
-          o.y = pack_bf16x2(silu8(a[4 * g + 2]) * a[4 * g + 10], silu8(a[4 * g + 3]) * a[4 * g + 11]);
+          o.x = pack_op2(silu8(a[4 * g + 0]) * a[4 * g + 8], silu8(a[4 * g + 1]) * a[4 * g + 9]);
+          o.y = pack_op2(silu8(a[4 * g + 2]) * a[4 * g + 10], silu8(a[4 * g + 3]) * a[4 * g + 11]);
           *(u32x2*)((bf16_t*)p.C + (size_t)m * p.ldc + (nfrag >> 1) + nl) = o;
         }
       } else {
@@ -1339,8 +1339,8 @@ __global__ __launch_bounds__(512, 2) void gemm_rp_kernel(GemmP8 p) {
             *(f32x4*)((float*)p.C + (size_t)m * p.ldc + n) = v;
           } else {
             u32x2 o;
-            o.x = pack_bf16x2(v[0], v[1]);
-            o.y = pack_bf16x2(v[2], v[3]);
+            o.x = pack_op2(v[0], v[1]);
+            o.y = pack_op2(v[2], v[3]);
             *(u32x2*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
           }
         }
@@ -1435,8 +1435,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_resid_kernel(const float* _
       if (live) {
         const f32x4 w4 = *(const f32x4*)(nf.out_w + c * 4);
         u32x2 o;
-        o.x = pack_bf16x2(acc[0] * w4[0], acc[1] * w4[1]);
-        o.y = pack_bf16x2(acc[2] * w4[2], acc[3] * w4[3]);
+        o.x = pack_op2(acc[0] * w4[0], acc[1] * w4[1]);
+        o.y = pack_op2(acc[2] * w4[2], acc[3] * w4[3]);
         *(u32x2*)(nf.out_xw + (size_t)m * nf.ld_xw + c * 4) = o;
         if ((c & 7) == 0) nf.out_partials[(size_t)(c >> 3) * nf.out_ldp + m] = ss;
       }

@@ -126,9 +126,9 @@ int vt_attn_temporal_launch(const bf16_t* qkv, bf16_t* out, int B, int T, int N,
 
 // ---- vt_region.hip --------------------------------------------------------------------------------
 // cell mask / count / masked mean per (box, 64-channel slab); optionally also LocationEncoder layer 0:
-// loc_out[b][n] = bf16(relu(coords[b][0..4) . loc_w0[n][0..4) + loc_b0[n])), n < loc_n
+// loc_out[b][n] = op16(relu(coords[b][0..4) . loc_w0[n][0..4) + loc_b0[n])), n < loc_n; coords fp32 [B][4]
 int vt_region_pool_launch(const bf16_t* feats, const int* slices, int B, int G, int image_size, int D,
-                          bf16_t* pooled, int* cell_mask, int* cell_count, const bf16_t* coords, const bf16_t* loc_w0,
+                          bf16_t* pooled, int* cell_mask, int* cell_count, const float* coords, const bf16_t* loc_w0,
                           const float* loc_b0, int loc_n, bf16_t* loc_out, int ld_loc, hipStream_t s);
 
 // ---- vt_llama.hip ---------------------------------------------------------------------------------

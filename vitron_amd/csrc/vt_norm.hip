@@ -63,8 +63,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, c
       const f32x4 g = *(const f32x4*)(gamma + c);
       const f32x4 b = *(const f32x4*)(beta + c);
       u32x2 o;
-      o.x = pack_bf16x2((v[i][0] - mean) * rstd * g[0] + b[0], (v[i][1] - mean) * rstd * g[1] + b[1]);
-      o.y = pack_bf16x2((v[i][2] - mean) * rstd * g[2] + b[2], (v[i][3] - mean) * rstd * g[3] + b[3]);
+      o.x = pack_op2((v[i][0] - mean) * rstd * g[0] + b[0], (v[i][1] - mean) * rstd * g[1] + b[1]);
+      o.y = pack_op2((v[i][2] - mean) * rstd * g[2] + b[2], (v[i][3] - mean) * rstd * g[3] + b[3]);
       *(u32x2*)(yr + c) = o;
     }
   }
@@ -98,8 +98,8 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
     if (c < D) {
       const f32x4 g = *(const f32x4*)(w + c);
       u32x2 o;
-      o.x = pack_bf16x2(v[i][0] * rstd * g[0], v[i][1] * rstd * g[1]);
-      o.y = pack_bf16x2(v[i][2] * rstd * g[2], v[i][3] * rstd * g[3]);
+      o.x = pack_op2(v[i][0] * rstd * g[0], v[i][1] * rstd * g[1]);
+      o.y = pack_op2(v[i][2] * rstd * g[2], v[i][3] * rstd * g[3]);
       *(u32x2*)(yr + c) = o;
     }
   }
@@ -143,8 +143,8 @@ __global__ __launch_bounds__(256) void rmsnorm_stream_kernel(const float* __rest
       const int c = (lane + i * 64) * 4;
       if (c < D) {
         u32x2 o;
-        o.x = pack_bf16x2(cur[i][0] * rstd * g[i][0], cur[i][1] * rstd * g[i][1]);
-        o.y = pack_bf16x2(cur[i][2] * rstd * g[i][2], cur[i][3] * rstd * g[i][3]);
+        o.x = pack_op2(cur[i][0] * rstd * g[i][0], cur[i][1] * rstd * g[i][1]);
+        o.y = pack_op2(cur[i][2] * rstd * g[i][2], cur[i][3] * rstd * g[i][3]);
         *(u32x2*)(yr + c) = o;
       }
     }
@@ -204,8 +204,8 @@ __global__ __launch_bounds__(256) void rmsnorm_row_block_kernel(const float* __r
     if (c < D) {
       const f32x4 g = *(const f32x4*)(w + c);
       u32x2 o;
-      o.x = pack_bf16x2(v[i][0] * rstd * g[0], v[i][1] * rstd * g[1]);
-      o.y = pack_bf16x2(v[i][2] * rstd * g[2], v[i][3] * rstd * g[3]);
+      o.x = pack_op2(v[i][0] * rstd * g[0], v[i][1] * rstd * g[1]);
+      o.y = pack_op2(v[i][2] * rstd * g[2], v[i][3] * rstd * g[3]);
       *(u32x2*)(yr + c) = o;
     }
   }
@@ -220,8 +220,8 @@ __global__ void gather_f32_to_bf16_kernel(const float* __restrict__ in, const in
   const int src = idx ? idx[r] : r;
   const f32x4 v = *(const f32x4*)(in + (size_t)src * D + c);
   u32x2 o;
-  o.x = pack_bf16x2(v[0], v[1]);
-  o.y = pack_bf16x2(v[2], v[3]);
+  o.x = pack_op2(v[0], v[1]);
+  o.y = pack_op2(v[2], v[3]);
   *(u32x2*)(out + (size_t)r * D + c) = o;
 }
 
@@ -234,8 +234,8 @@ __global__ void drop_cls_kernel(const float* __restrict__ x, bf16_t* __restrict_
   const size_t f = r / G2, p = r % G2;
   const f32x4 v = *(const f32x4*)(x + (f * (G2 + 1) + 1 + p) * D + c);
   u32x2 o;
-  o.x = pack_bf16x2(v[0], v[1]);
-  o.y = pack_bf16x2(v[2], v[3]);
+  o.x = pack_op2(v[0], v[1]);
+  o.y = pack_op2(v[2], v[3]);
   *(u32x2*)(out + r * D + c) = o;
 }
 
@@ -243,7 +243,7 @@ __global__ void bf16_to_f32_kernel(const bf16_t* __restrict__ in, float* __restr
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n4) return;
   const u32x2 w = *(const u32x2*)(in + i * 4);
-  f32x4 v = {bf16lo_to_f32(w.x), bf16hi_to_f32(w.x), bf16lo_to_f32(w.y), bf16hi_to_f32(w.y)};
+  f32x4 v = {oplo_to_f32(w.x), ophi_to_f32(w.x), oplo_to_f32(w.y), ophi_to_f32(w.y)};
   *(f32x4*)(out + i * 4) = v;
 }
 

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(PreP p) {
   for (int c = 0; c < 3; ++c) {
     const float o = (v[c] * p.pre - p.mean[c]) * p.istd[c];
     const long di = (long)c * p.dst_sc + (long)f * p.dst_sf + (long)y * p.S + x;
-    if constexpr (sizeof(DST) == 2) d[di] = f32_to_bf16(o);
+    if constexpr (sizeof(DST) == 2) d[di] = f32_to_op(o);
     else d[di] = o;
   }
 }

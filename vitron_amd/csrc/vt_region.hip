@@ -37,7 +37,7 @@ __device__ __forceinline__ void bilinear_taps(int dst, float scale, int in_size,
 __global__ __launch_bounds__(256) void region_pool_kernel(const bf16_t* __restrict__ feats, const int* __restrict__ slices, int G,
                                                           int image_size, int D, bf16_t* __restrict__ pooled,
                                                           int* __restrict__ cell_mask, int* __restrict__ cell_count,
-                                                          const bf16_t* __restrict__ coords, const bf16_t* __restrict__ loc_w0,
+                                                          const float* __restrict__ coords, const bf16_t* __restrict__ loc_w0,
                                                           const float* __restrict__ loc_b0, int loc_n, bf16_t* __restrict__ loc_out,
                                                           int ld_loc) {
   __shared__ unsigned long long s_bits[2];
@@ -85,14 +85,14 @@ __global__ __launch_bounds__(256) void region_pool_kernel(const bf16_t* __restri
       if (!(((rm >> i) & 1ull) && ((cm >> j) & 1ull))) continue;      // (the on-lines of a box are contiguous: never taken)
       const u32x4 w = *(const u32x4*)(base + (size_t)(i * G + j) * D);
       // reference: x * (mask / denorm) summed over the cells (layer.py:36-42); same products, summed in fp32
-      acc[0] += bf16lo_to_f32(w.x) * inv;
-      acc[1] += bf16hi_to_f32(w.x) * inv;
-      acc[2] += bf16lo_to_f32(w.y) * inv;
-      acc[3] += bf16hi_to_f32(w.y) * inv;
-      acc[4] += bf16lo_to_f32(w.z) * inv;
-      acc[5] += bf16hi_to_f32(w.z) * inv;
-      acc[6] += bf16lo_to_f32(w.w) * inv;
-      acc[7] += bf16hi_to_f32(w.w) * inv;
+      acc[0] += oplo_to_f32(w.x) * inv;
+      acc[1] += ophi_to_f32(w.x) * inv;
+      acc[2] += oplo_to_f32(w.y) * inv;
+      acc[3] += ophi_to_f32(w.y) * inv;
+      acc[4] += oplo_to_f32(w.z) * inv;
+      acc[5] += ophi_to_f32(w.z) * inv;
+      acc[6] += oplo_to_f32(w.w) * inv;
+      acc[7] += ophi_to_f32(w.w) * inv;
     }
   }
 #pragma unroll
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void region_pool_kernel(const bf16_t* __restri
   __syncthreads();
   if (threadIdx.x < 64) {
     const float v = (s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + (s_part[2][threadIdx.x] + s_part[3][threadIdx.x]);
-    pooled[(size_t)b * D + slab * 64 + threadIdx.x] = f32_to_bf16(v);
+    pooled[(size_t)b * D + slab * 64 + threadIdx.x] = f32_to_op(v);
   }
   // ---- LocationEncoder layer 0: this block's share of the loc_n outputs ------------------------------------------------------
   if (loc_out) {
@@ -118,14 +118,14 @@ __global__ __launch_bounds__(256) void region_pool_kernel(const bf16_t* __restri
     for (int t = threadIdx.x; t < per; t += blockDim.x) {
       const int n = slab * per + t;
       if (n >= loc_n) break;
-      const u32x2 cw = *(const u32x2*)(coords + (size_t)b * 8);        // {x1,y1,x2,y2} as bf16 (layer.py:126 casts to the model dtype)
-      const u32x2 ww = *(const u32x2*)(loc_w0 + (size_t)n * 8);
-      float v = bf16lo_to_f32(cw.x) * bf16lo_to_f32(ww.x);
-      v = fmaf(bf16hi_to_f32(cw.x), bf16hi_to_f32(ww.x), v);
-      v = fmaf(bf16lo_to_f32(cw.y), bf16lo_to_f32(ww.y), v);
-      v = fmaf(bf16hi_to_f32(cw.y), bf16hi_to_f32(ww.y), v);
+      const f32x4 cw = *(const f32x4*)(coords + (size_t)b * 4);        // {x1,y1,x2,y2} in fp32: a K = 4 layer costs nothing in full
+      const u32x2 ww = *(const u32x2*)(loc_w0 + (size_t)n * 8);         // precision, and integers above 256 are not bf16 values
+      float v = cw[0] * oplo_to_f32(ww.x);
+      v = fmaf(cw[1], ophi_to_f32(ww.x), v);
+      v = fmaf(cw[2], oplo_to_f32(ww.y), v);
+      v = fmaf(cw[3], ophi_to_f32(ww.y), v);
       v += loc_b0[n];
-      loc_out[(size_t)b * ld_loc + n] = f32_to_bf16(fmaxf(v, 0.f));
+      loc_out[(size_t)b * ld_loc + n] = f32_to_op(fmaxf(v, 0.f));
     }
   }
 }
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void region_pool_kernel(const bf16_t* __restri
 }  // namespace
 
 int vt_region_pool_launch(const bf16_t* feats, const int* slices, int B, int G, int image_size, int D,
-                          bf16_t* pooled, int* cell_mask, int* cell_count, const bf16_t* coords, const bf16_t* loc_w0,
+                          bf16_t* pooled, int* cell_mask, int* cell_count, const float* coords, const bf16_t* loc_w0,
                           const float* loc_b0, int loc_n, bf16_t* loc_out, int ld_loc, hipStream_t s) {
   VT_REQUIRE(feats && slices && pooled, "vt_region_pool: null pointer");
   VT_REQUIRE(B > 0 && G > 0 && G <= 64 && image_size >= G && D % 64 == 0,

@@ -15,7 +15,7 @@ namespace {
 template <typename PIX>
 __device__ __forceinline__ float pix_to_f32(PIX v);
 template <>
-__device__ __forceinline__ float pix_to_f32<bf16_t>(bf16_t v) { return bf16_to_f32(v); }
+__device__ __forceinline__ float pix_to_f32<bf16_t>(bf16_t v) { return op_to_f32(v); }
 template <>
 __device__ __forceinline__ float pix_to_f32<float>(float v) { return v; }
 
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void im2col_kernel(const PIX* __restrict__ pix
   if (video_layout) src = ((((size_t)b * 3 + c) * T + t) * H + (gy * P + py)) * W + gx * P;   // [B][3][T][H][W]
   else src = (((size_t)f * 3 + c) * H + (gy * P + py)) * W + gx * P;                          // [F][3][H][W]
   bf16_t* o = orow + (c * P + py) * P;
-  for (int px = 0; px < P; ++px) o[px] = f32_to_bf16(pix_to_f32<PIX>(pix[src + px]));
+  for (int px = 0; px < P; ++px) o[px] = f32_to_op(pix_to_f32<PIX>(pix[src + px]));
 }
 
 // x[f][0] = cls + pos[0]; x[f][1+p] = patch_out[f*G2+p] + pos[1+p]; x = LayerNorm(x) (fp32 in, fp32 out)

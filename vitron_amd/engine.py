@@ -11,6 +11,11 @@ HIP kernels want them:
   * biases / norm parameters / embeddings tables upcast to fp32 once.
 Each Packed* object owns its device tensors and the ctypes struct that points at them, and exposes one
 `forward` that is a single C-ABI call.
+
+Operand format: every Packed* takes `dtype` (torch.bfloat16, the default, or torch.float16 -- the reference's inference dtype,
+vitron/model/builder.py:47) and packs its GEMM weights in it; the dtype also selects the library build the object calls
+(_lib.lib_for). fp16 checkpoints are kept bit for bit in fp16 mode (no detour through bf16); bf16 / fp32 weights are
+rounded to fp16 once, saturating at +-65504.
 """
 from __future__ import annotations
 
@@ -30,8 +35,17 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
-def _bf(t: torch.Tensor, device) -> torch.Tensor:
-    return t.to(device=device, dtype=torch.bfloat16).contiguous()
+def _op(t: torch.Tensor, device, dtype=torch.bfloat16) -> torch.Tensor:
+    """A weight / activation in the operand format. fp16 saturates (a bf16 / fp32 value beyond +-65504 would become inf)."""
+    if dtype == torch.float16 and t.dtype != torch.float16:
+        return t.to(device=device, dtype=torch.float32).clamp_(-65504.0, 65504.0).to(torch.float16).contiguous()
+    return t.to(device=device, dtype=dtype).contiguous()
+
+
+def _dtype(dtype):
+    dt = dtype if dtype is not None else _lib.torch_dtype()
+    _lib.operand_of(dt)          # raises unless bf16 / fp16
+    return dt
 
 
 def _f32(t: torch.Tensor, device) -> torch.Tensor:
@@ -79,10 +93,16 @@ class Workspace:
 class PackedVit:
     """LanguageBind CLIP vision transformer in kernel layout (vt_vit_model)."""
 
-    def __init__(self, sd: SD, cfg: dict, device, select_layer: int = -2):
+    def __init__(self, sd: SD, cfg: dict, device, select_layer: int = -2, dtype=None):
         sd = merge_lora(sd, float(cfg.get("lora_alpha", 16.0))) if any(".lora_" in k for k in sd) else sd
         self.cfg = dict(cfg)
         self.device = torch.device(device)
+        self.dtype = dt = _dtype(dtype)
+        self.lib = _lib.lib_for(dt)
+
+        def _bf(t, dev):
+            return _op(t, dev, dt)
+
         D, heads, P = cfg["hidden_size"], cfg["num_attention_heads"], cfg["patch_size"]
         if D != heads * 64:
             raise _lib.VitronHipError("PackedVit: kernels are specialised for head_dim 64")
@@ -104,7 +124,7 @@ class PackedVit:
             self._keep.append(t)
             return t
 
-        wp = torch.zeros((D, self.k_pad), dtype=torch.bfloat16, device=dev)
+        wp = torch.zeros((D, self.k_pad), dtype=dt, device=dev)
         wp[:, : 3 * P * P] = _bf(sd["embeddings.patch_embedding.weight"].reshape(D, 3 * P * P), dev)
         self.w_patch = keep(wp)
         self.cls = keep(_f32(sd["embeddings.class_embedding"].reshape(D), dev))
@@ -163,9 +183,9 @@ class PackedVit:
         self.ws = Workspace(dev)
 
     def forward(self, pixels: torch.Tensor, return_hidden: bool = False):
-        """pixels [B,3,H,W] or [B,3,T,H,W] (bf16/fp32, on device) -> patch features bf16 [B(,T),G*G,D]
-        (= feature_select of hidden_states[select_layer]); optionally also the full fp32 hidden state."""
-        lib = _lib.load()
+        """pixels [B,3,H,W] or [B,3,T,H,W] (operand dtype or fp32, on device) -> patch features [B(,T),G*G,D] in the operand
+        dtype (= feature_select of hidden_states[select_layer]); optionally also the full fp32 hidden state."""
+        lib = self.lib
         if not pixels.is_cuda:
             raise _lib.VitronHipError("PackedVit.forward: pixels must live on the GPU")
         video = pixels.dim() == 5
@@ -176,18 +196,18 @@ class PackedVit:
             T = 1
         if Cc != 3 or H != self.image_size or W != self.image_size:
             raise _lib.VitronHipError(f"PackedVit.forward: expected 3x{self.image_size}x{self.image_size} pixels, got {tuple(pixels.shape)}")
-        if pixels.dtype not in (torch.bfloat16, torch.float32):
-            pixels = pixels.to(torch.bfloat16)
+        if pixels.dtype not in (self.dtype, torch.float32):
+            pixels = pixels.to(self.dtype)
         pixels = pixels.contiguous()
-        dt = _lib.DTYPE_BF16 if pixels.dtype == torch.bfloat16 else _lib.DTYPE_F32
+        dt = _lib.DTYPE_BF16 if pixels.dtype == self.dtype else _lib.DTYPE_F32
         G2 = self.G * self.G
-        out = torch.empty((B * T * G2, self.D), device=self.device, dtype=torch.bfloat16)
+        out = torch.empty((B * T * G2, self.D), device=self.device, dtype=self.dtype)
         hidden = torch.empty((B * T * (G2 + 1), self.D), device=self.device, dtype=torch.float32) if return_hidden else None
         nbytes = lib.vt_vit_workspace_bytes(C.byref(self.model), B, T)
         ws = self.ws.get(nbytes)
         _lib.check(lib.vt_vit_forward(C.byref(self.model), pixels.data_ptr(), dt, B, T, int(video), out.data_ptr(),
                                       None if hidden is None else hidden.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
-                   "vt_vit_forward")
+                   "vt_vit_forward", lib)
         feats = out.view(B, T, G2, self.D) if video else out.view(B, G2, self.D)
         if return_hidden:
             return feats, hidden.view(B * T, G2 + 1, self.D)
@@ -200,8 +220,13 @@ class PackedProjector:
     are ONE C call (vt_projector_forward); deeper stacks (N > 2: Linear-GELU-...-Linear) chain the same GEMM with the GELU
     epilogue, one launch per layer."""
 
-    def __init__(self, sd: SD, device):
+    def __init__(self, sd: SD, device, dtype=None, depth: Optional[int] = None):
         self.device = torch.device(device)
+        self.dtype = dt = _dtype(dtype)
+        self.lib = _lib.lib_for(dt)
+
+        def _bf(t, dev):
+            return _op(t, dev, dt)
         if "0.weight" in sd:
             n = 0
             while f"{2 * n}.weight" in sd:
@@ -209,6 +234,9 @@ class PackedProjector:
             self.layers = [(_bf(sd[f"{2 * i}.weight"], device), _f32(sd[f"{2 * i}.bias"], device)) for i in range(n)]
         else:
             self.layers = [(_bf(sd["weight"], device), _f32(sd["bias"], device))]
+        if depth is not None and len(self.layers) != depth:
+            # a state dict with a hole (e.g. '0.*' and '4.*' but no '2.*') would otherwise run silently as a shallower MLP
+            raise _lib.VitronHipError(f"PackedProjector: found {len(self.layers)} Linear layers, the projector type declares {depth}")
         for (w0, _), (w1, _) in zip(self.layers, self.layers[1:]):
             if w1.shape[1] != w0.shape[0]:
                 raise _lib.VitronHipError(f"PackedProjector: layer widths do not chain ({tuple(w0.shape)} -> {tuple(w1.shape)})")
@@ -219,9 +247,9 @@ class PackedProjector:
         self.ws = Workspace(device)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        lib = _lib.load()
+        lib = self.lib
         shp = x.shape
-        x2 = x.reshape(-1, shp[-1]).to(torch.bfloat16).contiguous()
+        x2 = x.reshape(-1, shp[-1]).to(self.dtype).contiguous()
         M = x2.shape[0]
         if len(self.layers) > 2:
             from . import ops
@@ -229,12 +257,12 @@ class PackedProjector:
             for i, (w, b) in enumerate(self.layers):
                 h = ops.gemm(h, w, b, ops.EPI_BF16 if i + 1 == len(self.layers) else ops.EPI_BF16_GELU)
             return h.view(*shp[:-1], self.dout)
-        out = torch.empty((M, self.dout), device=self.device, dtype=torch.bfloat16)
+        out = torch.empty((M, self.dout), device=self.device, dtype=self.dtype)
         ws = self.ws.get(lib.vt_projector_workspace_bytes(M, self.dh))
         _lib.check(lib.vt_projector_forward(x2.data_ptr(), M, self.din, self.w1.data_ptr(), self.b1.data_ptr(), self.dh,
                                             None if self.w2 is None else self.w2.data_ptr(),
                                             None if self.b2 is None else self.b2.data_ptr(), self.dout, out.data_ptr(),
-                                            ws.data_ptr(), ws.numel(), _stream()), "vt_projector_forward")
+                                            ws.data_ptr(), ws.numel(), _stream()), "vt_projector_forward", lib)
         return out.view(*shp[:-1], self.dout)
 
 
@@ -254,8 +282,13 @@ def resolve_region_slices(regions: Sequence[Sequence[float]], image_size: int) -
 class PackedRegion:
     """RegionExtractor (reference region_extractor/layer.py:58-130) in kernel layout."""
 
-    def __init__(self, sd: SD, device, image_size: int = 224, patch_size: int = 14):
+    def __init__(self, sd: SD, device, image_size: int = 224, patch_size: int = 14, dtype=None):
         self.device = torch.device(device)
+        self.dtype = dt = _dtype(dtype)
+        self.lib = _lib.lib_for(dt)
+
+        def _bf(t, dev):
+            return _op(t, dev, dt)
         self.image_size, self.patch_size = image_size, patch_size
         self._keep = []
         w = _lib.VtRegionWeights()
@@ -266,7 +299,7 @@ class PackedRegion:
             wt, bt = _bf(sd[f"region_linear.layers.{i}.weight"], device), _f32(sd[f"region_linear.layers.{i}.bias"], device)
             self._keep += [wt, bt]
             w.mlp_w[i], w.mlp_b[i] = wt.data_ptr(), bt.data_ptr()
-        l0 = torch.zeros((self.out_dim // 2, 8), dtype=torch.bfloat16, device=device)  # K padded 4 -> 8
+        l0 = torch.zeros((self.out_dim // 2, 8), dtype=dt, device=device)  # K padded 4 -> 8
         l0[:, :4] = _bf(sd["loc_encoder.loc_encoder.0.weight"], device)
         l0b = _f32(sd["loc_encoder.loc_encoder.0.bias"], device)
         # region_linear's last layer and LocationEncoder's last layer are added (layer.py:129): one GEMM over [h2 | loc hidden]
@@ -278,28 +311,28 @@ class PackedRegion:
         self.ws = Workspace(device)
 
     def forward(self, feats: torch.Tensor, regions: Sequence[Sequence[float]], return_mask: bool = False):
-        """feats [B,G*G,C] bf16 (pre-projector patch features), regions: B boxes -> [B,1,H] bf16."""
-        lib = _lib.load()
+        """feats [B,G*G,C] (pre-projector patch features, operand dtype), regions: B boxes -> [B,1,H]."""
+        lib = self.lib
         B, n, c = feats.shape
         G = int(math.sqrt(n))
         if len(regions) != B:  # the reference prints and carries on (layer.py:101-107); there is nothing sane to compute
             raise _lib.VitronHipError(f"region_extractor: {B} feature maps but {len(regions)} regions")
-        feats = feats.to(torch.bfloat16).contiguous()
-        out = torch.empty((B, self.out_dim), device=self.device, dtype=torch.bfloat16)
+        feats = feats.to(self.dtype).contiguous()
+        out = torch.empty((B, self.out_dim), device=self.device, dtype=self.dtype)
         mask = torch.empty((B, n), device=self.device, dtype=torch.int32) if return_mask else None
         count = torch.empty((B,), device=self.device, dtype=torch.int32) if return_mask else None
         for s in range(0, B, 16):
             e = min(B, s + 16)
             sl = torch.tensor(resolve_region_slices(regions[s:e], self.image_size), dtype=torch.int32, device=self.device)
-            co = torch.zeros((e - s, 8), dtype=torch.float32)
-            co[:, :4] = torch.tensor([list(map(float, r)) for r in regions[s:e]], dtype=torch.float32)
-            co = co.to(device=self.device, dtype=torch.bfloat16)  # torch.tensor(regions, dtype=model dtype), layer.py:126
+            # LocationEncoder input in fp32 [B][4]: the reference builds torch.tensor(regions, dtype=model dtype) (layer.py:126);
+            # bf16 cannot hold integers above 256, so the K = 4 layer takes the coordinates unrounded (include/vitron_hip.h)
+            co = torch.tensor([list(map(float, r)) for r in regions[s:e]], dtype=torch.float32).reshape(e - s, 4).to(self.device)
             ws = self.ws.get(lib.vt_region_workspace_bytes(e - s, self.in_dim, self.out_dim))
             _lib.check(lib.vt_region_forward(C.byref(self.weights), feats[s:e].data_ptr(), sl.data_ptr(), co.data_ptr(),
                                              e - s, G, self.image_size, out[s:e].data_ptr(),
                                              None if mask is None else mask[s:e].data_ptr(),
                                              None if count is None else count[s:e].data_ptr(), ws.data_ptr(), ws.numel(),
-                                             _stream()), "vt_region_forward")
+                                             _stream()), "vt_region_forward", lib)
         if return_mask:
             return out.unsqueeze(1), mask, count
         return out.unsqueeze(1)
@@ -323,9 +356,14 @@ def interleave_gate_up(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
 class PackedLlama:
     """LLaMA decoder weights in kernel layout (vt_llama_model) + embedding table."""
 
-    def __init__(self, sd: SD, cfg: dict, device, rope_len: Optional[int] = None):
+    def __init__(self, sd: SD, cfg: dict, device, rope_len: Optional[int] = None, dtype=None):
         self.cfg = dict(cfg)
         self.device = torch.device(device)
+        self.dtype = dt = _dtype(dtype)
+        self.lib = _lib.lib_for(dt)
+
+        def _bf(t, dev):
+            return _op(t, dev, dt)
         H, heads = cfg["hidden_size"], cfg["num_attention_heads"]
         self.H, self.heads, self.hd = H, heads, H // heads
         self.I, self.L = cfg["intermediate_size"], cfg["num_hidden_layers"]
@@ -352,7 +390,7 @@ class PackedLlama:
         self.final_norm = keep(_f32(sd["model.norm.weight"], dev))
         head = _bf(sd["lm_head.weight"], dev)
         if self.V_pad != self.V:
-            head = torch.cat([head, torch.zeros((self.V_pad - self.V, H), dtype=torch.bfloat16, device=dev)], 0).contiguous()
+            head = torch.cat([head, torch.zeros((self.V_pad - self.V, H), dtype=dt, device=dev)], 0).contiguous()
         self.lm_head = keep(head)
         self.rope_len = int(rope_len or max(cfg.get("max_position_embeddings", 4096), 8192))
         self.rope_cos, self.rope_sin = rope_tables(self.hd, self.rope_len, float(cfg.get("rope_theta", 10000.0)), dev)
@@ -396,14 +434,14 @@ class PackedLlama:
 
 
 class PagedKVCache:
-    """Paged KV pool: K pages [L][pages][heads][64][hd] bf16, V^T pages [L][pages][heads][hd][64] fp16; 64 tokens per page.
+    """Paged KV pool: K pages [L][pages][heads][64][hd] in the operand dtype, V^T pages [L][pages][heads][hd][64] fp16; 64 tokens per page.
     A free list hands out pages; sequences own a list of page ids (their block table)."""
 
     def __init__(self, llama: PackedLlama, num_pages: int):
         self.llama = llama
         self.num_pages = int(num_pages)
         n = llama.L * self.num_pages * llama.heads * PAGE_TOKENS * llama.hd
-        self.k = torch.zeros(n, dtype=torch.bfloat16, device=llama.device)
+        self.k = torch.zeros(n, dtype=llama.dtype, device=llama.device)
         self.vt = torch.zeros(n, dtype=torch.float16, device=llama.device)    # V^T pages hold fp16 (include/vitron_hip.h)
         self.free = list(range(self.num_pages - 1, -1, -1))
         c = _lib.VtKvCache()
@@ -430,15 +468,15 @@ class SequenceState:
 def llama_forward(llama: PackedLlama, kv: PagedKVCache, seqs: Sequence[SequenceState], embeds: torch.Tensor,
                   q_lens: Sequence[int], positions: Optional[torch.Tensor] = None, logit_rows: Optional[Sequence[int]] = None,
                   return_hidden: bool = False):
-    """One decoder pass over packed rows. embeds bf16 [sum(q_lens), H]: the new tokens of every sequence, sequence by
+    """One decoder pass over packed rows. embeds (operand dtype) [sum(q_lens), H]: the new tokens of every sequence, sequence by
     sequence. Appends their K/V to the cache, returns fp32 logits for `logit_rows` (default: last row of each
     sequence). positions default to cache position (length + i). Prefill and decode are the same call."""
-    lib = _lib.load()
+    lib = llama.lib
     dev = llama.device
     rows = int(sum(q_lens))
     if embeds.shape[0] != rows or embeds.shape[1] != llama.H:
         raise _lib.VitronHipError(f"llama_forward: embeds {tuple(embeds.shape)} vs rows={rows}, H={llama.H}")
-    embeds = embeds.to(torch.bfloat16).contiguous()
+    embeds = embeds.to(llama.dtype).contiguous()
     desc, table, pos_host = [], [], []
     row0 = 0
     max_new_tiles = 1
@@ -475,7 +513,7 @@ def llama_forward(llama: PackedLlama, kv: PagedKVCache, seqs: Sequence[SequenceS
                                     None if lr_t is None else lr_t.data_ptr(), n_logit,
                                     None if logits is None else logits.data_ptr(),
                                     None if hidden is None else hidden.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
-               "vt_llama_forward")
+               "vt_llama_forward", lib)
     for s, q in zip(seqs, q_lens):
         s.length += q
     if logits is not None and llama.V_pad != llama.V:
@@ -520,7 +558,7 @@ class DecodeState:
         self.eos = torch.tensor(sorted(int(e) for e in eos_ids), dtype=torch.int32, device=dev) if len(eos_ids) else None
         self.pad_id = int(pad_id)
         self.finished = torch.zeros(B, dtype=torch.int32, device=dev)
-        self.x = torch.empty((B, llama.H), dtype=torch.bfloat16, device=dev)
+        self.x = torch.empty((B, llama.H), dtype=llama.dtype, device=dev)
         self.tok_dev = [torch.empty((2, B), dtype=torch.int32, device=dev) for _ in range(2)]
         self.tok_pin = [torch.empty((2, B), dtype=torch.int32).pin_memory() for _ in range(2)]
         self.events = [torch.cuda.Event() for _ in range(2)]
@@ -547,8 +585,8 @@ class DecodeState:
         """One decoder pass over the rows feed() just wrote; fp32 logits [B, V]. No host -> device traffic."""
         if self.passes >= self.fed:
             raise _lib.VitronHipError("DecodeState.forward: feed() the sampled tokens first")
-        lib = _lib.load()
         llama, B = self.llama, self.B
+        lib = llama.lib
         for s in self.seqs:
             if s.length >= llama.rope_len:
                 raise _lib.VitronHipError(f"llama_forward: position {s.length} beyond rope table ({llama.rope_len})")
@@ -559,7 +597,7 @@ class DecodeState:
         _lib.check(lib.vt_llama_forward(C.byref(llama.model), C.byref(self.kv.struct), self.x.data_ptr(), B, self.pos.data_ptr(),
                                         self.desc.data_ptr(), B, 1, 1, int(self.max_len), self.table.data_ptr(),
                                         self.rows.data_ptr(), B, logits.data_ptr(), None, ws.data_ptr(), ws.numel(), _stream()),
-                   "vt_llama_forward")
+                   "vt_llama_forward", lib)
         for s in self.seqs:
             s.length += 1
         self.passes += 1

@@ -1,7 +1,9 @@
 """load_pretrained_model -- mirror of the reference's vitron/model/builder.py:27-171 (same arguments, same 4-tuple).
 
 Differences that are inherent to this implementation:
-  * weights end up packed for the HIP kernels (vitron_amd.engine) in bf16 -- the reference loads fp16 (builder.py:47);
+  * weights end up packed for the HIP kernels (vitron_amd.engine) in the operand dtype `torch_dtype`: a real checkpoint loads
+    as fp16 exactly like the reference (`kwargs['torch_dtype'] = torch.float16`, builder.py:47; towers :153,161) unless the
+    caller passes torch_dtype=torch.bfloat16; synthetic models default to bf16 (the benchmark's dtype);
   * load_8bit / load_4bit (bitsandbytes, builder.py:36-45) are rejected: there is no quantised kernel path;
   * device must be a GPU: there is no CPU execution path;
   * `model_path="synthetic"` (or a path that does not exist, with `synthetic_ok=True`) builds random-init weights of
@@ -76,11 +78,12 @@ def _processors(model):
     proc = {"image": None, "video": None}
     it, vt = model.get_image_tower(), model.get_video_tower()
     if it is not None and it.config is not None:
-        it.image_processor = it.image_processor or LanguageBindImageProcessor(image_size=it.config.image_size, device=model.device)
+        it.image_processor = it.image_processor or LanguageBindImageProcessor(image_size=it.config.image_size, device=model.device, dtype=model.dtype)
         proc["image"] = it.image_processor
     if vt is not None and vt.config is not None:
         vt.video_processor = vt.video_processor or LanguageBindVideoProcessor(image_size=vt.config.image_size,
-                                                                              num_frames=vt.config.num_frames, device=model.device)
+                                                                              num_frames=vt.config.num_frames, device=model.device,
+                                                                              dtype=model.dtype)
         proc["video"] = vt.video_processor
     return proc
 
@@ -93,12 +96,14 @@ def load_pretrained_model(model_path, model_base, model_name, load_8bit=False, l
         raise RuntimeError("vitron_amd runs on the GPU only (device must be 'cuda'); there is no CPU path")
     synthetic = kwargs.pop("synthetic", None)
     tokenizer = kwargs.pop("tokenizer", None)
+    torch_dtype = kwargs.pop("torch_dtype", None)
     if model_path == "synthetic" or synthetic is not None:
         spec = synthetic or {}
         cfg = LlavaConfig(**spec.get("llm", {}), mm_hidden_size=spec.get("image", spec.get("video", {})).get("hidden_size", 1024))
         model = LlavaLlamaForCausalLM(cfg)
         model.init_synthetic(device, seed=spec.get("seed", 1234), vit_image=spec.get("image"), vit_video=spec.get("video"),
-                             w_std=spec.get("w_std", 0.02), resize_for=lambda: _add_special_tokens(tokenizer, cfg))
+                             w_std=spec.get("w_std", 0.02), resize_for=lambda: _add_special_tokens(tokenizer, cfg),
+                             dtype=torch_dtype if torch_dtype is not None else spec.get("dtype"))
         context_len = getattr(cfg, "max_sequence_length", 2048)
         return tokenizer, model, _processors(model), context_len
 
@@ -151,6 +156,8 @@ def load_pretrained_model(model_path, model_base, model_name, load_8bit=False, l
         t = get()
         if t is not None and not t.is_loaded:
             t.load_model()
-    model.to(device)
+    # reference builder.py:47 loads the language model with torch_dtype=float16 and moves the towers with
+    # .to(device=device, dtype=torch.float16) (:153,161): fp16 is the default for a real checkpoint here too
+    model.to(device, dtype=torch_dtype if torch_dtype is not None else torch.float16)
     context_len = getattr(cfg, "max_sequence_length", 2048)   # reference builder.py:166-169
     return tokenizer, model, _processors(model), context_len

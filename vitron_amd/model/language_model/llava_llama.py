@@ -13,12 +13,24 @@ from typing import List, Optional
 
 import torch
 
-from ... import ops, synth
+from ... import _lib, ops, synth
 from ...engine import DecodeState, PackedLlama, PagedKVCache, SequenceState, llama_forward
 from ..llava_arch import LlavaMetaForCausalLM, LlavaMetaModel
 from ..multimodal_encoder.builder import build_image_tower, build_video_tower
 from ..multimodal_projector.builder import build_vision_projector
 from ..region_extractor.builder import build_region_extractor
+
+
+def _resolve_dtype(x):
+    """torch dtype for a config's `torch_dtype` entry ('float16' / 'bfloat16' strings as in a HF config.json, torch dtypes,
+    'fp16' / 'bf16'); None stays None (= the package default)."""
+    if x is None:
+        return None
+    if isinstance(x, str):
+        x = {"float16": torch.float16, "half": torch.float16, "fp16": torch.float16,
+             "bfloat16": torch.bfloat16, "bf16": torch.bfloat16}.get(x.replace("torch.", ""), x)
+    _lib.operand_of(x)
+    return x
 
 
 class LlavaConfig(SimpleNamespace):
@@ -98,6 +110,9 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
         self.vocab_size = config.vocab_size
         self._device = torch.device("cpu")
         self._llama_sd = None
+        # operand dtype of the packed weights and activations: bf16 (package default, BASELINE's dtype) or fp16 (the reference's
+        # inference dtype, builder.py:47); set by config.torch_dtype / .to(dtype=...) / .half() before the weights are packed
+        self._dtype = _resolve_dtype(getattr(config, "torch_dtype", None))
         self.kv: Optional[PagedKVCache] = None
         self.kv_pages = getattr(config, "kv_pages", None)
         # multi-turn reuse (vitron_amd/prefix_cache.py): generate() keeps the last conversation's KV pages and the encoded
@@ -116,7 +131,15 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
 
     @property
     def dtype(self):
-        return torch.bfloat16
+        if self.model.llama is not None:
+            return self.model.llama.dtype
+        return self._dtype or _lib.torch_dtype()
+
+    def half(self):
+        return self.to(dtype=torch.float16)
+
+    def bfloat16(self):
+        return self.to(dtype=torch.bfloat16)
 
     def eval(self):
         return self
@@ -168,16 +191,28 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
         return self
 
     def to(self, device=None, dtype=None):
+        """nn.Module.to: `dtype` (torch.bfloat16 / torch.float16) is the operand format the weights are packed in when they
+        reach the GPU; it cannot change once the decoder is packed (the checkpoint copy is dropped then)."""
+        if isinstance(device, torch.dtype):          # .to(torch.float16)
+            device, dtype = None, device
+        if dtype is not None:
+            _lib.operand_of(dtype)
+            if self.model.llama is not None and dtype != self.model.llama.dtype:
+                raise RuntimeError(f"model weights are already packed as {self.model.llama.dtype}; load the checkpoint again to change the dtype")
+            self._dtype = dtype
+            for m in (self.model.mm_projector, self.model.region_extractor, self.model.image_tower, self.model.video_tower):
+                if m is not None and hasattr(m, "to"):
+                    m.to(dtype=dtype)
         if device is None:
             return self
         dev = torch.device(device)
         if dev.type == "cuda":
             if self._llama_sd is not None:
-                self.model.llama = PackedLlama(self._llama_sd, self.config.to_dict(), dev)
+                self.model.llama = PackedLlama(self._llama_sd, self.config.to_dict(), dev, dtype=self._dtype)
                 self._llama_sd = None
             for m in (self.model.mm_projector, self.model.region_extractor, self.model.image_tower, self.model.video_tower):
                 if m is not None:
-                    m.to(dev)
+                    m.to(dev, dtype=self.dtype) if hasattr(m, "_dtype") else m.to(dev)
         self._device = dev
         return self
 
@@ -185,22 +220,31 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
         return self.to("cuda")
 
     def init_synthetic(self, device, seed=1234, vit_image: Optional[dict] = None, vit_video: Optional[dict] = None,
-                       w_std=0.02, resize_for=None):
-        """Random-init weights of the configured architecture, generated on `device` (no checkpoints exist offline)."""
+                       w_std=0.02, resize_for=None, dtype=None):
+        """Random-init weights of the configured architecture, generated on `device` (no checkpoints exist offline). The
+        values are drawn as bf16-representable numbers whatever `dtype` (the operand format they are packed in) is, so a
+        bf16 and an fp16 model built from one seed hold the same weights (bf16 -> fp16 is exact above 2^-14)."""
+        if dtype is not None:
+            self._dtype = _resolve_dtype(dtype)
         gen = synth.make_generator(seed, device)
         cfg = self.config
         self._llama_sd = synth.llama_state(cfg.to_dict(), gen, device, w_std)
         if vit_image is not None:
             self.model.image_tower = build_image_tower(SimpleNamespace(mm_image_tower="synthetic/LanguageBind_Image",
                                                                        mm_vision_select_layer=cfg.mm_vision_select_layer), delay_load=True)
+            self.model.image_tower._dtype = self._dtype
             self.model.image_tower.init_synthetic(vit_image, gen, device, w_std)
         if vit_video is not None:
             self.model.video_tower = build_video_tower(SimpleNamespace(mm_video_tower="synthetic/LanguageBind_Video_merge",
                                                                        mm_vision_select_layer=cfg.mm_vision_select_layer), delay_load=True)
+            self.model.video_tower._dtype = self._dtype
             self.model.video_tower.init_synthetic(vit_video, gen, device, w_std)
         if self.model.mm_projector is None:
             self.model.mm_projector = build_vision_projector(cfg)
             self.model.region_extractor = build_region_extractor(cfg)
+        for m in (self.model.mm_projector, self.model.region_extractor):
+            if hasattr(m, "_dtype"):
+                m._dtype = self._dtype
         self.model.mm_projector.init_synthetic(gen, device, w_std)
         self.model.region_extractor.init_synthetic(gen, device, w_std)
         if resize_for is not None:            # load_pretrained_model: tokenizer.add_tokens + resize_token_embeddings before packing
@@ -274,8 +318,8 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
         flat = inputs_embeds.reshape(B * S, H)
         if len(idx) != B * S:   # pack the valid rows (padding never enters the decoder): a row gather by the splice kernel
             rowsel = torch.tensor(idx, dtype=torch.int32, device=flat.device)
-            # (fp16 / fp32 inputs_embeds are legal here -- the reference model runs in fp16: the gather kernel moves bf16 rows)
-            flat = ops.embed_splice(flat.to(torch.bfloat16).contiguous(), None, None, torch.stack([torch.zeros_like(rowsel), rowsel], 1).contiguous())
+            # (inputs_embeds of another float dtype are legal here: the gather kernel moves rows in the model's operand dtype)
+            flat = ops.embed_splice(flat.to(llama.dtype).contiguous(), None, None, torch.stack([torch.zeros_like(rowsel), rowsel], 1).contiguous())
         rows = flat.shape[0]
         logits_p, hidden = llama_forward(llama, past.kv, seqs, flat, lens, logit_rows=list(range(rows)), return_hidden=True)
         if len(idx) != B * S:
@@ -362,7 +406,7 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
         flat = embeds.reshape(B * S, H)
         if len(idx) != B * S:
             rowsel = torch.tensor(idx, dtype=torch.int32, device=dev)
-            flat = ops.embed_splice(flat.to(torch.bfloat16).contiguous(), None, None, torch.stack([torch.zeros_like(rowsel), rowsel], 1).contiguous())
+            flat = ops.embed_splice(flat.to(llama.dtype).contiguous(), None, None, torch.stack([torch.zeros_like(rowsel), rowsel], 1).contiguous())
         seqs = [SequenceState() for _ in range(B)]
         # ---- multi-turn KV reuse (batch 1): keep the pages of the longest common whole-page prefix of the last call ------------
         sig = None

@@ -13,7 +13,7 @@ from types import SimpleNamespace
 
 import torch
 
-from .... import synth
+from .... import _lib, synth
 from ....engine import PackedVit
 
 OPENAI_DATASET_MEAN = (0.48145466, 0.4578275, 0.40821073)   # reference image/processing_image.py:7
@@ -69,6 +69,7 @@ class _Tower:
         self.packed = None
         self._device = torch.device("cpu")
         self._sd = None
+        self._dtype = None          # operand dtype (bf16 / fp16); None = the package default until .to(dtype=...) says otherwise
         if os.path.isdir(tower_name):
             with open(os.path.join(tower_name, "config.json")) as f:
                 c = json.load(f)
@@ -94,8 +95,15 @@ class _Tower:
         return self
 
     def to(self, device=None, dtype=None):
+        """nn.Module.to as the reference calls it on the towers (`.to(device=device, dtype=torch.float16)`, builder.py:153,161):
+        the dtype (bf16 / fp16) is the operand format the weights are packed in the first time they reach the GPU."""
+        if dtype is not None:
+            _lib.operand_of(dtype)
+            if self.packed is not None and dtype != self.packed.dtype:
+                raise RuntimeError(f"{type(self).__name__}: weights are already packed as {self.packed.dtype}; reload them to change the dtype")
+            self._dtype = dtype
         if device is not None and self._sd is not None and torch.device(device).type == "cuda":
-            self.packed = PackedVit(self._sd, self.config.to_dict(), device, self.select_layer)
+            self.packed = PackedVit(self._sd, self.config.to_dict(), device, self.select_layer, dtype=self._dtype)
             self._device = torch.device(device)
             self._sd = None  # the packed copy is the only one kept on the device
         return self
@@ -109,7 +117,7 @@ class _Tower:
         if self.packed is None:
             raise RuntimeError(f"{type(self).__name__} is not on the GPU: call load_model()/load_state() and .to('cuda')")
         if type(x) is list:
-            return [self.packed.forward(t.unsqueeze(0).to(self.device)).to(t.dtype if t.dtype != torch.float32 else torch.bfloat16) for t in x]
+            return [self.packed.forward(t.unsqueeze(0).to(self.device)).to(t.dtype if t.dtype != torch.float32 else self.dtype) for t in x]
         return self.packed.forward(x.to(self.device))
 
     __call__ = forward
@@ -120,7 +128,7 @@ class _Tower:
 
     @property
     def dtype(self):
-        return torch.bfloat16
+        return self.packed.dtype if self.packed is not None else (self._dtype or _lib.torch_dtype())
 
     @property
     def device(self):

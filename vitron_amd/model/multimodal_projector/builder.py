@@ -5,7 +5,7 @@ import re
 
 import torch
 
-from ... import synth
+from ... import _lib, synth
 from ...engine import PackedProjector
 
 
@@ -32,10 +32,14 @@ class VisionProjector:
         self.mm_hidden_size, self.hidden_size, self.depth = mm_hidden_size, hidden_size, depth
         self._sd = None
         self.packed = None
+        self._dtype = None
 
     def load_state_dict(self, sd, strict=True):
-        # nn.Sequential(Linear, GELU, Linear, GELU, Linear, ...): the Linear layers sit at the even indices (builder.py:41-45)
-        keys = [f"{2 * i}.{n}" for i in range(self.depth) for n in ("weight", "bias")] if self.depth >= 2 else ["weight", "bias"]
+        # nn.Sequential(Linear, GELU, Linear, GELU, Linear, ...): the Linear layers sit at the even indices (builder.py:41-45);
+        # 'linear' is a bare nn.Linear ('weight', 'bias') while 'mlp1x_gelu' is nn.Sequential(Linear) ('0.weight', '0.bias')
+        keys = [f"{2 * i}.{n}" for i in range(self.depth) for n in ("weight", "bias")]
+        if self.depth == 1 and "0.weight" not in sd:
+            keys = ["weight", "bias"]
         missing = [k for k in keys if k not in sd]
         if missing and strict:
             raise KeyError(f"mm_projector: missing keys {missing}")
@@ -47,8 +51,14 @@ class VisionProjector:
         return dict(self._sd or {})
 
     def to(self, device=None, dtype=None):
-        if device is not None and self._sd is not None and torch.device(device).type == "cuda":
-            self.packed = PackedProjector(self._sd, device)
+        if dtype is not None:
+            _lib.operand_of(dtype)
+            if self.packed is not None and dtype != self.packed.dtype:
+                device = device if device is not None else self.packed.device
+                self.packed = None          # the state dict is kept: repack below
+            self._dtype = dtype
+        if device is not None and self._sd is not None and torch.device(device).type == "cuda" and self.packed is None:
+            self.packed = PackedProjector(self._sd, device, dtype=self._dtype, depth=self.depth)
         return self
 
     def init_synthetic(self, gen, device, w_std=0.02, b_std=0.0):

@@ -3,7 +3,7 @@ from __future__ import annotations
 
 import torch
 
-from ... import synth
+from ... import _lib, synth
 from ...engine import PackedRegion
 
 
@@ -13,6 +13,7 @@ class RegionExtractor:
         self.image_size, self.patch_size = image_size, patch_size
         self._sd = None
         self.packed = None
+        self._dtype = None
 
     KEYS = [f"region_linear.layers.{i}.{p}" for i in range(3) for p in ("weight", "bias")] + \
            [f"loc_encoder.loc_encoder.{i}.{p}" for i in (0, 2) for p in ("weight", "bias")]
@@ -29,8 +30,14 @@ class RegionExtractor:
         return dict(self._sd or {})
 
     def to(self, device=None, dtype=None):
-        if device is not None and self._sd is not None and torch.device(device).type == "cuda":
-            self.packed = PackedRegion(self._sd, device, self.image_size, self.patch_size)
+        if dtype is not None:
+            _lib.operand_of(dtype)
+            if self.packed is not None and dtype != self.packed.dtype:
+                device = device if device is not None else self.packed.device
+                self.packed = None          # the state dict is kept: repack below
+            self._dtype = dtype
+        if device is not None and self._sd is not None and torch.device(device).type == "cuda" and self.packed is None:
+            self.packed = PackedRegion(self._sd, device, self.image_size, self.patch_size, dtype=self._dtype)
         return self
 
     def init_synthetic(self, gen, device, w_std=0.02, b_std=0.0):

@@ -23,6 +23,15 @@ def _p(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
 
+def _op16(t: torch.Tensor, name: str):
+    """(library, dtype) for a 16-bit operand tensor: its dtype (bf16 / fp16) picks the library build."""
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.VitronHipError(f"{name}: expected a CUDA/HIP tensor (vitron_amd has no CPU path)")
+    if t.dtype not in (torch.bfloat16, torch.float16):
+        raise _lib.VitronHipError(f"{name}: expected a bf16 or fp16 tensor, got {t.dtype}")
+    return _lib.lib_for(t), t.dtype
+
+
 def _chk(t: torch.Tensor, dtype, name: str):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise _lib.VitronHipError(f"{name}: expected a CUDA/HIP tensor (vitron_amd has no CPU path)")
@@ -35,18 +44,18 @@ def _chk(t: torch.Tensor, dtype, name: str):
 def gemm_plan(M: int, N: int, K: int, epi: int = EPI_BF16):
     """(cfg, rows_first) the dispatcher picks for an AUTO vt_gemm_bf16 of this shape (host logic, no launch; include/vitron_hip.h)."""
     import ctypes
-    lib = _lib.load()
+    lib = _lib.load_any()
     cfg, rows = ctypes.c_int(0), ctypes.c_int(0)
-    _lib.check(lib.vt_gemm_plan_query(M, N, K, epi, ctypes.byref(cfg), ctypes.byref(rows)), "vt_gemm_plan_query")
+    _lib.check(lib.vt_gemm_plan_query(M, N, K, epi, ctypes.byref(cfg), ctypes.byref(rows)), "vt_gemm_plan_query", lib)
     return cfg.value, rows.value
 
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, epi: int = EPI_BF16,
          out: Optional[torch.Tensor] = None, cfg: int = CFG_AUTO, row_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out = epi(row_scale[:, None] * (a[M,K] @ w[N,K]^T) + bias). EPI_F32_RESID accumulates into `out` (fp32, required)."""
-    lib = _lib.load()
-    _chk(a, torch.bfloat16, "gemm.a")
-    _chk(w, torch.bfloat16, "gemm.w")
+    lib, dt = _op16(a, "gemm.a")
+    _chk(a, dt, "gemm.a")
+    _chk(w, dt, "gemm.w")
     M, K = a.shape
     N, K2 = w.shape
     if K != K2:
@@ -54,7 +63,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     if bias is not None:
         _chk(bias, torch.float32, "gemm.bias")
     n_out = N // 2 if epi == EPI_SWIGLU_BF16 else N
-    odt = torch.float32 if epi in (EPI_F32, EPI_F32_RESID) else torch.bfloat16
+    odt = torch.float32 if epi in (EPI_F32, EPI_F32_RESID) else dt
     if out is None:
         if epi == EPI_F32_RESID:
             raise _lib.VitronHipError("gemm: EPI_F32_RESID needs `out` (the fp32 residual stream)")
@@ -65,45 +74,48 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         if row_scale.numel() != M:
             raise _lib.VitronHipError(f"gemm: row_scale has {row_scale.numel()} elements for M={M}")
     _lib.check(lib.vt_gemm_bf16(_p(a), a.stride(0), _p(w), w.stride(0), _p(out), out.stride(0), _p(bias), M, N, K, epi,
-                                cfg, _p(row_scale), _stream()), "vt_gemm_bf16")
+                                cfg, _p(row_scale), _stream()), "vt_gemm_bf16", lib)
     return out
 
 
 def gemm_resid_splitk(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bias: Optional[torch.Tensor] = None, ksplit: int = 0,
                       partials: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out (fp32) += a @ w^T + bias, optionally as a two-pass split-K through the fp32 workspace `partials`."""
-    lib = _lib.load()
-    _chk(a, torch.bfloat16, "gemm_resid_splitk.a")
-    _chk(w, torch.bfloat16, "gemm_resid_splitk.w")
+    lib, dt = _op16(a, "gemm_resid_splitk.a")
+    _chk(a, dt, "gemm_resid_splitk.a")
+    _chk(w, dt, "gemm_resid_splitk.w")
     _chk(out, torch.float32, "gemm_resid_splitk.out")
     M, K = a.shape
     N = w.shape[0]
     nbytes = 0 if partials is None else partials.numel() * partials.element_size()
     _lib.check(lib.vt_gemm_bf16_resid_splitk(_p(a), a.stride(0), _p(w), w.stride(0), _p(out), out.stride(0), _p(bias), M, N, K,
-                                             int(ksplit), _p(partials), nbytes, _stream()), "vt_gemm_bf16_resid_splitk")
+                                             int(ksplit), _p(partials), nbytes, _stream()), "vt_gemm_bf16_resid_splitk", lib)
     return out
 
 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, temb: Optional[torch.Tensor] = None,
-              tokens_per_frame: int = 0) -> torch.Tensor:
-    """bf16 LayerNorm of the fp32 rows of x; with temb ([T,D] fp32) x[row] += temb[(row//tokens_per_frame)%T] in place."""
-    lib = _lib.load()
+              tokens_per_frame: int = 0, dtype=None) -> torch.Tensor:
+    """16-bit (`dtype`: bf16 default / fp16) LayerNorm of the fp32 rows of x; with temb ([T,D] fp32)
+    x[row] += temb[(row//tokens_per_frame)%T] in place."""
+    dtype = dtype or _lib.torch_dtype()
+    lib = _lib.lib_for(dtype)
     _chk(x, torch.float32, "layernorm.x")
     rows, D = x.shape
-    y = torch.empty((rows, D), device=x.device, dtype=torch.bfloat16)
+    y = torch.empty((rows, D), device=x.device, dtype=dtype)
     T = 0 if temb is None else temb.shape[0]
     _lib.check(lib.vt_layernorm(_p(x), _p(temb), T, tokens_per_frame, _p(gamma), _p(beta), _p(y), rows, D, eps, _stream()),
-               "vt_layernorm")
+               "vt_layernorm", lib)
     return y
 
 
-def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float, idx: Optional[torch.Tensor] = None) -> torch.Tensor:
-    lib = _lib.load()
+def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float, idx: Optional[torch.Tensor] = None, dtype=None) -> torch.Tensor:
+    dtype = dtype or _lib.torch_dtype()
+    lib = _lib.lib_for(dtype)
     _chk(x, torch.float32, "rmsnorm.x")
     rows = x.shape[0] if idx is None else idx.shape[0]
     D = x.shape[1]
-    y = torch.empty((rows, D), device=x.device, dtype=torch.bfloat16)
-    _lib.check(lib.vt_rmsnorm(_p(x), _p(idx), _p(w), _p(y), rows, D, eps, _stream()), "vt_rmsnorm")
+    y = torch.empty((rows, D), device=x.device, dtype=dtype)
+    _lib.check(lib.vt_rmsnorm(_p(x), _p(idx), _p(w), _p(y), rows, D, eps, _stream()), "vt_rmsnorm", lib)
     return y
 
 
@@ -116,35 +128,40 @@ def kv_tiles(qkv: torch.Tensor, q_col0: int, k_col0: int, v_col0: int, k_tiles: 
              tile_table: torch.Tensor, seq_desc: torch.Tensor, max_new_tiles: int, heads: int, head_dim: int,
              rope_cos: Optional[torch.Tensor] = None, rope_sin: Optional[torch.Tensor] = None,
              positions: Optional[torch.Tensor] = None) -> None:
-    lib = _lib.load()
-    _chk(qkv, torch.bfloat16, "kv_tiles.qkv")
+    lib, dt = _op16(qkv, "kv_tiles.qkv")
+    _chk(qkv, dt, "kv_tiles.qkv")
+    _chk(k_tiles, dt, "kv_tiles.k_tiles")
+    if vt_tiles.element_size() != 2:        # fp16 bits in both builds; tests hand in raw 16-bit storage of either dtype
+        raise _lib.VitronHipError("kv_tiles.vt_tiles: expected a 16-bit tensor (the V^T pages hold fp16 bits)")
     _lib.check(lib.vt_kv_tiles(_p(qkv), qkv.stride(0), q_col0, k_col0, v_col0, _p(k_tiles), _p(vt_tiles), _p(tile_table),
                                _p(seq_desc), seq_desc.shape[0], max_new_tiles, heads, head_dim, _p(rope_cos), _p(rope_sin),
-                               _p(positions), _stream()), "vt_kv_tiles")
+                               _p(positions), _stream()), "vt_kv_tiles", lib)
 
 
 def flash_attn(q: torch.Tensor, k_tiles: torch.Tensor, vt_tiles: torch.Tensor, tile_table: torch.Tensor,
                seq_desc: torch.Tensor, max_q_len: int, heads: int, head_dim: int, causal: bool, scale: float,
                out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """q: bf16 [rows, ldq] view whose first heads*head_dim columns are the queries (e.g. the fused QKV buffer)."""
-    lib = _lib.load()
+    lib, dt = _op16(q, "flash_attn.q")
+    if k_tiles.dtype != dt:
+        raise _lib.VitronHipError(f"flash_attn: q is {dt} but the K tiles are {k_tiles.dtype}")
     if out is None:
-        out = torch.empty((q.shape[0], heads * head_dim), device=q.device, dtype=torch.bfloat16)
+        out = torch.empty((q.shape[0], heads * head_dim), device=q.device, dtype=dt)
     _lib.check(lib.vt_flash_attn(_p(q), q.stride(0), _p(k_tiles), _p(vt_tiles), _p(tile_table), _p(seq_desc),
                                  seq_desc.shape[0], max_q_len, _p(out), out.stride(0), heads, head_dim, int(causal),
-                                 float(scale), _stream()), "vt_flash_attn")
+                                 float(scale), _stream()), "vt_flash_attn", lib)
     return out
 
 
 def attn_decode(q: torch.Tensor, k_tiles: torch.Tensor, vt_tiles: torch.Tensor, tile_table: torch.Tensor,
                 seq_desc: torch.Tensor, heads: int, head_dim: int, scale: float, max_kv_len: int) -> torch.Tensor:
-    lib = _lib.load()
-    out = torch.empty((q.shape[0], heads * head_dim), device=q.device, dtype=torch.bfloat16)
+    lib, dt = _op16(q, "attn_decode.q")
+    out = torch.empty((q.shape[0], heads * head_dim), device=q.device, dtype=dt)
     nseq = seq_desc.shape[0]
     scratch = torch.empty(lib.vt_attn_decode_scratch_bytes(nseq, heads, head_dim, int(max_kv_len)), dtype=torch.uint8, device=q.device)
     _lib.check(lib.vt_attn_decode(_p(q), q.stride(0), _p(k_tiles), _p(vt_tiles), _p(tile_table), _p(seq_desc), nseq, _p(out),
                                   out.stride(0), heads, head_dim, float(scale), int(max_kv_len), _p(scratch), scratch.numel(),
-                                  _stream()), "vt_attn_decode")
+                                  _stream()), "vt_attn_decode", lib)
     return out
 
 
@@ -153,34 +170,40 @@ def attn_decode_fused(qkv: torch.Tensor, q_col0: int, k_col0: int, v_col0: int, 
                       rope_cos: Optional[torch.Tensor] = None, rope_sin: Optional[torch.Tensor] = None,
                       positions: Optional[torch.Tensor] = None) -> torch.Tensor:
     """One decode step's attention: rotary on the new q/k rows, k/v append to the paged tiles, attention, combine."""
-    lib = _lib.load()
-    _chk(qkv, torch.bfloat16, "attn_decode_fused.qkv")
-    out = torch.empty((qkv.shape[0], heads * head_dim), device=qkv.device, dtype=torch.bfloat16)
+    lib, dt = _op16(qkv, "attn_decode_fused.qkv")
+    _chk(qkv, dt, "attn_decode_fused.qkv")
+    _chk(k_tiles, dt, "attn_decode_fused.k_tiles")
+    out = torch.empty((qkv.shape[0], heads * head_dim), device=qkv.device, dtype=dt)
     _lib.check(lib.vt_attn_decode_fused(_p(qkv), qkv.stride(0), q_col0, k_col0, v_col0, _p(k_tiles), _p(vt_tiles), _p(tile_table),
                                         _p(seq_desc), seq_desc.shape[0], _p(out), out.stride(0), heads, head_dim, float(scale),
-                                        _p(rope_cos), _p(rope_sin), _p(positions), _stream()), "vt_attn_decode_fused")
+                                        _p(rope_cos), _p(rope_sin), _p(positions), _stream()), "vt_attn_decode_fused", lib)
     return out
 
 
 def attn_temporal(qkv: torch.Tensor, B: int, T: int, N: int, heads: int) -> torch.Tensor:
-    lib = _lib.load()
-    _chk(qkv, torch.bfloat16, "attn_temporal.qkv")
-    out = torch.empty((qkv.shape[0], heads * 64), device=qkv.device, dtype=torch.bfloat16)
-    _lib.check(lib.vt_attn_temporal(_p(qkv), _p(out), B, T, N, heads, _stream()), "vt_attn_temporal")
+    lib, dt = _op16(qkv, "attn_temporal.qkv")
+    _chk(qkv, dt, "attn_temporal.qkv")
+    out = torch.empty((qkv.shape[0], heads * 64), device=qkv.device, dtype=dt)
+    _lib.check(lib.vt_attn_temporal(_p(qkv), _p(out), B, T, N, heads, _stream()), "vt_attn_temporal", lib)
     return out
 
 
-def im2col(pixels: torch.Tensor, patch: int, k_pad: int) -> torch.Tensor:
-    lib = _lib.load()
+def im2col(pixels: torch.Tensor, patch: int, k_pad: int, dtype=None) -> torch.Tensor:
+    """pixels fp32 or 16-bit; patches come out in `dtype` (default: the pixels' own 16-bit dtype, else the default operand)."""
+    if dtype is None:
+        dtype = pixels.dtype if pixels.dtype in (torch.bfloat16, torch.float16) else _lib.torch_dtype()
+    lib = _lib.lib_for(dtype)
+    if pixels.dtype not in (dtype, torch.float32):
+        raise _lib.VitronHipError(f"im2col: pixels are {pixels.dtype}, expected {dtype} or fp32")
     video = pixels.dim() == 5
     if video:
         B, _, T, H, W = pixels.shape
     else:
         B, _, H, W = pixels.shape
         T = 1
-    dt = {torch.bfloat16: _lib.DTYPE_BF16, torch.float32: _lib.DTYPE_F32}[pixels.dtype]
-    out = torch.empty((B * T * (H // patch) * (W // patch), k_pad), device=pixels.device, dtype=torch.bfloat16)
-    _lib.check(lib.vt_im2col(_p(pixels.contiguous()), dt, _p(out), B, T, H, W, patch, k_pad, int(video), _stream()), "vt_im2col")
+    dt = _lib.DTYPE_F32 if pixels.dtype == torch.float32 else _lib.DTYPE_BF16
+    out = torch.empty((B * T * (H // patch) * (W // patch), k_pad), device=pixels.device, dtype=dtype)
+    _lib.check(lib.vt_im2col(_p(pixels.contiguous()), dt, _p(out), B, T, H, W, patch, k_pad, int(video), _stream()), "vt_im2col", lib)
     return out
 
 
@@ -193,30 +216,33 @@ def _chk_rows(t: torch.Tensor, dtype, name: str):
 
 
 def embed_splice(tok_table: torch.Tensor, vis: Optional[torch.Tensor], reg: Optional[torch.Tensor], plan: torch.Tensor) -> torch.Tensor:
-    lib = _lib.load()
-    _chk(tok_table, torch.bfloat16, "embed_splice.tok_table")
+    lib, dt = _op16(tok_table, "embed_splice.tok_table")
+    _chk(tok_table, dt, "embed_splice.tok_table")
+    for name, t in (("vis", vis), ("reg", reg)):
+        if t is not None and t.dtype != dt:
+            raise _lib.VitronHipError(f"embed_splice.{name}: {t.dtype} rows cannot be spliced into a {dt} sequence")
     rows, H = plan.shape[0], tok_table.shape[1]
-    out = torch.empty((rows, H), device=tok_table.device, dtype=torch.bfloat16)
+    out = torch.empty((rows, H), device=tok_table.device, dtype=dt)
     _lib.check(lib.vt_embed_splice(_p(tok_table), tok_table.shape[0], _p(vis), 0 if vis is None else vis.shape[0], _p(reg),
-                                   0 if reg is None else reg.shape[0], _p(plan), rows, H, _p(out), _stream()), "vt_embed_splice")
+                                   0 if reg is None else reg.shape[0], _p(plan), rows, H, _p(out), _stream()), "vt_embed_splice", lib)
     return out
 
 
 def argmax(logits: torch.Tensor) -> torch.Tensor:
-    lib = _lib.load()
+    lib = _lib.load_any()
     _chk_rows(logits, torch.float32, "argmax.logits")
     rows, V = logits.shape
     out = torch.empty((rows,), device=logits.device, dtype=torch.int32)
-    _lib.check(lib.vt_argmax(_p(logits), rows, V, logits.stride(0), _p(out), _stream()), "vt_argmax")
+    _lib.check(lib.vt_argmax(_p(logits), rows, V, logits.stride(0), _p(out), _stream()), "vt_argmax", lib)
     return out
 
 
 def decode_feed(tok_table: torch.Tensor, next_ids: torch.Tensor, finished: torch.Tensor, eos_ids: Optional[torch.Tensor],
                 pad_id: int, tokens_out: torch.Tensor, x: torch.Tensor, seq_desc: torch.Tensor, positions: torch.Tensor) -> None:
     """In-place decode-loop feedback (vt_decode_feed): token resolution, EOS flags, next input rows, metadata advance."""
-    lib = _lib.load()
-    _chk(tok_table, torch.bfloat16, "decode_feed.tok_table")
-    _chk(x, torch.bfloat16, "decode_feed.x")
+    lib, dt = _op16(tok_table, "decode_feed.tok_table")
+    _chk(tok_table, dt, "decode_feed.tok_table")
+    _chk(x, dt, "decode_feed.x")
     for name, t in (("next_ids", next_ids), ("finished", finished), ("tokens_out", tokens_out), ("seq_desc", seq_desc),
                     ("positions", positions)):
         _chk(t, torch.int32, f"decode_feed.{name}")
@@ -229,26 +255,26 @@ def decode_feed(tok_table: torch.Tensor, next_ids: torch.Tensor, finished: torch
         _chk(eos_ids, torch.int32, "decode_feed.eos_ids")
     _lib.check(lib.vt_decode_feed(_p(tok_table), tok_table.shape[1], tok_table.shape[0], _p(next_ids), _p(finished),
                                   _p(eos_ids) if n_eos else None, n_eos, int(pad_id), _p(tokens_out), _p(x), _p(seq_desc),
-                                  _p(positions), nseq, _stream()), "vt_decode_feed")
+                                  _p(positions), nseq, _stream()), "vt_decode_feed", lib)
 
 
 def sample_top_p(logits: torch.Tensor, temperature: float, top_p: float, seed: int, step: int, return_kept: bool = False,
                  top_k: int = 0):
     """One sampled token id per row (int32), on device; see vt_sample_top_p in include/vitron_hip.h."""
-    lib = _lib.load()
+    lib = _lib.load_any()
     _chk_rows(logits, torch.float32, "sample_top_p.logits")
     rows, V = logits.shape
     out = torch.empty((rows,), device=logits.device, dtype=torch.int32)
     kept = torch.empty((rows,), device=logits.device, dtype=torch.int32) if return_kept else None
     _lib.check(lib.vt_sample_top_p(_p(logits), rows, V, logits.stride(0), float(temperature), int(top_k or 0),
                                    float(top_p if top_p else 1.0), int(seed) & (2 ** 64 - 1), int(step), _p(out), _p(kept),
-                                   _stream()), "vt_sample_top_p")
+                                   _stream()), "vt_sample_top_p", lib)
     return (out, kept) if return_kept else out
 
 
 def cross_entropy(logits: torch.Tensor, labels: torch.Tensor, ignore_index: int = -100) -> torch.Tensor:
     """Mean cross entropy of fp32 logits [rows, V] against int labels [rows] (rows with `ignore_index` skipped); 0-dim tensor."""
-    lib = _lib.load()
+    lib = _lib.load_any()
     _chk_rows(logits, torch.float32, "cross_entropy.logits")
     rows, V = logits.shape
     lab = labels.to(device=logits.device, dtype=torch.int32).contiguous()
@@ -260,5 +286,5 @@ def cross_entropy(logits: torch.Tensor, labels: torch.Tensor, ignore_index: int 
     nll = torch.empty((rows,), device=logits.device, dtype=torch.float32)
     loss = torch.empty((1,), device=logits.device, dtype=torch.float32)
     _lib.check(lib.vt_cross_entropy(_p(logits), rows, V, logits.stride(0), _p(lab), int(ignore_index), _p(nll), _p(loss), _stream()),
-               "vt_cross_entropy")
+               "vt_cross_entropy", lib)
     return loss[0]

@@ -25,10 +25,12 @@ def sample_frame_indices(duration: int, num_frames: int) -> np.ndarray:
 
 
 def preprocess_frames(frames: torch.Tensor, size: int, bicubic: bool, clip_layout: bool, flip: bool = False,
-                      dtype=torch.bfloat16, mean=OPENAI_DATASET_MEAN, std=OPENAI_DATASET_STD) -> torch.Tensor:
+                      dtype=None, mean=OPENAI_DATASET_MEAN, std=OPENAI_DATASET_STD) -> torch.Tensor:
     """frames: [F,H,W,3] uint8 (or float in [0,1]... pass uint8 for the /255) on the GPU.
-    Returns [F,3,S,S] (images) or [3,F,S,S] (clip_layout: the (C,T,H,W) clip the video tower takes)."""
-    lib = _lib.load()
+    Returns [F,3,S,S] (images) or [3,F,S,S] (clip_layout: the (C,T,H,W) clip the video tower takes) in `dtype`
+    (bf16 -- the package default -- / fp16: the towers' operand dtype, or fp32)."""
+    dtype = dtype if dtype is not None else _lib.torch_dtype()
+    lib = _lib.load_any() if dtype == torch.float32 else _lib.lib_for(dtype)
     if not frames.is_cuda:
         raise _lib.VitronHipError("preprocess_frames: frames must be on the GPU")
     if frames.dim() != 4 or frames.shape[-1] != 3:
@@ -42,9 +44,9 @@ def preprocess_frames(frames: torch.Tensor, size: int, bicubic: bool, clip_layou
     sc, sf = (F_ * S * S, S * S) if clip_layout else (S * S, 3 * S * S)
     m = (C.c_float * 3)(*mean)
     s = (C.c_float * 3)(*std)
-    dt = _lib.DTYPE_BF16 if dtype == torch.bfloat16 else _lib.DTYPE_F32
+    dt = _lib.DTYPE_F32 if dtype == torch.float32 else _lib.DTYPE_BF16      # DTYPE_BF16 = "the library's 16-bit operand format"
     _lib.check(lib.vt_preprocess(frames.data_ptr(), int(frames.dtype == torch.uint8), 1, F_, H, W, int(bicubic), S, m, s, int(flip),
-                                 out.data_ptr(), dt, sc, sf, torch.cuda.current_stream().cuda_stream), "vt_preprocess")
+                                 out.data_ptr(), dt, sc, sf, torch.cuda.current_stream().cuda_stream), "vt_preprocess", lib)
     return out
 
 
@@ -102,7 +104,7 @@ def _to_u8_hwc(img, device) -> torch.Tensor:
 class LanguageBindImageProcessor:
     """preprocess(images)['pixel_values'] -> [N,3,S,S]; same attributes app.py / mm_utils read (image_mean, crop_size)."""
 
-    def __init__(self, config=None, image_size: int = 224, device="cuda", dtype=torch.bfloat16):
+    def __init__(self, config=None, image_size: int = 224, device="cuda", dtype=None):
         vc = getattr(config, "vision_config", config)
         self.size = int(getattr(vc, "image_size", image_size) or image_size)
         self.device, self.dtype = device, dtype
@@ -121,7 +123,7 @@ class LanguageBindVideoProcessor:
     """__call__(videos)['pixel_values'] -> [N,3,T,S,S]; a video is a decoded uint8 tensor [frames,H,W,3] (all frames of
     the file: `num_frames` are sampled uniformly like the reference) or an already sampled [T,H,W,3] one."""
 
-    def __init__(self, config=None, image_size: int = 224, num_frames: int = 8, device="cuda", dtype=torch.bfloat16, flip: bool = False,
+    def __init__(self, config=None, image_size: int = 224, num_frames: int = 8, device="cuda", dtype=None, flip: bool = False,
                  video_decode_backend: str = "opencv"):
         vc = getattr(config, "vision_config", config)
         self.video_decode_backend = getattr(vc, "video_decode_backend", video_decode_backend) or video_decode_backend

@@ -14,6 +14,13 @@ Admission runs the request's multimodal prefill on its own (towers -> splice -> 
 including the visual-feature cache), so a request's tokens are bit-identical to running it alone with greedy decoding as long
 as the decode batch stays on one kernel path (<= 16 rows: the folded-norm path; the engine never mixes a sequence between the
 <= 16 and > 16 row paths within one request unless max_batch > 16).
+
+Failures are isolated per request: a request whose own multimodal encoding or prefill fails (bad image shape, bad region, a prompt
+beyond the rotary table) is moved to `failed` with its exception and leaves the queue -- the requests behind it are served. Only
+errors that are not tied to one request (a HIP runtime error, the pool held by someone else) propagate out of step(), with every
+page this call took given back and the candidates re-queued. `kv_pages` given to the constructor is an UPPER BOUND of the pool: the
+engine never rebuilds a larger one behind the caller's back; requests that do not fit next to the running ones wait, and one that
+cannot fit even an empty pool of that size fails instead of blocking the queue forever.
 """
 from __future__ import annotations
 
@@ -41,6 +48,7 @@ class _Request:
     done: bool = False
     flat: Optional[torch.Tensor] = None      # spliced prompt rows [rows, H] (kept while the request waits for pages)
     need: int = 0                            # KV pages for prompt + max_new_tokens
+    error: Optional[BaseException] = None    # set when the request failed on its own (it is in ServingEngine.failed then)
 
 
 class ServingEngine:
@@ -55,11 +63,14 @@ class ServingEngine:
         self.waiting: "collections.deque[_Request]" = collections.deque()
         self.active: List[_Request] = []
         self.finished: Dict[int, _Request] = {}
+        self.failed: Dict[int, _Request] = {}            # requests that failed on their own (`.error` holds the exception)
         self._next_id = 0
         self._step = 0
+        self.kv_cap: Optional[int] = None                # upper bound of the pool (pages) when the caller fixed one
         if kv_pages is not None:
             model.reset_prefix_cache()
             model.kv = PagedKVCache(model.get_model().llama, int(kv_pages))
+            self.kv_cap = int(kv_pages)
         from .prefix_cache import VisualFeatureCache
         self._vis_cache = VisualFeatureCache(int(getattr(model.config, "vis_cache_entries", 16)))
 
@@ -78,6 +89,28 @@ class ServingEngine:
 
     def pending(self) -> int:
         return len(self.waiting) + len(self.active)
+
+    def cancel(self, rid: int) -> bool:
+        """Drop a request that is still waiting (True) -- a running or finished one is left alone (False)."""
+        for r in self.waiting:
+            if r.rid == rid:
+                self.waiting.remove(r)
+                r.flat = None
+                return True
+        return False
+
+    def _fail(self, r: _Request, exc: BaseException) -> None:
+        """The request failed on its own: it leaves the engine with its exception; nothing else is disturbed."""
+        if r.seq.pages:
+            self.model.kv.release(r.seq.pages)
+        r.seq.pages, r.seq.length, r.last, r.flat = [], 0, None, None
+        r.error, r.done = exc, True
+        self.failed[r.rid] = r
+
+    @staticmethod
+    def _is_device_error(exc: BaseException) -> bool:
+        """Errors that are not one request's fault: the HIP runtime (status -2 of the C ABI), the allocator."""
+        return isinstance(exc, torch.cuda.OutOfMemoryError) or "status -2" in str(exc) or "HIP error" in str(exc)
 
     # ---- one scheduling step ---------------------------------------------------------------------------------------------
     def _pick(self, logits: torch.Tensor) -> torch.Tensor:
@@ -99,25 +132,52 @@ class ServingEngine:
         request while it waits), decoder prefill per request (default) or one packed pass for all of them (batch_prefill). Every
         admitted request RESERVES its worst case up front -- pages for prompt + max_new_tokens are allocated here, so a sequence
         that is already decoding can never find the pool empty because a later admission took its pages. When nothing of this
-        engine is live the pool is (re)built for the WHOLE candidate batch; otherwise requests that do not fit right now are
-        returned (in order) and go back to the head of the queue -- also one that is larger than the current pool: it is admitted
-        once the engine is idle and the pool can grow. A failure in here (e.g. pages held by someone else while the pool would
-        have to grow) leaves the engine as it was: pages taken by this call are released, the candidates stay queued."""
+        engine is live the pool is (re)built for the candidate batch, never beyond the constructor's `kv_pages`; if it cannot be
+        grown (out of memory, pages held by someone else) the prefix of `reqs` that fits the pool there is gets admitted and the rest
+        waits, as requests that do not fit next to running ones always do. Returns the requests that stay queued, in order.
+        A request that fails on its own is moved to `failed` (module docstring); a device-level error propagates with the engine left
+        as it was: pages taken by this call released, the surviving candidates back at the head of the queue."""
         m = self.model
         llama = m.get_model().llama
-        admitted: List[_Request] = []
-        try:
-            for r in reqs:
-                if r.flat is None:
+        live: List[_Request] = []                           # candidates that are still in the game
+        for r in reqs:
+            if r.flat is None:
+                try:
                     r.flat = self._embed(r)
                     r.need = (r.flat.shape[0] + r.max_new_tokens + 63) // 64 + 1
-            if not self.active:
-                # idle: size the pool for every candidate (the first len(reqs) <= max_batch requests decode together)
-                total = sum(r.need for r in reqs)
-                if m.kv is None or len(m.kv.free) < total:
-                    m._ensure_kv(total)
-            for r in reqs:
+                except Exception as e:  # noqa: BLE001 -- classified below
+                    if self._is_device_error(e):
+                        for q in reversed([x for x in reqs if x.error is None]):
+                            self.waiting.appendleft(q)
+                        raise
+                    self._fail(r, e)                        # bad image shape / region / ids: this request's own problem
+                    continue
+            if self.kv_cap is not None and r.need > self.kv_cap:      # larger than the pool may ever be: no point in waiting
+                self._fail(r, RuntimeError(f"request {r.rid} needs {r.need} KV pages, the pool is capped at {self.kv_cap}"))
+                continue
+            live.append(r)
+        admitted: List[_Request] = []
+        try:
+            if not self.active and live:
+                # idle: size the pool for every candidate (the first len(reqs) <= max_batch requests decode together), within the cap
+                total = sum(r.need for r in live)
+                want = total if self.kv_cap is None else min(total, self.kv_cap)
+                if m.kv is None or len(m.kv.free) < want:
+                    try:
+                        m._ensure_kv(want)
+                    except (RuntimeError, torch.cuda.OutOfMemoryError):
+                        if m.kv is None:
+                            raise                           # no pool at all: nothing can be scheduled
+                        # the pool could not grow: go on with the one that is there (the prefix that fits is admitted below)
+            for r in live:
                 if len(m.kv.free) < r.need:
+                    if not admitted and not self.active and len(m.kv.free) == m.kv.num_pages:
+                        # nothing is running, every page of the pool is free, the pool is as large as it could be made (the cap, or
+                        # what the allocator gave), and the head request still does not fit: it never will -- fail it instead of
+                        # blocking everything behind it
+                        self._fail(r, RuntimeError(f"request {r.rid} needs {r.need} KV pages, the pool holds {m.kv.num_pages}"
+                                                   + (f" (capped at {self.kv_cap})" if self.kv_cap is not None else "")))
+                        continue
                     break                                   # wait for running requests to retire (or for an idle engine to grow the pool)
                 r.seq.pages = m.kv.alloc(r.need)
                 admitted.append(r)
@@ -125,30 +185,52 @@ class ServingEngine:
             for r in admitted:
                 m.kv.release(r.seq.pages)
                 r.seq.pages = []
-            for r in reversed(reqs):
-                self.waiting.appendleft(r)
+            for r in reversed(live):
+                if r.error is None:
+                    self.waiting.appendleft(r)
             raise
-        rest = reqs[len(admitted):]
-        flats = [r.flat for r in admitted]
+        rest = [r for r in live if r.error is None and r not in admitted]
+        ok: List[_Request] = []
+
+        def prefill_one(r):
+            try:
+                r.last = self._pick(llama_forward(llama, m.kv, [r.seq], r.flat, [r.flat.shape[0]]))
+                ok.append(r)
+            except Exception as e:  # noqa: BLE001
+                if self._is_device_error(e):
+                    raise
+                self._fail(r, e)                            # e.g. a prompt beyond the rotary table: this request's own problem
+
         try:
             if self.batch_prefill and len(admitted) > 1:
-                logits = llama_forward(llama, m.kv, [r.seq for r in admitted], torch.cat(flats, 0), [f.shape[0] for f in flats])
-                nxt = self._pick(logits)
-                for i, r in enumerate(admitted):
-                    r.last = nxt[i:i + 1]
+                try:
+                    flats = [r.flat for r in admitted]
+                    logits = llama_forward(llama, m.kv, [r.seq for r in admitted], torch.cat(flats, 0), [f.shape[0] for f in flats])
+                    nxt = self._pick(logits)
+                    for i, r in enumerate(admitted):
+                        r.last = nxt[i:i + 1]
+                    ok = list(admitted)
+                except Exception as e:  # noqa: BLE001
+                    if self._is_device_error(e):
+                        raise
+                    for r in admitted:                      # find the culprit: every request on its own (a solo prefill is always legal)
+                        r.seq.length = 0
+                        prefill_one(r)
             else:
-                for r, f in zip(admitted, flats):
-                    r.last = self._pick(llama_forward(llama, m.kv, [r.seq], f, [f.shape[0]]))
-        except Exception:                                   # a failed prefill gives its pages back and leaves every candidate queued
+                for r in admitted:
+                    prefill_one(r)
+        except Exception:                                   # device-level: pages back, every surviving candidate queued again
             for r in admitted:
-                m.kv.release(r.seq.pages)
-                r.seq.pages, r.seq.length, r.last = [], 0, None
-            for r in reversed(reqs):
-                self.waiting.appendleft(r)
+                if r.error is None:
+                    m.kv.release(r.seq.pages)
+                    r.seq.pages, r.seq.length, r.last = [], 0, None
+            for r in reversed(live):
+                if r.error is None:
+                    self.waiting.appendleft(r)
             raise
-        for r in admitted:
+        for r in ok:
             r.flat = None                                   # the rows are in the cache now
-        self.active += admitted
+        self.active += ok
         return rest
 
     def _retire(self, r: _Request) -> None:
@@ -199,3 +281,7 @@ class ServingEngine:
                 if on_token is not None:
                     on_token(rid, t)
         return {rid: torch.tensor(r.tokens, dtype=torch.long) for rid, r in sorted(self.finished.items())}
+
+    def errors(self) -> Dict[int, BaseException]:
+        """{request id: exception} of the requests that failed on their own."""
+        return {rid: r.error for rid, r in sorted(self.failed.items())}
