@@ -553,7 +553,7 @@ def gather_report(dev, world, dist, frames, image_size, iters=10):
     return res
 
 
-def fp16_ab_report(args, dev, model_bf16, step_bf16, ids, ids_host, clip_bf16):
+def fp16_ab_report(args, dev, model_bf16, step_bf16, ids, ids_host, clip_bf16, vit_image=None):
     """The headline workload on the fp16-operand build (libvitron_hip_f16.so: the reference's own inference dtype), same box, same
     seed, same inputs, arms alternated (bf16, fp16, bf16, fp16; K steps each): does the step time move, and how far are the two
     builds' last-position logits apart. Outside the timed region of the headline; BASELINE's dtype stays bf16."""
@@ -566,7 +566,8 @@ def fp16_ab_report(args, dev, model_bf16, step_bf16, ids, ids_host, clip_bf16):
     G = args.image_size // 14
     S = args.frames * G * G + args.text_len
     m16 = LlavaLlamaForCausalLM(LlavaConfig(**synth.VICUNA_7B, mm_hidden_size=1024))
-    m16.init_synthetic(dev, seed=args.seed, vit_image=None,
+    # (the same tower list as the headline model: the weights come from ONE seeded stream, so an extra tower shifts everything behind it)
+    m16.init_synthetic(dev, seed=args.seed, vit_image=vit_image,
                        vit_video=dict(synth.VIT_L14, image_size=args.image_size, add_time_attn=True, num_frames=args.frames), dtype=torch.float16)
     l16 = m16.get_model().llama
     m16._ensure_kv((S + 63) // 64 + 4)
@@ -679,18 +680,36 @@ def stub_main(args):
         dist.destroy_process_group()
 
 
-def event_pair_overhead_ms(n=200):
-    """What an EMPTY HIP-event pair measures on the compute stream (record, record, elapsed): the per-launch bias of the per-class
-    event times. On 8-32 us decode launches it is a visible fraction; the decode report subtracts launches x this."""
+def event_pair_overhead_ms(n=64):
+    """How much a HIP-event pair around ONE short launch inflates it, measured on a decode-shaped weight-streaming GEMM (M = 4,
+    22016 x 4096, the step's largest launch): n launches each inside its own pair (what vt_profile_* does) against the same n
+    launches inside ONE pair; (sum of pairs - single pair) / n. The decode report subtracts launches x this from the per-class event
+    times: a pair measures from the completion of the command before it, i.e. it also counts the dispatch gap in front of the kernel,
+    which rocprofv3's kernel durations (profiles/r<N>_decode_rocprofv3_kernel_stats.csv) do not."""
     import torch
+
+    from vitron_amd import _lib, ops
+    dev = torch.device("cuda", torch.cuda.current_device())
+    a = torch.randn((4, 4096), device=dev).to(torch.bfloat16)
+    w = torch.randn((22016, 4096), device=dev).to(torch.bfloat16)
+    out = torch.empty((4, 22016), device=dev, dtype=torch.bfloat16)
+    for _ in range(8):
+        ops.gemm(a, w, None, ops.EPI_BF16, out=out, cfg=_lib.CFG_SKINNY)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
     torch.cuda.synchronize()
-    for a, b in ev:
-        a.record()
-        b.record()
+    for e0, e1 in ev:
+        e0.record()
+        ops.gemm(a, w, None, ops.EPI_BF16, out=out, cfg=_lib.CFG_SKINNY)
+        e1.record()
     torch.cuda.synchronize()
-    v = sorted(a.elapsed_time(b) for a, b in ev)
-    return v[len(v) // 2]
+    per_pair = sum(e0.elapsed_time(e1) for e0, e1 in ev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        ops.gemm(a, w, None, ops.EPI_BF16, out=out, cfg=_lib.CFG_SKINNY)
+    e1.record()
+    torch.cuda.synchronize()
+    return max(per_pair - e0.elapsed_time(e1), 0.0) / n
 
 
 def main():
@@ -915,7 +934,7 @@ def main():
             if emp.get("d2d_copy_GBps") and "decode" in out:
                 out["decode"]["roofline"]["frac_of_empirical_copy_rate"] = out["decode"]["roofline"]["achieved"] / emp["d2d_copy_GBps"]
         if world == 1 and args.dtype == "bf16" and args.fp16_ab_steps > 0:
-            out["config"]["fp16_ab"] = fp16_ab_report(args, dev, model, step, ids, ids_host, clip)
+            out["config"]["fp16_ab"] = fp16_ab_report(args, dev, model, step, ids, ids_host, clip, vit_image)
         if world == 1 and not args.no_cpu_baseline:
             torch.cuda.synchronize()
             out["cpu_baseline"] = cpu_baseline(args.image_size, args.frames, args.text_len, args.seed, mode=args.cpu_baseline)

@@ -457,20 +457,21 @@ def test_serving_engine_pool_sizing_and_waiting(dev, model):
     outs = eng.run()
     assert [outs[i].tolist() for i in range(3)] == solo and sorted(embeds) == [0, 1, 2]
     assert len(model.kv.free) == model.kv.num_pages == 7
-    # (3) a request larger than the pool: waits behind the running one, then the idle engine grows the pool
+    # (3) the constructor's kv_pages is an UPPER BOUND (round 4): a request that cannot fit a pool of that size fails on its
+    # own -- with its exception, without being re-raised on every step -- and the requests around it are served; the pool is not rebuilt
     eng = ServingEngine(model, max_batch=4, kv_pages=3)
     eng.submit(reqs[0]["input_ids"], max_new_tokens=reqs[0]["max_new_tokens"], eos_token_id=-1)
     eng.step()
-    eng.submit(reqs[1]["input_ids"], max_new_tokens=reqs[1]["max_new_tokens"], eos_token_id=-1)     # needs 5 pages, the pool has 3
+    big = eng.submit(reqs[1]["input_ids"], max_new_tokens=reqs[1]["max_new_tokens"], eos_token_id=-1)     # needs 5 pages, the pool is capped at 3
+    eng.submit(reqs[0]["input_ids"], max_new_tokens=reqs[0]["max_new_tokens"], eos_token_id=-1)           # behind it: must not starve
     outs = eng.run()
-    assert outs[0].tolist() == solo[0] and outs[1].tolist() == solo[1] and model.kv.num_pages >= 5
-    # (4) pages held by someone else while the pool would have to grow: the error leaves everything in place
-    eng = ServingEngine(model, max_batch=4, kv_pages=3)
-    held = model.kv.alloc(1)
+    assert outs[0].tolist() == solo[0] and outs[2].tolist() == solo[0] and big not in outs and model.kv.num_pages == 3
+    assert big in eng.errors() and "capped at 3" in str(eng.errors()[big]) and len(model.kv.free) == 3
+    # (4) pages held by someone else: the request does not fit right now -> it WAITS (no exception, nothing leaked) and runs once they return
+    eng = ServingEngine(model, max_batch=4, kv_pages=6)
+    held = model.kv.alloc(2)
     eng.submit(reqs[1]["input_ids"], max_new_tokens=reqs[1]["max_new_tokens"], eos_token_id=-1)
-    with pytest.raises(RuntimeError):
-        eng.step()
-    assert len(eng.waiting) == 1 and not eng.active and len(model.kv.free) == 2
+    assert eng.step() == [] and len(eng.waiting) == 1 and not eng.active and len(model.kv.free) == 4
     model.kv.release(held)
     assert eng.run()[0].tolist() == solo[1]
     model.config.kv_prefix_reuse = True

@@ -17,8 +17,9 @@ MEASURED_X_1_5 = {"rmsnorm": 1e-6, "qkv_gemm": 6.3e-5, "rope_q": 1e-5, "rope_k_p
 # fp16-operand build (libvitron_hip_f16.so): one store leaves 2^-12 per element (2.1e-4 rel-L2) instead of bf16's 2^-9 (1.66e-3),
 # so the operators are also compared with PLAIN fp32 here -- north_star's 1e-3 against an fp32 evaluation, not only against the
 # emulation of the kernel's own storage points. Bounds = first measurement x 1.5 (profiles/r4_parity_ops_fullwidth_fp16.txt).
-MEASURED_X_1_5_FP16 = {"rmsnorm": 1e-6, "qkv_gemm": 6.3e-5, "rope_q": 1e-5, "rope_k_pages": 1e-5, "flash_attn": 1.0e-3, "o_proj_resid": 1e-6,
-                       "rmsnorm2": 3e-5, "swiglu_gemm": 7.8e-5, "down_proj_resid": 1.1e-6, "whole_layer_hidden": 5.0e-3}
+# measured: rmsnorm 2.7e-6, qkv 1.5e-5, rope 3.6e-6, flash attention 2.5e-4 (2.6e-4 from plain fp32), swiglu 1.9e-5, whole layer 6.7e-4
+MEASURED_X_1_5_FP16 = {"rmsnorm": 4.1e-6, "qkv_gemm": 2.3e-5, "rope_q": 5.4e-6, "rope_k_pages": 5.3e-6, "flash_attn": 3.8e-4, "o_proj_resid": 1e-6,
+                       "rmsnorm2": 7.7e-6, "swiglu_gemm": 2.9e-5, "down_proj_resid": 1.1e-6, "whole_layer_hidden": 1.0e-3}
 
 
 @pytest.mark.parametrize("operand", ["bf16", "fp16"])
@@ -35,3 +36,5 @@ def test_every_decoder_operator_within_1e3_of_the_emulation_at_7b_width(operand)
             assert r["vs_emu"] <= TOL_OP, (name, r)
     fa = rep["flash_attn"]
     assert fa["vs_fp32"] <= 1.25 * fa["emu_vs_fp32"] + 2e-4, fa          # no farther from fp32 than the emulation of its storage points
+    if operand == "fp16":       # the whole LAYER, free running, is inside north_star's 1e-3 of the emulation, and attention of plain fp32
+        assert rep["whole_layer_hidden"]["vs_emu"] <= TOL_OP and fa["vs_fp32"] <= 4e-4, (rep["whole_layer_hidden"], fa)
