@@ -118,6 +118,12 @@ int vt_rmsnorm(const float* x, const int* idx, const float* w, uint16_t* y, int 
 int vt_flash_attn(const uint16_t* Q, int ldq, const uint16_t* k_tiles, const uint16_t* vt_tiles, const int* tile_table,
                   const int* seq_desc, int nseq, int max_q_len, uint16_t* O, int ldo, int heads, int head_dim,
                   int causal, float scale, void* stream);
+/* Which prefill kernel vt_flash_attn (and the composite operators) run for head_dim 128 -- a process-wide switch for A/B measurements
+ * and for the tests that hold the kernels to each other; results are the same contract either way. 0 = automatic (the one-wave-per-SIMD
+ * kernel on 256-row blocks once heads x sequences x blocks fills the 256 CUs, else the two-waves-per-SIMD kernel on 128-row blocks),
+ * 1 = always the two-waves-per-SIMD kernel, 2 = always the one-wave-per-SIMD kernel, 3 = that kernel with its pipeline stages run one
+ * after the other instead of the hand-placed schedule (its reference). No reference counterpart. */
+int vt_flash_attn_select(int kernel);
 /* Residual GEMM C[M,N] (fp32) += A[M,K] W[N,K]^T + bias with an optional split-K workspace: when the 256x256 tile grid would
  * cover at most half of the chip (M ~ 1000 rows at N = 4096, the ViT's N = 1024 projections) the K loop is split over up to 8
  * workgroups per tile, fp32 partial products go to `partials` and a second kernel adds them in split order (deterministic).

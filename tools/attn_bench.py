@@ -45,6 +45,18 @@ def run(S, heads, hd, nseq, causal):
                       "tflops": round(flops / ms / 1e9, 1), "kv_tiles_ms": round(ms_kv, 4)}), flush=True)
 
 
+if __name__ == "__main__" and os.environ.get("ATTN_BENCH_KERNELS"):
+    # A/B of the head_dim-128 prefill kernels (vt_flash_attn_select): ATTN_BENCH_KERNELS=1,2,3 python tools/attn_bench.py
+    _lib.load()
+    for rep in range(2):
+        for k in [int(x) for x in os.environ["ATTN_BENCH_KERNELS"].split(",")]:
+            ops.flash_attn_select(k)
+            print(f"# kernel {k} (pass {rep})", flush=True)
+            run(5120, 32, 128, 1, True)
+            run(2048, 32, 128, 4, True)
+            run(5120, 32, 128, 8, True)
+    ops.flash_attn_select(0)
+    sys.exit(0)
 if __name__ == "__main__" and os.environ.get("ATTN_BENCH_ONLY_C3"):
     _lib.load(ablations=True)
     run(5120, 32, 128, 1, True)

@@ -78,6 +78,7 @@ SIGNATURES = {
     "vt_layernorm": (_i, [vp, vp, _i, _i, vp, vp, vp, _i, _i, _f, vp]),
     "vt_rmsnorm": (_i, [vp, vp, vp, vp, _i, _i, _f, vp]),
     "vt_flash_attn": (_i, [vp, _i, vp, vp, vp, vp, _i, _i, vp, _i, _i, _i, _i, _f, vp]),
+    "vt_flash_attn_select": (_i, [_i]),
     "vt_attn_decode_scratch_bytes": (_sz, [_i, _i, _i, _i]),
     "vt_attn_decode": (_i, [vp, _i, vp, vp, vp, vp, _i, vp, _i, _i, _i, _f, _i, vp, _sz, vp]),
     "vt_gemm_plan_query": (_i, [_i, _i, _i, _i, vp, vp]),
@@ -148,7 +149,7 @@ def set_default_operand(operand) -> None:
 def _needs_build(path: Path) -> bool:
     if not path.exists():
         return True
-    srcs = list((PKG_DIR / "csrc").glob("*.hip")) + list((PKG_DIR / "csrc").glob("*.h")) + \
+    srcs = list((PKG_DIR / "csrc").glob("*.hip")) + list((PKG_DIR / "csrc").glob("*.h")) + list((PKG_DIR / "csrc").glob("*.inc")) + \
         list((PKG_DIR.parent / "include").glob("*.h"))
     if not srcs:
         return False

@@ -26,7 +26,7 @@ F16_LIB_PATH = PKG_DIR / "libvitron_hip_f16.so"
 # results by construction) and their environment switches. Only tools/ load it (vitron_amd._lib.load(ablations=True)); the
 # product library above contains none of that code.
 ABL_LIB_PATH = PKG_DIR / "libvitron_hip_abl.so"
-SOURCES = ["vt_api.hip", "vt_gemm.hip", "vt_gemm8.hip", "vt_norm.hip", "vt_attn.hip", "vt_vit.hip", "vt_region.hip", "vt_llama.hip", "vt_preproc.hip"]
+SOURCES = ["vt_api.hip", "vt_gemm.hip", "vt_gemm8.hip", "vt_norm.hip", "vt_attn.hip", "vt_attn_w4.hip", "vt_vit.hip", "vt_region.hip", "vt_llama.hip", "vt_preproc.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
          "-Wno-unused-but-set-variable", "-Wno-unused-variable"]
@@ -40,13 +40,17 @@ def _hipcc() -> str:
 
 
 def _deps_mtime() -> float:
-    hdrs = list(CSRC.glob("*.h")) + list(INCLUDE.glob("*.h"))
+    hdrs = list(CSRC.glob("*.h")) + list(CSRC.glob("*.inc")) + list(INCLUDE.glob("*.h"))
     return max(p.stat().st_mtime for p in hdrs)
+
+
+# per-file flags. vt_attn_w4.hip: its hand-placed VALU stream must not be SLP-packed into v_pk_*_f32 (an anti-lever beside MFMAs)
+FILE_FLAGS = {"vt_attn_w4.hip": ["-fno-slp-vectorize"]}
 
 
 def _compile_one(src: Path, obj: Path, verbose: bool, extra=()) -> None:
     tmp = obj.with_suffix(f".tmp{os.getpid()}.o")
-    cmd = [_hipcc(), *FLAGS, *extra, "-c", str(src), "-o", str(tmp)]
+    cmd = [_hipcc(), *FLAGS, *FILE_FLAGS.get(src.name, []), *extra, "-c", str(src), "-o", str(tmp)]
     if verbose:
         print("[vitron_amd.build]", " ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)

@@ -151,6 +151,12 @@ int vt_flash_attn(const uint16_t* Q, int ldq, const uint16_t* k_tiles, const uin
                               ldo, heads, head_dim, causal, scale, S(stream));
 }
 
+int vt_flash_attn_select(int kernel) {
+  VT_REQUIRE(kernel >= 0 && kernel <= 3, "vt_flash_attn_select: kernel %d (0 auto, 1 two-waves-per-SIMD, 2 one-wave-per-SIMD placed, 3 unplaced)", kernel);
+  g_vt_flash_attn_kernel = kernel;
+  return VT_OK;
+}
+
 size_t vt_attn_decode_scratch_bytes(int nseq, int heads, int head_dim, int max_kv_len);  // defined in vt_attn.hip (C++ linkage there)
 int vt_attn_decode(const uint16_t* Q, int ldq, const uint16_t* k_tiles, const uint16_t* vt_tiles, const int* tile_table,
                    const int* seq_desc, int nseq, uint16_t* O, int ldo, int heads, int head_dim, float scale,

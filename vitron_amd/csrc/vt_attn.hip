@@ -968,6 +968,8 @@ __global__ __launch_bounds__(256) void attn_temporal8_kernel(const bf16_t* __res
 
 }  // namespace
 
+int g_vt_flash_attn_kernel = 0;
+
 int vt_flash_attn_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf16_t* Vt, const int* tile_table,
                          const VtAttnSeq* seqs, int nseq, int max_q_len, bf16_t* O, int ldo, int heads, int HD,
                          int causal, float scale, hipStream_t s) {
@@ -978,6 +980,16 @@ int vt_flash_attn_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf16_
   const float sl2 = scale * 1.4426950408889634f;
   // algorithmic FLOP are not known here without reading seq_desc back; the caller-side bench computes them.
   VtProfScope prof(VT_PROF_FLASH_ATTN, 0.0, s);
+  // head_dim 128, long sequences: the one-wave-per-SIMD kernel on 256-row blocks (vt_attn_w4.hip) once its grid fills the chip --
+  // (heads x sequences x 256-row blocks) >= 256 workgroups, one per CU; shorter prompts keep the 128-row blocks below (two per CU)
+  if (HD == 128 && g_vt_flash_attn_kernel != 1) {
+    const bool fills = (long)heads * nseq * cdiv(max_q_len, 256) >= 256 && max_q_len >= 1024;
+    if (g_vt_flash_attn_kernel >= 2 || fills) {
+      VT_REQUIRE(ldo % 4 == 0, "vt_flash_attn: ldo %% 4 must be 0");
+      return vt_flash_attn_w4_launch(Q, ldq, Kt, Vt, tile_table, seqs, nseq, max_q_len, O, ldo, heads, causal, sl2,
+                                     g_vt_flash_attn_kernel == 3 ? 0 : 1, s);
+    }
+  }
   // long sequences: 256-row blocks, 3-stage ring; short ones (ViT frames, small prefills): 128-row blocks
   // measured (tools/attn_bench.py, S=5120 causal): 128-row blocks (2 per CU) 272 us vs 256-row blocks 288 us -- the finer
   // causal granularity wins; the 8-wave / 3-stage variant stays selectable for experiments

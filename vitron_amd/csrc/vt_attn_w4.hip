@@ -1,0 +1,374 @@
+// vt_attn_w4.hip -- flash_attn_w4_kernel: prefill attention (head_dim 128) with ONE wave per SIMD and the K step placed by hand.
+//
+// Replaces, for long sequences, the two-waves-per-SIMD kernel of vt_attn.hip (flash_attn_kernel<128, *, 4, 2>): there every wave owns
+// 32 query rows and reads the WHOLE K and V^T tile from LDS (32 FLOP per LDS byte: the LDS pipe and the matrix pipe are co-limited,
+// PMC: MFMA busy 43 %), and the softmax VALU work of one wave only overlaps the other wave's MFMAs by arbitration (13 % co-execution).
+// Here (round 4; the structure /opt/skills/guides/cdna_hip_programming.md prices at 1.25-1.40 PFLOP/s, built with the discipline of
+// gemm_w4_kernel instead of compiler scheduling):
+//   * a workgroup = 4 waves = 256 query rows, a wave = 64 rows = two 32-row halves that SHARE every K / V^T fragment read (half the LDS
+//     bytes per FLOP), one wave per SIMD with the whole register file: O^T (128 registers) lives in the accumulator file, pinned by
+//     inline-asm MFMAs ("+a"), Q (64) sits there too as the B operand of the score MFMAs ("a"), the arch VGPRs hold two S buffers, two P
+//     buffers and three-deep K / V^T fragment windows;
+//   * the softmax unit is a 32-key SUB tile and the loop is software-pipelined three deep: in one sub-iteration the matrix pipe runs
+//     PV(u) and QK(u+2) (16 + 16 MFMAs of 32 cycles, alternating, so dependent MFMAs are 4 / 16 issues apart) while the vector pipe
+//     runs the whole softmax of sub tile u+1 (row max, deferred rescale test, scale-and-shift, exp2, row sum, fp16 pack: ~140 VALU
+//     instructions) -- co-issue works for instructions of ONE wave, not between the two waves of a SIMD;
+//   * every MFMA gap carries its share of that stream plus the LDS fragment reads (8 + 8 ds_read_b128), the LDS-DMA of the tile three
+//     ahead (8 pieces through a buffer resource built once per tile) and the address updates: placed gap by gap by
+//     tools/gen_attn_w4.py (-> vt_attn_w4_si0.inc / vt_attn_w4_si1.inc), fenced with sched_barrier; the VALU work goes through
+//     single-instruction asm helpers (no SLP packing into v_pk_*, no canonicalising v_max in front of the MFMA outputs);
+//   * K / V^T tiles arrive by LDS-DMA into a four-deep ring (K ring [0, 64 KiB), V^T ring [64, 128 KiB)), K of tile T+3 first and
+//     waited for at the end of the tile (counted vmcnt), V^T of T+3 one tile later; ONE barrier per 64-key tile;
+//   * deferred rescale as in the other kernel (threshold 2^8, fp16 P with exponent bias 2^7); the rare O rescale is applied between
+//     two sub-iterations so that it never splits a pending P.V product.
+// Same tile / page layout, same permuted K rows, same results contract as flash_attn_kernel (tests compare the two kernels).
+// PLACED = false keeps the same pipeline with the three stages run one after the other by simple loops: the reference the placed
+// schedule is tested against, and the prologue / tail of the placed kernel.
+#include <stdlib.h>
+
+#include "vt_common.h"
+#include "vt_kernels.h"
+
+namespace {
+
+#define W4A_THR 8.0f
+#define W4A_BIAS 7.0f
+
+// single-instruction VALU helpers (see header)
+__device__ __forceinline__ float a_max3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float a_max(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// (fma / exp2 / add / pack are compiler-visible instructions, not asm: the hazard recognizer counts an inline-asm statement as ZERO wait
+// states, so a chain of asm helpers gets an s_nop between every dependent pair -- one per exponential. This file is built with
+// -fno-slp-vectorize (vitron_amd/build.py) so that adjacent scalar fmas / adds are not packed into v_pk_*_f32, an anti-lever beside
+// MFMAs. v_max3 stays asm: fmaxf on values the compiler cannot prove canonical costs an extra v_max per input.)
+__device__ __forceinline__ float a_fma_s(float s, float scale_sgpr, float add) { return __builtin_fmaf(s, scale_sgpr, add); }
+__device__ __forceinline__ float a_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float a_add(float a, float b) { return a + b; }
+__device__ __forceinline__ uint32_t a_cvt_pk_f16(float lo, float hi) { return pack_f16x2(lo, hi); }
+// value of the other half-wave's lane (lane ^ 32) combined by max: one v_permlane32_swap + one v_max
+__device__ __forceinline__ float a_max_halves(float x) {
+  const unsigned u = __builtin_bit_cast(unsigned, x);
+  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return a_max(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+}
+
+#define W4A_QK0(D, A, B) asm volatile(VT_MFMA_32x32x16_ASM " %0, %1, %2, 0" : "=&v"(D) : "v"(A), "a"(B))
+#define W4A_QK(D, A, B) asm volatile(VT_MFMA_32x32x16_ASM " %0, %1, %2, %0" : "+v"(D) : "v"(A), "a"(B))
+#define W4A_PV(D, A, B) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(D) : "v"(A), "v"(B))
+#define W4A_LDS(p) ((__attribute__((address_space(3))) void*)(p))
+
+template <bool CAUSAL, bool PLACED>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void flash_attn_w4_kernel(
+    const op16_t* __restrict__ Q, int ldq, const op16_t* __restrict__ Kt, const op16_t* __restrict__ Vt,
+    const int* __restrict__ tile_table, const VtAttnSeq* __restrict__ seqs, op16_t* __restrict__ O, int ldo, int heads,
+    float scale_log2e) {
+  constexpr int HD = 128, QBLK = 256, TB = 64 * HD * 2, VRING = 4 * TB;   // 16-KiB tiles; K ring then V^T ring, 4 slots each
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const VtAttnSeq sq = seqs[blockIdx.z];
+  const int nqb = (sq.q_len + QBLK - 1) / QBLK;
+  const int qb = nqb - 1 - (int)blockIdx.y;   // heaviest (latest) causal blocks of all heads first
+  if (qb < 0) return;
+  const int head = blockIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ql = lane & 31, hh = lane >> 5;
+  const int past = sq.kv_len - sq.q_len;
+  const int q0 = qb * QBLK;
+  int ntiles = (sq.kv_len + 63) >> 6;
+  if (CAUSAL) {
+    const int last_key = past + min(q0 + QBLK - 1, sq.q_len - 1);
+    ntiles = min(ntiles, (last_key >> 6) + 1);
+  }
+  const int wrow0 = q0 + wave * 64;          // first row of this wave inside the sequence
+  int qrow[2];
+  qrow[0] = wrow0 + ql;
+  qrow[1] = wrow0 + 32 + ql;
+
+  // ---- Q fragments (B operand of the score MFMAs): lane (q, h) holds d = ks*16 + h*8 .. +7 of its row, both row halves --------
+  bf16x8 qf[2][8];
+#pragma unroll
+  for (int rh = 0; rh < 2; ++rh) {
+    const op16_t* qp = Q + (size_t)(sq.q_row0 + min(qrow[rh], sq.q_len - 1)) * ldq + head * HD + hh * 8;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[rh][ks] = *(const bf16x8*)(qp + ks * 16);
+  }
+
+  // ---- LDS-DMA: piece p = wave*4 + i of a tile covers LDS bytes [p*1024, +1024); swizzle applied on the SOURCE side -------------
+  int k_vo[4], v_vo[4];   // byte offsets inside the 16-KiB source tile
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int byte = (wave * 4 + i) * 1024 + lane * 16;
+    {
+      const int row = byte >> 8, c = (byte & 255) >> 4;            // K rows are 256 B
+      k_vo[i] = (row * HD + ((c ^ (row & 15)) << 3)) * 2;
+    }
+    {
+      const int row = byte >> 7, c = (byte & 127) >> 4;            // V^T rows are 64 keys = 128 B
+      v_vo[i] = (row * 64 + ((c ^ ((row >> 1) & 7)) << 3)) * 2;
+    }
+  }
+  const size_t head_off = (size_t)head * 64 * HD;
+  const size_t tile_stride = (size_t)heads * 64 * HD;
+  const int* table = tile_table + sq.table_off;
+  // (the pool can exceed 4 GiB: the buffer resource is rebuilt per tile around the tile's own 16 KiB -- scalar work only)
+#define W4A_RSRC(BASE, T) __builtin_amdgcn_make_buffer_rsrc((void*)((BASE) + (size_t)table[min((T), ntiles - 1)] * tile_stride + head_off), 0, TB, 0x00020000)
+#define W4A_DMA_K(R, SLOT, I) __builtin_amdgcn_raw_ptr_buffer_load_lds(R, W4A_LDS(smem + (SLOT) * TB + (wave * 4 + (I)) * 1024), 16, k_vo[I], 0, 0, 0)
+#define W4A_DMA_V(R, SLOT, I) __builtin_amdgcn_raw_ptr_buffer_load_lds(R, W4A_LDS(smem + VRING + (SLOT) * TB + (wave * 4 + (I)) * 1024), 16, v_vo[I], 0, 0, 0)
+
+  // ---- fragment read offsets (bytes inside a ring slot) ------------------------------------------------------------------------------
+  // K: MFMA row i = lane&31 reads key pi(i) of the 32-key sub tile (so that a lane's 16 scores are 16 consecutive keys), chunk ks*2 + h
+  const int pi = 16 * ((ql >> 2) & 1) + (ql & 3) + 4 * (ql >> 3);
+  int kfix[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) kfix[ks] = pi * 256 + (((ks * 2 + hh) ^ (pi & 15)) << 4);
+  // V^T: MFMA row i reads d = db*32 + i, chunk sub*4 + 2h + j
+  int vfix[2][2];
+#pragma unroll
+  for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) vfix[sub][j] = VRING + ql * 128 + (((sub * 4 + 2 * hh + j) ^ ((ql >> 1) & 7)) << 4);
+
+  // ---- state ---------------------------------------------------------------------------------------------------------------------------
+  f32x16 oacc[2][4];   // [row half][32-wide d block], accumulator file
+#pragma unroll
+  for (int rh = 0; rh < 2; ++rh)
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[rh][db][r] = 0.f;
+  f32x16 sacc[2][2];   // [S buffer = sub][row half]
+  u32x4 pfr[2][2][2];  // [P buffer = sub][row half][j]: fp16 softmax weights, B operand of the P.V MFMAs
+  float mrun[2] = {-INFINITY, -INFINITY}, lrun[2] = {0.f, 0.f};
+  float mb[2] = {W4A_BIAS, W4A_BIAS};            // P_BIAS - (m_run or 0)
+  float mthr[2] = {-INFINITY, -INFINITY};        // m_run + threshold
+  float apend[2] = {1.f, 1.f};                   // O rescale decided in the last softmax, applied before the next P.V
+  bool pend = false;
+
+  // ---- the three stages as plain loops (prologue, tail, and the whole loop when !PLACED) ---------------------------------------------
+  auto qk_stage = [&](f32x16(&S)[2], int slot, int sub) {
+    const char* kb = smem + slot * TB + sub * 8192;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const bf16x8 kf = *(const bf16x8*)(kb + kfix[ks]);
+#pragma unroll
+      for (int rh = 0; rh < 2; ++rh) {
+        if (ks == 0) W4A_QK0(S[rh], kf, qf[rh][0]);
+        else W4A_QK(S[rh], kf, qf[rh][ks]);
+      }
+    }
+  };
+  auto pv_stage = [&](u32x4(&P)[2][2], int slot, int sub) {
+    const char* vb = smem + slot * TB;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        const f16x8 vf = *(const f16x8*)(vb + db * 4096 + vfix[sub][j]);
+#pragma unroll
+        for (int rh = 0; rh < 2; ++rh) W4A_PV(oacc[rh][db], vf, P[rh][j]);
+      }
+  };
+  // O *= alpha of the last rescale decision: between two sub-iterations, i.e. after every issued P.V product and before the next
+  auto apply_pending = [&]() {
+    if (pend) {
+      asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // last MFMA results -> v_accvgpr_read (the compiler cannot see the hazard)
+#pragma unroll
+      for (int rh = 0; rh < 2; ++rh)
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[rh][db][r] *= apend[rh];
+      asm volatile("s_nop 4" ::: "memory");                             // v_accvgpr_write -> MFMA reading it as C
+      pend = false;
+    }
+  };
+  // mask of sub tile (T, sub) -- only tiles that touch the diagonal or the end of the keys (wave-uniform test)
+  auto mask_stage = [&](f32x16(&S)[2], int key0) {
+    const bool need = (key0 + 32 > sq.kv_len) || (CAUSAL && (key0 + 31 > past + wrow0));
+    if (need) {
+      asm volatile("" ::: "memory");   // a REAL branch (if-converted this costs 3 VALU per score on every tile)
+#pragma unroll
+      for (int rh = 0; rh < 2; ++rh) {
+        const int lim = CAUSAL ? min(sq.kv_len - 1, past + qrow[rh]) : (sq.kv_len - 1);   // last visible key
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (key0 + 16 * hh + r > lim) S[rh][r] = -INFINITY;
+      }
+    }
+  };
+  // rare path of the softmax: the running maximum moves (decided wave-wide), l follows at once, O at the next apply_pending()
+  auto rescale = [&](const float(&mt)[2]) {
+#pragma unroll
+    for (int rh = 0; rh < 2; ++rh) {
+      const float m_new = fmaxf(mrun[rh], mt[rh]);
+      const float alpha = (m_new == -INFINITY) ? 1.f : fast_exp2(mrun[rh] - m_new);   // m_run = -inf -> 0 (l and O are 0 then)
+      mrun[rh] = m_new;
+      lrun[rh] *= alpha;
+      apend[rh] = pend ? apend[rh] * alpha : alpha;
+      mb[rh] = W4A_BIAS - ((m_new == -INFINITY) ? 0.f : m_new);
+      mthr[rh] = m_new + W4A_THR;
+    }
+    pend = true;
+  };
+  auto sm_stage = [&](f32x16(&S)[2], u32x4(&P)[2][2], int key0) {
+    mask_stage(S, key0);
+    float mt[2];
+#pragma unroll
+    for (int rh = 0; rh < 2; ++rh) {
+      float mx = a_max3(S[rh][0], S[rh][1], S[rh][2]);
+#pragma unroll
+      for (int r = 3; r < 15; r += 2) mx = a_max3(mx, S[rh][r], S[rh][r + 1]);
+      mx = a_max(mx, S[rh][15]);
+      mt[rh] = a_max_halves(mx) * scale_log2e;
+    }
+    if (__builtin_amdgcn_ballot_w64((mt[0] > mthr[0]) || (mt[1] > mthr[1])) != 0) rescale(mt);
+#pragma unroll
+    for (int rh = 0; rh < 2; ++rh) {
+      float ps0 = 0.f, ps1 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const float e0 = a_exp2(a_fma_s(S[rh][8 * j + 2 * w], scale_log2e, mb[rh]));
+          const float e1 = a_exp2(a_fma_s(S[rh][8 * j + 2 * w + 1], scale_log2e, mb[rh]));
+          ps0 = a_add(ps0, e0);
+          ps1 = a_add(ps1, e1);
+          P[rh][j][w] = a_cvt_pk_f16(e0, e1);
+        }
+      lrun[rh] += ps0 + ps1;
+    }
+  };
+
+  // ---- prologue: tiles 0..2 in flight, scores of tile 0, softmax of its first half ---------------------------------------------------
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const __amdgpu_buffer_rsrc_t rk = W4A_RSRC(Kt, t), rv = W4A_RSRC(Vt, t);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) W4A_DMA_K(rk, t, i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) W4A_DMA_V(rv, t, i);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  qk_stage(sacc[0], 0, 0);
+  qk_stage(sacc[1], 0, 1);
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA results -> VALU
+  sm_stage(sacc[0], pfr[0], 0);
+
+  // fragment windows of the placed loop: K of k-step ks in kfr[ks % 3], V^T fragment p = (j, db) in vfr[p % 3]; the first three of
+  // each are read one sub-iteration ahead (here: K of tile 1 / sub 0 -- a re-fetched copy when there is no tile 1, never used then --
+  // and V^T of tile 0 / sub 0)
+  bf16x8 kfr[3];
+  f16x8 vfr[3];
+  if constexpr (PLACED) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      kfr[i] = *(const bf16x8*)(smem + TB + kfix[i]);
+      vfr[i] = *(const f16x8*)(smem + i * 4096 + vfix[0][0]);
+    }
+  }
+  // ---- steady state: one 64-key tile per iteration = two sub-iterations, each  P.V(u) || softmax(u+1) || Q.K^T(u+2) -----------------
+  int T = 0;
+  for (; T + 1 < ntiles; ++T) {
+    const int slot_c = T & 3, slot_n = (T + 1) & 3, slot_d = (T + 3) & 3;
+    const __amdgpu_buffer_rsrc_t rk = W4A_RSRC(Kt, T + 3), rv = W4A_RSRC(Vt, T + 3);   // past the end: the last tile again, harmless
+    if constexpr (!PLACED) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) W4A_DMA_K(rk, slot_d, i);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) W4A_DMA_V(rv, slot_d, i);
+      apply_pending();
+      pv_stage(pfr[0], slot_c, 0);
+      sm_stage(sacc[1], pfr[1], T * 64 + 32);
+      qk_stage(sacc[0], slot_n, 0);
+      apply_pending();
+      pv_stage(pfr[1], slot_c, 1);
+      sm_stage(sacc[0], pfr[0], (T + 1) * 64);
+      qk_stage(sacc[1], slot_n, 1);
+    } else {
+      // the two hand-placed sub-iterations (tools/gen_attn_w4.py; gap tables in the headers of the .inc files)
+      const int so_c = slot_c * TB, so_n = slot_n * TB, so_nn = ((T + 2) & 3) * TB;
+#include "vt_attn_w4_si0.inc"
+#include "vt_attn_w4_si1.inc"
+    }
+    // K of tile T+3 has landed (its V^T, 4 younger pieces, may stay in flight: first used three tiles from now), every fragment read of
+    // this tile is done -> slot T&3 may be refilled by the next iteration's DMA
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // ---- tail: the last tile's second half and both P.V products -----------------------------------------------------------------------
+  {
+    const int slot_c = T & 3;
+    apply_pending();
+    pv_stage(pfr[0], slot_c, 0);
+    sm_stage(sacc[1], pfr[1], T * 64 + 32);
+    apply_pending();
+    pv_stage(pfr[1], slot_c, 1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the tail's redundant pieces
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");     // last MFMA results -> the epilogue's v_accvgpr_read
+
+  // ---- epilogue ------------------------------------------------------------------------------------------------------------------------
+#pragma unroll
+  for (int rh = 0; rh < 2; ++rh) {
+    const float l_tot = lrun[rh] + __shfl_xor(lrun[rh], 32, 64);
+    const float inv = (l_tot > 0.f) ? 1.f / l_tot : 0.f;
+    if (qrow[rh] < sq.q_len) {
+      op16_t* op = O + (size_t)(sq.q_row0 + qrow[rh]) * ldo + head * HD + 4 * hh;
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          u32x2 o;
+          o.x = pack_op2(oacc[rh][db][4 * g + 0] * inv, oacc[rh][db][4 * g + 1] * inv);
+          o.y = pack_op2(oacc[rh][db][4 * g + 2] * inv, oacc[rh][db][4 * g + 3] * inv);
+          *(u32x2*)(op + db * 32 + 8 * g) = o;
+        }
+    }
+  }
+}
+
+}  // namespace
+
+bool vt_flash_attn_w4_supported(int HD, int max_q_len, int heads, int nseq) {
+  (void)heads;
+  (void)nseq;
+  return HD == 128 && max_q_len >= 1;
+}
+
+int vt_flash_attn_w4_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf16_t* Vt, const int* tile_table, const VtAttnSeq* seqs,
+                            int nseq, int max_q_len, bf16_t* O, int ldo, int heads, int causal, float scale_log2e, int placed,
+                            hipStream_t s) {
+  constexpr int smem = 8 * 16384;   // K ring + V^T ring, four 16-KiB slots each
+#define VT_FAW4(CV, PV_)                                                                                       \
+  do {                                                                                                         \
+    auto kern = flash_attn_w4_kernel<CV, PV_>;                                                                 \
+    static bool done = false;                                                                                  \
+    if (!done) {                                                                                               \
+      VT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));        \
+      done = true;                                                                                             \
+    }                                                                                                          \
+    hipLaunchKernelGGL(kern, dim3(heads, cdiv(max_q_len, 256), nseq), dim3(256), smem, s, Q, ldq, Kt, Vt, tile_table, seqs, O, ldo, \
+                       heads, scale_log2e);                                                                    \
+  } while (0)
+  if (placed) {
+    if (causal) VT_FAW4(true, true); else VT_FAW4(false, true);
+  } else {
+    if (causal) VT_FAW4(true, false); else VT_FAW4(false, false);
+  }
+#undef VT_FAW4
+  VT_LAUNCH_CHECK();
+  return VT_OK;
+}
