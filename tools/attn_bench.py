@@ -26,7 +26,8 @@ def timeit(fn, iters=10):
 def run(S, heads, hd, nseq, causal):
     dev = torch.device("cuda:0")
     D = heads * hd
-    qkv = torch.randn((nseq * S, 3 * D), device=dev).bfloat16()
+    dt = torch.float16 if os.environ.get("ATTN_BENCH_DTYPE") == "fp16" else torch.bfloat16
+    qkv = torch.randn((nseq * S, 3 * D), device=dev).to(dt)
     if os.environ.get("ATTN_BENCH_DATA") == "zeros":      # operand values change the sustained clock on this part
         qkv.zero_()
     elif os.environ.get("ATTN_BENCH_DATA") == "small":
@@ -34,10 +35,10 @@ def run(S, heads, hd, nseq, causal):
     nt = (S + 63) // 64
     desc = torch.tensor([[i * S, S, S, i * nt] for i in range(nseq)], dtype=torch.int32, device=dev)
     table = torch.arange(nseq * nt, dtype=torch.int32, device=dev)
-    kt = torch.zeros(nseq * nt * heads * 64 * hd, dtype=torch.bfloat16, device=dev)
+    kt = torch.zeros(nseq * nt * heads * 64 * hd, dtype=dt, device=dev)
     vt = torch.zeros_like(kt)
     ops.kv_tiles(qkv, 0, D, 2 * D, kt, vt, table, desc, nt, heads, hd)
-    out = torch.empty((nseq * S, D), dtype=torch.bfloat16, device=dev)
+    out = torch.empty((nseq * S, D), dtype=dt, device=dev)
     ms = timeit(lambda: ops.flash_attn(qkv, kt, vt, table, desc, S, heads, hd, causal, 1 / math.sqrt(hd), out=out))
     flops = nseq * heads * 4 * hd * (S * (S + 1) / 2 if causal else S * S)
     ms_kv = timeit(lambda: ops.kv_tiles(qkv, 0, D, 2 * D, kt, vt, table, desc, nt, heads, hd))
@@ -45,6 +46,13 @@ def run(S, heads, hd, nseq, causal):
                       "tflops": round(flops / ms / 1e9, 1), "kv_tiles_ms": round(ms_kv, 4)}), flush=True)
 
 
+if __name__ == "__main__" and os.environ.get("VT_W4_ABL"):
+    # timing ablations of the one-wave-per-SIMD kernel's placed loop (test library; results are garbage): VT_W4_ABL=<bits>
+    _lib.load(ablations=True)
+    _lib.load().vt_flash_attn_select(2)
+    run(5120, 32, 128, 1, True)
+    run(5120, 32, 128, 8, True)
+    sys.exit(0)
 if __name__ == "__main__" and os.environ.get("ATTN_BENCH_KERNELS"):
     # A/B of the head_dim-128 prefill kernels (vt_flash_attn_select): ATTN_BENCH_KERNELS=1,2,3 python tools/attn_bench.py
     _lib.load()

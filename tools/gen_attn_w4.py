@@ -51,23 +51,26 @@ def memory_ops(sub):
         g.setdefault(gap, []).append(stmt)
 
     # K fragments of THIS sub-iteration: tile T+1 (slot so_n), sub
+    # (read positions: K reads in gaps = 2 mod 4, V^T reads in gaps = 1 mod 4; the compiler's lgkmcnt waits fall into gaps = 3 and = 0
+    #  mod 4, right before the consuming MFMAs -- so every gap carries one compiler-visible instruction, and the hazard recognizer,
+    #  which counts an asm block as zero wait states, finds its wait state between two dependent blocks without adding an s_nop)
     for ks in range(3, 8):
-        put(4 * ks - 9, f"kfr[{ks % 3}] = *(const bf16x8*)(smem + so_n + {sub * 8192} + kfix[{ks}]);")
+        put(4 * ks - 10, f"kfr[{ks % 3}] = *(const bf16x8*)(smem + so_n + {sub * 8192} + kfix[{ks}]);")
     # ... and the first three of the next one: SI0 -> (T+1, sub 1), SI1 -> (T+2, sub 0)
     nxt_k = "so_n + 8192" if sub == 0 else "so_nn"
-    for ks, gap in ((2, 23), (0, 27), (1, 31)):
+    for ks, gap in ((2, 22), (0, 26), (1, 30)):
         put(gap, f"kfr[{ks}] = *(const bf16x8*)(smem + {nxt_k} + kfix[{ks}]);")
     # V^T fragments of THIS sub-iteration: tile T (slot so_c), sub
     for p in range(3, 8):
         j, db = p // 4, p % 4
-        put(4 * p - 8, f"vfr[{p % 3}] = *(const f16x8*)(smem + so_c + {db * 4096} + vfix[{sub}][{j}]);")
+        put(4 * p - 7, f"vfr[{p % 3}] = *(const f16x8*)(smem + so_c + {db * 4096} + vfix[{sub}][{j}]);")
     nxt_v = ("so_c", 1) if sub == 0 else ("so_n", 0)
-    for p, gap in ((2, 24), (0, 28), (1, 31)):
+    for p, gap in ((2, 25), (0, 29), (1, 31)):
         put(gap, f"vfr[{p}] = *(const f16x8*)(smem + {nxt_v[0]} + {p * 4096} + vfix[{nxt_v[1]}][0]);")
     if sub == 0:
-        for i, gap in enumerate((0, 2, 4, 6)):
+        for i, gap in enumerate((0, 3, 4, 7)):
             put(gap, f"W4A_DMA_K(rk, slot_d, {i});")
-        for i, gap in enumerate((10, 14, 18, 22)):
+        for i, gap in enumerate((11, 15, 19, 23)):
             put(gap, f"W4A_DMA_V(rv, slot_d, {i});")
     return g
 
@@ -124,29 +127,42 @@ def softmax_program(sub):
     """(max blocks: list of Blocks for gaps 0.., exp instruction list [(op, dst, srcs)], tail statements)."""
     sb = 1 - sub
     S = lambda rh, i: f"sacc[{sb}][{rh}][{i}]"      # noqa: E731
+    # row max of the 16 scores of a lane as a TREE (5 independent v_max3, then 2, then 1: depth 3) -- a chain of 8 dependent v_max3
+    # per row half makes the first four gaps of a sub-iteration wait on VALU latency
     chains = []
     for rh in range(2):
-        c = [("v_max3_f32", f"mx{rh}", [S(rh, 0), S(rh, 1), S(rh, 2)])]
-        for r in range(3, 15, 2):
-            c.append(("v_max3_f32", f"mx{rh}", [f"mx{rh}", S(rh, r), S(rh, r + 1)]))
-        c.append(("v_max_f32", f"mx{rh}", [f"mx{rh}", S(rh, 15)]))
+        t = [f"mx{rh}t{i}" for i in range(5)]
+        c = [("v_max3_f32", t[i], [S(rh, 3 * i), S(rh, 3 * i + 1), S(rh, 3 * i + 2)]) for i in range(5)]
+        c += [("v_max3_f32", t[0], [t[0], t[1], t[2]]),
+              ("v_max3_f32", t[3], [t[3], t[4], S(rh, 15)]),
+              ("v_max_f32", f"mx{rh}", [t[0], t[3]])]
         chains.append(c)
     maxins = []
     for a, b in zip(*chains):
         maxins += [a, b]
     ex = []
-    for k in range(8):          # pair k: scores 2k, 2k+1 -> word w of fragment j
+    pending_cvt = None          # the pack of a pair is issued behind the NEXT pair's exponentials: a transcendental result may not be
+    for k in range(8):          # consumed by the instruction right behind it (pair k: scores 2k, 2k+1 -> word w of fragment j)
         j, w = k // 4, k % 4
         for rh in range(2):
             i0, i1 = 2 * k, 2 * k + 1
-            ya, yb = f"y{rh}a", f"y{rh}b"     # temporaries, reused pair after pair (per row half)
+            # temporaries, reused pair after pair (per row half); the first pair's exponentials ARE the row-sum accumulators
+            ya, yb = (f"ps{rh}a", f"ps{rh}b") if k == 0 else (f"y{rh}a", f"y{rh}b")
             ex += [("v_fma_f32", ya, [S(rh, i0), "scale_log2e", f"mb[{rh}]"]),
                    ("v_fma_f32", yb, [S(rh, i1), "scale_log2e", f"mb[{rh}]"]),
                    ("v_exp_f32", ya, [ya]),
-                   ("v_exp_f32", yb, [yb]),
-                   ("v_add_f32", f"ps{rh}a", [f"ps{rh}a", ya]),
-                   ("v_add_f32", f"ps{rh}b", [f"ps{rh}b", yb]),
-                   ("v_cvt_pk_f16_f32", f"pfr[{sb}][{rh}][{j}][{w}]", [ya, yb])]
+                   ("v_exp_f32", yb, [yb])]
+            if pending_cvt is not None:
+                ex.append(pending_cvt)
+            if k > 0:
+                ex += [("v_add_f32", f"ps{rh}a", [f"ps{rh}a", ya]),
+                       ("v_add_f32", f"ps{rh}b", [f"ps{rh}b", yb])]
+            pending_cvt = ("v_cvt_pk_f16_f32", f"pfr[{sb}][{rh}][{j}][{w}]", [ya, yb])
+    ex.append(pending_cvt)
+    # (the last pack follows two adds: its inputs were written three instructions earlier)
+    for n in range(1, len(ex)):
+        if ex[n - 1][0] == "v_exp_f32":
+            assert ex[n - 1][1] not in ex[n][2], (n, ex[n - 1], ex[n])
     return maxins, ex
 
 
@@ -167,14 +183,15 @@ def generate(sub):
            "{",
            "  apply_pending();",
            f"  mask_stage(sacc[{sb}], {'T * 64 + 32' if sub == 0 else '(T + 1) * 64'});",
-           "  float mx0, mx1, mt[2];",
+           "  float mx0, mx1, mxh[2];",
+           "  float mx0t0, mx0t1, mx0t2, mx0t3, mx0t4, mx1t0, mx1t1, mx1t2, mx1t3, mx1t4;",
            "  float y0a, y0b, y1a, y1b;",
-           "  float ps0a = 0.f, ps0b = 0.f, ps1a = 0.f, ps1b = 0.f;"]
+           "  float ps0a, ps0b, ps1a, ps1b;"]
     counts = []
     qi = 0
     for gap in range(n_gaps):
         out.append(f"  // ---- MFMA {gap}")
-        out.append("  " + mfma(gap, sub))
+        out.append(f"  if constexpr (!(ABL & {16 if gap % 2 else 32})) " + mfma(gap, sub))      # ablations 16 / 32: no P.V / no score MFMAs
         blk = Block()
         post = []
         if gap < max_gaps:
@@ -182,10 +199,9 @@ def generate(sub):
             for ins in maxins[gap * share:(gap + 1) * share]:
                 blk.add(ins[0], ins[1], *ins[2])
             if gap == max_gaps - 1:
-                # half-wave exchange, scale, wave-wide test (compiler-visible: it knows the permlane / v_cmp hazards), rare rescale
-                post += ["mt[0] = a_max_halves(mx0) * scale_log2e;",
-                         "mt[1] = a_max_halves(mx1) * scale_log2e;",
-                         "if (__builtin_amdgcn_ballot_w64((mt[0] > mthr[0]) || (mt[1] > mthr[1])) != 0) rescale(mt);"]
+                # wave-wide test on the half-row maxima (two compares + a scalar or); the exchange and the scaling live in the rare path
+                post += ["mxh[0] = mx0;", "mxh[1] = mx1;",
+                         "if (__builtin_expect((__builtin_amdgcn_ballot_w64(mx0 > mthr[0]) | __builtin_amdgcn_ballot_w64(mx1 > mthr[1])) != 0, 0)) rescale(mxh);"]
         else:
             left_gaps = n_gaps - gap
             left = len(ex) - qi
@@ -197,16 +213,25 @@ def generate(sub):
             for ins in ex[qi:qi + take]:
                 blk.add(ins[0], ins[1], *ins[2])
             qi += take
-        out += blk.emit()
+        emitted = blk.emit()
+        if emitted and gap >= max_gaps:          # timing ablation 2 (test library): no exp phase
+            out.append("  if constexpr (!(ABL & 2)) {")
+            out += ["  " + e for e in emitted]
+            out.append("  }")
+        else:
+            out += emitted
         for s in post:
             out.append("  " + s)
         for s in mem.get(gap, []):
-            out.append("  " + s)
+            if "W4A_DMA" in s:
+                out.append("  if constexpr (!(ABL & 1)) " + s)        # timing ablation 1: no LDS-DMA in the loop
+            else:
+                out.append("  if constexpr (!(ABL & 4)) " + s)        # timing ablation 4: no fragment reads
         if gap == n_gaps - 1:
             out.append("  lrun[0] += ps0a + ps0b;")
             out.append("  lrun[1] += ps1a + ps1b;")
         out.append("  __builtin_amdgcn_sched_barrier(0);")
-        counts.append(len(blk) + len(mem.get(gap, [])) + (8 if post else 0))
+        counts.append(len(blk) + len(mem.get(gap, [])) + (5 if post else 0))
     assert qi == len(ex)
     out.append("}")
     out.insert(1, f"// instructions placed per MFMA gap (without the compiler's own waits / address adds): {counts}  total {sum(counts)}")

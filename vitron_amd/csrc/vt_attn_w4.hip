@@ -53,11 +53,15 @@ __device__ __forceinline__ float a_fma_s(float s, float scale_sgpr, float add) {
 __device__ __forceinline__ float a_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float a_add(float a, float b) { return a + b; }
 __device__ __forceinline__ uint32_t a_cvt_pk_f16(float lo, float hi) { return pack_f16x2(lo, hi); }
-// value of the other half-wave's lane (lane ^ 32) combined by max: one v_permlane32_swap + one v_max
+// max of a value with the other half-wave's lane (lane ^ 32): v_permlane32_swap exchanges the upper half of its first operand with
+// the lower half of its second; with both holding x the results are (x_lo, x_lo) and (x_hi, x_hi), and their max is the row's.
+// Spelled in asm: this toolchain's __builtin_amdgcn_permlane32_swap hands back its FIRST result for both elements of the pair it
+// returns (checked in the ISA: the max of the halves silently became max(own half, own half), harmless on mild scores because of the
+// deferred-rescale slack, overflowing the fp16 softmax weights on wide ones). s_nop 1: VALU write -> permlane read.
 __device__ __forceinline__ float a_max_halves(float x) {
-  const unsigned u = __builtin_bit_cast(unsigned, x);
-  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-  return a_max(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+  float t, y = x;
+  asm("v_mov_b32 %0, %1\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_max_f32 %0, %0, %1" : "=&v"(t), "+v"(y));
+  return t;
 }
 
 #define W4A_QK0(D, A, B) asm volatile(VT_MFMA_32x32x16_ASM " %0, %1, %2, 0" : "=&v"(D) : "v"(A), "a"(B))
@@ -65,7 +69,9 @@ __device__ __forceinline__ float a_max_halves(float x) {
 #define W4A_PV(D, A, B) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(D) : "v"(A), "v"(B))
 #define W4A_LDS(p) ((__attribute__((address_space(3))) void*)(p))
 
-template <bool CAUSAL, bool PLACED>
+// ABL (timing ablations of the placed loop, results are garbage; test library only): 1 = no LDS-DMA, 2 = no exp phase of the softmax,
+// 4 = no fragment reads, 8 = no end-of-tile waits / barrier, 16 = no P.V MFMAs, 32 = no score MFMAs
+template <bool CAUSAL, bool PLACED, int ABL = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void flash_attn_w4_kernel(
     const op16_t* __restrict__ Q, int ldq, const op16_t* __restrict__ Kt, const op16_t* __restrict__ Vt,
     const int* __restrict__ tile_table, const VtAttnSeq* __restrict__ seqs, op16_t* __restrict__ O, int ldo, int heads,
@@ -120,7 +126,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const size_t tile_stride = (size_t)heads * 64 * HD;
   const int* table = tile_table + sq.table_off;
   // (the pool can exceed 4 GiB: the buffer resource is rebuilt per tile around the tile's own 16 KiB -- scalar work only)
-#define W4A_RSRC(BASE, T) __builtin_amdgcn_make_buffer_rsrc((void*)((BASE) + (size_t)table[min((T), ntiles - 1)] * tile_stride + head_off), 0, TB, 0x00020000)
+#define W4A_RSRC_PG(BASE, PG) __builtin_amdgcn_make_buffer_rsrc((void*)((BASE) + (size_t)(PG) * tile_stride + head_off), 0, TB, 0x00020000)
+#define W4A_RSRC(BASE, T) W4A_RSRC_PG(BASE, table[min((T), ntiles - 1)])
 #define W4A_DMA_K(R, SLOT, I) __builtin_amdgcn_raw_ptr_buffer_load_lds(R, W4A_LDS(smem + (SLOT) * TB + (wave * 4 + (I)) * 1024), 16, k_vo[I], 0, 0, 0)
 #define W4A_DMA_V(R, SLOT, I) __builtin_amdgcn_raw_ptr_buffer_load_lds(R, W4A_LDS(smem + VRING + (SLOT) * TB + (wave * 4 + (I)) * 1024), 16, v_vo[I], 0, 0, 0)
 
@@ -149,10 +156,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   u32x4 pfr[2][2][2];  // [P buffer = sub][row half][j]: fp16 softmax weights, B operand of the P.V MFMAs
   float mrun[2] = {-INFINITY, -INFINITY}, lrun[2] = {0.f, 0.f};
   float mb[2] = {W4A_BIAS, W4A_BIAS};            // P_BIAS - (m_run or 0)
-  float mthr[2] = {-INFINITY, -INFINITY};        // m_run + threshold
+  float mthr[2] = {-INFINITY, -INFINITY};        // (m_run + threshold) / scale_log2e: what a RAW score is compared with
   float apend[2] = {1.f, 1.f};                   // O rescale decided in the last softmax, applied before the next P.V
   bool pend = false;
 
+  // a wait that the accumulator reads / writes around it cannot be moved across
+#define W4A_SETTLE_O()                                                                                                              \
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15"                                                                                   \
+               : "+a"(oacc[0][0]), "+a"(oacc[0][1]), "+a"(oacc[0][2]), "+a"(oacc[0][3]), "+a"(oacc[1][0]), "+a"(oacc[1][1]),       \
+                 "+a"(oacc[1][2]), "+a"(oacc[1][3]))
   // ---- the three stages as plain loops (prologue, tail, and the whole loop when !PLACED) ---------------------------------------------
   auto qk_stage = [&](f32x16(&S)[2], int slot, int sub) {
     const char* kb = smem + slot * TB + sub * 8192;
@@ -165,6 +177,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         else W4A_QK(S[rh], kf, qf[rh][ks]);
       }
     }
+    // MFMA results -> VALU: the compiler cannot see that the asm above is an MFMA, and the softmax of this stage-by-stage form is
+    // compiler-visible arithmetic that it is free to hoist right behind it; the wait takes S as operands so that nothing crosses it.
+    // (The placed loop consumes S a whole sub-iteration later, through asm blocks in program order.)
+    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(S[0]), "+v"(S[1]));
   };
   auto pv_stage = [&](u32x4(&P)[2][2], int slot, int sub) {
     const char* vb = smem + slot * TB;
@@ -179,22 +195,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   };
   // O *= alpha of the last rescale decision: between two sub-iterations, i.e. after every issued P.V product and before the next
   auto apply_pending = [&]() {
-    if (pend) {
-      asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // last MFMA results -> v_accvgpr_read (the compiler cannot see the hazard)
+    if (__builtin_expect(pend, 0)) {      // (cold: laid out behind the loop, the hot path falls through)
+      // last MFMA results -> v_accvgpr_read: the compiler cannot see the hazard, and a bare s_nop statement does not hold the reads
+      // back either (they have no dependence on it and were hoisted above it): the wait takes the accumulators as operands
+      W4A_SETTLE_O();
 #pragma unroll
       for (int rh = 0; rh < 2; ++rh)
 #pragma unroll
         for (int db = 0; db < 4; ++db)
 #pragma unroll
           for (int r = 0; r < 16; ++r) oacc[rh][db][r] *= apend[rh];
-      asm volatile("s_nop 4" ::: "memory");                             // v_accvgpr_write -> MFMA reading it as C
+      W4A_SETTLE_O();                                                   // v_accvgpr_write -> MFMA reading it as C
       pend = false;
     }
   };
   // mask of sub tile (T, sub) -- only tiles that touch the diagonal or the end of the keys (wave-uniform test)
   auto mask_stage = [&](f32x16(&S)[2], int key0) {
     const bool need = (key0 + 32 > sq.kv_len) || (CAUSAL && (key0 + 31 > past + wrow0));
-    if (need) {
+    if (__builtin_expect(need, 0)) {
       asm volatile("" ::: "memory");   // a REAL branch (if-converted this costs 3 VALU per score on every tile)
 #pragma unroll
       for (int rh = 0; rh < 2; ++rh) {
@@ -206,31 +224,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
   };
   // rare path of the softmax: the running maximum moves (decided wave-wide), l follows at once, O at the next apply_pending()
-  auto rescale = [&](const float(&mt)[2]) {
+  // (the common path only asks "does any half row's raw maximum exceed its threshold": two compares and a scalar or; the half-wave
+  // exchange that makes the row maximum, and the scaling, happen here)
+  const float inv_scale = 1.0f / scale_log2e;
+  auto rescale = [&](const float(&mxh)[2]) {
 #pragma unroll
     for (int rh = 0; rh < 2; ++rh) {
-      const float m_new = fmaxf(mrun[rh], mt[rh]);
+      const float m_new = fmaxf(mrun[rh], a_max_halves(mxh[rh]) * scale_log2e);
       const float alpha = (m_new == -INFINITY) ? 1.f : fast_exp2(mrun[rh] - m_new);   // m_run = -inf -> 0 (l and O are 0 then)
       mrun[rh] = m_new;
       lrun[rh] *= alpha;
       apend[rh] = pend ? apend[rh] * alpha : alpha;
       mb[rh] = W4A_BIAS - ((m_new == -INFINITY) ? 0.f : m_new);
-      mthr[rh] = m_new + W4A_THR;
+      mthr[rh] = (m_new + W4A_THR) * inv_scale;
     }
     pend = true;
   };
   auto sm_stage = [&](f32x16(&S)[2], u32x4(&P)[2][2], int key0) {
     mask_stage(S, key0);
-    float mt[2];
+    float mxh[2];
 #pragma unroll
     for (int rh = 0; rh < 2; ++rh) {
       float mx = a_max3(S[rh][0], S[rh][1], S[rh][2]);
 #pragma unroll
       for (int r = 3; r < 15; r += 2) mx = a_max3(mx, S[rh][r], S[rh][r + 1]);
-      mx = a_max(mx, S[rh][15]);
-      mt[rh] = a_max_halves(mx) * scale_log2e;
+      mxh[rh] = a_max(mx, S[rh][15]);
     }
-    if (__builtin_amdgcn_ballot_w64((mt[0] > mthr[0]) || (mt[1] > mthr[1])) != 0) rescale(mt);
+    if (__builtin_expect((__builtin_amdgcn_ballot_w64(mxh[0] > mthr[0]) | __builtin_amdgcn_ballot_w64(mxh[1] > mthr[1])) != 0, 0)) rescale(mxh);
 #pragma unroll
     for (int rh = 0; rh < 2; ++rh) {
       float ps0 = 0.f, ps1 = 0.f;
@@ -262,7 +282,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   __builtin_amdgcn_sched_barrier(0);
   qk_stage(sacc[0], 0, 0);
   qk_stage(sacc[1], 0, 1);
-  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // MFMA results -> VALU
   sm_stage(sacc[0], pfr[0], 0);
 
   // fragment windows of the placed loop: K of k-step ks in kfr[ks % 3], V^T fragment p = (j, db) in vfr[p % 3]; the first three of
@@ -279,34 +298,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
   // ---- steady state: one 64-key tile per iteration = two sub-iterations, each  P.V(u) || softmax(u+1) || Q.K^T(u+2) -----------------
   int T = 0;
-  for (; T + 1 < ntiles; ++T) {
-    const int slot_c = T & 3, slot_n = (T + 1) & 3, slot_d = (T + 3) & 3;
-    const __amdgpu_buffer_rsrc_t rk = W4A_RSRC(Kt, T + 3), rv = W4A_RSRC(Vt, T + 3);   // past the end: the last tile again, harmless
-    if constexpr (!PLACED) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) W4A_DMA_K(rk, slot_d, i);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) W4A_DMA_V(rv, slot_d, i);
-      apply_pending();
-      pv_stage(pfr[0], slot_c, 0);
-      sm_stage(sacc[1], pfr[1], T * 64 + 32);
-      qk_stage(sacc[0], slot_n, 0);
-      apply_pending();
-      pv_stage(pfr[1], slot_c, 1);
-      sm_stage(sacc[0], pfr[0], (T + 1) * 64);
-      qk_stage(sacc[1], slot_n, 1);
-    } else {
-      // the two hand-placed sub-iterations (tools/gen_attn_w4.py; gap tables in the headers of the .inc files)
-      const int so_c = slot_c * TB, so_n = slot_n * TB, so_nn = ((T + 2) & 3) * TB;
-#include "vt_attn_w4_si0.inc"
-#include "vt_attn_w4_si1.inc"
-    }
-    // K of tile T+3 has landed (its V^T, 4 younger pieces, may stay in flight: first used three tiles from now), every fragment read of
-    // this tile is done -> slot T&3 may be refilled by the next iteration's DMA
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
+  int pg = table[min(3, ntiles - 1)];     // page of the tile the next body fetches: read one body ahead (a scalar load at the top of the
+                                          // body would make the wave wait for it AND for every fragment read in flight)
+  // One body per ring slot: the loop is unrolled four times so that every LDS offset of a body (fragment reads, DMA destinations) is an
+  // instruction immediate -- with run-time slots each of the 32 fragment reads of a tile cost a scalar add and a vector add on top
+  // (PMC of the first version: 8.1 instructions per MFMA, issue-bound; the MFMA itself takes about three of the eight issue slots of
+  // its 32 cycles). The body is vt_attn_w4_body.inc, included once per slot.
+  for (;;) {
+    if (T + 1 >= ntiles) break;
+#define W4A_SC 0
+#include "vt_attn_w4_body.inc"
+#undef W4A_SC
+    if (T + 1 >= ntiles) break;
+#define W4A_SC 1
+#include "vt_attn_w4_body.inc"
+#undef W4A_SC
+    if (T + 1 >= ntiles) break;
+#define W4A_SC 2
+#include "vt_attn_w4_body.inc"
+#undef W4A_SC
+    if (T + 1 >= ntiles) break;
+#define W4A_SC 3
+#include "vt_attn_w4_body.inc"
+#undef W4A_SC
   }
   // ---- tail: the last tile's second half and both P.V products -----------------------------------------------------------------------
   {
@@ -318,7 +332,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     pv_stage(pfr[1], slot_c, 1);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the tail's redundant pieces
-  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");     // last MFMA results -> the epilogue's v_accvgpr_read
+  W4A_SETTLE_O();                                                    // last MFMA results -> the epilogue's v_accvgpr_read
 
   // ---- epilogue ------------------------------------------------------------------------------------------------------------------------
 #pragma unroll
@@ -352,9 +366,9 @@ int vt_flash_attn_w4_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf
                             int nseq, int max_q_len, bf16_t* O, int ldo, int heads, int causal, float scale_log2e, int placed,
                             hipStream_t s) {
   constexpr int smem = 8 * 16384;   // K ring + V^T ring, four 16-KiB slots each
-#define VT_FAW4(CV, PV_)                                                                                       \
+#define VT_FAW4(CV, PV_, ...)                                                                                  \
   do {                                                                                                         \
-    auto kern = flash_attn_w4_kernel<CV, PV_>;                                                                 \
+    auto kern = flash_attn_w4_kernel<CV, PV_ __VA_OPT__(,) __VA_ARGS__>;                                                                 \
     static bool done = false;                                                                                  \
     if (!done) {                                                                                               \
       VT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));        \
@@ -363,6 +377,29 @@ int vt_flash_attn_w4_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf
     hipLaunchKernelGGL(kern, dim3(heads, cdiv(max_q_len, 256), nseq), dim3(256), smem, s, Q, ldq, Kt, Vt, tile_table, seqs, O, ldo, \
                        heads, scale_log2e);                                                                    \
   } while (0)
+#ifdef VT_ABLATIONS   // VT_W4_ABL=<bits> python tools/attn_bench.py (test library only)
+  static const int abl = getenv("VT_W4_ABL") ? atoi(getenv("VT_W4_ABL")) : 0;
+  if (placed && causal && abl) {
+    switch (abl) {
+      case 1: VT_FAW4(true, true, 1); break;
+      case 2: VT_FAW4(true, true, 2); break;
+      case 3: VT_FAW4(true, true, 3); break;
+      case 4: VT_FAW4(true, true, 4); break;
+      case 5: VT_FAW4(true, true, 5); break;
+      case 6: VT_FAW4(true, true, 6); break;
+      case 7: VT_FAW4(true, true, 7); break;
+      case 8: VT_FAW4(true, true, 8); break;
+      case 9: VT_FAW4(true, true, 9); break;
+      case 15: VT_FAW4(true, true, 15); break;
+      case 31: VT_FAW4(true, true, 31); break;
+      case 47: VT_FAW4(true, true, 47); break;
+      case 63: VT_FAW4(true, true, 63); break;
+      default: VT_FAW4(true, true); break;
+    }
+    VT_LAUNCH_CHECK();
+    return VT_OK;
+  }
+#endif
   if (placed) {
     if (causal) VT_FAW4(true, true); else VT_FAW4(false, true);
   } else {
