@@ -680,3 +680,52 @@ def test_serving_admission_host_logic_with_a_stub_model(monkeypatch):
     w = eng2.submit(ids(10), max_new_tokens=2)
     assert eng2.cancel(w) is True and not eng2.waiting
     assert (a, b, c, big) == (0, 1, 2, 3)
+
+
+def test_hand_placed_attention_kernel_compiles_without_scratch():
+    """flash_attn_w4_kernel counts its LDS-DMA pieces with s_waitcnt vmcnt(N): a register spill would put scratch accesses -- which
+    count in vmcnt too -- between them and turn the counted wait into a race (seen once on the GPU, in the reference form of the
+    kernel). Both operand builds of every variant must therefore compile with ScratchSize 0 and stay inside the register file of one
+    wave per SIMD; hipcc cross-compiles for gfx950 without a GPU (3 s per build)."""
+    import shutil
+    import subprocess
+    import tempfile
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "vitron_amd", "csrc", "vt_attn_w4.hip")
+    for extra in ([], ["-DVT_OPERAND_F16=1"]):
+        with tempfile.TemporaryDirectory() as tmp:
+            r = subprocess.run([hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fno-slp-vectorize", "-Rpass-analysis=kernel-resource-usage",
+                                *extra, "-c", src, "-o", os.path.join(tmp, "w4.o")], capture_output=True, text=True, cwd=tmp)
+        assert r.returncode == 0, r.stderr[-2000:]
+        names = re.findall(r"Function Name: (\S+)", r.stderr)
+        scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", r.stderr)]
+        vgprs = [int(x) for x in re.findall(r" VGPRs: (\d+)", r.stderr)]
+        agprs = [int(x) for x in re.findall(r"AGPRs: (\d+)", r.stderr)]
+        assert len(names) == 4 and all("flash_attn_w4_kernel" in n for n in names), names      # causal / not x placed / reference
+        assert scratch == [0, 0, 0, 0], dict(zip(names, scratch))
+        assert all(v <= 256 for v in vgprs) and all(a <= 256 for a in agprs), (vgprs, agprs)
+
+
+def test_hand_placed_attention_schedule_is_what_the_generator_emits():
+    """vt_attn_w4_si0.inc / si1.inc are generated (tools/gen_attn_w4.py): the committed files must be the generator's output, every
+    sub-iteration must carry its 32 MFMAs (16 score + 16 P.V), 8 + 8 fragment reads, and SI0 the 8 LDS-DMA pieces of the tile."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_attn_w4", os.path.join(ROOT, "tools", "gen_attn_w4.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    for sub in (0, 1):
+        text = gen.generate(sub)
+        with open(os.path.join(ROOT, "vitron_amd", "csrc", f"vt_attn_w4_si{sub}.inc")) as f:
+            assert f.read() == text, f"vt_attn_w4_si{sub}.inc is stale: run python tools/gen_attn_w4.py"
+        assert text.count("W4A_QK(") + text.count("W4A_QK0(") == 16 and text.count("W4A_PV(") == 16
+        assert text.count("kfr[") - text.count("kfr[", 0, 0) >= 8 and len(re.findall(r"kfr\[\d\] = ", text)) == 8 and len(re.findall(r"vfr\[\d\] = ", text)) == 8
+        assert text.count("W4A_DMA_K(") == (4 if sub == 0 else 0) and text.count("W4A_DMA_V(") == (4 if sub == 0 else 0)
+        assert text.count("v_exp_f32") == 32 and text.count("v_cvt_pk_f16_f32") == 16 and text.count("v_fma_f32") == 32
+        # a transcendental result is never consumed by the instruction right behind it inside a block (the hardware asks for one wait state)
+        for blk in re.findall(r'asm volatile\("([^"]*)"', text):
+            ins = blk.split("\\n\\t")
+            for a, b in zip(ins, ins[1:]):
+                if a.startswith("v_exp_f32"):
+                    assert a.split()[1].rstrip(",") not in [x.rstrip(",") for x in b.split()[2:]], (a, b)

@@ -181,8 +181,8 @@ def generate(sub):
     max_gaps = 4                      # 16 v_max3/v_max: 4 per gap
     out = [f"// generated by tools/gen_attn_w4.py -- sub-iteration SI{sub} of flash_attn_w4_kernel; do not edit by hand",
            "{",
-           "  apply_pending();",
-           f"  mask_stage(sacc[{sb}], {'T * 64 + 32' if sub == 0 else '(T + 1) * 64'});",
+           "  if constexpr (!(ABL & 128)) apply_pending();",
+           f"  if constexpr (!(ABL & 128)) mask_stage(sacc[{sb}], {'T * 64 + 32' if sub == 0 else '(T + 1) * 64'});",
            "  float mx0, mx1, mxh[2];",
            "  float mx0t0, mx0t1, mx0t2, mx0t3, mx0t4, mx1t0, mx1t1, mx1t2, mx1t3, mx1t4;",
            "  float y0a, y0b, y1a, y1b;",
@@ -214,14 +214,14 @@ def generate(sub):
                 blk.add(ins[0], ins[1], *ins[2])
             qi += take
         emitted = blk.emit()
-        if emitted and gap >= max_gaps:          # timing ablation 2 (test library): no exp phase
-            out.append("  if constexpr (!(ABL & 2)) {")
+        if emitted:          # timing ablations (test library): 2 = no exp phase, 64 = no max phase / rescale test
+            out.append(f"  if constexpr (!(ABL & {2 if gap >= max_gaps else 64})) {{")
             out += ["  " + e for e in emitted]
             out.append("  }")
-        else:
-            out += emitted
-        for s in post:
-            out.append("  " + s)
+        if post:
+            out.append("  if constexpr (!(ABL & 64)) {")
+            out += ["    " + s for s in post]
+            out.append("  }")
         for s in mem.get(gap, []):
             if "W4A_DMA" in s:
                 out.append("  if constexpr (!(ABL & 1)) " + s)        # timing ablation 1: no LDS-DMA in the loop

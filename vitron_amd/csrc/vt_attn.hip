@@ -983,9 +983,10 @@ int vt_flash_attn_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf16_
   // head_dim 128, long sequences: the one-wave-per-SIMD kernel on 256-row blocks (vt_attn_w4.hip) once its grid fills the chip --
   // (heads x sequences x 256-row blocks) >= 256 workgroups, one per CU; shorter prompts keep the 128-row blocks below (two per CU)
   if (HD == 128 && g_vt_flash_attn_kernel != 1) {
+    const bool aligned = ldo % 8 == 0 && (((size_t)O) & 15) == 0;   // it stores 16-byte chunks
     const bool fills = (long)heads * nseq * cdiv(max_q_len, 256) >= 256 && max_q_len >= 1024;
-    if (g_vt_flash_attn_kernel >= 2 || fills) {
-      VT_REQUIRE(ldo % 4 == 0, "vt_flash_attn: ldo %% 4 must be 0");
+    if (g_vt_flash_attn_kernel >= 2 || (fills && aligned)) {
+      VT_REQUIRE(aligned, "vt_flash_attn: the one-wave-per-SIMD kernel stores 16-byte chunks: O 16-byte aligned, ldo %% 8 == 0");
       return vt_flash_attn_w4_launch(Q, ldq, Kt, Vt, tile_table, seqs, nseq, max_q_len, O, ldo, heads, causal, sl2,
                                      g_vt_flash_attn_kernel == 3 ? 0 : 1, s);
     }

@@ -304,23 +304,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // instruction immediate -- with run-time slots each of the 32 fragment reads of a tile cost a scalar add and a vector add on top
   // (PMC of the first version: 8.1 instructions per MFMA, issue-bound; the MFMA itself takes about three of the eight issue slots of
   // its 32 cycles). The body is vt_attn_w4_body.inc, included once per slot.
-  for (;;) {
-    if (T + 1 >= ntiles) break;
+  if constexpr (PLACED) {
+    for (;;) {
+      if (T + 1 >= ntiles) break;
 #define W4A_SC 0
 #include "vt_attn_w4_body.inc"
 #undef W4A_SC
-    if (T + 1 >= ntiles) break;
+      if (T + 1 >= ntiles) break;
 #define W4A_SC 1
 #include "vt_attn_w4_body.inc"
 #undef W4A_SC
-    if (T + 1 >= ntiles) break;
+      if (T + 1 >= ntiles) break;
 #define W4A_SC 2
 #include "vt_attn_w4_body.inc"
 #undef W4A_SC
-    if (T + 1 >= ntiles) break;
+      if (T + 1 >= ntiles) break;
 #define W4A_SC 3
 #include "vt_attn_w4_body.inc"
 #undef W4A_SC
+    }
+  } else {
+    // the reference form: stages one after the other, run-time ring slots, uncounted waits -- kept as simple as possible
+    for (; T + 1 < ntiles; ++T) {
+      const int slot_c = T & 3, slot_n = (T + 1) & 3, slot_d = (T + 3) & 3;
+      const __amdgpu_buffer_rsrc_t rk = W4A_RSRC(Kt, T + 3), rv = W4A_RSRC(Vt, T + 3);   // past the end: the last tile again, harmless
+#pragma unroll
+      for (int i = 0; i < 4; ++i) W4A_DMA_K(rk, slot_d, i);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) W4A_DMA_V(rv, slot_d, i);
+      apply_pending();
+      pv_stage(pfr[0], slot_c, 0);
+      sm_stage(sacc[1], pfr[1], T * 64 + 32);
+      qk_stage(sacc[0], slot_n, 0);
+      apply_pending();
+      pv_stage(pfr[1], slot_c, 1);
+      sm_stage(sacc[0], pfr[0], (T + 1) * 64);
+      qk_stage(sacc[1], slot_n, 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
   // ---- tail: the last tile's second half and both P.V products -----------------------------------------------------------------------
   {
@@ -334,22 +358,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the tail's redundant pieces
   W4A_SETTLE_O();                                                    // last MFMA results -> the epilogue's v_accvgpr_read
 
-  // ---- epilogue ------------------------------------------------------------------------------------------------------------------------
+  // ---- epilogue: O / l, packed to 16 bit, staged through LDS and stored as whole rows -------------------------------------------------
+  // A lane holds 4 consecutive d (8 bytes) of ITS row per (d block, group): stored straight from the registers that is 32 eight-byte
+  // stores per lane, each instruction touching 32 rows -- store-ISSUE-bound (the guide prices such a tail at ~9k cycles per block; with
+  // one workgroup per CU nothing overlaps it). Instead every wave parks its 64 rows x 256 B in the K ring (not read any more: the
+  // barrier below is behind everybody's last K read AND behind everybody's last LDS-DMA, whose redundant tail pieces would otherwise
+  // land on the staged rows), 16-byte chunks XOR-swizzled by the row, and stores 16 bytes per lane: one instruction = 4 rows of 256
+  // contiguous bytes.
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");      // (the barrier builtin is not a compiler fence for LDS accesses)
+  char* stage = smem + wave * (64 * 256);
 #pragma unroll
   for (int rh = 0; rh < 2; ++rh) {
     const float l_tot = lrun[rh] + __shfl_xor(lrun[rh], 32, 64);
     const float inv = (l_tot > 0.f) ? 1.f / l_tot : 0.f;
-    if (qrow[rh] < sq.q_len) {
-      op16_t* op = O + (size_t)(sq.q_row0 + qrow[rh]) * ldo + head * HD + 4 * hh;
+    const int row = rh * 32 + ql;
 #pragma unroll
-      for (int db = 0; db < 4; ++db)
+    for (int db = 0; db < 4; ++db)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          u32x2 o;
-          o.x = pack_op2(oacc[rh][db][4 * g + 0] * inv, oacc[rh][db][4 * g + 1] * inv);
-          o.y = pack_op2(oacc[rh][db][4 * g + 2] * inv, oacc[rh][db][4 * g + 3] * inv);
-          *(u32x2*)(op + db * 32 + 8 * g) = o;
-        }
+      for (int g = 0; g < 4; ++g) {
+        u32x2 o;
+        o.x = pack_op2(oacc[rh][db][4 * g + 0] * inv, oacc[rh][db][4 * g + 1] * inv);
+        o.y = pack_op2(oacc[rh][db][4 * g + 2] * inv, oacc[rh][db][4 * g + 3] * inv);
+        *(u32x2*)(stage + row * 256 + (((db * 4 + g) ^ (row & 15)) << 4) + hh * 8) = o;      // d = db*32 + 8g + 4hh .. +3
+      }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the wave's own writes (the region is wave-private: no barrier)
+  {
+    const int c = lane & 15, r4 = lane >> 4;             // 16-byte chunk of the row, row inside a group of 4
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = i * 4 + r4;
+      const u32x4 v = *(const u32x4*)(stage + row * 256 + ((c ^ (row & 15)) << 4));
+      if (wrow0 + row < sq.q_len) *(u32x4*)(O + (size_t)(sq.q_row0 + wrow0 + row) * ldo + head * HD + c * 8) = v;
     }
   }
 }
@@ -394,6 +436,9 @@ int vt_flash_attn_w4_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf
       case 31: VT_FAW4(true, true, 31); break;
       case 47: VT_FAW4(true, true, 47); break;
       case 63: VT_FAW4(true, true, 63); break;
+      case 127: VT_FAW4(true, true, 127); break;
+      case 191: VT_FAW4(true, true, 191); break;
+      case 255: VT_FAW4(true, true, 255); break;
       default: VT_FAW4(true, true); break;
     }
     VT_LAUNCH_CHECK();
