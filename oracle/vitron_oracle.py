@@ -415,16 +415,27 @@ def llama_forward(sd: SD, cfg: dict, inputs_embeds: torch.Tensor, position_ids: 
 
 def greedy_generate(sd: SD, cfg: dict, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor,
                     position_ids: torch.Tensor, max_new_tokens: int, emulate_bf16: bool = False,
-                    eos_token_id: Optional[int] = None):
+                    eos_token_id: Optional[int] = None, ids_mask: Optional[torch.Tensor] = None):
     """Greedy GenerationMixin loop with Vitron's decode-step fix-up (reference llava_arch.py:196-205): on every
-    step the mask is extended to past_len+1 and position_ids = sum(mask) - 1. Returns [B, <=max_new_tokens] ids."""
+    step the mask is extended to past_len+1 and position_ids = sum(mask) - 1. Returns [B, <=max_new_tokens] ids.
+
+    ids_mask=None: the mask that is extended is the spliced one and the first token is read at every sample's last VALID row --
+    for batch 1 (what app.py / inference_image.py run) that is exactly the reference, and for a padded batch it is what every
+    sample gets when run alone (the behaviour vitron_amd keeps by packing).
+    ids_mask=[B, L_ids] (the mask generate() was CALLED with): the reference's padded-batch behaviour to the letter -- transformers
+    4.31's greedy_search reads logits[:, -1] (a pad row for a right-padded shorter sample) and carries the ids-length mask, which
+    the fix-up extends with ones, so pad rows of the spliced batch are attended (pinned by tests/golden/greedy_batch.npz)."""
     B = inputs_embeds.shape[0]
     embed = sd["model.embed_tokens.weight"].float()
     logits, past = llama_forward(sd, cfg, inputs_embeds, position_ids, attention_mask, None, emulate_bf16)
-    last = attention_mask.long().sum(1) - 1  # right padding: last valid position
-    nxt = logits[torch.arange(B), last].argmax(-1)
+    if ids_mask is None:
+        last = attention_mask.long().sum(1) - 1  # right padding: last valid position
+        nxt = logits[torch.arange(B), last].argmax(-1)
+        mask = attention_mask.clone()
+    else:
+        nxt = logits[:, -1].argmax(-1)
+        mask = ids_mask.clone()
     out = [nxt]
-    mask = attention_mask.clone()
     finished = torch.zeros(B, dtype=torch.bool)
     for _ in range(max_new_tokens - 1):
         if eos_token_id is not None:

@@ -420,6 +420,81 @@ def gen_greedy(ns):
           f"{time.time() - t0:.1f}s")
 
 
+def _padded_batch_greedy_hf431(model, embeds, spliced_mask, position_ids, ids_mask, embed_table, steps):
+    """The reference's B > 1 generate(), restated step by step over the REFERENCE's own forward (with its KV cache):
+      * prefill: LlavaLlamaForCausalLM.forward on the spliced, right-padded batch with the spliced mask / positions that
+        prepare_inputs_labels_for_multimodal returned (llava_arch.py:520-573);
+      * next token of every sample = arg-max of the LAST column of the logits (transformers 4.31 GenerationMixin.greedy_search:
+        `outputs.logits[:, -1, :]` -- for a right-padded shorter sample that is a PAD row, not its last valid position);
+      * every later step: GenerationMixin appends one column of ones to the mask it was GIVEN (the input_ids-length mask, NOT the
+        spliced one), and the reference's fix-up (llava_arch.py:196-205) pads that with ones up to past_len + 1 and sets
+        position_ids = sum(mask) - 1. So the pad rows of the spliced batch are attended, and the zeros of the ids-length mask land
+        on whatever spliced rows share their index.
+    transformers 4.31 itself is not in this image (5.x is): the two GenerationMixin rules above are restated from its published
+    greedy_search / _update_model_kwargs_for_generation; the arithmetic of every step is the reference's own forward."""
+    import contextlib
+    import io
+    B = embeds.shape[0]
+    with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+        out = model(inputs_embeds=embeds, attention_mask=spliced_mask, position_ids=position_ids, use_cache=True)
+    past = out.past_key_values
+    nxt = out.logits[:, -1].float().argmax(-1)
+    ids = [nxt]
+    mask = ids_mask.clone()
+    past_len = embeds.shape[1]
+    for _ in range(steps - 1):
+        mask = torch.cat([mask, torch.ones((B, 1), dtype=mask.dtype)], dim=1)                 # _update_model_kwargs_for_generation
+        m = torch.cat([mask, torch.ones((B, past_len + 1 - mask.shape[1]), dtype=mask.dtype)], dim=1)   # llava_arch.py:197-203
+        pos = m.sum(1, keepdim=True) - 1                                                       # :204
+        with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+            out = model(inputs_embeds=embed_table[nxt].unsqueeze(1), attention_mask=m, position_ids=pos, past_key_values=past,
+                        use_cache=True)
+        past = out.past_key_values
+        past_len += 1
+        nxt = out.logits[:, -1].float().argmax(-1)
+        ids.append(nxt)
+    return torch.stack(ids, dim=1)
+
+
+def gen_greedy_batch(ns):
+    """What B > 1 generate() returns in the reference, next to what each sample returns ALONE (batch 1), for the right-padded
+    `batch_pad` glue case: this repo packs the batch, so it returns the batch-1 rows; the fixture keeps both so that a GPU test can
+    assert the first and REPORT the distance to the second (VERDICT r3 #8)."""
+    import contextlib
+    import io
+    model = build_ref_llava(ns)
+    table = model.get_model().embed_tokens.weight.detach()
+    case = cases.glue_cases()["batch_pad"]
+    model.config.tokenizer_model_max_length = None
+    model.config.tokenizer_padding_side = "right"
+    out = {}
+    # transformers 4.31 LlamaForCausalLM.prepare_inputs_for_generation hands the prefill position_ids = cumsum(mask) - 1 (1 at the
+    # pads), so prepare_inputs_labels_for_multimodal returns ITS OWN spliced positions (llava_arch.py:535-566: arange over the valid
+    # rows, 0 at the pads) instead of None
+    am = case["attention_mask"]
+    pos_in = (am.long().cumsum(-1) - 1).masked_fill(am == 0, 1)
+    with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+        (_, pos, mask, _, embeds, _) = model.prepare_inputs_labels_for_multimodal(
+            case["input_ids"], pos_in, am, None, None, case["images"], case["regions"])
+    B = embeds.shape[0]
+    assert pos is not None
+    batch_ids = _padded_batch_greedy_hf431(model, embeds, mask, pos, case["attention_mask"], table, GREEDY_STEPS_TINY)
+    out["batch_pad_padded_ids"] = batch_ids.numpy().astype(np.int64)
+    out["batch_pad_spliced_lengths"] = mask.long().sum(1).numpy()
+    for b in range(B):
+        n = int(case["attention_mask"][b].sum())
+        with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+            (_, _, _, _, e1, _) = model.prepare_inputs_labels_for_multimodal(
+                case["input_ids"][b:b + 1, :n], None, None, None, None, [case["images"][b]], [case["regions"][b]])
+        ids, rows = _greedy_over_reference_forward(model, e1, table, GREEDY_STEPS_TINY)
+        top2 = rows.topk(2, dim=-1).values
+        out[f"batch_pad_alone{b}_ids"] = np.array(ids, dtype=np.int64)
+        out[f"batch_pad_alone{b}_margin"] = (top2[:, 0] - top2[:, 1]).numpy()
+        out[f"batch_pad_alone{b}_rms"] = rows.double().pow(2).mean(-1).sqrt().numpy()
+    np.savez_compressed(os.path.join(OUT, "greedy_batch.npz"), **out)
+    print("greedy_batch.npz", {k: v.tolist() for k, v in out.items()})
+
+
 def gen_f1(ns):
     """SURVEY.md 8(a) row F1's other branches, from the reference's own classes:
       * CLIPVisionTower (vitron/model/multimodal_encoder/clip_encoder.py:7-78) around a transformers CLIPVisionModel with seeded
@@ -480,6 +555,9 @@ if __name__ == "__main__":
     if "--greedy-only" in sys.argv:
         gen_greedy(ns)
         sys.exit(0)
+    if "--greedy-batch-only" in sys.argv:
+        gen_greedy_batch(ns)
+        sys.exit(0)
     if "--f1-only" in sys.argv:
         gen_f1(ns)
         sys.exit(0)
@@ -493,4 +571,5 @@ if __name__ == "__main__":
     gen_state_dict_keys(ns)
     gen_fullwidth(ns)
     gen_greedy(ns)
+    gen_greedy_batch(ns)
     gen_f1(ns)

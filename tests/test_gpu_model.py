@@ -263,6 +263,40 @@ def test_greedy_generate_token_ids(dev, model):
                 assert float(top2[0] - top2[1]) < 3e-2 * float(lg.abs().max()), (name, b, agree, got, ref.tolist())
 
 
+def test_batched_generate_rows_are_the_batch1_rows_of_the_reference(dev, model, record_property):
+    """B > 1 generate: this package packs a batch, so every sample gets the ids the REFERENCE returns for that
+    sample ALONE (tests/golden/greedy_batch.npz: the reference's own prepare + forward per sample, make_golden.gen_greedy_batch).
+    The reference's padded-batch generate() differs from that for every sample shorter than the longest: transformers 4.31 reads
+    the next token from the last COLUMN (a pad row for a right-padded sample), and the decode-step fix-up (llava_arch.py:196-205)
+    extends the ids-length mask with ones, which attends the pad rows. Asserted here: ours == the batch-1 rows wherever the
+    reference's top-2 margin is above the bf16 noise; the longest sample also == the reference's padded-batch row. Reported: how
+    many ids of the shorter sample differ from the reference's padded-batch row (all 12 in the fixture)."""
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "greedy_batch.npz"))
+    case = cases.glue_cases()["batch_pad"]
+    ids = case["input_ids"].to(dev)
+    n_new = int(G["batch_pad_padded_ids"].shape[1])
+    out, step_logits = model.generate(ids, images=[im.to(dev).bfloat16() for im in case["images"]], regions=case["regions"],
+                                      attention_mask=case["attention_mask"].to(dev), do_sample=False, max_new_tokens=n_new,
+                                      eos_token_id=-1, return_logits=True)
+    new = out[:, ids.shape[1]:].cpu()
+    lengths = G["batch_pad_spliced_lengths"]
+    longest = int(lengths.argmax())
+    report = {}
+    for b in range(ids.shape[0]):
+        want, margin, rms = G[f"batch_pad_alone{b}_ids"], G[f"batch_pad_alone{b}_margin"], G[f"batch_pad_alone{b}_rms"]
+        got = new[b].tolist()
+        agree = next((t for t in range(n_new) if got[t] != int(want[t])), n_new)
+        if agree < n_new:           # a flip is allowed only where the reference's own margin is within the bf16 noise of the row
+            assert float(margin[agree]) < 3e-2 * float(rms[agree]), (b, agree, got, want.tolist(), float(margin[agree]))
+        report[f"sample{b}_ids_equal_to_reference_batch1"] = agree
+        report[f"sample{b}_ids_differing_from_reference_padded_batch"] = int(sum(int(g != int(w)) for g, w in zip(got[:agree], G["batch_pad_padded_ids"][b][:agree])))
+    assert G["batch_pad_padded_ids"][longest].tolist() == G[f"batch_pad_alone{longest}_ids"].tolist()   # the fixture's own statement
+    shorter = 1 - longest
+    assert report[f"sample{shorter}_ids_differing_from_reference_padded_batch"] > 0     # the quirk is real and we do not reproduce it
+    record_property("batched_generate_vs_reference", report)
+    print("batched generate vs the reference:", report)
+
+
 def test_decode_matches_prefill(dev, model):
     from vitron_amd.engine import PagedKVCache, SequenceState, llama_forward
     llama = model.get_model().llama

@@ -178,6 +178,33 @@ def test_greedy_ids_against_the_reference(name):
     assert rel(torch.stack(rows), ref_rows) <= 1e-4
 
 
+def test_padded_batch_greedy_ids_against_the_reference():
+    """tests/golden/greedy_batch.npz (make_golden.gen_greedy_batch): the reference's padded-batch generate() restated over its own
+    forward, next to every sample run alone. The oracle reproduces BOTH: ids_mask=... follows the padded-batch behaviour to the
+    letter (pad rows attended, first token read from the last column), ids_mask=None gives the batch-1 rows -- and the two differ
+    for the shorter sample, which is the difference vitron_amd's packed generate() keeps."""
+    g = np.load(os.path.join(G, "greedy_batch.npz"))
+    case = cases.glue_cases()["batch_pad"]
+    w, cfgs = oracle_weights()
+    embeds, mask, pos = O.multimodal_prepare(w, cfgs, case["input_ids"], case["attention_mask"], case["images"], case["regions"])
+    assert mask.long().sum(1).tolist() == g["batch_pad_spliced_lengths"].tolist()
+    n = g["batch_pad_padded_ids"].shape[1]
+    padded = O.greedy_generate(w["llama"], cfgs["llama"], embeds, mask.long(), pos, n, ids_mask=case["attention_mask"].long())
+    assert padded.tolist() == g["batch_pad_padded_ids"].tolist()
+    alone = O.greedy_generate(w["llama"], cfgs["llama"], embeds, mask.long(), pos, n)
+    differing = 0
+    for b in range(embeds.shape[0]):
+        assert float(g[f"batch_pad_alone{b}_margin"].min()) > 1e-3
+        L = int(mask[b].sum())
+        one = O.greedy_generate(w["llama"], cfgs["llama"], embeds[b:b + 1, :L], torch.ones(1, L, dtype=torch.long),
+                                torch.arange(L).unsqueeze(0), n)
+        assert one[0].tolist() == g[f"batch_pad_alone{b}_ids"].tolist()
+        differing += int(one[0].tolist() != g["batch_pad_padded_ids"][b].tolist())
+    assert differing == 1                                    # the shorter sample; the longest is the same either way
+    longest = int(mask.long().sum(1).argmax())
+    assert alone[longest].tolist() == g[f"batch_pad_alone{longest}_ids"].tolist()
+
+
 def _proj3_state():
     H = cases.LLM["hidden_size"]
     g = synth.make_generator(cases.SEED_PROJ + 3)
