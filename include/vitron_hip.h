@@ -122,7 +122,10 @@ int vt_flash_attn(const uint16_t* Q, int ldq, const uint16_t* k_tiles, const uin
  * and for the tests that hold the kernels to each other; results are the same contract either way. 0 = automatic (the one-wave-per-SIMD
  * kernel on 256-row blocks once heads x sequences x blocks fills the 256 CUs, else the two-waves-per-SIMD kernel on 128-row blocks),
  * 1 = always the two-waves-per-SIMD kernel, 2 = always the one-wave-per-SIMD kernel, 3 = that kernel with its pipeline stages run one
- * after the other instead of the hand-placed schedule (its reference). No reference counterpart. */
+ * after the other instead of the hand-placed schedule (its reference), 4 = the one-wave-per-SIMD kernel in its persistent form (one
+ * workgroup per CU walking the block list, K / V^T stream running on across block seams; `kernel = 4 | (n << 8)` caps it at n
+ * workgroups -- a test hook that forces many blocks per workgroup). The persistent form keeps its block tickets in device globals:
+ * one launch of it at a time per library (launches on one stream are ordered). No reference counterpart. */
 int vt_flash_attn_select(int kernel);
 /* Residual GEMM C[M,N] (fp32) += A[M,K] W[N,K]^T + bias with an optional split-K workspace: when the 256x256 tile grid would
  * cover at most half of the chip (M ~ 1000 rows at N = 4096, the ViT's N = 1024 projections) the K loop is split over up to 8

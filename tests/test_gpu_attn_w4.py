@@ -81,7 +81,7 @@ CASES = [(True, [700, 300, 64, 1], [0, 0, 0, 0]), (False, [577, 130], [0, 0]), (
 
 
 @pytest.mark.parametrize("op", ["bf16", "fp16"])
-@pytest.mark.parametrize("kernel", [2, 3])
+@pytest.mark.parametrize("kernel", [2, 3, 4, 4 | (8 << 8)])
 @pytest.mark.parametrize("causal,lens,pasts", CASES)
 def test_w4_kernel_vs_fp64_and_vs_the_two_wave_kernel(dev, causal, lens, pasts, kernel, op):
     from vitron_amd import ops
@@ -113,11 +113,41 @@ def test_w4_placed_equals_unplaced_bit_for_bit(dev, op):
     q, kt, vt, table, desc, _ = _problem(dev, dt, heads, lens, pasts, seed=300)
     scale = 1.0 / math.sqrt(hd)
     outs = []
-    for kernel in (2, 3):
+    for kernel in (2, 3, 4, 4 | (3 << 8)):
         ops.flash_attn_select(kernel)
         outs.append(ops.flash_attn(q, kt, vt, table, desc, max(lens), heads, hd, True, scale).clone())
     torch.cuda.synchronize()
-    assert torch.equal(outs[0], outs[1])
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+
+
+@pytest.mark.parametrize("op", ["bf16", "fp16"])
+@pytest.mark.parametrize("heads,lens,pasts,cap", [(8, [1024, 768, 512, 256], [0, 0, 0, 0], 8), (8, [1024, 300, 1280, 64], [0, 100, 0, 256], 16),
+                                                  (3, [1536, 700], [0, 0], 2), (16, [2048], [0], 0), (8, [512, 512, 512], [64, 0, 128], 8)])
+def test_w4_persistent_form_walks_the_block_list(dev, op, heads, lens, pasts, cap):
+    """The persistent form (vt_flash_attn_select(4)): workgroups take (sequence, block, head) tickets per XCD, the K / V^T stream runs on
+    across block seams whenever a block has a multiple of 4 tiles (prefill blocks without past: warm seams) and restarts cold otherwise
+    (ragged tails, blocks with past) -- mixed here, with the workgroup count capped so that every workgroup walks many blocks. Same
+    arithmetic per row as the one-block-per-workgroup launch: bit-identical output, also on the second launch (the ticket counters reset
+    themselves) and next to rows the launch must not touch."""
+    from vitron_amd import ops
+    dt = DT[op]
+    hd = 128
+    q, kt, vt, table, desc, _ = _problem(dev, dt, heads, lens, pasts, seed=500)
+    scale = 1.0 / math.sqrt(hd)
+    ops.flash_attn_select(2)
+    want = ops.flash_attn(q, kt, vt, table, desc, max(lens), heads, hd, True, scale).clone()
+    ops.flash_attn_select(4 | (cap << 8))
+    for rep in range(3):
+        out = torch.full_like(want, float("nan"))
+        ops.flash_attn(q, kt, vt, table, desc, max(lens), heads, hd, True, scale, out=out)
+        torch.cuda.synchronize()
+        assert torch.equal(out, want), (rep, heads, lens)
+    ops.flash_attn_select(2)
+    want_nc = ops.flash_attn(q, kt, vt, table, desc, max(lens), heads, hd, False, scale).clone()
+    ops.flash_attn_select(4 | (cap << 8))
+    got_nc = ops.flash_attn(q, kt, vt, table, desc, max(lens), heads, hd, False, scale)
+    torch.cuda.synchronize()
+    assert torch.equal(got_nc, want_nc)
 
 
 @pytest.mark.parametrize("variant", ["wide", "ascending"])
@@ -148,7 +178,7 @@ def test_w4_kernel_score_range_edges(dev, variant):
     assert float(s.max() - s.min()) > 60.0
     s = s.masked_fill((torch.arange(L)[None, :] > torch.arange(L)[:, None])[None], float("-inf"))
     ref = torch.einsum("hqk,khd->qhd", torch.softmax(s, -1), v).reshape(L, D).float().bfloat16().float()
-    for kernel in (2, 3):
+    for kernel in (2, 3, 4):
         ops.flash_attn_select(kernel)
         out = ops.flash_attn(qd, kt, vt, table, desc, L, heads, hd, True, scale).float().cpu()
         err = rel_l2(out, ref)

@@ -46,6 +46,24 @@ def run(S, heads, hd, nseq, causal):
                       "tflops": round(flops / ms / 1e9, 1), "kv_tiles_ms": round(ms_kv, 4)}), flush=True)
 
 
+if __name__ == "__main__" and os.environ.get("VT_W4_PROF"):
+    # phase clocks of the persistent attention kernel (test library): one workgroup's waves, summed over its blocks, in shader cycles
+    import ctypes
+    lib = _lib.load(ablations=True)
+    names = ["seam", "set-up", "wait operands", "barrier", "hand-over+reset", "prologue stages", "steady state", "tail", "barrier", "epilogue"]
+    for nseq, kern in ((1, 2), (1, 4), (8, 2), (8, 4)):
+        lib.vt_flash_attn_select(kern)
+        lib.vt_debug_w4_prof(None, 1)
+        run(5120, 32, 128, nseq, True)
+        buf = (ctypes.c_ulonglong * 64)()
+        lib.vt_debug_w4_prof(buf, 0)
+        for w in range(4):
+            v = buf[16 * w:16 * w + 16]
+            calls = 12                      # timeit: 2 warm-up + 10 timed launches of flash_attn (kv_tiles launches follow but do not touch the counters)
+            tot = sum(v[:10])
+            print(f"kernel {kern} nseq {nseq} wave {w}: blocks/launch {v[10] / calls:.1f} tiles/launch {v[11] / calls:.0f} warm seams {v[12] / calls:.1f}; cycles per block: "
+                  + ", ".join(f"{n} {v[i] / max(v[10], 1):.0f}" for i, n in enumerate(names)) + f"; total/launch {tot / calls:.0f}", flush=True)
+    sys.exit(0)
 if __name__ == "__main__" and os.environ.get("VT_W4_ABL"):
     # timing ablations of the one-wave-per-SIMD kernel's placed loop (test library; results are garbage): VT_W4_ABL=<bits>
     _lib.load(ablations=True)

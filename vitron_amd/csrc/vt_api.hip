@@ -152,8 +152,12 @@ int vt_flash_attn(const uint16_t* Q, int ldq, const uint16_t* k_tiles, const uin
 }
 
 int vt_flash_attn_select(int kernel) {
-  VT_REQUIRE(kernel >= 0 && kernel <= 3, "vt_flash_attn_select: kernel %d (0 auto, 1 two-waves-per-SIMD, 2 one-wave-per-SIMD placed, 3 unplaced)", kernel);
-  g_vt_flash_attn_kernel = kernel;
+  const int k = kernel & 0xff, wgs = kernel >> 8;
+  VT_REQUIRE(kernel >= 0 && k <= 4 && (wgs == 0 || k == 4),
+             "vt_flash_attn_select: kernel %d (0 auto, 1 two-waves-per-SIMD, 2 one-wave-per-SIMD placed, 3 unplaced, 4 placed + persistent; "
+             "bits 8.. = workgroup cap of 4)", kernel);
+  g_vt_flash_attn_kernel = k;
+  g_vt_flash_attn_wgs = wgs;
   return VT_OK;
 }
 

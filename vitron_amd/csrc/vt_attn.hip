@@ -969,6 +969,7 @@ __global__ __launch_bounds__(256) void attn_temporal8_kernel(const bf16_t* __res
 }  // namespace
 
 int g_vt_flash_attn_kernel = 0;
+int g_vt_flash_attn_wgs = 0;
 
 int vt_flash_attn_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf16_t* Vt, const int* tile_table,
                          const VtAttnSeq* seqs, int nseq, int max_q_len, bf16_t* O, int ldo, int heads, int HD,
@@ -988,7 +989,7 @@ int vt_flash_attn_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf16_
     if (g_vt_flash_attn_kernel >= 2 || (fills && aligned)) {
       VT_REQUIRE(aligned, "vt_flash_attn: the one-wave-per-SIMD kernel stores 16-byte chunks: O 16-byte aligned, ldo %% 8 == 0");
       return vt_flash_attn_w4_launch(Q, ldq, Kt, Vt, tile_table, seqs, nseq, max_q_len, O, ldo, heads, causal, sl2,
-                                     g_vt_flash_attn_kernel == 3 ? 0 : 1, s);
+                                     g_vt_flash_attn_kernel == 3 ? 0 : g_vt_flash_attn_kernel == 4 ? 2 : 1, s);
     }
   }
   // long sequences: 256-row blocks, 3-stage ring; short ones (ViT frames, small prefills): 128-row blocks

@@ -69,44 +69,85 @@ __device__ __forceinline__ float a_max_halves(float x) {
 #define W4A_PV(D, A, B) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(D) : "v"(A), "v"(B))
 #define W4A_LDS(p) ((__attribute__((address_space(3))) void*)(p))
 
+// Ticket counters of the persistent form, one per XCD; self-resetting: every launch performs exactly (blocks + workgroups) increments
+// per counter with atomicInc's wrap value set to that count - 1, so the counter is back at 0 when the launch retires. One launch of
+// this kernel at a time per operand library (launches of one stream are ordered; do not run it on two streams concurrently).
+__device__ unsigned g_w4_ticket[8];
+#ifdef VT_ABLATIONS   // phase clocks of the persistent form (test library only: VT_W4_PROF=1 python tools/attn_bench.py prints them)
+__device__ unsigned long long g_w4_prof[4][16];
+#define W4A_PROF(I)                                                                                                     \
+  do {                                                                                                                  \
+    if ((PERSIST ? blockIdx.x == 8 : (blockIdx.x == 8 && blockIdx.y == 0 && blockIdx.z == 0)) && lane == 0) {          \
+      const unsigned long long now_ = __builtin_readcyclecounter();                                                    \
+      g_w4_prof[wave][I] += now_ - prof_t;                                                                              \
+      prof_t = now_;                                                                                                    \
+    }                                                                                                                   \
+  } while (0)
+#else
+#define W4A_PROF(I) do {} while (0)
+#endif
+
 // ABL (timing ablations of the placed loop, results are garbage; test library only): 1 = no LDS-DMA, 2 = no exp phase of the softmax,
 // 4 = no fragment reads, 8 = no end-of-tile waits / barrier, 16 = no P.V MFMAs, 32 = no score MFMAs
-template <bool CAUSAL, bool PLACED, int ABL = 0>
+// PERSIST: gridDim.x workgroups (one per CU) walk the (sequence, block, head) list instead of one workgroup per block:
+//   * workgroup w serves XCD x = w % nx (nx = 8 when heads % 8 == 0: a head's K / V^T pages are then only ever read through ONE L2) and
+//     takes tickets from g_w4_ticket[x]; ticket j -> block y = j / (hpx * nseq) counted from the heaviest (last) causal block, sequence
+//     z = (j / hpx) % nseq, head = (j % hpx) * nx + x. Wave 0 takes the ticket two blocks ahead (the atomic is issued before a wait the
+//     block start performs anyway) and hands it to the other waves through one LDS word;
+//   * the K / V^T stream runs on ACROSS the block seam: a block whose tile count is a multiple of 4 (every causal prefill block of a
+//     sequence without past) ends with its last tile in ring slot 3, so the steady-state bodies that consume tiles n-3 and n-2 fetch
+//     tiles 0 and 1 of the NEXT block into slots 0 and 1 (where they belong), the tail fetches its tile 2 and loads its Q rows into the
+//     registers the last score MFMA has just released, and O is staged in the two slots the tail frees (K slot 3, V^T slot 3) -- the next
+//     block starts with its operands in flight or landed instead of cold. Other tile counts fall back to a cold start per block.
+template <bool CAUSAL, bool PLACED, int ABL = 0, bool PERSIST = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void flash_attn_w4_kernel(
     const op16_t* __restrict__ Q, int ldq, const op16_t* __restrict__ Kt, const op16_t* __restrict__ Vt,
     const int* __restrict__ tile_table, const VtAttnSeq* __restrict__ seqs, op16_t* __restrict__ O, int ldo, int heads,
-    float scale_log2e) {
+    float scale_log2e, int nqb_max, int nseq, int nx) {
   constexpr int HD = 128, QBLK = 256, TB = 64 * HD * 2, VRING = 4 * TB;   // 16-KiB tiles; K ring then V^T ring, 4 slots each
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  const VtAttnSeq sq = seqs[blockIdx.z];
-  const int nqb = (sq.q_len + QBLK - 1) / QBLK;
-  const int qb = nqb - 1 - (int)blockIdx.y;   // heaviest (latest) causal blocks of all heads first
-  if (qb < 0) return;
-  const int head = blockIdx.x;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ql = lane & 31, hh = lane >> 5;
-  const int past = sq.kv_len - sq.q_len;
-  const int q0 = qb * QBLK;
-  int ntiles = (sq.kv_len + 63) >> 6;
-  if (CAUSAL) {
-    const int last_key = past + min(q0 + QBLK - 1, sq.q_len - 1);
-    ntiles = min(ntiles, (last_key >> 6) + 1);
-  }
-  const int wrow0 = q0 + wave * 64;          // first row of this wave inside the sequence
-  int qrow[2];
-  qrow[0] = wrow0 + ql;
-  qrow[1] = wrow0 + 32 + ql;
+
+  // ---- the block this workgroup works on (wave-uniform; re-assigned per block in the persistent form) ---------------------------------
+  VtAttnSeq sq;
+  int head = 0, qb = 0, past = 0, ntiles = 0, wrow0 = 0;
+  const size_t tile_stride = (size_t)heads * 64 * HD;
+  auto tiles_of = [&](const VtAttnSeq& s, int qb_) {
+    int n = (s.kv_len + 63) >> 6;
+    if (CAUSAL) {
+      const int last_key = (s.kv_len - s.q_len) + min(qb_ * QBLK + QBLK - 1, s.q_len - 1);
+      n = min(n, (last_key >> 6) + 1);
+    }
+    return n;
+  };
+  auto set_block = [&](const VtAttnSeq& s, int head_, int qb_) {
+    sq = s;
+    head = head_;
+    qb = qb_;
+    past = s.kv_len - s.q_len;
+    ntiles = tiles_of(s, qb_);
+    wrow0 = qb_ * QBLK + wave * 64;          // first row of this wave inside the sequence
+  };
+  // the block after it (persistent form): what the seam needs of it
+  VtAttnSeq nsq = {0, 0, 0, 0};
+  int nhead = 0, nqb = 0, n_ntiles = 1;
+  bool warm_next = false;   // this block hands its successor a running K / V^T stream
+  bool warm_now = false;    // ... and this block was handed one
 
   // ---- Q fragments (B operand of the score MFMAs): lane (q, h) holds d = ks*16 + h*8 .. +7 of its row, both row halves --------
   bf16x8 qf[2][8];
+  auto load_q = [&](const VtAttnSeq& s, int head_, int qb_) {
 #pragma unroll
-  for (int rh = 0; rh < 2; ++rh) {
-    const op16_t* qp = Q + (size_t)(sq.q_row0 + min(qrow[rh], sq.q_len - 1)) * ldq + head * HD + hh * 8;
+    for (int rh = 0; rh < 2; ++rh) {
+      const int row = qb_ * QBLK + wave * 64 + rh * 32 + ql;
+      const op16_t* qp = Q + (size_t)(s.q_row0 + min(row, s.q_len - 1)) * ldq + head_ * HD + hh * 8;
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) qf[rh][ks] = *(const bf16x8*)(qp + ks * 16);
-  }
+      for (int ks = 0; ks < 8; ++ks) qf[rh][ks] = *(const bf16x8*)(qp + ks * 16);
+    }
+  };
 
   // ---- LDS-DMA: piece p = wave*4 + i of a tile covers LDS bytes [p*1024, +1024); swizzle applied on the SOURCE side -------------
   int k_vo[4], v_vo[4];   // byte offsets inside the 16-KiB source tile
@@ -122,14 +163,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       v_vo[i] = (row * 64 + ((c ^ ((row >> 1) & 7)) << 3)) * 2;
     }
   }
-  const size_t head_off = (size_t)head * 64 * HD;
-  const size_t tile_stride = (size_t)heads * 64 * HD;
-  const int* table = tile_table + sq.table_off;
   // (the pool can exceed 4 GiB: the buffer resource is rebuilt per tile around the tile's own 16 KiB -- scalar work only)
-#define W4A_RSRC_PG(BASE, PG) __builtin_amdgcn_make_buffer_rsrc((void*)((BASE) + (size_t)(PG) * tile_stride + head_off), 0, TB, 0x00020000)
-#define W4A_RSRC(BASE, T) W4A_RSRC_PG(BASE, table[min((T), ntiles - 1)])
+#define W4A_RSRC_OFF(BASE, OFF) __builtin_amdgcn_make_buffer_rsrc((void*)((BASE) + (OFF)), 0, TB, 0x00020000)
 #define W4A_DMA_K(R, SLOT, I) __builtin_amdgcn_raw_ptr_buffer_load_lds(R, W4A_LDS(smem + (SLOT) * TB + (wave * 4 + (I)) * 1024), 16, k_vo[I], 0, 0, 0)
 #define W4A_DMA_V(R, SLOT, I) __builtin_amdgcn_raw_ptr_buffer_load_lds(R, W4A_LDS(smem + VRING + (SLOT) * TB + (wave * 4 + (I)) * 1024), 16, v_vo[I], 0, 0, 0)
+  // page and head offset of tile i of the K / V^T stream: tile i of this block, or -- past its end, when the stream runs on -- tile
+  // i - ntiles of the next one; otherwise the last tile again (a harmless re-fetch into a slot nobody reads any more). The page is a
+  // scalar load: callers take it one body ahead of its first use.
+  auto stream_page = [&](int i, int& pg_, size_t& ho_) {
+    const bool nx_ = warm_next && i >= ntiles;
+    const int a = sq.table_off + min(i, ntiles - 1), b = nsq.table_off + min(i - ntiles, n_ntiles - 1);
+    const int ha = head, hb = nhead;
+    pg_ = tile_table[nx_ ? b : a];
+    ho_ = (size_t)(nx_ ? hb : ha) * (64 * HD);
+  };
+  auto stream_off = [&](int i) -> size_t {
+    int pg_;
+    size_t ho_;
+    stream_page(i, pg_, ho_);
+    return (size_t)pg_ * tile_stride + ho_;
+  };
 
   // ---- fragment read offsets (bytes inside a ring slot) ------------------------------------------------------------------------------
   // K: MFMA row i = lane&31 reads key pi(i) of the 32-key sub tile (so that a lane's 16 scores are 16 consecutive keys), chunk ks*2 + h
@@ -146,18 +199,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
   // ---- state ---------------------------------------------------------------------------------------------------------------------------
   f32x16 oacc[2][4];   // [row half][32-wide d block], accumulator file
-#pragma unroll
-  for (int rh = 0; rh < 2; ++rh)
-#pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[rh][db][r] = 0.f;
   f32x16 sacc[2][2];   // [S buffer = sub][row half]
   u32x4 pfr[2][2][2];  // [P buffer = sub][row half][j]: fp16 softmax weights, B operand of the P.V MFMAs
-  float mrun[2] = {-INFINITY, -INFINITY}, lrun[2] = {0.f, 0.f};
-  float mb[2] = {W4A_BIAS, W4A_BIAS};            // P_BIAS - (m_run or 0)
-  float mthr[2] = {-INFINITY, -INFINITY};        // (m_run + threshold) / scale_log2e: what a RAW score is compared with
-  float apend[2] = {1.f, 1.f};                   // O rescale decided in the last softmax, applied before the next P.V
+  float mrun[2], lrun[2];
+  float mb[2];                                   // P_BIAS - (m_run or 0)
+  float mthr[2];                                 // (m_run + threshold) / scale_log2e: what a RAW score is compared with
+  float apend[2];                                // O rescale decided in the last softmax, applied before the next P.V
   bool pend = false;
 
   // a wait that the accumulator reads / writes around it cannot be moved across
@@ -213,10 +260,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   auto mask_stage = [&](f32x16(&S)[2], int key0) {
     const bool need = (key0 + 32 > sq.kv_len) || (CAUSAL && (key0 + 31 > past + wrow0));
     if (__builtin_expect(need, 0)) {
-      asm volatile("" ::: "memory");   // a REAL branch (if-converted this costs 3 VALU per score on every tile)
+      // a REAL branch (if-converted this costs 3 VALU per score on every tile). In the placed loop the scores of (T+1, sub 0) come out of
+      // MFMAs issued a few instructions before this point and the compiler cannot see that (asm): without the wait the selects below read
+      // the buffer's PREVIOUS contents for the keys they keep (seen once the persistent form changed the instruction distance: rows lost
+      // accuracy in proportion to their visible keys of the diagonal sub tile). Taken on diagonal / last tiles only.
+      asm volatile("s_nop 15\n\ts_nop 15" : "+v"(S[0]), "+v"(S[1]));
 #pragma unroll
       for (int rh = 0; rh < 2; ++rh) {
-        const int lim = CAUSAL ? min(sq.kv_len - 1, past + qrow[rh]) : (sq.kv_len - 1);   // last visible key
+        const int lim = CAUSAL ? min(sq.kv_len - 1, past + wrow0 + rh * 32 + ql) : (sq.kv_len - 1);   // last visible key
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           if (key0 + 16 * hh + r > lim) S[rh][r] = -INFINITY;
@@ -268,135 +319,313 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
   };
 
-  // ---- prologue: tiles 0..2 in flight, scores of tile 0, softmax of its first half ---------------------------------------------------
-#pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    const __amdgpu_buffer_rsrc_t rk = W4A_RSRC(Kt, t), rv = W4A_RSRC(Vt, t);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) W4A_DMA_K(rk, t, i);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) W4A_DMA_V(rv, t, i);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_sched_barrier(0);
-  qk_stage(sacc[0], 0, 0);
-  qk_stage(sacc[1], 0, 1);
-  sm_stage(sacc[0], pfr[0], 0);
-
-  // fragment windows of the placed loop: K of k-step ks in kfr[ks % 3], V^T fragment p = (j, db) in vfr[p % 3]; the first three of
-  // each are read one sub-iteration ahead (here: K of tile 1 / sub 0 -- a re-fetched copy when there is no tile 1, never used then --
-  // and V^T of tile 0 / sub 0)
-  bf16x8 kfr[3];
-  f16x8 vfr[3];
-  if constexpr (PLACED) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      kfr[i] = *(const bf16x8*)(smem + TB + kfix[i]);
-      vfr[i] = *(const f16x8*)(smem + i * 4096 + vfix[0][0]);
+  // ---- which block(s) ----------------------------------------------------------------------------------------------------------------
+  // persistent form: tickets (see the header). t_cur / t_nxt are known to every wave; the one after them travels through tick[0].
+  volatile unsigned* tick = (volatile unsigned*)(smem + 8 * TB);
+  const int xcd = PERSIST ? (int)(blockIdx.x % (unsigned)nx) : 0;
+  const int hpx = PERSIST ? heads / nx : heads;
+  const unsigned nblk = PERSIST ? (unsigned)(hpx * nseq * nqb_max) : 0u;
+  const unsigned nwg_x = PERSIST ? (gridDim.x + (unsigned)(nx - 1 - xcd)) / (unsigned)nx : 0u;
+  unsigned t_cur = 0, t_nxt = 0;
+  unsigned t_grab = 0;      // (per lane: lane 0 of wave 0 holds the returned value)
+  bool grab_out = false;    // wave 0: an atomic is in flight in t_grab
+  auto ticket_block = [&](unsigned t, int& z_, int& head_, int& y_) {
+    const int per_y = hpx * nseq;
+    y_ = (int)t / per_y;
+    const int r = (int)t % per_y;
+    z_ = r / hpx;
+    head_ = (r % hpx) * nx + xcd;
+  };
+  auto ticket_valid = [&](unsigned t) {        // a block of the grid that exists for its sequence (shorter sequences have fewer blocks)
+    if (t >= nblk) return true;                // ... or the end marker
+    int z_, h_, y_;
+    ticket_block(t, z_, h_, y_);
+    return y_ < (seqs[z_].q_len + QBLK - 1) / QBLK;
+  };
+  auto grab_issue = [&]() {                    // (wave 0 only) ONE increment per wave; the value comes back in lane 0's t_grab
+    if (lane == 0) t_grab = atomicInc(&g_w4_ticket[xcd], nblk + nwg_x - 1u);
+  };
+  auto grab_take = [&]() -> unsigned { return (unsigned)__builtin_amdgcn_readfirstlane((int)t_grab); };
+  auto grab_valid = [&](bool issued) -> unsigned {   // (wave 0 only) the next ticket that names a real block, or the end marker
+    if (!issued) grab_issue();
+    unsigned t = grab_take();
+    while (!ticket_valid(t)) {
+      grab_issue();
+      t = grab_take();
     }
+    return t;
+  };
+  if constexpr (PERSIST) {
+    if (wave == 0) {
+      const unsigned a = grab_valid(false);
+      const unsigned b = a < nblk ? grab_valid(false) : a;
+      if (lane == 0) {
+        tick[1] = a;
+        tick[2] = b;
+      }
+      if (b < nblk) {
+        grab_issue();
+        grab_out = true;
+      }
+    }
+    __syncthreads();
+    t_cur = (unsigned)__builtin_amdgcn_readfirstlane((int)tick[1]);
+    t_nxt = (unsigned)__builtin_amdgcn_readfirstlane((int)tick[2]);
+  } else {
+    const VtAttnSeq s0 = seqs[blockIdx.z];
+    const int qb0 = (s0.q_len + QBLK - 1) / QBLK - 1 - (int)blockIdx.y;   // heaviest (latest) causal blocks of all heads first
+    if (qb0 < 0) return;
+    set_block(s0, (int)blockIdx.x, qb0);
   }
-  // ---- steady state: one 64-key tile per iteration = two sub-iterations, each  P.V(u) || softmax(u+1) || Q.K^T(u+2) -----------------
-  int T = 0;
-  int pg = table[min(3, ntiles - 1)];     // page of the tile the next body fetches: read one body ahead (a scalar load at the top of the
-                                          // body would make the wave wait for it AND for every fragment read in flight)
-  // One body per ring slot: the loop is unrolled four times so that every LDS offset of a body (fragment reads, DMA destinations) is an
-  // instruction immediate -- with run-time slots each of the 32 fragment reads of a tile cost a scalar add and a vector add on top
-  // (PMC of the first version: 8.1 instructions per MFMA, issue-bound; the MFMA itself takes about three of the eight issue slots of
-  // its 32 cycles). The body is vt_attn_w4_body.inc, included once per slot.
-  if constexpr (PLACED) {
-    for (;;) {
-      if (T + 1 >= ntiles) break;
+
+  unsigned long long prof_t = __builtin_readcyclecounter();
+  (void)prof_t;
+  for (;;) {
+    W4A_PROF(0);      // seam + whatever preceded the loop top
+    if constexpr (PERSIST) {
+      if (t_cur >= nblk) break;
+      if (!warm_now) {                                   // (a warm block was set up at the seam that handed it over)
+        int z_, h_, y_;
+        ticket_block(t_cur, z_, h_, y_);
+        const VtAttnSeq s_ = seqs[z_];
+        set_block(s_, h_, (s_.q_len + QBLK - 1) / QBLK - 1 - y_);
+      }
+      warm_next = false;
+      if (t_nxt < nblk) {
+        int z_, y_;
+        ticket_block(t_nxt, z_, nhead, y_);
+        nsq = seqs[z_];
+        nqb = (nsq.q_len + QBLK - 1) / QBLK - 1 - y_;
+        n_ntiles = tiles_of(nsq, nqb);
+        warm_next = PLACED && (ntiles & 3) == 0 && ntiles >= 4;
+      }
+    }
+    // ---- cold start: Q rows and tiles 0..2 requested now (a warm block got them from its predecessor) --------------------------------
+    if (!warm_now) {
+      load_q(sq, head, qb);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const size_t off = stream_off(min(t, ntiles - 1));
+        const __amdgpu_buffer_rsrc_t rk = W4A_RSRC_OFF(Kt, off), rv = W4A_RSRC_OFF(Vt, off);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) W4A_DMA_K(rk, t, i);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) W4A_DMA_V(rv, t, i);
+      }
+    }
+    W4A_PROF(1);      // block set-up, cold start issue
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    W4A_PROF(2);      // wait for the operands
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    W4A_PROF(3);      // barrier
+    if constexpr (PERSIST) {
+      // Q arrives from two program points (cold start above, the previous block's tail): pin it to the accumulator file HERE, once per
+      // block -- otherwise the register allocator carries some fragments in VGPRs and copies them (v_accvgpr_write) straight in front
+      // of the asm MFMAs that read them, a hazard it cannot see (the MFMA then reads the register's previous contents)
+#pragma unroll
+      for (int rh = 0; rh < 2; ++rh)
+        asm volatile("" : "+a"(qf[rh][0]), "+a"(qf[rh][1]), "+a"(qf[rh][2]), "+a"(qf[rh][3]), "+a"(qf[rh][4]), "+a"(qf[rh][5]), "+a"(qf[rh][6]), "+a"(qf[rh][7]));
+      // the ticket two blocks ahead: its atomic went out before the wait above; every wave has read the previous one by now
+      if (wave == 0) {
+        unsigned t = nblk;
+        if (grab_out) {
+          t = grab_valid(true);
+          grab_out = false;
+        }
+        if (lane == 0) tick[0] = t;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int rh = 0; rh < 2; ++rh) {
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[rh][db][r] = 0.f;
+      mrun[rh] = -INFINITY;
+      lrun[rh] = 0.f;
+      mb[rh] = W4A_BIAS;
+      mthr[rh] = -INFINITY;
+      apend[rh] = 1.f;
+    }
+    pend = false;
+
+    W4A_PROF(4);      // ticket hand-over (wave 0), state reset
+    // ---- prologue: scores of tile 0, softmax of its first half -----------------------------------------------------------------------
+    qk_stage(sacc[0], 0, 0);
+    qk_stage(sacc[1], 0, 1);
+    sm_stage(sacc[0], pfr[0], 0);
+
+    // fragment windows of the placed loop: K of k-step ks in kfr[ks % 3], V^T fragment p = (j, db) in vfr[p % 3]; the first three of
+    // each are read one sub-iteration ahead (here: K of tile 1 / sub 0 -- a re-fetched copy when there is no tile 1, never used then --
+    // and V^T of tile 0 / sub 0)
+    bf16x8 kfr[3];
+    f16x8 vfr[3];
+    if constexpr (PLACED) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        kfr[i] = *(const bf16x8*)(smem + TB + kfix[i]);
+        vfr[i] = *(const f16x8*)(smem + i * 4096 + vfix[0][0]);
+      }
+    }
+    W4A_PROF(5);      // prologue stages
+    // ---- steady state: one 64-key tile per iteration = two sub-iterations, each  P.V(u) || softmax(u+1) || Q.K^T(u+2) ---------------
+    int T = 0;
+    int pg;                               // page of the tile the next body fetches: looked up one body ahead (a scalar load at the top of
+    size_t pg_head_off;                   // the body would make the wave wait for it AND for every fragment read in flight)
+    stream_page(3, pg, pg_head_off);
+    // One body per ring slot: the loop is unrolled four times so that every LDS offset of a body (fragment reads, DMA destinations) is an
+    // instruction immediate -- with run-time slots each of the 32 fragment reads of a tile cost a scalar add and a vector add on top
+    // (PMC of the first version: 8.1 instructions per MFMA, issue-bound; the MFMA itself takes about three of the eight issue slots of
+    // its 32 cycles). The body is vt_attn_w4_body.inc, included once per slot.
+    if constexpr (PLACED) {
+      for (;;) {
+        if (T + 1 >= ntiles) break;
 #define W4A_SC 0
 #include "vt_attn_w4_body.inc"
 #undef W4A_SC
-      if (T + 1 >= ntiles) break;
+        if (T + 1 >= ntiles) break;
 #define W4A_SC 1
 #include "vt_attn_w4_body.inc"
 #undef W4A_SC
-      if (T + 1 >= ntiles) break;
+        if (T + 1 >= ntiles) break;
 #define W4A_SC 2
 #include "vt_attn_w4_body.inc"
 #undef W4A_SC
-      if (T + 1 >= ntiles) break;
+        if (T + 1 >= ntiles) break;
 #define W4A_SC 3
 #include "vt_attn_w4_body.inc"
 #undef W4A_SC
+      }
+    } else {
+      // the reference form: stages one after the other, run-time ring slots, uncounted waits -- kept as simple as possible
+      for (; T + 1 < ntiles; ++T) {
+        const int slot_c = T & 3, slot_n = (T + 1) & 3, slot_d = (T + 3) & 3;
+        const size_t off = stream_off(T + 3);                                             // past the end: the last tile again, harmless
+        const __amdgpu_buffer_rsrc_t rk = W4A_RSRC_OFF(Kt, off), rv = W4A_RSRC_OFF(Vt, off);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) W4A_DMA_K(rk, slot_d, i);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) W4A_DMA_V(rv, slot_d, i);
+        apply_pending();
+        pv_stage(pfr[0], slot_c, 0);
+        sm_stage(sacc[1], pfr[1], T * 64 + 32);
+        qk_stage(sacc[0], slot_n, 0);
+        apply_pending();
+        pv_stage(pfr[1], slot_c, 1);
+        sm_stage(sacc[0], pfr[0], (T + 1) * 64);
+        qk_stage(sacc[1], slot_n, 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
-  } else {
-    // the reference form: stages one after the other, run-time ring slots, uncounted waits -- kept as simple as possible
-    for (; T + 1 < ntiles; ++T) {
-      const int slot_c = T & 3, slot_n = (T + 1) & 3, slot_d = (T + 3) & 3;
-      const __amdgpu_buffer_rsrc_t rk = W4A_RSRC(Kt, T + 3), rv = W4A_RSRC(Vt, T + 3);   // past the end: the last tile again, harmless
+    W4A_PROF(6);      // steady state
+    // ---- tail: the last tile's second half and both P.V products -----------------------------------------------------------------------
+    if constexpr (PERSIST) {
+      if (warm_next) {
+        // the seam: Q of the next block into the registers the last score MFMA released, its tile 2 into slot 2 (tile n-2's: every
+        // wave is behind the barrier that ended the body which read it); tiles 0 and 1 were fetched by the bodies of tiles n-3 and n-2
+        load_q(nsq, nhead, nqb);
+        const size_t off = stream_off(ntiles + 2);
+        const __amdgpu_buffer_rsrc_t rk = W4A_RSRC_OFF(Kt, off), rv = W4A_RSRC_OFF(Vt, off);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) W4A_DMA_K(rk, slot_d, i);
+        for (int i = 0; i < 4; ++i) W4A_DMA_K(rk, 2, i);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) W4A_DMA_V(rv, slot_d, i);
+        for (int i = 0; i < 4; ++i) W4A_DMA_V(rv, 2, i);
+      }
+    }
+    {
+      const int slot_c = T & 3;
       apply_pending();
       pv_stage(pfr[0], slot_c, 0);
       sm_stage(sacc[1], pfr[1], T * 64 + 32);
-      qk_stage(sacc[0], slot_n, 0);
       apply_pending();
       pv_stage(pfr[1], slot_c, 1);
-      sm_stage(sacc[0], pfr[0], (T + 1) * 64);
-      qk_stage(sacc[1], slot_n, 1);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
     }
-  }
-  // ---- tail: the last tile's second half and both P.V products -----------------------------------------------------------------------
-  {
-    const int slot_c = T & 3;
-    apply_pending();
-    pv_stage(pfr[0], slot_c, 0);
-    sm_stage(sacc[1], pfr[1], T * 64 + 32);
-    apply_pending();
-    pv_stage(pfr[1], slot_c, 1);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the tail's redundant pieces
-  W4A_SETTLE_O();                                                    // last MFMA results -> the epilogue's v_accvgpr_read
+    if (!warm_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail's redundant pieces (none when the stream runs on)
+    W4A_SETTLE_O();                                                    // last MFMA results -> the epilogue's v_accvgpr_read
 
-  // ---- epilogue: O / l, packed to 16 bit, staged through LDS and stored as whole rows -------------------------------------------------
-  // A lane holds 4 consecutive d (8 bytes) of ITS row per (d block, group): stored straight from the registers that is 32 eight-byte
-  // stores per lane, each instruction touching 32 rows -- store-ISSUE-bound (the guide prices such a tail at ~9k cycles per block; with
-  // one workgroup per CU nothing overlaps it). Instead every wave parks its 64 rows x 256 B in the K ring (not read any more: the
-  // barrier below is behind everybody's last K read AND behind everybody's last LDS-DMA, whose redundant tail pieces would otherwise
-  // land on the staged rows), 16-byte chunks XOR-swizzled by the row, and stores 16 bytes per lane: one instruction = 4 rows of 256
-  // contiguous bytes.
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");      // (the barrier builtin is not a compiler fence for LDS accesses)
-  char* stage = smem + wave * (64 * 256);
+    // ---- epilogue: O / l, packed to 16 bit, staged through LDS and stored as whole rows -----------------------------------------------
+    // A lane holds 4 consecutive d (8 bytes) of ITS row per (d block, group): stored straight from the registers that is 32 eight-byte
+    // stores per lane, each instruction touching 32 rows -- store-ISSUE-bound (the guide prices such a tail at ~9k cycles per block; with
+    // one workgroup per CU nothing overlaps it). Instead every wave parks 32 rows x 256 B at a time in the two ring slots the tail has
+    // released -- K slot 3 (waves 0, 1) and V^T slot 3 (waves 2, 3): with the next block's tiles landing in slots 0..2 these are the only
+    // free ones; the barrier below is behind everybody's last read of them AND (vmcnt(0) above, cold case) behind everybody's last
+    // LDS-DMA -- 16-byte chunks XOR-swizzled by the row, and stores 16 bytes per lane: one instruction = 4 rows of 256 contiguous bytes.
+    W4A_PROF(7);      // tail
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");      // (the barrier builtin is not a compiler fence for LDS accesses)
+    W4A_PROF(8);      // barrier
+    char* stage = smem + (wave < 2 ? 3 * TB : VRING + 3 * TB) + (wave & 1) * 8192;
 #pragma unroll
-  for (int rh = 0; rh < 2; ++rh) {
-    const float l_tot = lrun[rh] + __shfl_xor(lrun[rh], 32, 64);
-    const float inv = (l_tot > 0.f) ? 1.f / l_tot : 0.f;
-    const int row = rh * 32 + ql;
+    for (int rh = 0; rh < 2; ++rh) {
+      const float l_tot = lrun[rh] + __shfl_xor(lrun[rh], 32, 64);
+      const float inv = (l_tot > 0.f) ? 1.f / l_tot : 0.f;
 #pragma unroll
-    for (int db = 0; db < 4; ++db)
+      for (int db = 0; db < 4; ++db)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        u32x2 o;
-        o.x = pack_op2(oacc[rh][db][4 * g + 0] * inv, oacc[rh][db][4 * g + 1] * inv);
-        o.y = pack_op2(oacc[rh][db][4 * g + 2] * inv, oacc[rh][db][4 * g + 3] * inv);
-        *(u32x2*)(stage + row * 256 + (((db * 4 + g) ^ (row & 15)) << 4) + hh * 8) = o;      // d = db*32 + 8g + 4hh .. +3
+        for (int g = 0; g < 4; ++g) {
+          u32x2 o;
+          o.x = pack_op2(oacc[rh][db][4 * g + 0] * inv, oacc[rh][db][4 * g + 1] * inv);
+          o.y = pack_op2(oacc[rh][db][4 * g + 2] * inv, oacc[rh][db][4 * g + 3] * inv);
+          *(u32x2*)(stage + ql * 256 + (((db * 4 + g) ^ (ql & 15)) << 4) + hh * 8) = o;      // d = db*32 + 8g + 4hh .. +3
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the wave's own writes (the region is wave-private: no barrier)
+      const int c = lane & 15, r4 = lane >> 4;               // 16-byte chunk of the row, row inside a group of 4
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int rl = i * 4 + r4, row = rh * 32 + rl;
+        const u32x4 v = *(const u32x4*)(stage + rl * 256 + ((c ^ (rl & 15)) << 4));
+        if (wrow0 + row < sq.q_len) *(u32x4*)(O + (size_t)(sq.q_row0 + wrow0 + row) * ldo + head * HD + c * 8) = v;
       }
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the wave's own writes (the region is wave-private: no barrier)
-  {
-    const int c = lane & 15, r4 = lane >> 4;             // 16-byte chunk of the row, row inside a group of 4
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int row = i * 4 + r4;
-      const u32x4 v = *(const u32x4*)(stage + row * 256 + ((c ^ (row & 15)) << 4));
-      if (wrow0 + row < sq.q_len) *(u32x4*)(O + (size_t)(sq.q_row0 + wrow0 + row) * ldo + head * HD + c * 8) = v;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // ... read back before the second half overwrites them
+    }
+    W4A_PROF(9);      // epilogue
+#ifdef VT_ABLATIONS
+    if (!PERSIST && blockIdx.x == 8 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0) {
+      g_w4_prof[wave][10] += 1;
+      g_w4_prof[wave][11] += (unsigned long long)ntiles;
+    }
+#endif
+    if constexpr (!PERSIST) break;
+    // ---- seam ---------------------------------------------------------------------------------------------------------------------------
+    {
+      const unsigned t_nn = (unsigned)__builtin_amdgcn_readfirstlane((int)tick[0]);   // written by wave 0 behind this block's first barrier, read behind its last
+      if (wave == 0 && t_nn < nblk) {            // the ticket after that one: out now, picked up behind the next block's first wait
+        grab_issue();
+        grab_out = true;
+      }
+#ifdef VT_ABLATIONS
+      if (blockIdx.x == 8 && lane == 0) {
+        g_w4_prof[wave][10] += 1;
+        g_w4_prof[wave][11] += (unsigned long long)ntiles;
+        g_w4_prof[wave][12] += warm_next ? 1 : 0;
+      }
+#endif
+      t_cur = t_nxt;
+      t_nxt = t_nn;
+      warm_now = warm_next;
+      if (warm_now) set_block(nsq, nhead, nqb);
     }
   }
 }
 
 }  // namespace
+
+#ifdef VT_ABLATIONS
+extern "C" int vt_debug_w4_prof(unsigned long long* out, int reset) {   // (test library only, not in the header)
+  if (out) VT_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_w4_prof), sizeof(unsigned long long) * 64));
+  if (reset) {
+    static unsigned long long z[64];
+    VT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_w4_prof), z, sizeof(z)));
+  }
+  return VT_OK;
+}
+#endif
 
 bool vt_flash_attn_w4_supported(int HD, int max_q_len, int heads, int nseq) {
   (void)heads;
@@ -407,7 +636,19 @@ bool vt_flash_attn_w4_supported(int HD, int max_q_len, int heads, int nseq) {
 int vt_flash_attn_w4_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf16_t* Vt, const int* tile_table, const VtAttnSeq* seqs,
                             int nseq, int max_q_len, bf16_t* O, int ldo, int heads, int causal, float scale_log2e, int placed,
                             hipStream_t s) {
-  constexpr int smem = 8 * 16384;   // K ring + V^T ring, four 16-KiB slots each
+  constexpr int smem = 8 * 16384 + 16;   // K ring + V^T ring, four 16-KiB slots each (+ the persistent form's ticket words)
+  const int nqb_max = cdiv(max_q_len, 256);
+  // placed == 2: the persistent form -- one workgroup per CU walking the block list (kernel header)
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    VT_HIP(hipGetDevice(&dev));
+    VT_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+  }
+  const int nx = (heads % 8 == 0 && ncu % 8 == 0) ? 8 : 1;
+  const long nblocks = (long)heads * nseq * nqb_max;
+  const long cap = g_vt_flash_attn_wgs > 0 ? std::max(g_vt_flash_attn_wgs / nx, 1) * nx : ncu;
+  const int ngrid = (int)std::min<long>(cap, std::max<long>(nblocks / nx, 1) * nx);   // a multiple of nx: every XCD gets the same number of workgroups
 #define VT_FAW4(CV, PV_, ...)                                                                                  \
   do {                                                                                                         \
     auto kern = flash_attn_w4_kernel<CV, PV_ __VA_OPT__(,) __VA_ARGS__>;                                                                 \
@@ -416,12 +657,12 @@ int vt_flash_attn_w4_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf
       VT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));        \
       done = true;                                                                                             \
     }                                                                                                          \
-    hipLaunchKernelGGL(kern, dim3(heads, cdiv(max_q_len, 256), nseq), dim3(256), smem, s, Q, ldq, Kt, Vt, tile_table, seqs, O, ldo, \
-                       heads, scale_log2e);                                                                    \
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, Q, ldq, Kt, Vt, tile_table, seqs, O, ldo, heads, scale_log2e, nqb_max, nseq, nx); \
   } while (0)
+  dim3 grid(heads, nqb_max, nseq);
 #ifdef VT_ABLATIONS   // VT_W4_ABL=<bits> python tools/attn_bench.py (test library only)
   static const int abl = getenv("VT_W4_ABL") ? atoi(getenv("VT_W4_ABL")) : 0;
-  if (placed && causal && abl) {
+  if (placed == 1 && causal && abl) {
     switch (abl) {
       case 1: VT_FAW4(true, true, 1); break;
       case 2: VT_FAW4(true, true, 2); break;
@@ -445,7 +686,10 @@ int vt_flash_attn_w4_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf
     return VT_OK;
   }
 #endif
-  if (placed) {
+  if (placed == 2) {
+    grid = dim3(ngrid);
+    if (causal) VT_FAW4(true, true, 0, true); else VT_FAW4(false, true, 0, true);
+  } else if (placed) {
     if (causal) VT_FAW4(true, true); else VT_FAW4(false, true);
   } else {
     if (causal) VT_FAW4(true, false); else VT_FAW4(false, false);

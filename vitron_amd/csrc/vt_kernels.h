@@ -121,6 +121,7 @@ int vt_flash_attn_w4_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf
 // which prefill kernel vt_flash_attn_launch runs for head_dim 128 (vt_flash_attn_select): 0 auto, 1 two-waves-per-SIMD kernel,
 // 2 one-wave-per-SIMD kernel (placed), 3 the same unplaced
 extern int g_vt_flash_attn_kernel;
+extern int g_vt_flash_attn_wgs;   // persistent form: workgroup cap (0 = one per CU); tests use it to force many blocks per workgroup
 int vt_kv_tiles_launch(bf16_t* qkv, int ldqkv, int q_col0, int k_col0, int v_col0, bf16_t* Kt, bf16_t* Vt,
                        const int* tile_table, const VtAttnSeq* seqs, int nseq, int max_new_tiles, int heads, int HD,
                        const float* rope_cos, const float* rope_sin, const int* positions, hipStream_t s);
