@@ -107,6 +107,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   constexpr int HD = 128, QBLK = 256, TB = 64 * HD * 2, VRING = 4 * TB;   // 16-KiB tiles; K ring then V^T ring, 4 slots each
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
+  // every pointer argument is asked for NOW (the launcher has checked them): left to itself the compiler fetches the descriptor pointer
+  // first and the rest of the argument block only behind the descriptor's own load -- one more scalar round trip in front of the first
+  // DMA of every block. (Not an asm statement: a volatile asm in front of the descriptor load turns it into a VECTOR load -- the
+  // "not clobbered" proof scalar loads need fails -- and everything derived from it into divergent values.)
+  if (__builtin_expect(!Q || !Kt || !Vt || !tile_table || !seqs || !O || heads <= 0 || ldq <= 0 || ldo <= 0, 0)) return;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ql = lane & 31, hh = lane >> 5;
@@ -403,9 +408,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // ---- cold start: Q rows and tiles 0..2 requested now (a warm block got them from its predecessor) --------------------------------
     if (!warm_now) {
       load_q(sq, head, qb);
+      // (the three page look-ups go out together: taken one by one, each is a scalar round trip in front of its tile's DMA -- the phase
+      // clocks of the first version showed 7.7-10 k cycles of block set-up, three quarters of it these waits)
+      int pg3[3];
+      {
+        const int* tp = tile_table + sq.table_off;
+        if (ntiles >= 3) {                               // consecutive entries, no clamping: three loads, one wait
+          pg3[0] = tp[0];
+          pg3[1] = tp[1];
+          pg3[2] = tp[2];
+        } else {
+          pg3[0] = tp[0];
+          pg3[1] = pg3[2] = tp[ntiles - 1];              // (the last tile again)
+        }
+      }
 #pragma unroll
       for (int t = 0; t < 3; ++t) {
-        const size_t off = stream_off(min(t, ntiles - 1));
+        const size_t off = (size_t)pg3[t] * tile_stride + (size_t)head * (64 * HD);
         const __amdgpu_buffer_rsrc_t rk = W4A_RSRC_OFF(Kt, off), rv = W4A_RSRC_OFF(Vt, off);
 #pragma unroll
         for (int i = 0; i < 4; ++i) W4A_DMA_K(rk, t, i);
