@@ -443,6 +443,31 @@ def empirical_peaks(dev):
             res[f"d2d_copy_{name}_GBps"] = rate
             best = max(best, rate)
         res["d2d_copy_GBps"] = best
+        del src, dst
+        # the matrix pipe ALONE under this box's power limit (vt_probe_mfma: one wave per SIMD, operands in registers, nothing but
+        # v_mfma_f32_16x16x32 on the GEMM's 128 x 128 wave tile), on operand values distributed like the workload's (activations ~ N(0,1),
+        # weights ~ N(0, 0.02^2)) and on zeros: what "MFMA peak" means on this part once the operands are not constant
+        from vitron_amd import _lib
+        lib = _lib.load(operand="bf16")
+        ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+        outp = torch.empty(ncu * 256, dtype=torch.float32, device=dev)
+        iters = 4000
+        flop = 2.0 * 128 * 128 * 64 * iters * 4 * ncu
+        for name, fa, fb in (("workload_like_operands", lambda: torch.randn(65536 * 8, device=dev), lambda: torch.randn(65536 * 8, device=dev) * 0.02),
+                             ("zero_operands", lambda: torch.zeros(65536 * 8, device=dev), lambda: torch.zeros(65536 * 8, device=dev))):
+            a, b = fa().to(torch.bfloat16), fb().to(torch.bfloat16)
+            st = torch.cuda.current_stream().cuda_stream
+            for _ in range(3):
+                _lib.check(lib.vt_probe_mfma(a.data_ptr(), b.data_ptr(), outp.data_ptr(), iters, st), "vt_probe_mfma", lib)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n = 0
+            while time.perf_counter() - t0 < 0.5:
+                for _ in range(10):
+                    lib.vt_probe_mfma(a.data_ptr(), b.data_ptr(), outp.data_ptr(), iters, st)
+                torch.cuda.synchronize()
+                n += 10
+            res[f"mfma_only_bf16_tflops_{name}"] = flop * n / (time.perf_counter() - t0) / 1e12
     except Exception as e:  # noqa: BLE001 -- a measurement aid must not take the benchmark down
         res["error"] = f"{type(e).__name__}: {e}"
     return res
@@ -929,6 +954,10 @@ def main():
         if world == 1 and not args.no_empirical_peaks:
             emp = empirical_peaks(dev)
             out["roofline"]["empirical_peaks"] = emp
+            if emp.get("mfma_only_bf16_tflops_workload_like_operands"):
+                out["roofline"]["frac_of_mfma_only_rate"] = achieved / emp["mfma_only_bf16_tflops_workload_like_operands"]
+                out["roofline"]["frac_of_mfma_only_rate_note"] = ("achieved / what a loop of NOTHING BUT MFMAs sustains on this box under its power limit on "
+                                                                  "workload-like operand values (roofline.empirical_peaks); `frac` stays against the 2.5 PFLOP/s dense bf16 peak")
             if emp.get("hipblaslt_bf16_gemm_8192_tflops"):
                 out["roofline"]["frac_of_empirical_gemm_peak"] = achieved / emp["hipblaslt_bf16_gemm_8192_tflops"]
             if emp.get("d2d_copy_GBps") and "decode" in out:

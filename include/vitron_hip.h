@@ -359,6 +359,12 @@ int vt_llama_forward(const vt_llama_model* m, const vt_kv_cache* kv, const uint1
 enum { VT_PROF_GEMM_TILE = 0, VT_PROF_FLASH_ATTN = 1, VT_PROF_GEMM_SKINNY = 2, VT_PROF_ATTN_DECODE = 3, VT_PROF_CLASSES = 4 };
 int vt_profile_begin(void);
 int vt_profile_end(int* launches, double* total_ms, double* total_work);
+/* What the matrix pipe sustains by itself on THIS device (measurement aid for the roofline, no reference counterpart): one wave per SIMD
+ * on every CU, operands in registers, nothing but v_mfma_f32_16x16x32 (bf16 or f16: the library's operand format) on a 128 x 128
+ * accumulator tile in the loop -- the four-wave GEMM's wave tile without its memory side. a, b: at least 64 Ki 16-byte fragments each
+ * (8 operand values: the caller chooses their distribution -- the sustained clock of this part depends on the operand VALUES, zeros
+ * run ~19 % faster than N(0,1)); out: multiprocessors x 256 floats. FLOP per launch = 2 * 128*128*64 * iters * 4 * multiprocessors. */
+int vt_probe_mfma(const uint16_t* a, const uint16_t* b, float* out, int iters, void* stream);
 
 #ifdef __cplusplus
 }

@@ -670,3 +670,20 @@ def test_flash_attention_ragged_multi_sequence_chunked_vs_fp64(dev, causal, lens
         ref = torch.einsum("hqk,khd->qhd", torch.softmax(s, -1), vv).reshape(q, D).float()
         assert rel_l2(got[r0:r0 + q].float(), bf16r(ref)) <= 1.3e-3, (i, rel_l2(got[r0:r0 + q].float(), bf16r(ref)))
         r0 += q
+
+
+@pytest.mark.parametrize("op", ["bf16", "fp16"])
+def test_mfma_probe_counts_what_it_claims(dev, op):
+    """vt_probe_mfma (the "matrix pipe alone" measurement aid behind roofline.empirical_peaks): with all-ones operands every accumulator
+    element is the number of k it saw, so every thread must report 64 tiles x 2 elements x 64 k per iteration -- the FLOP count bench.py
+    divides by is what the kernel really executes (nothing folded away by the compiler)."""
+    from vitron_amd import _lib
+    lib = _lib.load(operand=op)
+    dt = torch.bfloat16 if op == "bf16" else torch.float16
+    a = torch.ones(65536 * 8, dtype=dt, device=dev)
+    ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+    out = torch.zeros(ncu * 256, dtype=torch.float32, device=dev)
+    for iters in (1, 3):
+        _lib.check(lib.vt_probe_mfma(a.data_ptr(), a.data_ptr(), out.data_ptr(), iters, torch.cuda.current_stream().cuda_stream), "vt_probe_mfma", lib)
+        torch.cuda.synchronize()
+        assert torch.equal(out, torch.full_like(out, 64 * 2 * 64 * iters)), (iters, out[:4].tolist())

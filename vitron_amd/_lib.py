@@ -105,6 +105,7 @@ SIGNATURES = {
                               _i, vp, vp, vp, _sz, vp]),
     "vt_profile_begin": (_i, []),
     "vt_profile_end": (_i, [C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "vt_probe_mfma": (_i, [vp, vp, vp, _i, vp]),
 }
 PROF_CLASSES = ("gemm_tile", "flash_attn", "gemm_skinny", "attn_decode")
 

@@ -72,6 +72,43 @@ inline hipStream_t S(void* s) { return (hipStream_t)s; }
 inline hipStream_t S_(void* s) { return (hipStream_t)s; }
 }  // namespace
 
+namespace {
+// vt_probe_mfma: the matrix pipe alone (include/vitron_hip.h). 8 x 8 accumulator quads = the 128 x 128 wave tile of gemm_w4_kernel,
+// two k-halves of fragments held in registers, 128 MFMAs per iteration and nothing else.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void probe_mfma_kernel(const bf16x8* __restrict__ a,
+                                                                                                    const bf16x8* __restrict__ b,
+                                                                                                    float* __restrict__ out, int iters) {
+  const int t = threadIdx.x + blockIdx.x * 256;
+  bf16x8 fa[2][8], fb[2][8];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      fa[h][i] = a[(t * 16 + h * 8 + i) & 0xffff];
+      fb[h][i] = b[(t * 16 + h * 8 + i) & 0xffff];
+    }
+  f32x4 acc[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = VT_MFMA_16x16x32(fa[h][i], fb[h][j], acc[i][j]);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += acc[i][j][0] + acc[i][j][3];
+  out[t] = s;
+}
+}  // namespace
+
 extern "C" {
 
 int vt_version(void) { return 110; }
@@ -96,6 +133,16 @@ int vt_profile_begin(void) {
   }
   g_prof_recs.clear();
   g_prof_on = true;
+  return VT_OK;
+}
+
+int vt_probe_mfma(const uint16_t* a, const uint16_t* b, float* out, int iters, void* stream) {
+  VT_REQUIRE(a && b && out && iters > 0, "vt_probe_mfma: null pointer or iters <= 0");
+  int dev = 0, ncu = 0;
+  VT_HIP(hipGetDevice(&dev));
+  VT_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+  hipLaunchKernelGGL(probe_mfma_kernel, dim3(ncu), dim3(256), 0, S(stream), (const bf16x8*)a, (const bf16x8*)b, out, iters);
+  VT_LAUNCH_CHECK();
   return VT_OK;
 }
 
