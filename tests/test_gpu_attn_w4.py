@@ -81,7 +81,7 @@ CASES = [(True, [700, 300, 64, 1], [0, 0, 0, 0]), (False, [577, 130], [0, 0]), (
 
 
 @pytest.mark.parametrize("op", ["bf16", "fp16"])
-@pytest.mark.parametrize("kernel", [2, 3, 4, 4 | (8 << 8)])
+@pytest.mark.parametrize("kernel", [2, 3, 4, 4 | (8 << 8), 5])
 @pytest.mark.parametrize("causal,lens,pasts", CASES)
 def test_w4_kernel_vs_fp64_and_vs_the_two_wave_kernel(dev, causal, lens, pasts, kernel, op):
     from vitron_amd import ops
@@ -184,6 +184,24 @@ def test_w4_kernel_score_range_edges(dev, variant):
         err = rel_l2(out, ref)
         print(f"[w4-edges] {variant} kernel {kernel}: rel_l2 {err:.3e}", flush=True)
         assert torch.isfinite(out).all() and err <= 1.1e-3, (variant, kernel, err)
+
+
+@pytest.mark.parametrize("op", ["bf16", "fp16"])
+def test_w4_planned_dispatch_order_changes_nothing_but_the_schedule(dev, op):
+    """One long causal sequence on 32 heads (here 2304 rows: 288 blocks, more than one round of the 256 CUs): kernel 2 dispatches its
+    blocks in the order vt_flash_attn_block_order planned, kernel 5 in the grid's natural order -- the same blocks, the same arithmetic
+    per block: identical bits. (The timing side is tools/attn_bench.py ATTN_BENCH_KERNELS=2,5.)"""
+    from vitron_amd import ops
+    heads, hd = 32, 128
+    scale = 1.0 / math.sqrt(hd)
+    for S, past in ((2304, 0), (2100, 192), (5120, 0)):
+        q, kt, vt, table, desc, _ = _problem(dev, DT[op], heads, [S], [past], seed=700)
+        outs = []
+        for kernel in (5, 2):
+            ops.flash_attn_select(kernel)
+            outs.append(ops.flash_attn(q, kt, vt, table, desc, S, heads, hd, True, scale).clone())
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0], outs[1]), (S, past)
 
 
 def test_w4_kernel_is_what_a_long_prefill_runs(dev):

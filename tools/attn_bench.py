@@ -71,6 +71,12 @@ if __name__ == "__main__" and os.environ.get("VT_W4_ABL"):
     run(5120, 32, 128, 1, True)
     run(5120, 32, 128, 8, True)
     sys.exit(0)
+if __name__ == "__main__" and os.environ.get("VT_W4_ORDER_FIXED"):
+    # cost model of the planned dispatch order (test library): VT_W4_ORDER_FIXED=<cycles per block outside the tile loop>
+    _lib.load(ablations=True).vt_flash_attn_select(2)
+    for _ in range(12):                         # (the first windows of a fresh process run at a lower clock: read the last ones)
+        run(5120, 32, 128, 1, True)
+    sys.exit(0)
 if __name__ == "__main__" and os.environ.get("ATTN_BENCH_KERNELS"):
     # A/B of the head_dim-128 prefill kernels (vt_flash_attn_select): ATTN_BENCH_KERNELS=1,2,3 python tools/attn_bench.py
     _lib.load()

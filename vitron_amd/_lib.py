@@ -106,6 +106,7 @@ SIGNATURES = {
     "vt_profile_begin": (_i, []),
     "vt_profile_end": (_i, [C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "vt_probe_mfma": (_i, [vp, vp, vp, _i, vp]),
+    "vt_flash_attn_block_order": (_i, [_i, _i, _i, _i, C.POINTER(C.c_int), _i]),
 }
 PROF_CLASSES = ("gemm_tile", "flash_attn", "gemm_skinny", "attn_decode")
 

@@ -200,12 +200,21 @@ int vt_flash_attn(const uint16_t* Q, int ldq, const uint16_t* k_tiles, const uin
 
 int vt_flash_attn_select(int kernel) {
   const int k = kernel & 0xff, wgs = kernel >> 8;
-  VT_REQUIRE(kernel >= 0 && k <= 4 && (wgs == 0 || k == 4),
-             "vt_flash_attn_select: kernel %d (0 auto, 1 two-waves-per-SIMD, 2 one-wave-per-SIMD placed, 3 unplaced, 4 placed + persistent; "
-             "bits 8.. = workgroup cap of 4)", kernel);
-  g_vt_flash_attn_kernel = k;
+  VT_REQUIRE(kernel >= 0 && k <= 5 && (wgs == 0 || k == 4),
+             "vt_flash_attn_select: kernel %d (0 auto, 1 two-waves-per-SIMD, 2 one-wave-per-SIMD placed, 3 unplaced, 4 placed + persistent, "
+             "5 placed in the grid's natural block order; bits 8.. = workgroup cap of 4)", kernel);
+  g_vt_flash_attn_kernel = k == 5 ? 2 : k;
+  g_vt_flash_attn_order = k == 5 ? 0 : 1;
   g_vt_flash_attn_wgs = wgs;
   return VT_OK;
+}
+
+int vt_flash_attn_block_order(int heads, int q_blocks, int nseq, int multiprocessors, int* order, int capacity) {
+  VT_REQUIRE(heads > 0 && q_blocks > 0 && nseq > 0 && multiprocessors > 0, "vt_flash_attn_block_order: empty problem");
+  const std::vector<int> o = vt_flash_attn_w4_block_order(heads, q_blocks, nseq, multiprocessors);
+  VT_REQUIRE(o.empty() || (order && capacity >= (int)o.size()), "vt_flash_attn_block_order: order[] holds %d entries, need %d", capacity, (int)o.size());
+  for (size_t i = 0; i < o.size(); ++i) order[i] = o[i];
+  return (int)o.size();
 }
 
 size_t vt_attn_decode_scratch_bytes(int nseq, int heads, int head_dim, int max_kv_len);  // defined in vt_attn.hip (C++ linkage there)

@@ -970,6 +970,7 @@ __global__ __launch_bounds__(256) void attn_temporal8_kernel(const bf16_t* __res
 
 int g_vt_flash_attn_kernel = 0;
 int g_vt_flash_attn_wgs = 0;
+int g_vt_flash_attn_order = 1;
 
 int vt_flash_attn_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf16_t* Vt, const int* tile_table,
                          const VtAttnSeq* seqs, int nseq, int max_q_len, bf16_t* O, int ldo, int heads, int HD,

@@ -26,6 +26,12 @@
 // schedule is tested against, and the prologue / tail of the placed kernel.
 #include <stdlib.h>
 
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
 #include "vt_common.h"
 #include "vt_kernels.h"
 
@@ -103,7 +109,7 @@ template <bool CAUSAL, bool PLACED, int ABL = 0, bool PERSIST = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void flash_attn_w4_kernel(
     const op16_t* __restrict__ Q, int ldq, const op16_t* __restrict__ Kt, const op16_t* __restrict__ Vt,
     const int* __restrict__ tile_table, const VtAttnSeq* __restrict__ seqs, op16_t* __restrict__ O, int ldo, int heads,
-    float scale_log2e, int nqb_max, int nseq, int nx) {
+    float scale_log2e, int nqb_max, int nseq, int nx, const int* __restrict__ order) {
   constexpr int HD = 128, QBLK = 256, TB = 64 * HD * 2, VRING = 4 * TB;   // 16-KiB tiles; K ring then V^T ring, 4 slots each
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -377,10 +383,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     t_cur = (unsigned)__builtin_amdgcn_readfirstlane((int)tick[1]);
     t_nxt = (unsigned)__builtin_amdgcn_readfirstlane((int)tick[2]);
   } else {
-    const VtAttnSeq s0 = seqs[blockIdx.z];
-    const int qb0 = (s0.q_len + QBLK - 1) / QBLK - 1 - (int)blockIdx.y;   // heaviest (latest) causal blocks of all heads first
+    // which block: the grid itself (head fastest, heaviest causal blocks of all heads first), or -- causal launches of more than one
+    // round -- the dispatch order the launcher planned (w4_block_order below): entry i names the block of workgroup i
+    int bx = (int)blockIdx.x, by = (int)blockIdx.y, bz = (int)blockIdx.z;
+    if (order) {
+      const int lin = order[blockIdx.x];
+      bx = lin % heads;
+      by = (lin / heads) % nqb_max;
+      bz = lin / (heads * nqb_max);
+    }
+    const VtAttnSeq s0 = seqs[bz];
+    const int qb0 = (s0.q_len + QBLK - 1) / QBLK - 1 - by;
     if (qb0 < 0) return;
-    set_block(s0, (int)blockIdx.x, qb0);
+    set_block(s0, bx, qb0);
   }
 
   unsigned long long prof_t = __builtin_readcyclecounter();
@@ -646,6 +661,111 @@ extern "C" int vt_debug_w4_prof(unsigned long long* out, int reset) {   // (test
 }
 #endif
 
+// ------------------------------------------------------------------------------------------------------------------
+// Dispatch order of a causal launch (host). The hardware hands workgroups to CUs in index order, each to the first CU that frees up
+// (list scheduling); with the grid's natural order -- heaviest blocks first -- that is LPT, and for ONE 5120-token sequence (640
+// blocks of 4 .. 80 tiles on 256 CUs, 2.5 per CU) LPT ends 11.8 % above the mean load: it spends the 256 largest blocks on 256 CUs
+// and stacks the small ones on top of pairs that are already too long. A bin packing at a target makespan (MULTIFIT: first-fit
+// decreasing inside a binary search on the capacity) finds the assignment LPT cannot -- the seven largest sizes paired with their
+// complements, an eighth of the CUs running nothing but chains of small blocks: 2.9 % above the mean -- and listing the blocks by
+// their PLANNED START TIME makes the dispatcher reproduce it (the CU that frees up at a block's planned start is the one it was packed
+// on). Planned per XCD (workgroup i runs on XCD i % 8; heads = XCD mod 8 keeps a head's K / V^T pages in one L2), identical plans
+// interleaved. Block cost = 21.8 k cycles + 3183 per 64-key tile (phase clocks of the kernel); sequences are taken as
+// equally long (their lengths live on the device): the order is a permutation of the grid whatever it is, only the balance depends on
+// the model. Returns the plan only where it beats the natural order under the model by more than 2 %.
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+struct W4Job {
+  double cost;
+  int lin;      // head-group-local linear id: hl + hpx * (y + nqb * z)
+};
+double w4_list_makespan(const std::vector<W4Job>& order, int m) {
+  std::vector<double> cu(m, 0.0);   // (m <= 256: a linear scan per job is cheap enough)
+  for (const W4Job& j : order) {
+    int best = 0;
+    for (int i = 1; i < m; ++i)
+      if (cu[i] < cu[best]) best = i;
+    cu[best] += j.cost;
+  }
+  return *std::max_element(cu.begin(), cu.end());
+}
+bool w4_ffd(const std::vector<W4Job>& sorted, double T, int m, std::vector<std::vector<W4Job>>& bins) {
+  bins.clear();
+  std::vector<double> load;
+  for (const W4Job& j : sorted) {
+    size_t b = 0;
+    for (; b < bins.size(); ++b)
+      if (load[b] + j.cost <= T) break;
+    if (b == bins.size()) {
+      if ((int)bins.size() >= m) return false;
+      bins.emplace_back();
+      load.push_back(0.0);
+    }
+    bins[b].push_back(j);
+    load[b] += j.cost;
+  }
+  return true;
+}
+}  // namespace
+
+// order[i] = block (head + heads * (y + nqb * z)) of workgroup i; empty = keep the grid's natural order
+std::vector<int> vt_flash_attn_w4_block_order(int heads, int nqb, int nseq, int ncu) {
+  const int nx = (heads % 8 == 0 && ncu % 8 == 0) ? 8 : 1;
+  const int hpx = heads / nx, m = ncu / nx;
+  const long n = (long)hpx * nqb * nseq;
+  if (n <= m || n > 4096) return {};                 // one round, or so many blocks that list scheduling balances by itself
+  double fixed = 21.8e3;                           // per-block cycles outside the tile loop
+#ifdef VT_ABLATIONS
+  if (getenv("VT_W4_ORDER_FIXED")) fixed = atof(getenv("VT_W4_ORDER_FIXED"));   // (test library: A/B of the cost model)
+#endif
+  std::vector<W4Job> jobs;
+  jobs.reserve(n);
+  for (int z = 0; z < nseq; ++z)
+    for (int y = 0; y < nqb; ++y)
+      for (int hl = 0; hl < hpx; ++hl) jobs.push_back({fixed + 3183.0 * 4 * (nqb - y), hl + hpx * (y + nqb * z)});
+  // the natural order, y-major per sequence (what the 3-D grid dispatches) -- and its makespan under the model
+  const double natural = w4_list_makespan(jobs, m);
+  std::vector<W4Job> sorted = jobs;
+  std::stable_sort(sorted.begin(), sorted.end(), [](const W4Job& a, const W4Job& b) { return a.cost > b.cost; });
+  double total = 0.0;
+  for (const W4Job& j : jobs) total += j.cost;
+  double lo = std::max(total / m, sorted[0].cost), hi = 2.0 * lo;
+  std::vector<std::vector<W4Job>> bins, best;
+  for (int it = 0; it < 24; ++it) {
+    const double T = 0.5 * (lo + hi);
+    if (w4_ffd(sorted, T, m, bins)) {
+      best = bins;
+      hi = T;
+    } else {
+      lo = T;
+    }
+  }
+  if (best.empty()) return {};
+  struct Ev {
+    double start, cost;
+    int lin;
+  };
+  std::vector<Ev> ev;
+  for (const auto& b : best) {
+    double t = 0.0;
+    for (const W4Job& j : b) {            // (largest first inside a bin: first-fit decreasing filled it that way)
+      ev.push_back({t, j.cost, j.lin});
+      t += j.cost;
+    }
+  }
+  std::stable_sort(ev.begin(), ev.end(), [](const Ev& a, const Ev& b) { return a.start != b.start ? a.start < b.start : a.cost > b.cost; });
+  std::vector<W4Job> planned;
+  for (const Ev& e : ev) planned.push_back({e.cost, e.lin});
+  if (w4_list_makespan(planned, m) > 0.98 * natural) return {};
+  std::vector<int> order((size_t)n * nx);
+  for (long p = 0; p < n; ++p)
+    for (int x = 0; x < nx; ++x) {
+      const int lin = planned[p].lin, hl = lin % hpx, yz = lin / hpx;   // XCD x runs the same plan on its own heads
+      order[(size_t)p * nx + x] = (hl * nx + x) + heads * yz;
+    }
+  return order;
+}
+
 bool vt_flash_attn_w4_supported(int HD, int max_q_len, int heads, int nseq) {
   (void)heads;
   (void)nseq;
@@ -676,9 +796,29 @@ int vt_flash_attn_w4_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf
       VT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));        \
       done = true;                                                                                             \
     }                                                                                                          \
-    hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, Q, ldq, Kt, Vt, tile_table, seqs, O, ldo, heads, scale_log2e, nqb_max, nseq, nx); \
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, Q, ldq, Kt, Vt, tile_table, seqs, O, ldo, heads, scale_log2e, nqb_max, nseq, nx, order); \
   } while (0)
   dim3 grid(heads, nqb_max, nseq);
+  // causal launches of more than one round: the planned dispatch order (above), computed once per shape and kept on the device
+  const int* order = nullptr;
+  if (causal && placed != 2 && g_vt_flash_attn_order) {
+    static std::mutex mu;
+    static std::map<std::tuple<int, int, int>, int*> cache;
+    std::lock_guard<std::mutex> lk(mu);
+    const auto key = std::make_tuple(heads, nqb_max, nseq);
+    auto it = cache.find(key);
+    if (it == cache.end()) {
+      const std::vector<int> o = vt_flash_attn_w4_block_order(heads, nqb_max, nseq, ncu);
+      int* d = nullptr;
+      if (!o.empty()) {
+        VT_HIP(hipMalloc((void**)&d, o.size() * sizeof(int)));
+        VT_HIP(hipMemcpy(d, o.data(), o.size() * sizeof(int), hipMemcpyHostToDevice));
+      }
+      it = cache.emplace(key, d).first;
+    }
+    order = it->second;
+    if (order) grid = dim3((unsigned)nblocks);
+  }
 #ifdef VT_ABLATIONS   // VT_W4_ABL=<bits> python tools/attn_bench.py (test library only)
   static const int abl = getenv("VT_W4_ABL") ? atoi(getenv("VT_W4_ABL")) : 0;
   if (placed == 1 && causal && abl) {

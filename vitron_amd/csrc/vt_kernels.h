@@ -1,6 +1,7 @@
 // vt_kernels.h -- internal launch prototypes shared by the .hip translation units and vt_api.hip.
 // Not part of the public C-ABI (that is include/vitron_hip.h).
 #pragma once
+#include <vector>
 #include "vt_common.h"
 #include "../../include/vitron_hip.h"
 
@@ -115,12 +116,14 @@ int vt_flash_attn_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf16_
 // vt_attn_w4.hip: the one-wave-per-SIMD prefill kernel (head_dim 128, 256-row blocks). placed = 1: hand-placed sub-iterations,
 // 0: the same pipeline with its stages run one after the other (reference of the placed schedule)
 bool vt_flash_attn_w4_supported(int HD, int max_q_len, int heads, int nseq);
+std::vector<int> vt_flash_attn_w4_block_order(int heads, int nqb, int nseq, int ncu);
 int vt_flash_attn_w4_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf16_t* Vt, const int* tile_table, const VtAttnSeq* seqs,
                             int nseq, int max_q_len, bf16_t* O, int ldo, int heads, int causal, float scale_log2e, int placed,
                             hipStream_t s);
 // which prefill kernel vt_flash_attn_launch runs for head_dim 128 (vt_flash_attn_select): 0 auto, 1 two-waves-per-SIMD kernel,
 // 2 one-wave-per-SIMD kernel (placed), 3 the same unplaced
 extern int g_vt_flash_attn_kernel;
+extern int g_vt_flash_attn_order;  // 1 (default): causal launches of the one-wave-per-SIMD kernel use the planned dispatch order
 extern int g_vt_flash_attn_wgs;   // persistent form: workgroup cap (0 = one per CU); tests use it to force many blocks per workgroup
 int vt_kv_tiles_launch(bf16_t* qkv, int ldqkv, int q_col0, int k_col0, int v_col0, bf16_t* Kt, bf16_t* Vt,
                        const int* tile_table, const VtAttnSeq* seqs, int nseq, int max_new_tiles, int heads, int HD,

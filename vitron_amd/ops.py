@@ -156,7 +156,8 @@ def flash_attn(q: torch.Tensor, k_tiles: torch.Tensor, vt_tiles: torch.Tensor, t
 def flash_attn_select(kernel: int) -> None:
     """Process-wide choice of the head_dim-128 prefill kernel in BOTH operand builds (vt_flash_attn_select, include/vitron_hip.h):
     0 automatic, 1 two-waves-per-SIMD kernel, 2 one-wave-per-SIMD hand-placed kernel, 3 that kernel unplaced (its reference), 4 the
-    hand-placed kernel in its persistent form (4 | (n << 8): at most n workgroups)."""
+    hand-placed kernel in its persistent form (4 | (n << 8): at most n workgroups), 5 kernel 2 in the grid's natural block order
+    instead of the planned dispatch order."""
     for op in ("bf16", "fp16"):
         lib = _lib.load(operand=op)
         _lib.check(lib.vt_flash_attn_select(int(kernel)), "vt_flash_attn_select", lib)
