@@ -166,13 +166,6 @@ def softmax_program(sub):
     return maxins, ex
 
 
-def split_ok(ex, cut):
-    """A block boundary may not separate a transcendental from a consumer that would then sit right behind it in the NEXT block without
-    another instruction of that block in between -- the MFMA between two blocks is the one wait state the hardware asks for, so any cut
-    is legal; but keep a pair's two fmas / two exps together (they were written for that interleave)."""
-    return True
-
-
 def generate(sub):
     mem = memory_ops(sub)
     maxins, ex = softmax_program(sub)
