@@ -24,6 +24,9 @@
 // Same tile / page layout, same permuted K rows, same results contract as flash_attn_kernel (tests compare the two kernels).
 // PLACED = false keeps the same pipeline with the three stages run one after the other by simple loops: the reference the placed
 // schedule is tested against, and the prologue / tail of the placed kernel.
+// Around the kernel (host side, end of this file): causal launches of more than one round hand their blocks to the dispatcher in a
+// PLANNED order (vt_flash_attn_w4_block_order: the order is the schedule); PERSIST = true is the persistent form (one workgroup per CU
+// walking the block list, K / V^T stream running on across block seams) -- correct, selectable, slower today.
 #include <stdlib.h>
 
 #include <algorithm>
