@@ -226,6 +226,65 @@ def cpu_baseline(image_size, frames, text_len, seed, mode="full", budget_s=420.0
             "est_seconds_per_step": total, "measured_seconds": time.perf_counter() - t_start}
 
 
+def cpu_baseline_reference(dev, image_sizes, frames, text_len, seed, budget_s=330.0):
+    """kind "reference" (SURVEY.md 8(d) "CPU baseline timed beside it"): the REFERENCE's OWN modules on THIS box's host
+    cores -- LanguageBind video tower (24 layers, as the reference runs them) + mlp2x_gelu projector + prepare_inputs_labels_for_multimodal
+    + LlavaLlamaForCausalLM.forward (32 layers, eager S x S attention, logits of all positions), fp32, full depth, 32 DISTINCT decoder
+    layers (27 GB of fp32 weights: no cache flattery), run once per image size. The modules come from oracle/_ref/vitron_ref.zip, staged
+    from /root/reference by __graft_entry__.build() (oracle/stage_ref.py), imported through oracle/ref_shim.py. Returns None when
+    neither the archive nor the reference tree is there (the caller falls back to the port)."""
+    import torch
+
+    from oracle import ref_model, ref_shim
+    from vitron_amd import synth
+
+    if not ref_shim.available():
+        return None
+    t_start = time.perf_counter()
+    ncpu = os.cpu_count() or 1
+    ns = ref_shim.install()
+    # weights: counter-based streams evaluated on the GPU (seconds), moved to the host tensor by tensor
+    model = ref_model.build_decoder(ns, synth.VICUNA_7B, synth.llama_state(synth.VICUNA_7B, synth.HashGenerator(seed + 10), dev))
+    psd = {k: v.cpu() for k, v in synth.projector_state(1024, 4096, synth.HashGenerator(seed + 12), dev).items()}
+    t_build = time.perf_counter() - t_start
+    # thread count: fastest of a short calibration on the MLP GEMM shape (PyTorch's CPU GEMMs stop scaling long before 256 threads)
+    a, w = torch.randn((1024, 4096)), torch.randn((11008, 4096))
+    cal = {}
+    for c in sorted({c for c in (16, 32, 64, 96, 128) if c <= ncpu} | {min(ncpu, 8)}):
+        torch.set_num_threads(c)
+        torch.matmul(a, w.t())
+        t0 = time.perf_counter()
+        for _ in range(3):
+            torch.matmul(a, w.t())
+        cal[c] = (time.perf_counter() - t0) / 3
+    cores = min(cal, key=cal.get)
+    torch.set_num_threads(cores)
+    res = {}
+    for size in sorted(image_sizes):                       # smallest first: its time decides whether the larger one fits the budget
+        G = size // 14
+        S = frames * G * G + text_len
+        if res:
+            (s0, r0), = list(res.items())[-1:]
+            predicted = r0["seconds_total"] * (S / r0["S"]) * (1.0 + 0.15 * S / 5120)
+            if time.perf_counter() - t_start + predicted > budget_s:
+                res[size] = {"S": S, "skipped": f"predicted {predicted:.0f} s on top of {time.perf_counter() - t_start:.0f} s spent exceeds the {budget_s:.0f} s budget of this leg"}
+                continue
+        vcfg = dict(synth.VIT_L14, image_size=size, add_time_attn=True, num_frames=frames)
+        ref_model.attach(ns, model, vcfg, {k: v.cpu() for k, v in synth.vit_state(vcfg, synth.HashGenerator(seed + 11), dev).items()}, psd)
+        g = torch.Generator().manual_seed(seed + size)
+        clip = torch.randn((3, frames, size, size), generator=g).to(torch.bfloat16).float()
+        ids = torch.cat([torch.tensor([1]), torch.full((frames,), -200), torch.randint(3, 32000, (text_len - 1,), generator=g)]).unsqueeze(0)
+        logits, embeds, t_front, t_dec = ref_model.prefill(model, ids, clip)
+        assert embeds.shape[1] == S and logits.shape[1] == S
+        res[size] = {"S": S, "tokens_per_s": S / (t_front + t_dec), "seconds_total": t_front + t_dec,
+                     "seconds_towers_projector_splice": t_front, "seconds_decoder": t_dec}
+        del logits, embeds
+    del model
+    return {"cores": cores, "host_threads_available": ncpu, "calibration_s_per_mlp_gemm": {c: round(v, 4) for c, v in cal.items()},
+            "modules_from": ref_shim.source(), "seconds_model_build": t_build, "by_image_size": res,
+            "measured_seconds": time.perf_counter() - t_start}
+
+
 def decode_report_synthetic(model, llama, dev, steps, batch=4, ctx=609):
     """Sub-field of the decode report (round 2's number, kept for continuity): BASELINE configs[4]-shaped decode -- `batch`
     sequences with a `ctx`-token context (576 visual + region + prompt tokens in the real flow; synthetic embedding rows
@@ -398,6 +457,81 @@ def c2_report(model, llama, dev, seed, reps=10):
     gt = prof["gemm_tile"]
     return {"workload": "BASELINE configs[1]: one 336x336 image (576 visual tokens) + 512-token prompt -> S=1088; LanguageBind image ViT-L/14 (23 of 24 layers) + "
                         "mlp2x_gelu projector + Vicuna-7B-shaped decoder prefill (32 layers, paged KV), last-position logits + greedy token",
+            "S": S, "reps": reps, "ms_per_step": dt * 1e3, "ms_per_step_hipevent_median": ev[len(ev) // 2], "tokens_per_s": S / dt,
+            "algorithmic_tflop_per_step": fl["total"] / 1e12, "end_to_end_frac_of_mfma_peak": fl["total"] / 1e12 / dt / MFMA_BF16_PEAK_TFLOPS,
+            "gemm_class_tflops": gt["work"] / (gt["ms"] * 1e-3) / 1e12 if gt["ms"] > 0 else 0.0,
+            "kernel_ms_per_step": {k: v["ms"] / 3 for k, v in prof.items() if v["launches"]}}
+
+
+def prefill_report_224(model, llama, dev, seed, kind, reps, frames=8, text_len=512):
+    """The REFERENCE-NATIVE image size (the reference's processors are hard-wired to 224 x 224 --
+    image/processing_image.py:20-21, video/processing_video.py:50-51, region_extractor/layer.py:60 -- so N = 257 tokens per frame and
+    G = 16 are the only shapes a real Vitron checkpoint runs). kind "clip": C3-224 = one 8-frame 224 px clip + 512 tokens, S = 2560,
+    36.60 TFLOP; kind "image": C2-224 = one 224 px image + 512 tokens, S = 768, 10.27 TFLOP. Same full-work step as the headline
+    (tower, projector, splice, 32 layers, last-position logits, arg-max; nothing cached), with a temporary 224 px tower of the same
+    random init. Outside the headline's timed region."""
+    import torch
+    from types import SimpleNamespace
+
+    from vitron_amd import _lib, ops, synth
+    from vitron_amd.engine import SequenceState, llama_forward
+    from vitron_amd.model.multimodal_encoder.builder import build_image_tower, build_video_tower
+
+    clip_kind = kind == "clip"
+    gen = synth.make_generator(seed + (224 if clip_kind else 225), dev)
+    vcfg = dict(synth.VIT_L14, image_size=224, add_time_attn=clip_kind, num_frames=frames if clip_kind else 1)
+    sel = model.config.mm_vision_select_layer
+    if clip_kind:
+        tower = build_video_tower(SimpleNamespace(mm_video_tower="synthetic224/LanguageBind_Video_merge", mm_vision_select_layer=sel), delay_load=True)
+        slot = "video_tower"
+    else:
+        tower = build_image_tower(SimpleNamespace(mm_image_tower="synthetic224/LanguageBind_Image", mm_vision_select_layer=sel), delay_load=True)
+        slot = "image_tower"
+    tower._dtype = llama.dtype
+    tower.init_synthetic(vcfg, gen, dev)
+    n_img = frames if clip_kind else 1
+    pix = torch.randn((3, frames, 224, 224) if clip_kind else (3, 224, 224), generator=gen, device=dev).to(llama.dtype)
+    ids = torch.cat([torch.tensor([1], device=dev), torch.full((n_img,), -200, device=dev),
+                     torch.randint(3, 32000, (text_len - 1,), generator=gen, device=dev)]).unsqueeze(0)
+    ids_host = ids.cpu()
+    S = n_img * 256 + text_len
+    model._ensure_kv((S + 63) // 64 + 4)
+    inner = model.get_model()
+    keep = getattr(inner, slot, None)
+    setattr(inner, slot, tower)
+    try:
+        def step():
+            (_, _, _, _, embeds, _) = model.prepare_inputs_labels_for_multimodal(ids, None, None, None, None, [pix], None, input_ids_host=ids_host)
+            seq = SequenceState()
+            ops.argmax(llama_forward(llama, model.kv, [seq], embeds[0], [embeds.shape[1]]))
+            model.kv.release(seq.pages)
+            return embeds.shape[1]
+
+        for _ in range(3):
+            assert step() == S
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        marks[0].record()
+        for k in range(reps):
+            step()
+            marks[k + 1].record()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        ev = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(reps))
+        _lib.profile_begin()
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        prof = _lib.profile_end()
+    finally:
+        setattr(inner, slot, keep)
+    fl = algorithmic_flops(S, n_img * 256, n_img, 257, 256, temporal=clip_kind)
+    gt = prof["gemm_tile"]
+    return {"workload": (f"{'BASELINE configs[2]' if clip_kind else 'BASELINE configs[1]'} at the reference-native 224 px: "
+                         f"{'one 8-frame 224x224 clip (2048 visual tokens)' if clip_kind else 'one 224x224 image (256 visual tokens)'} + {text_len}-token prompt -> S={S}; "
+                         f"LanguageBind {'video' if clip_kind else 'image'} ViT-L/14 (23 of 24 layers, N = 257) + mlp2x_gelu projector + Vicuna-7B-shaped decoder "
+                         "prefill (32 layers, paged KV), last-position logits + greedy token"),
             "S": S, "reps": reps, "ms_per_step": dt * 1e3, "ms_per_step_hipevent_median": ev[len(ev) // 2], "tokens_per_s": S / dt,
             "algorithmic_tflop_per_step": fl["total"] / 1e12, "end_to_end_frac_of_mfma_peak": fl["total"] / 1e12 / dt / MFMA_BF16_PEAK_TFLOPS,
             "gemm_class_tflops": gt["work"] / (gt["ms"] * 1e-3) / 1e12 if gt["ms"] > 0 else 0.0,
@@ -737,6 +871,43 @@ def event_pair_overhead_ms(n=64):
     return max(per_pair - e0.elapsed_time(e1), 0.0) / n
 
 
+def cpu_baseline_line(args, dev):
+    """The driver line's `cpu_baseline`: kind "reference" -- the reference's own modules on this box's host cores, at the headline's
+    image size and at the other of {224, 336} -- whenever the staged modules are there, with the PORT (the oracle; bounded sample) kept
+    beside it; the port at full depth (round 2-4 behaviour) when they are not or --cpu-baseline-kind port asks for it."""
+    kind = args.cpu_baseline_kind
+    ref = None
+    if kind in ("auto", "reference"):
+        try:
+            sizes = sorted({args.image_size, 224 if args.image_size != 224 else 336})
+            ref = cpu_baseline_reference(dev, sizes, args.frames, args.text_len, args.seed)
+        except Exception as e:  # noqa: BLE001 -- a measurement aid must not take the bench line down
+            ref = None
+            print(f"[bench] cpu_baseline: the reference leg failed ({type(e).__name__}: {e}); falling back to the port", file=sys.stderr, flush=True)
+    main_size = ref["by_image_size"].get(args.image_size) if ref else None
+    if ref is None or not main_size or "tokens_per_s" not in main_size:
+        out = cpu_baseline(args.image_size, args.frames, args.text_len, args.seed, mode=args.cpu_baseline)
+        if ref is not None:
+            out["reference_other_sizes"] = ref
+        m = cpu_reference_measurement()
+        if m is not None:
+            out["reference_measured"] = {k: m[k] for k in ("kind", "tokens_per_s", "seconds_total", "cores", "where", "what") if k in m}
+        return out
+    port = cpu_baseline(args.image_size, args.frames, args.text_len, args.seed, mode="sample")
+    out = {"value": main_size["tokens_per_s"], "unit": "tokens/s", "cores": ref["cores"], "kind": "reference",
+           "sample": (f"the WHOLE workload at FULL depth, once, through the REFERENCE's own modules (oracle/_ref/vitron_ref.zip staged from the reference "
+                      f"tree by oracle/stage_ref.py; imported via oracle/ref_shim.py; source: {ref['modules_from']}): LanguageBind video tower (24 layers) on the "
+                      f"{args.frames}-frame {args.image_size}px clip, mlp2x_gelu projector, prepare_inputs_labels_for_multimodal, LlavaLlamaForCausalLM.forward over all "
+                      f"{main_size['S']} positions (32 DISTINCT layers, eager attention), fp32, on {ref['cores']} torch threads of {ref['host_threads_available']} "
+                      "host threads (fastest of the calibration)"),
+           "seconds_total": main_size["seconds_total"], "seconds_towers_projector_splice": main_size["seconds_towers_projector_splice"],
+           "seconds_decoder": main_size["seconds_decoder"], "by_image_size": ref["by_image_size"],
+           "calibration_s_per_mlp_gemm": ref["calibration_s_per_mlp_gemm"], "seconds_model_build": ref["seconds_model_build"],
+           "measured_seconds": ref["measured_seconds"] + port.get("measured_seconds", 0.0),
+           "port": {k: port[k] for k in ("value", "unit", "cores", "kind", "sample", "est_seconds_per_step", "seconds_total") if k in port}}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -748,11 +919,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline", choices=("full", "sample"), default="full",
                     help="N=1 only: time the CPU oracle on the whole workload at full depth (~2 min of CPU work) or on a bounded sample")
+    ap.add_argument("--cpu-baseline-kind", choices=("auto", "reference", "port"), default="auto",
+                    help="N=1 only: 'reference' = the reference's own modules (staged archive oracle/_ref/vitron_ref.zip) at full depth at 336 and 224 "
+                         "(~3-4 min of CPU work) with a bounded sample of the port beside it; 'port' = the oracle only; 'auto' = reference when staged")
     ap.add_argument("--decode-steps", type=int, default=1024,
                     help="N=1 only: after the timed prefill region, BASELINE configs[4]: 4 x (image + box) prefill + this many batch-4 "
                          "greedy decode steps through generate() (0 = skip)")
     ap.add_argument("--c2-reps", type=int, default=10,
                     help="N=1 only: after the timed region, BASELINE configs[1] (one 336 px image + 512 tokens) this many times (0 = skip)")
+    ap.add_argument("--reps-224", type=int, default=10,
+                    help="N=1 only: after the timed region, configs[2] and configs[1] at the reference-native 224 px (S = 2560 / 768) this many times (0 = skip)")
     ap.add_argument("--no-empirical-peaks", action="store_true", help="skip the hipBLASLt-8192^3 / D2D-copy empirical peaks")
     ap.add_argument("--c4-steps", type=int, default=5,
                     help="after the timed region: the fixed 8-clip global batch of BASELINE configs[3] for this many steps (0 = skip)")
@@ -948,6 +1124,10 @@ def main():
             out["config"]["visual_token_exchange"] = gather
         if world == 1 and args.c2_reps > 0:
             out["config"]["c2"] = c2_report(model, llama, dev, args.seed, args.c2_reps)
+        if world == 1 and args.reps_224 > 0:
+            # the reference-native image size: both BASELINE prefill configurations again at 224 px
+            out["config"]["c3_224"] = prefill_report_224(model, llama, dev, args.seed, "clip", args.reps_224, args.frames, args.text_len)
+            out["config"]["c2_224"] = prefill_report_224(model, llama, dev, args.seed, "image", args.reps_224, args.frames, args.text_len)
         if world == 1 and args.decode_steps > 0:
             out["decode"] = c5_report(model, llama, dev, args.decode_steps, args.seed)
             out["decode"]["synthetic_context_64_steps"] = decode_report_synthetic(model, llama, dev, 64)
@@ -966,10 +1146,7 @@ def main():
             out["config"]["fp16_ab"] = fp16_ab_report(args, dev, model, step, ids, ids_host, clip, vit_image)
         if world == 1 and not args.no_cpu_baseline:
             torch.cuda.synchronize()
-            out["cpu_baseline"] = cpu_baseline(args.image_size, args.frames, args.text_len, args.seed, mode=args.cpu_baseline)
-            ref = cpu_reference_measurement()
-            if ref is not None:
-                out["cpu_baseline"]["reference_measured"] = {k: ref[k] for k in ("kind", "tokens_per_s", "seconds_total", "cores", "where", "what") if k in ref}
+            out["cpu_baseline"] = cpu_baseline_line(args, dev)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

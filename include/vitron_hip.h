@@ -21,6 +21,11 @@
  *   - every function is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream),
  *     re-entrant, and returns 0 on success or a negative vt_status; vt_last_error() gives the message of the
  *     calling thread's last failure. Nothing throws, nothing synchronises the device.
+ *   - ONE exception to "never allocates": the head_dim-128 prefill attention keeps, per (device, heads, query blocks, sequences)
+ *     shape, its planned block-dispatch order in a small device buffer (heads * blocks * sequences int32) that it allocates the
+ *     first time the shape is launched and uploads with hipMemcpyAsync on `stream` (no device synchronisation; other streams are
+ *     ordered behind the upload by an event). A HIP graph capture must see a shape for the second time; vt_flash_attn_select(5)
+ *     turns the planned order -- and with it the allocation -- off. All cached per-process state is keyed by device ordinal.
  *   - "host struct" arguments (vt_vit_model, vt_llama_model, ...) are read on the host during the call; the
  *     pointers inside them are device pointers.
  */

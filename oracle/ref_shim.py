@@ -19,10 +19,40 @@ import sys
 import types
 
 REFERENCE_ROOT = os.environ.get("VITRON_REFERENCE_ROOT", "/root/reference")
+# the staged archive of exactly the modules imported below (oracle/stage_ref.py, written by __graft_entry__.build() in the build
+# container; git-ignored, travels to the GPU box): used when the reference tree itself is absent -- bench.py's cpu_baseline leg
+STAGED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "vitron_ref.zip")
+_unpacked = None
+
+
+def _resolve_root() -> str:
+    """REFERENCE_ROOT if the tree is there; else the staged archive unpacked into a temporary directory (once per process)."""
+    global REFERENCE_ROOT, _unpacked
+    if os.path.isdir(os.path.join(REFERENCE_ROOT, "vitron", "model")):
+        return REFERENCE_ROOT
+    if os.path.exists(STAGED):
+        if _unpacked is None:
+            import atexit
+            import shutil
+            import tempfile
+            import zipfile
+            _unpacked = tempfile.mkdtemp(prefix="vitron_ref_")
+            atexit.register(shutil.rmtree, _unpacked, ignore_errors=True)
+            with zipfile.ZipFile(STAGED) as z:
+                z.extractall(_unpacked)
+        REFERENCE_ROOT = _unpacked
+    return REFERENCE_ROOT
 
 
 def available() -> bool:
-    return os.path.isdir(os.path.join(REFERENCE_ROOT, "vitron", "model"))
+    return os.path.isdir(os.path.join(_resolve_root(), "vitron", "model"))
+
+
+def source() -> str:
+    """'tree' (the reference tree itself), 'staged' (oracle/_ref/vitron_ref.zip) or 'absent'."""
+    if not available():
+        return "absent"
+    return "staged" if _unpacked is not None and REFERENCE_ROOT == _unpacked else "tree"
 
 
 class _Any:

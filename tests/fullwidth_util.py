@@ -11,35 +11,46 @@ from tests.golden import cases
 from vitron_amd import synth
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "fullwidth.npz")
+GOLDEN_224 = os.path.join(os.path.dirname(__file__), "golden", "fullwidth_224.npz")     # the reference-native 224 px shapes (round 5)
+ALL_LLAMA = dict(cases.FW_LLAMA, **cases.FW224_LLAMA)
 
 
-def golden():
-    return np.load(GOLDEN)
+def golden(which="336"):
+    return np.load(GOLDEN_224 if str(which) == "224" else GOLDEN)
+
+
+def golden_of(name):
+    """The golden file that holds a decoder / tower case name."""
+    return golden("224" if (name in cases.FW224_LLAMA or name.endswith("224")) else "336")
 
 
 def llama_case(name):
-    S, L = cases.FW_LLAMA[name]
+    S, L = ALL_LLAMA[name]
     cfg = dict(synth.VICUNA_7B, num_hidden_layers=L)
     sd = synth.llama_state(cfg, synth.make_generator(cases.FW_SEED + L), **cases.FW_INIT)
     return cfg, sd, cases.fw_llama_embeds(S, cases.FW_SEED + S)
 
 
 def vit_case(name):
-    video = name == "video336"
-    cfg = dict(synth.VIT_L14, image_size=336, add_time_attn=video, num_frames=8 if video else 1, num_hidden_layers=cases.FW_VIT_LAYERS)
+    """name = 'video336' | 'image336' | 'video224' | 'image224'."""
+    video, size = name.startswith("video"), int(name[-3:])
+    cfg = dict(synth.VIT_L14, image_size=size, add_time_attn=video, num_frames=8 if video else 1, num_hidden_layers=cases.FW_VIT_LAYERS)
     sd = synth.vit_state(cfg, synth.make_generator(cases.FW_SEED + 7), **cases.FW_INIT)
-    return cfg, sd, cases.pixels(cases.FW_VIDEO_SHAPE if video else cases.FW_IMAGE_SHAPE, cases.FW_SEED + 8)
+    shape = {("video", 336): cases.FW_VIDEO_SHAPE, ("image", 336): cases.FW_IMAGE_SHAPE,
+             ("video", 224): cases.FW224_VIDEO_SHAPE, ("image", 224): cases.FW224_IMAGE_SHAPE}[(name[:5], size)]
+    return cfg, sd, cases.pixels(shape, cases.FW_SEED + 8)
 
 
-def projector_case():
+def projector_case(which="336"):
     sd = synth.projector_state(1024, 4096, synth.make_generator(cases.FW_SEED + 9), **cases.FW_INIT)
-    return sd, cases.features((cases.FW_PROJ_ROWS, 1024), cases.FW_SEED + 10)
+    return sd, cases.features((cases.FW224_PROJ_ROWS if str(which) == "224" else cases.FW_PROJ_ROWS, 1024), cases.FW_SEED + 10)
 
 
-def region_case(canvas):
+def region_case(canvas, grid=24):
+    """grid = 24: the 336 px tower's patch grid on a 224 / 336 canvas; grid = 16: the reference-native case (224 px tower, 224 canvas)."""
     sd = synth.region_state(1024, 4096, synth.make_generator(cases.FW_SEED + 11), **cases.FW_INIT)
-    boxes = cases.FW_BOXES_224 if canvas == 224 else cases.FW_BOXES_336
-    return sd, cases.features((len(boxes), 24 * 24, 1024), cases.FW_SEED + 12), boxes
+    boxes = cases.FW224_BOXES if grid == 16 else (cases.FW_BOXES_224 if canvas == 224 else cases.FW_BOXES_336)
+    return sd, cases.features((len(boxes), grid * grid, 1024), cases.FW_SEED + 12), boxes
 
 
 def operand(op):

@@ -187,6 +187,19 @@ FW_BOXES_336 = [[0, 0, 336, 336], [10.5, 20.25, 320.75, 200.0], [100, 20, 180, 3
                 [55.9, 168.0, 56.1, 169.0], [168, 168, 336, 336]]
 
 
+# ---- the REFERENCE-NATIVE 224 px shapes (processing_image.py:20-21, processing_video.py:50-51, layer.py:60) ----
+# N = 257 tokens per frame, G = 16; C2-224: S = 256 + 512 = 768, C3-224: S = 8 * 256 + 512 = 2560 -- the only shapes a real Vitron
+# checkpoint runs (round 5; tests/golden/fullwidth_224.npz)
+FW224_LLAMA = {"s768_l2": (768, 2), "s2560_l1": (2560, 1)}
+FW224_VIDEO_SHAPE = (1, 3, 8, 224, 224)            # one 8-frame clip: 2056 token rows (C3-224)
+FW224_IMAGE_SHAPE = (2, 3, 224, 224)               # two images: 2 x 257 rows (C2-224 / C5-224)
+FW224_PROJ_ROWS = 512
+# boxes for RegionExtractor(1024, 4096) on its default 224 canvas and the 16 x 16 grid of the 224 px tower (scale 14: the case the
+# reference itself runs, app.py:533 / inference_image.py:34 rescale every box to [224, 224])
+FW224_BOXES = [[0, 0, 224, 224], [0, 58.94736842105263, 117.89473684210526, 117.89473684210526], [100, 20, 180, 200], [7, 7, 8, 8],
+               [0, 0, 6, 6], [223, 0, 224, 224], [37.3, 112.0, 37.9, 113.0], [112, 112, 224, 224], [10.5, 20.25, 120.75, 200.0]]
+
+
 def fw_directions(dim, n=FW_NPROJ, seed=FW_SEED):
     g = torch.Generator().manual_seed(seed + dim)
     return torch.randn((dim, n), generator=g, dtype=torch.float64)

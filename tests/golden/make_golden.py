@@ -261,18 +261,32 @@ def _compact(t, tag, out, top5=False, nrows=cases.FW_ROWS):
         out[f"{tag}_top5"] = t.float().topk(5, dim=-1).indices.numpy().astype(np.int32)
 
 
-def gen_fullwidth(ns):
-    """The reference's own modules at the BASELINE widths (H=4096 / I=11008 / 32 heads; ViT-L/14 at 336 px, T = 8; projector
-    1024 -> 4096; RegionExtractor(1024, 4096) on a 24 x 24 grid), weights drawn exactly as bench.py draws them."""
+FW_SPECS = {
+    # outfile, decoder cases, (tower name, pixel shape, temporal) list, image size, projector rows, (canvas, grid, boxes) list
+    "336": dict(out="fullwidth.npz", llama=cases.FW_LLAMA, image=336, proj_rows=cases.FW_PROJ_ROWS,
+                towers=(("video336", cases.FW_VIDEO_SHAPE, True), ("image336", cases.FW_IMAGE_SHAPE, False)),
+                regions=((224, 24, cases.FW_BOXES_224), (336, 24, cases.FW_BOXES_336))),
+    # the reference-native 224 px shapes (round 5): N = 257, 2056 tower rows per clip, G = 16, S = 768 / 2560
+    "224": dict(out="fullwidth_224.npz", llama=cases.FW224_LLAMA, image=224, proj_rows=cases.FW224_PROJ_ROWS,
+                towers=(("video224", cases.FW224_VIDEO_SHAPE, True), ("image224", cases.FW224_IMAGE_SHAPE, False)),
+                regions=((224, 16, cases.FW224_BOXES),)),
+}
+
+
+def gen_fullwidth(ns, which="336"):
+    """The reference's own modules at the BASELINE widths (H=4096 / I=11008 / 32 heads; ViT-L/14, T = 8; projector 1024 -> 4096;
+    RegionExtractor(1024, 4096)), weights drawn exactly as bench.py draws them. which = "336": the BASELINE image size (24 x 24
+    grid); "224": the size the reference's processors are hard-wired to (16 x 16 grid, 257 tokens per frame)."""
     import contextlib
     import io
     import time
     from vitron_amd.synth import VICUNA_7B, VIT_L14
+    spec = FW_SPECS[which]
     out = {}
     t0 = time.time()
     # ---- decoder: LlavaLlamaForCausalLM.forward(inputs_embeds=...) ----------------------------------------------------
     ll = ns.llava_llama
-    for name, (S, L) in cases.FW_LLAMA.items():
+    for name, (S, L) in spec["llama"].items():
         c = dict(VICUNA_7B, num_hidden_layers=L)
         sd = synth.llama_state(c, synth.make_generator(cases.FW_SEED + L), **cases.FW_INIT)
         cfg = ll.LlavaConfig(hidden_size=c["hidden_size"], intermediate_size=c["intermediate_size"], num_hidden_layers=L,
@@ -298,8 +312,8 @@ def gen_fullwidth(ns):
         del model, sd
         print(f"llama {name}: {time.time() - t0:.1f}s", flush=True)
     # ---- towers: CLIPVisionTransformer (video / image) ---------------------------------------------------------------------
-    for name, shape, time_attn in (("video336", cases.FW_VIDEO_SHAPE, True), ("image336", cases.FW_IMAGE_SHAPE, False)):
-        c = dict(VIT_L14, image_size=336, add_time_attn=time_attn, num_frames=8 if time_attn else 1,
+    for name, shape, time_attn in spec["towers"]:
+        c = dict(VIT_L14, image_size=spec["image"], add_time_attn=time_attn, num_frames=8 if time_attn else 1,
                  num_hidden_layers=cases.FW_VIT_LAYERS)
         sd = synth.vit_state(c, synth.make_generator(cases.FW_SEED + 7), **cases.FW_INIT)
         m = build_ref_vit(ns, c, sd)
@@ -315,25 +329,29 @@ def gen_fullwidth(ns):
     cfg = types.SimpleNamespace(mm_projector_type="mlp2x_gelu", mm_hidden_size=1024, hidden_size=4096)
     pm = ns.projector_builder.build_vision_projector(cfg).eval()
     pm.load_state_dict(f32(sd))
-    x = cases.features((cases.FW_PROJ_ROWS, 1024), cases.FW_SEED + 10)
+    x = cases.features((spec["proj_rows"], 1024), cases.FW_SEED + 10)
     with torch.no_grad():
         _compact(pm(x), "projector", out)
     out["projector_checksum"] = np.float64(synth.checksum(sd))
-    # ---- region extractor at G = 24 on the 224 canvas (reference default) and on a 336 canvas -----------------------------------
+    # ---- region extractor: RegionExtractor(1024, 4096, image_size=canvas) on the tower's G x G grid ------------------------------
     sd = synth.region_state(1024, 4096, synth.make_generator(cases.FW_SEED + 11), **cases.FW_INIT)
-    for canvas, boxes in ((224, cases.FW_BOXES_224), (336, cases.FW_BOXES_336)):
+    for canvas, G, boxes in spec["regions"]:
         m = ns.region_layer.RegionExtractor(1024, 4096, image_size=canvas).eval()
         m.load_state_dict(f32(sd))
-        feats = cases.features((len(boxes), 24 * 24, 1024), cases.FW_SEED + 12)
+        feats = cases.features((len(boxes), G * G, 1024), cases.FW_SEED + 12)
         with torch.no_grad():
             r = m(feats, boxes)
             cv = m.transform_bbox_2_mask(boxes, m.image_size, feats.device, feats.dtype).unsqueeze(1)
-            grid = torch.nn.functional.interpolate(cv, size=(24, 24), mode="bilinear", align_corners=False)
+            grid = torch.nn.functional.interpolate(cv, size=(G, G), mode="bilinear", align_corners=False)
         out[f"region_c{canvas}_out"] = r[:, 0].numpy()
         out[f"region_c{canvas}_cells"] = (grid > 0).reshape(len(boxes), -1).numpy().astype(np.int32)
     out["region_checksum"] = np.float64(synth.checksum(sd))
-    np.savez_compressed(os.path.join(OUT, "fullwidth.npz"), **out)
-    print("fullwidth.npz", {k: getattr(v, "shape", v) for k, v in out.items()}, f"{time.time() - t0:.1f}s")
+    np.savez_compressed(os.path.join(OUT, spec["out"]), **out)
+    print(spec["out"], {k: getattr(v, "shape", v) for k, v in out.items()}, f"{time.time() - t0:.1f}s")
+
+
+def gen_fullwidth_224(ns):
+    gen_fullwidth(ns, "224")
 
 
 GREEDY_TINY = ("image_region", "video", "text_only", "video_image_trunc")   # the batch-1 glue cases (what app.py / inference_image.py run)
@@ -552,6 +570,9 @@ if __name__ == "__main__":
     if "--fullwidth-only" in sys.argv:
         gen_fullwidth(ns)
         sys.exit(0)
+    if "--fullwidth-224-only" in sys.argv:
+        gen_fullwidth_224(ns)
+        sys.exit(0)
     if "--greedy-only" in sys.argv:
         gen_greedy(ns)
         sys.exit(0)
@@ -570,6 +591,7 @@ if __name__ == "__main__":
     gen_glue_random(ns)
     gen_state_dict_keys(ns)
     gen_fullwidth(ns)
+    gen_fullwidth_224(ns)
     gen_greedy(ns)
     gen_greedy_batch(ns)
     gen_f1(ns)

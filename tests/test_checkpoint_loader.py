@@ -201,3 +201,49 @@ def test_full_checkpoint_written_with_reference_names_loads(tmp_path, dtype):
     a = model(input_ids=ids, images=images, regions=case["regions"], use_cache=False).logits
     b = direct(input_ids=ids, images=images, regions=case["regions"], use_cache=False).logits
     assert torch.equal(a, b)          # same tensors, same packing: bit-identical
+
+
+def test_config_torch_dtype_is_advisory():
+    """a config.json whose "torch_dtype" is not an operand format ("float32", unknown strings) must not fail the
+    constructor -- the reference ignores the stored value and forces fp16 (builder.py:47); explicit arguments are still validated."""
+    from vitron_amd._lib import VitronHipError
+    from vitron_amd.model import LlavaConfig, LlavaLlamaForCausalLM
+    for stored, want in (("float32", None), ("torch.float32", None), ("nonsense", None), (torch.float32, None), (None, None),
+                         ("float16", torch.float16), ("bfloat16", torch.bfloat16), (torch.float16, torch.float16)):
+        m = LlavaLlamaForCausalLM(LlavaConfig(**cases.LLM, torch_dtype=stored))
+        assert m._dtype == want, (stored, m._dtype)
+    with pytest.raises(VitronHipError):
+        LlavaLlamaForCausalLM(LlavaConfig(**cases.LLM)).to(dtype=torch.float32)
+
+
+@pytest.mark.gpu
+def test_projector_only_checkpoint_with_model_base(tmp_path):
+    """reference builder.py:87-103 (`elif model_base is not None`): language model from `model_base` under the config of `model_path`,
+    model_path/mm_projector.bin laid over it; the config carries "torch_dtype": "float32" (as a projector-pretraining run writes it)."""
+    from vitron_amd.model import LlavaConfig, LlavaLlamaForCausalLM, load_pretrained_model
+    from tests.util import rel_l2
+    ck = _write_checkpoint(str(tmp_path))
+    pdir = os.path.join(str(tmp_path), "vitron-pretrain")
+    os.makedirs(pdir)
+    cfg = json.load(open(os.path.join(ck["ckpt"], "config.json")))
+    json.dump(dict(cfg, torch_dtype="float32"), open(os.path.join(pdir, "config.json"), "w"))
+    torch.save({"model.mm_projector." + k: v.float() for k, v in ck["proj"].items()}, os.path.join(pdir, "mm_projector.bin"))
+    with pytest.raises(FileNotFoundError):
+        load_pretrained_model(ck["ckpt"], ck["base"], "vitron-7b-pretrain", device="cuda", tokenizer=object())     # no mm_projector.bin there
+    tok, model, procs, ctx = load_pretrained_model(pdir, ck["base"], "vitron-7b-pretrain", device="cuda", tokenizer=object())
+    assert model.dtype == torch.float16                     # the reference's default, whatever config.json says
+    dev = torch.device("cuda:0")
+    ref = LlavaLlamaForCausalLM(LlavaConfig(**cases.LLM, mm_hidden_size=cases.MM_HIDDEN, mm_image_tower="x/LanguageBind_Image",
+                                            mm_video_tower="x/LanguageBind_Video_merge"))
+    ref.get_image_tower().load_state(cases.VIT_IMAGE, {k: v.bfloat16() for k, v in ck["image_ref"].items()})
+    ref.get_video_tower().load_state(cases.VIT_VIDEO, ck["video"])
+    sd = dict(synth.llama_state(cases.LLM, synth.make_generator(cases.SEED_LLM), **cases.LLM_INIT))       # the UNMERGED base
+    sd.update({"model.mm_projector." + k: v for k, v in ck["proj"].items()})
+    ref.load_state_dict(sd, strict=False)
+    ref.to(dev, dtype=torch.float16)
+    case = cases.glue_cases()["video"]
+    ids = case["input_ids"].to(dev)
+    images = [im.to(dev).half() for im in case["images"]]
+    a = model(input_ids=ids, images=images, regions=None, use_cache=False).logits
+    b = ref(input_ids=ids, images=images, regions=None, use_cache=False).logits
+    assert rel_l2(a, b) <= 1e-3

@@ -506,6 +506,9 @@ def test_serving_engine_pool_sizing_and_waiting(dev, model):
     held = model.kv.alloc(2)
     eng.submit(reqs[1]["input_ids"], max_new_tokens=reqs[1]["max_new_tokens"], eos_token_id=-1)
     assert eng.step() == [] and len(eng.waiting) == 1 and not eng.active and len(model.kv.free) == 4
+    with pytest.raises(RuntimeError, match="no progress"):        # run() must not spin while the caller holds the pages
+        eng.run()
+    assert len(eng.waiting) == 1 and len(model.kv.free) == 4      # the request is still queued, nothing leaked
     model.kv.release(held)
     assert eng.run()[0].tolist() == solo[1]
     model.config.kv_prefix_reuse = True

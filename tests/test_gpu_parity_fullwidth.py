@@ -67,11 +67,11 @@ def _note(name, **kw):
 
 
 @pytest.mark.parametrize("op", OPERANDS)
-@pytest.mark.parametrize("name", list(cases.FW_LLAMA))
+@pytest.mark.parametrize("name", list(FW.ALL_LLAMA))      # S = 1088 / 2048 (336 px) and S = 768 / 2560 (the reference-native 224 px)
 def test_decoder_prefill_at_7b_width_vs_oracle_and_reference(dev, name, op):
     from vitron_amd.engine import PackedLlama, PagedKVCache, SequenceState, llama_forward
     odt, emu, _ = FW.operand(op)
-    g = FW.golden()
+    g = FW.golden_of(name)
     cfg, sd, x = FW.llama_case(name)
     S = x.shape[0]
     llama = PackedLlama(sd, cfg, dev, dtype=odt)
@@ -99,11 +99,11 @@ def test_decoder_prefill_at_7b_width_vs_oracle_and_reference(dev, name, op):
 
 
 @pytest.mark.parametrize("op", OPERANDS)
-@pytest.mark.parametrize("name", ["video336", "image336"])
+@pytest.mark.parametrize("name", ["video336", "image336", "video224", "image224"])   # 224: N = 257, 2056 / 514 token rows
 def test_towers_at_vit_l_336_vs_oracle_and_reference(dev, name, op):
     from vitron_amd.engine import PackedVit
     odt, emu, rnd = FW.operand(op)
-    g = FW.golden()
+    g = FW.golden_of(name)
     cfg, sd, x = FW.vit_case(name)
     for nl in (1, cases.FW_VIT_LAYERS):
         vit = PackedVit(sd, cfg, dev, select_layer=nl, dtype=odt)
@@ -127,26 +127,29 @@ def test_towers_at_vit_l_336_vs_oracle_and_reference(dev, name, op):
         assert d_f32 <= 1.25 * emu_f32 + 2e-4 and ref_rows <= 1.25 * emu_f32 + 3e-4, (nl, d_f32, ref_rows, emu_f32)
 
 
+@pytest.mark.parametrize("which", ["336", "224"])
 @pytest.mark.parametrize("op", OPERANDS)
-def test_projector_and_region_at_full_width_vs_oracle_and_reference(dev, op):
+def test_projector_and_region_at_full_width_vs_oracle_and_reference(dev, op, which):
+    """which = "336": the 24 x 24 grid of the BASELINE image size on a 224 and a 336 canvas; "224": RegionExtractor exactly as the
+    reference ships it (224 canvas, layer.py:60) on the 16 x 16 grid of the 224 px tower, projector on 2 x 256 rows."""
     from vitron_amd.engine import PackedProjector, PackedRegion
     odt, emu, _ = FW.operand(op)
-    g = FW.golden()
-    sd, x = FW.projector_case()
+    g = FW.golden(which)
+    sd, x = FW.projector_case(which)
     out = PackedProjector(sd, dev, dtype=odt).forward(x.to(dev).to(odt)).float().cpu()
     with torch.no_grad():
         o32, oem = O.projector_forward(f32(sd), x), O.projector_forward(f32(sd), x, emulate_bf16=emu)
     d_emu, d_f32, emu_f32 = FW.rel(out, oem), FW.rel(out, o32), FW.rel(oem, o32)
     ref_proj, ref_rows = FW.vs_pin(out, g, "projector")
-    _note(f"projector_{op}", rows=x.shape[0], vs_emulation=d_emu, vs_fp32=d_f32, emulation_vs_fp32=emu_f32, vs_reference_rows=ref_rows)
+    _note(f"projector_{which}_{op}", rows=x.shape[0], vs_emulation=d_emu, vs_fp32=d_f32, emulation_vs_fp32=emu_f32, vs_reference_rows=ref_rows)
     assert d_emu <= 1e-3 and d_f32 <= 1.25 * emu_f32 + 2e-4 and ref_rows <= 1.25 * emu_f32 + 3e-4, (d_emu, d_f32, ref_rows, emu_f32)
     if op == "fp16":
         assert d_f32 <= FP16_TOL_VS_FP32_TOWER and ref_rows <= FP16_TOL_VS_FP32_TOWER, (d_f32, ref_rows)
-    for canvas in (224, 336):
-        sd, feats, boxes = FW.region_case(canvas)
+    for canvas, grid in (((224, 24), (336, 24)) if which == "336" else ((224, 16),)):
+        sd, feats, boxes = FW.region_case(canvas, grid)
         reg = PackedRegion(sd, dev, image_size=canvas, dtype=odt)
         out, cells, count = reg.forward(feats.to(dev).to(odt), boxes, return_mask=True)
-        assert np.array_equal(cells.cpu().numpy(), g[f"region_c{canvas}_cells"])        # bit exact vs the REFERENCE at G = 24
+        assert np.array_equal(cells.cpu().numpy(), g[f"region_c{canvas}_cells"])        # bit exact vs the REFERENCE at G = 24 / 16
         assert count.cpu().tolist() == g[f"region_c{canvas}_cells"].sum(-1).tolist()
         with torch.no_grad():        # (box coordinates reach the LocationEncoder in fp32 since round 4: no rounding to emulate)
             oem, _, _ = O.region_forward(f32(sd), feats, boxes, canvas, emu)
@@ -154,7 +157,7 @@ def test_projector_and_region_at_full_width_vs_oracle_and_reference(dev, op):
         got = out[:, 0].float().cpu()
         d_emu, d_f32, emu_f32 = FW.rel(got, oem[:, 0]), FW.rel(got, o32[:, 0]), FW.rel(oem[:, 0], o32[:, 0])
         d_ref = FW.rel(got, g[f"region_c{canvas}_out"])
-        _note(f"region_canvas{canvas}_{op}", boxes=len(boxes), vs_emulation=d_emu, vs_fp32=d_f32, emulation_vs_fp32=emu_f32, vs_reference=d_ref)
+        _note(f"region_canvas{canvas}_grid{grid}_{op}", boxes=len(boxes), vs_emulation=d_emu, vs_fp32=d_f32, emulation_vs_fp32=emu_f32, vs_reference=d_ref)
         assert d_emu <= FW_TOL_EMU and d_f32 <= 1.25 * emu_f32 + 5e-4 and d_ref <= 1.25 * emu_f32 + 5e-4, (canvas, d_emu, d_f32, d_ref, emu_f32)
         if op == "fp16":
             assert d_f32 <= FP16_TOL_VS_FP32_TOWER and d_ref <= FP16_TOL_VS_FP32_TOWER, (canvas, d_f32, d_ref)

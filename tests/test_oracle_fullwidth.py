@@ -18,9 +18,9 @@ def f32(sd):
     return {k: v.float() for k, v in sd.items()}
 
 
-@pytest.mark.parametrize("name", list(cases.FW_LLAMA))
+@pytest.mark.parametrize("name", list(FW.ALL_LLAMA))
 def test_oracle_decoder_at_7b_width(name):
-    g = FW.golden()
+    g = FW.golden_of(name)
     cfg, sd, x = FW.llama_case(name)
     assert synth.checksum(sd) == pytest.approx(float(g[f"llama_{name}_checksum"]), rel=1e-12)
     with torch.no_grad():
@@ -32,9 +32,9 @@ def test_oracle_decoder_at_7b_width(name):
     assert top1 >= 0.999 and top5 >= 0.999, (top1, top5)
 
 
-@pytest.mark.parametrize("name", ["video336", "image336"])
+@pytest.mark.parametrize("name", ["video336", "image336", "video224", "image224"])
 def test_oracle_towers_at_vit_l_336(name):
-    g = FW.golden()
+    g = FW.golden_of(name)
     cfg, sd, x = FW.vit_case(name)
     assert synth.checksum(sd) == pytest.approx(float(g[f"vit_{name}_checksum"]), rel=1e-12)
     with torch.no_grad():
@@ -64,6 +64,29 @@ def test_oracle_projector_and_region_at_full_width():
     for canvas in (224, 336):
         cells = g[f"region_c{canvas}_cells"].sum(-1).tolist()
         assert cells[0] == 576 and min(cells) == 0 and len({c for c in cells if c}) >= 4, cells
+
+
+def test_oracle_projector_and_region_at_224():
+    """The reference-native geometry: RegionExtractor(1024, 4096) exactly as the reference builds it (224 canvas,
+    layer.py:60) on the 16 x 16 grid of the 224 px tower, and the projector on 2 x 256 visual rows -- tests/golden/fullwidth_224.npz."""
+    g = FW.golden("224")
+    sd, x = FW.projector_case("224")
+    assert synth.checksum(sd) == pytest.approx(float(g["projector_checksum"]), rel=1e-12)
+    with torch.no_grad():
+        dp, dr = FW.vs_pin(O.projector_forward(f32(sd), x), g, "projector")
+    assert dp <= TOL and dr <= TOL, (dp, dr)
+    sd, feats, boxes = FW.region_case(224, grid=16)
+    assert synth.checksum(sd) == pytest.approx(float(g["region_checksum"]), rel=1e-12)
+    with torch.no_grad():
+        out, cells, count = O.region_forward(f32(sd), feats, boxes, 224)
+    assert np.array_equal(cells.numpy(), g["region_c224_cells"])                         # bit exact: the G = 16 geometry
+    assert count.tolist() == g["region_c224_cells"].sum(-1).tolist()
+    assert FW.rel(out[:, 0], g["region_c224_out"]) <= TOL
+    n = g["region_c224_cells"].sum(-1).tolist()
+    # SURVEY.md 8(c)'s known answers: the whole canvas = 256 cells; [0, 58.9, 117.9, 117.9] = rows 0-7 x cols 4-7 = 32 cells;
+    # [7, 7, 8, 8] = the single 2 x 2-centre hit; [0, 0, 6, 6] = empty
+    assert n[0] == 256 and n[1] == 32 and n[3] == 1 and n[4] == 0, n
+    assert np.array_equal(g["region_c224_cells"][1].reshape(16, 16).nonzero()[0], np.repeat(np.arange(8), 4))
 
 
 def test_oracle_greedy_ids_at_7b_width():

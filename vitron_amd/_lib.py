@@ -231,6 +231,8 @@ def check(status: int, what: str = "", lib=None) -> None:
 
 
 def profile_begin() -> None:
+    if not _libs:
+        load()            # nothing loaded yet: profile the default library (never a silent no-op)
     for lib in _libs.values():
         check(lib.vt_profile_begin(), "vt_profile_begin", lib)
 

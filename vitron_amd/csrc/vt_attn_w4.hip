@@ -30,6 +30,8 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <atomic>
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -781,11 +783,15 @@ int vt_flash_attn_w4_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf
   constexpr int smem = 8 * 16384 + 16;   // K ring + V^T ring, four 16-KiB slots each (+ the persistent form's ticket words)
   const int nqb_max = cdiv(max_q_len, 256);
   // placed == 2: the persistent form -- one workgroup per CU walking the block list (kernel header)
-  static int ncu = 0;
+  // per-DEVICE state: CU count, the dynamic-LDS attribute of each instantiation, the planned-order buffers
+  int dev = 0;
+  VT_HIP(hipGetDevice(&dev));
+  VT_REQUIRE(dev >= 0 && dev < 64, "vt_flash_attn_w4_launch: device ordinal %d", dev);
+  static std::atomic<int> ncu_of[64];
+  int ncu = ncu_of[dev].load(std::memory_order_relaxed);
   if (!ncu) {
-    int dev = 0;
-    VT_HIP(hipGetDevice(&dev));
     VT_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+    ncu_of[dev].store(ncu, std::memory_order_relaxed);
   }
   const int nx = (heads % 8 == 0 && ncu % 8 == 0) ? 8 : 1;
   const long nblocks = (long)heads * nseq * nqb_max;
@@ -794,10 +800,10 @@ int vt_flash_attn_w4_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf
 #define VT_FAW4(CV, PV_, ...)                                                                                  \
   do {                                                                                                         \
     auto kern = flash_attn_w4_kernel<CV, PV_ __VA_OPT__(,) __VA_ARGS__>;                                                                 \
-    static bool done = false;                                                                                  \
-    if (!done) {                                                                                               \
+    static std::atomic<unsigned long long> done{0};                                                            \
+    if (!((done.load(std::memory_order_relaxed) >> dev) & 1ull)) {                                             \
       VT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));        \
-      done = true;                                                                                             \
+      done.fetch_or(1ull << dev, std::memory_order_relaxed);                                                   \
     }                                                                                                          \
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, Q, ldq, Kt, Vt, tile_table, seqs, O, ldo, heads, scale_log2e, nqb_max, nseq, nx, order); \
   } while (0)
@@ -805,21 +811,37 @@ int vt_flash_attn_w4_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf
   // causal launches of more than one round: the planned dispatch order (above), computed once per shape and kept on the device
   const int* order = nullptr;
   if (causal && placed != 2 && g_vt_flash_attn_order) {
+    // The one documented exception to "never allocates" (include/vitron_hip.h, Conventions): the FIRST launch of a new
+    // (device, heads, blocks, sequences) shape plans the order on the host (~0.1 ms), keeps it in a pinned host buffer and a device
+    // buffer of heads * blocks * sequences ints that live as long as the process (at most a few KiB per shape; the serving shapes
+    // are a handful), and uploads it with hipMemcpyAsync on `s` -- stream-ordered before the launch below, no device
+    // synchronisation. A stream capture must therefore see a shape for the second time (warm it once, as for any graph).
+    struct OrderBuf { int* dev; int* host; hipEvent_t ready; hipStream_t up; bool landed; };
     static std::mutex mu;
-    static std::map<std::tuple<int, int, int>, int*> cache;
+    static std::map<std::tuple<int, int, int, int>, OrderBuf> cache;
     std::lock_guard<std::mutex> lk(mu);
-    const auto key = std::make_tuple(heads, nqb_max, nseq);
+    const auto key = std::make_tuple(dev, heads, nqb_max, nseq);
     auto it = cache.find(key);
     if (it == cache.end()) {
       const std::vector<int> o = vt_flash_attn_w4_block_order(heads, nqb_max, nseq, ncu);
-      int* d = nullptr;
+      OrderBuf b{nullptr, nullptr, nullptr, s, false};
       if (!o.empty()) {
-        VT_HIP(hipMalloc((void**)&d, o.size() * sizeof(int)));
-        VT_HIP(hipMemcpy(d, o.data(), o.size() * sizeof(int), hipMemcpyHostToDevice));
+        const size_t bytes = o.size() * sizeof(int);
+        VT_HIP(hipHostMalloc((void**)&b.host, bytes, hipHostMallocDefault));
+        std::memcpy(b.host, o.data(), bytes);
+        VT_HIP(hipMalloc((void**)&b.dev, bytes));
+        VT_HIP(hipMemcpyAsync(b.dev, b.host, bytes, hipMemcpyHostToDevice, s));
+        VT_HIP(hipEventCreateWithFlags(&b.ready, hipEventDisableTiming));
+        VT_HIP(hipEventRecord(b.ready, s));
       }
-      it = cache.emplace(key, d).first;
+      it = cache.emplace(key, b).first;
     }
-    order = it->second;
+    OrderBuf& ob = it->second;
+    if (ob.dev && !ob.landed && ob.up != s) {       // another stream than the one that carries the upload: order behind it
+      if (hipEventQuery(ob.ready) == hipSuccess) ob.landed = true;
+      else VT_HIP(hipStreamWaitEvent(s, ob.ready, 0));
+    }
+    order = ob.dev;
     if (order) grid = dim3((unsigned)nblocks);
   }
 #ifdef VT_ABLATIONS   // VT_W4_ABL=<bits> python tools/attn_bench.py (test library only)

@@ -98,7 +98,12 @@ __device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
 }
 __device__ __forceinline__ float f16lo_to_f32(uint32_t w) { return (float)__builtin_bit_cast(vt_f16v2, w).x; }
 __device__ __forceinline__ float f16hi_to_f32(uint32_t w) { return (float)__builtin_bit_cast(vt_f16v2, w).y; }
-__device__ __forceinline__ float vt_clamp_f16(float x) { return __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f); }   // one v_med3_f32
+// saturate to the fp16 range, NaN preserved (v_med3_f32 alone returns min3 of the non-NaN inputs = -65504 for a NaN: a numerical blow-up
+// would turn finite and vanish -- engine._op / the oracle's fp16_store keep NaN, so do the kernels): v_med3 + v_cmp_u + v_cndmask
+__device__ __forceinline__ float vt_clamp_f16(float x) {
+  const float c = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
+  return x != x ? x : c;
+}
 __device__ __forceinline__ float f16_bits_to_f32(uint16_t h) { return f16lo_to_f32((uint32_t)h); }
 
 // ---- operand <-> f32: the ONLY places where the two builds differ in their arithmetic -------------------------------------------

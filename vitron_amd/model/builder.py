@@ -10,7 +10,8 @@ Differences that are inherent to this implementation:
     the configured architecture -- the only thing available offline (checkpoints/ holds only download scripts).
 LoRA checkpoints follow the reference's layout (builder.py:53-86): base weights from `model_base`, projector /
 region_extractor from `non_lora_trainables.bin`, adapters from `adapter_model.bin|safetensors`, merged here as
-W += (lora_alpha / r) * B @ A.
+W += (lora_alpha / r) * B @ A. A `model_base` WITHOUT 'lora' in the name is the projector-only layout (builder.py:87-103):
+language model from `model_base`, config from `model_path`, `mm_projector.bin` laid over it.
 """
 from __future__ import annotations
 
@@ -139,6 +140,17 @@ def load_pretrained_model(model_path, model_base, model_name, load_8bit=False, l
             with open(os.path.join(model_path, "adapter_config.json")) as f:
                 acfg = json.load(f)
         sd = _merge_llm_lora(sd, ad, float(acfg.get("lora_alpha", 16)), acfg.get("r"))
+    elif model_base is not None:
+        # "this may be mm projector only" (reference builder.py:87-103): the language model comes from `model_base` under the CONFIG of
+        # `model_path`, and model_path/mm_projector.bin (keys model.mm_projector.*, possibly model.region_extractor.*) is laid over it
+        # non-strictly -- what a projector-pretraining stage leaves behind
+        sd = _load_weight_files(model_base)
+        mp = os.path.join(model_path, "mm_projector.bin")
+        if not os.path.exists(mp):
+            raise FileNotFoundError(f"{mp}: `model_base` given without 'lora' in model_name means a projector-only checkpoint "
+                                    "(reference builder.py:100: torch.load(os.path.join(model_path, 'mm_projector.bin')))")
+        extra = torch.load(mp, map_location="cpu")
+        sd.update({k: v.to(torch.float16) for k, v in extra.items()})          # :101 casts the projector weights to fp16
     else:
         sd = _load_weight_files(model_path)
     # a LoRA adapter's config may name more vocabulary rows than the base checkpoint holds: the reference re-creates lm_head /

@@ -21,14 +21,18 @@ from ..multimodal_projector.builder import build_vision_projector
 from ..region_extractor.builder import build_region_extractor
 
 
-def _resolve_dtype(x):
-    """torch dtype for a config's `torch_dtype` entry ('float16' / 'bfloat16' strings as in a HF config.json, torch dtypes,
-    'fp16' / 'bf16'); None stays None (= the package default)."""
+def _resolve_dtype(x, strict=True):
+    """torch dtype for a `torch_dtype` entry ('float16' / 'bfloat16' strings as in a HF config.json, torch dtypes,
+    'fp16' / 'bf16'); None stays None (= the package default). strict=False (a value READ FROM A CHECKPOINT's config.json): anything
+    that is not one of the two operand formats -- "float32", unknown strings -- is treated as None instead of raising: the reference
+    ignores the stored value and forces fp16 (builder.py:47), so a checkpoint saved with "torch_dtype": "float32" must still load."""
     if x is None:
         return None
     if isinstance(x, str):
         x = {"float16": torch.float16, "half": torch.float16, "fp16": torch.float16,
              "bfloat16": torch.bfloat16, "bf16": torch.bfloat16}.get(x.replace("torch.", ""), x)
+    if not strict and x not in (torch.float16, torch.bfloat16):
+        return None
     _lib.operand_of(x)
     return x
 
@@ -112,7 +116,8 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
         self._llama_sd = None
         # operand dtype of the packed weights and activations: bf16 (package default, BASELINE's dtype) or fp16 (the reference's
         # inference dtype, builder.py:47); set by config.torch_dtype / .to(dtype=...) / .half() before the weights are packed
-        self._dtype = _resolve_dtype(getattr(config, "torch_dtype", None))
+        # (a config.json value is advisory: unsupported entries fall back to the default; explicit .to(dtype=) / torch_dtype= arguments are validated)
+        self._dtype = _resolve_dtype(getattr(config, "torch_dtype", None), strict=False)
         self.kv: Optional[PagedKVCache] = None
         self.kv_pages = getattr(config, "kv_pages", None)
         # multi-turn reuse (vitron_amd/prefix_cache.py): generate() keeps the last conversation's KV pages and the encoded

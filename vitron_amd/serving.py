@@ -17,8 +17,9 @@ as the decode batch stays on one kernel path (<= 16 rows: the folded-norm path; 
 
 Failures are isolated per request: a request whose own multimodal encoding or prefill fails (bad image shape, bad region, a prompt
 beyond the rotary table) is moved to `failed` with its exception and leaves the queue -- the requests behind it are served. Only
-errors that are not tied to one request (a HIP runtime error, the pool held by someone else) propagate out of step(), with every
-page this call took given back and the candidates re-queued. `kv_pages` given to the constructor is an UPPER BOUND of the pool: the
+errors that are not tied to one request (a HIP runtime error) propagate out of step(), with every page this call took given back
+and the candidates re-queued. A pool whose pages are held by someone else (a `past_key_values` the caller keeps) makes the waiting
+requests WAIT: step() returns [] and run() raises "no progress" instead of spinning when nothing is active and nothing can be admitted. `kv_pages` given to the constructor is an UPPER BOUND of the pool: the
 engine never rebuilds a larger one behind the caller's back; requests that do not fit next to the running ones wait, and one that
 cannot fit even an empty pool of that size fails instead of blocking the queue forever.
 """
@@ -165,9 +166,9 @@ class ServingEngine:
                 if m.kv is None or len(m.kv.free) < want:
                     try:
                         m._ensure_kv(want)
-                    except (RuntimeError, torch.cuda.OutOfMemoryError):
-                        if m.kv is None:
-                            raise                           # no pool at all: nothing can be scheduled
+                    except (RuntimeError, torch.cuda.OutOfMemoryError) as e:
+                        if m.kv is None or (self._is_device_error(e) and not isinstance(e, torch.cuda.OutOfMemoryError)):
+                            raise                           # no pool at all, or a HIP runtime error: nothing can be scheduled
                         # the pool could not grow: go on with the one that is there (the prefix that fits is admitted below)
             for r in live:
                 if len(m.kv.free) < r.need:
@@ -277,9 +278,17 @@ class ServingEngine:
     def run(self, on_token=None) -> Dict[int, torch.Tensor]:
         """Drive step() until every submitted request has finished; returns {request id: LongTensor of generated tokens}."""
         while self.pending():
-            for rid, t in self.step():
+            before = (len(self.waiting), len(self.failed), len(self.finished))
+            emitted = self.step()
+            for rid, t in emitted:
                 if on_token is not None:
                     on_token(rid, t)
+            if not emitted and not self.active and (len(self.waiting), len(self.failed), len(self.finished)) == before:
+                # nothing admitted, nothing failed, nothing running: the KV pages the waiting requests need are held OUTSIDE this
+                # engine (e.g. a past_key_values the caller keeps alive) and no later step can change that -- do not spin
+                free = len(self.model.kv.free) if self.model.kv is not None else 0
+                raise RuntimeError(f"ServingEngine.run: no progress -- {len(self.waiting)} request(s) waiting, none active, {free} KV pages free "
+                                   f"(the head request needs {self.waiting[0].need}); pages are held outside the engine")
         return {rid: torch.tensor(r.tokens, dtype=torch.long) for rid, r in sorted(self.finished.items())}
 
     def errors(self) -> Dict[int, BaseException]:
