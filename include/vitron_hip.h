@@ -340,6 +340,13 @@ typedef struct vt_llama_model {
   int qkv_fuse;                 /* 1: prefills write rotated q / K pages / V^T pages from the QKV projection's epilogue instead of the
                                    separate vt_kv_tiles pass. Bit-identical results; measured 20 us per launch SLOWER at S = 5120 (the
                                    epilogue of a one-workgroup-per-CU kernel overlaps with nothing: 455 vs 386 + 48.5 us): default 0. */
+  int precise_qk;               /* 1 (head_dim 128): PREFILLS carry everything that reaches the softmax's argument as operand PAIRS
+                                   (hi + lo, 2 x 16 bit): the input-norm output feeds the q / k projection as A_hi.W^T + A_lo.W^T into fp32,
+                                   the rotary embedding runs in fp32, and the attention scores are K_hi.(Q_hi + Q_lo)^T + K_lo.Q_hi^T -- so the
+                                   scores see ~2^-20 of operand rounding instead of 2^-12 (fp16) / 2^-9 (bf16). Removes the five storage points
+                                   the softmax amplifies: fp16 full-depth logits 1.3e-3 -> below 1e-3 of the reference's fp32.
+                                   Costs two extra GEMM launches, +2 MFMAs per score k-step and the workspace for the pairs; the K pages hold
+                                   K_hi (decode steps and later passes are unchanged). Default 0. */
 } vt_llama_model;
 
 /* KV pool: k  [num_layers][num_pages][heads][64][head_dim]   (K rows, rotary applied)

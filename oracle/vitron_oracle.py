@@ -66,6 +66,15 @@ def _r(x: torch.Tensor, emulate) -> torch.Tensor:
     return bf16_round(x) if emulate else x
 
 
+def _pair(x: torch.Tensor, emulate) -> torch.Tensor:
+    """An operand PAIR of the precise_qk mode (vt_llama_model.precise_qk): hi = store(x), lo = store(x - hi); the kernels multiply both
+    halves, so what the arithmetic sees is hi + lo (2 x 11 / 2 x 8 mantissa bits). Identity when nothing is emulated."""
+    if not emulate:
+        return x
+    hi = _r(x, emulate)
+    return hi + _r(x - hi, emulate)
+
+
 def _lin(x, w, b=None):
     return F.linear(x, w.float(), None if b is None else b.float())
 
@@ -352,9 +361,13 @@ def rmsnorm(x, w, eps):
 
 def llama_forward(sd: SD, cfg: dict, inputs_embeds: torch.Tensor, position_ids: Optional[torch.Tensor] = None,
                   attention_mask: Optional[torch.Tensor] = None, past: Optional[list] = None,
-                  emulate_bf16: bool = False, num_layers: Optional[int] = None, return_hidden: bool = False):
+                  emulate_bf16: bool = False, num_layers: Optional[int] = None, return_hidden: bool = False,
+                  precise_qk: bool = False):
     """LlamaModel + lm_head. inputs_embeds [B,S,H]; attention_mask [B, past+S] (1 = attend) or None;
-    past = list of (k,v) per layer, each [B,heads,Sp,hd]. Returns (logits [B,S,V] fp32, new_past[, hidden])."""
+    past = list of (k,v) per layer, each [B,heads,Sp,hd]. Returns (logits [B,S,V] fp32, new_past[, hidden]).
+    precise_qk (with an emulation mode): the storage points of the kernels' precise_qk prefill -- the input-norm output reaches the
+    q / k projection as an operand pair, q / k stay fp32 through the rotary embedding and are stored once, as pairs; v, P, V^T and
+    everything behind the attention are stored as usual. (The K_lo.Q_lo term the kernel drops is 2^-22 of a score: not modelled.)"""
     B, S, H = inputs_embeds.shape
     heads = cfg["num_attention_heads"]
     hd = H // heads
@@ -379,12 +392,21 @@ def llama_forward(sd: SD, cfg: dict, inputs_embeds: torch.Tensor, position_ids: 
     new_past = []
     for l in range(L):
         p = f"model.layers.{l}."
-        h = _r(rmsnorm(x, sd[p + "input_layernorm.weight"], eps), emulate_bf16)
-        q = _r(_lin(h, sd[p + "self_attn.q_proj.weight"]), emulate_bf16).view(B, S, heads, hd).transpose(1, 2)
-        k = _r(_lin(h, sd[p + "self_attn.k_proj.weight"]), emulate_bf16).view(B, S, heads, hd).transpose(1, 2)
-        v = _r(_lin(h, sd[p + "self_attn.v_proj.weight"]), emulate_bf16).view(B, S, heads, hd).transpose(1, 2)
-        q = _r(_rope(q, cos, sin), emulate_bf16)
-        k = _r(_rope(k, cos, sin), emulate_bf16)
+        if precise_qk and emulate_bf16:
+            hn = rmsnorm(x, sd[p + "input_layernorm.weight"], eps)
+            h, hp = _r(hn, emulate_bf16), _pair(hn, emulate_bf16)
+            q = _lin(hp, sd[p + "self_attn.q_proj.weight"]).view(B, S, heads, hd).transpose(1, 2)
+            k = _lin(hp, sd[p + "self_attn.k_proj.weight"]).view(B, S, heads, hd).transpose(1, 2)
+            v = _r(_lin(h, sd[p + "self_attn.v_proj.weight"]), emulate_bf16).view(B, S, heads, hd).transpose(1, 2)
+            q = _pair(_rope(q, cos, sin), emulate_bf16)
+            k = _pair(_rope(k, cos, sin), emulate_bf16)
+        else:
+            h = _r(rmsnorm(x, sd[p + "input_layernorm.weight"], eps), emulate_bf16)
+            q = _r(_lin(h, sd[p + "self_attn.q_proj.weight"]), emulate_bf16).view(B, S, heads, hd).transpose(1, 2)
+            k = _r(_lin(h, sd[p + "self_attn.k_proj.weight"]), emulate_bf16).view(B, S, heads, hd).transpose(1, 2)
+            v = _r(_lin(h, sd[p + "self_attn.v_proj.weight"]), emulate_bf16).view(B, S, heads, hd).transpose(1, 2)
+            q = _r(_rope(q, cos, sin), emulate_bf16)
+            k = _r(_rope(k, cos, sin), emulate_bf16)
         if past is not None:
             k = torch.cat([past[l][0], k], dim=2)
             v = torch.cat([past[l][1], v], dim=2)

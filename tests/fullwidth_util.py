@@ -84,16 +84,17 @@ def topk_agreement(logits, g, tag):
 _ORACLE_CACHE = {}
 
 
-def oracle_llama(name, emulate):
+def oracle_llama(name, emulate, precise_qk=False):
     """(logits [S, V], final hidden [S, H]) of the oracle on llama_case(name): fp32 (emulate False), bf16-storage emulation (True) or
-    fp16-storage emulation ("fp16") -- computed once per test session: the prefill and the decode parity tests compare against the
-    same passes (each ~1 min of host time at the 7B width)."""
+    fp16-storage emulation ("fp16"; precise_qk=True: with the storage points of the precise_qk prefill) -- computed once per test
+    session: the prefill and the decode parity tests compare against the same passes (each ~1 min of host time at the 7B width)."""
     from oracle import vitron_oracle as O
     emulate = emulate if isinstance(emulate, str) else bool(emulate)
-    key = (name, emulate)
+    key = (name, emulate, bool(precise_qk))
     if key not in _ORACLE_CACHE:
         cfg, sd, x = llama_case(name)
         with torch.no_grad():
-            lg, _, h = O.llama_forward({k: v.float() for k, v in sd.items()}, cfg, x.unsqueeze(0), emulate_bf16=emulate, return_hidden=True)
+            lg, _, h = O.llama_forward({k: v.float() for k, v in sd.items()}, cfg, x.unsqueeze(0), emulate_bf16=emulate, return_hidden=True,
+                                       precise_qk=precise_qk)
         _ORACLE_CACHE[key] = (lg[0], h[0])
     return _ORACLE_CACHE[key]

@@ -61,7 +61,7 @@ class VtLlamaModel(C.Structure):
     _fields_ = [("hidden", C.c_int), ("heads", C.c_int), ("head_dim", C.c_int), ("intermediate", C.c_int),
                 ("num_layers", C.c_int), ("vocab", C.c_int), ("rms_eps", C.c_float), ("final_norm", vp),
                 ("lm_head", vp), ("rope_cos", vp), ("rope_sin", vp), ("rope_len", C.c_int),
-                ("layers", C.POINTER(VtLlamaLayer)), ("prefill_norm_fold", C.c_int), ("qkv_fuse", C.c_int)]
+                ("layers", C.POINTER(VtLlamaLayer)), ("prefill_norm_fold", C.c_int), ("qkv_fuse", C.c_int), ("precise_qk", C.c_int)]
 
 
 class VtKvCache(C.Structure):

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 extern "C" {
 
-int vt_version(void) { return 110; }
+int vt_version(void) { return 111; }
 
 int vt_operand_format(void) { return VT_OPERAND_F16 ? VT_OPERAND_FP16 : VT_OPERAND_BF16; }
 
@@ -452,6 +452,10 @@ struct LlamaWs {
   float* attn_scratch;
   size_t attn_scratch_bytes;
   int* row_slot;        // prefill: cache slot of every new row (fused QKV epilogue)
+  // precise_qk prefills: the low half of the norm output, the fp32 q | k projection, the low halves of rotated q and of the new keys
+  bf16_t *ylo, *qlo, *klo;
+  float* qk32;
+  int klo_tiles;        // K_lo tiles per sequence
   size_t total;
 };
 LlamaWs llama_carve(const vt_llama_model* m, int rows, int n_logit, int nseq, int max_kv_len, void* p, size_t n) {
@@ -473,6 +477,17 @@ LlamaWs llama_carve(const vt_llama_model* m, int rows, int n_logit, int nseq, in
   w.attn_scratch_bytes = vt_attn_decode_scratch_bytes(nseq > 0 ? nseq : 1, m->heads, m->head_dim, max_kv_len > 0 ? max_kv_len : 64);
   w.attn_scratch = (float*)ws.take(w.attn_scratch_bytes);
   w.row_slot = (int*)ws.take((size_t)rows * 4);
+  w.ylo = w.qlo = w.klo = nullptr;
+  w.qk32 = nullptr;
+  w.klo_tiles = 0;
+  if (m->precise_qk == 1 && m->head_dim == 128 && rows > 1) {   // (sized whenever the mode is on: the query does not know max_q_len)
+    w.ylo = (bf16_t*)ws.take((size_t)rows * H * 2);
+    w.qlo = (bf16_t*)ws.take((size_t)rows * H * 2);
+    w.qk32 = (float*)ws.take((size_t)rows * 2 * H * 4);
+    // a sequence of q rows touches at most rows / 64 + 2 tiles; every sequence gets the same number of slots
+    w.klo_tiles = rows / 64 + 2;
+    w.klo = (bf16_t*)ws.take((size_t)(nseq > 0 ? nseq : 1) * w.klo_tiles * H * 64 * 2);
+  }
   w.total = ws.off + 256;
   return w;
 }
@@ -524,6 +539,8 @@ int vt_llama_forward(const vt_llama_model* m, const vt_kv_cache* kv, const uint1
   // opt-in (vt_llama_model.qkv_fuse): prefill with the QKV projection on ONE launch of the 256x256 ping-pong kernel whose epilogue
   // writes rotated q / K pages / V^T pages itself (no vt_kv_tiles pass). Bit-identical, measured slower: default off
   const bool fuse_qkv = max_q_len > 1 && !fold_tile && m->qkv_fuse == 1 && vt_gemm_qkv_fused_supported(rows, H, HD);
+  // opt-in (vt_llama_model.precise_qk): prefills carry q and k as operand pairs through the QKV projection and the attention scores
+  const bool precise = max_q_len > 1 && !fold_norm && m->precise_qk == 1 && HD == 128 && w.qk32 != nullptr && max_new_tiles <= w.klo_tiles;
   if (fuse_qkv) VT_TRY(vt_row_slot_launch((const VtAttnSeq*)seq_desc, nseq, max_q_len, tile_table, w.row_slot, s));
   for (int l = 0; l < m->num_layers; ++l) {
     const vt_llama_layer& L = m->layers[l];
@@ -563,6 +580,23 @@ int vt_llama_forward(const vt_llama_model* m, const vt_kv_cache* kv, const uint1
     // (opt-in, see above).
     VtGemmNormFuse cons_t;
     cons_t.row_scale = w.rstd;
+    if (precise) {
+      // precise_qk: the q / k projection as A_hi.W^T + A_lo.W^T into fp32 (two tile GEMMs, the second accumulating), v as usual;
+      // rotary in fp32, q / k rounded once into operand pairs; attention on K_hi.(Q_hi + Q_lo)^T + K_lo.Q_hi^T
+      VT_TRY(vt_rmsnorm_hilo_launch(w.x, L.rms1, w.y, w.ylo, rows, H, m->rms_eps, s));
+      VT_TRY(vt_gemm_launch(w.y, H, L.wqkv, H, w.qk32, 2 * H, nullptr, rows, 2 * H, H, VT_EPI_F32, AUTO, s));
+      VT_TRY(vt_gemm_resid_launch(w.ylo, H, L.wqkv, H, w.qk32, 2 * H, nullptr, rows, 2 * H, H, 0, w.splitk, w.splitk_bytes, s));
+      VT_TRY(vt_gemm_launch(w.y, H, L.wqkv + (size_t)2 * H * H, H, w.qkv + 2 * H, 3 * H, nullptr, rows, H, H, VT_EPI_BF16, AUTO, s));
+      VT_TRY(vt_kv_tiles_precise_launch(w.qk32, w.qkv, 3 * H, 0, 2 * H, w.qlo, kt, vt, w.klo, tile_table, (const VtAttnSeq*)seq_desc, nseq,
+                                        max_new_tiles, heads, HD, m->rope_cos, m->rope_sin, positions, s));
+      VT_TRY(vt_flash_attn_precise_launch(w.qkv, 3 * H, w.qlo, H, kt, w.klo, max_new_tiles, vt, tile_table, (const VtAttnSeq*)seq_desc, nseq,
+                                          max_q_len, w.att, H, heads, HD, 1, scale, s));
+      VT_TRY(vt_gemm_resid_launch(w.att, H, L.wo, H, w.x, H, nullptr, rows, H, H, 0, w.splitk, w.splitk_bytes, s));
+      VT_TRY(vt_rmsnorm_launch(w.x, nullptr, L.rms2, w.y, rows, H, m->rms_eps, s));
+      VT_TRY(vt_gemm_launch(w.y, H, L.wgu, H, w.h, I, nullptr, rows, 2 * I, H, VT_EPI_SWIGLU_BF16, AUTO, s));
+      VT_TRY(vt_gemm_resid_launch(w.h, I, L.wdown, I, w.x, H, nullptr, rows, H, I, 0, w.splitk, w.splitk_bytes, s));
+      continue;
+    }
     if (fold_tile && l > 0) {
       VT_TRY(vt_gemm_launch(w.y, H, L.wqkv, H, w.qkv, 3 * H, nullptr, rows, 3 * H, H, VT_EPI_BF16, AUTO, s, &cons_t));
     } else if (fuse_qkv) {

@@ -22,6 +22,8 @@
 //    (reference modeling_video.py:105-127) -- one wavefront per (clip, position, head).
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "vt_common.h"
 #include "vt_kernels.h"
 
@@ -308,6 +310,237 @@ __global__ __launch_bounds__(64 * NWAVES, (NWAVES == 8) ? 2 : 2) void flash_attn
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// flash_attn_precise_kernel (vt_llama_model.precise_qk; head_dim 128, 4 waves x 32 query rows, 2-stage ring): flash_attn_kernel's
+// formulation with q and k as operand PAIRS written by kv_tiles_precise_kernel -- S^T = K_hi.(Q_hi + Q_lo)^T + K_lo.Q_hi^T, three MFMAs
+// per k step instead of one (the K_lo.Q_lo term is 2^-22 of the score and dropped): the score carries ~2^-20 of operand
+// rounding instead of 2^-12 (fp16) / 2^-9 (bf16), which is what the softmax amplifies. K_lo exists for the keys this
+// pass appended (a per-pass workspace: tile `t - (past >> 6)` of the sequence); older keys (prefix reuse, chunked prefill) have
+// K_hi only. P, V^T and the P.V MFMA are unchanged. LDS: K_hi + K_lo + V^T = 48 KiB per stage, 96 KiB: one workgroup per CU.
+// ------------------------------------------------------------------------------------------------------------------
+template <bool CAUSAL>
+__global__ __launch_bounds__(256, 1) void flash_attn_precise_kernel(const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ Qlo,
+                                                                    int ldqlo, const bf16_t* __restrict__ Kt,
+                                                                    const bf16_t* __restrict__ Klo, int klo_tiles_per_seq,
+                                                                    const bf16_t* __restrict__ Vt, const int* __restrict__ tile_table,
+                                                                    const VtAttnSeq* __restrict__ seqs, bf16_t* __restrict__ O, int ldo,
+                                                                    int heads, float scale_log2e) {
+  constexpr int HD = 128, NWAVES = 4;
+  constexpr int KS = HD / 16, DB = HD / 32, KROW = HD * 2, TILE_BYTES = 64 * HD * 2, STAGE_BYTES = 3 * TILE_BYTES;
+  constexpr int PIECES = TILE_BYTES / 1024, PPW = PIECES / NWAVES, QBLK = 32 * NWAVES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const VtAttnSeq sq = seqs[blockIdx.z];
+  const int nqb = (sq.q_len + QBLK - 1) / QBLK;
+  const int qb = nqb - 1 - (int)blockIdx.y;
+  if (qb < 0) return;
+  const int head = blockIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ql = lane & 31, hh = lane >> 5;
+  const int past = sq.kv_len - sq.q_len;
+  const int q0 = qb * QBLK;
+  const int qrow = q0 + wave * 32 + ql;
+  const int qrow_c = min(qrow, sq.q_len - 1);
+  int ntiles = (sq.kv_len + 63) >> 6;
+  if (CAUSAL) {
+    const int last_key = past + min(q0 + QBLK - 1, sq.q_len - 1);
+    ntiles = min(ntiles, (last_key >> 6) + 1);
+  }
+  const int t_new0 = past >> 6;    // first tile that holds a key of this pass: K_lo exists from here on
+
+  bf16x8 qf[KS], qfl[KS];
+  {
+    const bf16_t* qp = Q + (size_t)(sq.q_row0 + qrow_c) * ldq + head * HD + hh * 8;
+    const bf16_t* qlp = Qlo + (size_t)(sq.q_row0 + qrow_c) * ldqlo + head * HD + hh * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      qf[ks] = *(const bf16x8*)(qp + ks * 16);
+      qfl[ks] = *(const bf16x8*)(qlp + ks * 16);
+    }
+  }
+  int k_src_off[PPW], v_src_off[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int byte = (wave * PPW + i) * 1024 + lane * 16;
+    {
+      const int row = byte / KROW, c = (byte % KROW) >> 4;
+      k_src_off[i] = row * HD + ((c ^ k_swz<HD>(row)) << 3);
+    }
+    {
+      const int row = byte >> 7, c = (byte & 127) >> 4;
+      v_src_off[i] = row * 64 + ((c ^ v_swz(row)) << 3);
+    }
+  }
+  const size_t head_off = (size_t)head * 64 * HD;
+  const size_t tile_stride = (size_t)heads * 64 * HD;
+  const int* table = tile_table + sq.table_off;
+  const bf16_t* klo_seq = Klo + (size_t)blockIdx.z * klo_tiles_per_seq * tile_stride + head_off;
+
+  auto stage = [&](int buf, int t) {
+    const size_t toff = (size_t)table[t] * tile_stride + head_off;
+    char* base = smem + buf * STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) glds16(Kt + toff + k_src_off[i], base + (wave * PPW + i) * 1024);
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) glds16(Vt + toff + v_src_off[i], base + TILE_BYTES + (wave * PPW + i) * 1024);
+    if (t >= t_new0) {
+      const bf16_t* kl = klo_seq + (size_t)(t - t_new0) * tile_stride;
+#pragma unroll
+      for (int i = 0; i < PPW; ++i) glds16(kl + k_src_off[i], base + 2 * TILE_BYTES + (wave * PPW + i) * 1024);
+    }
+  };
+
+  const int pi = 16 * ((ql >> 2) & 1) + (ql & 3) + 4 * (ql >> 3);
+  int k_row_off[2];
+#pragma unroll
+  for (int sub = 0; sub < 2; ++sub) k_row_off[sub] = (sub * 32 + pi) * KROW;
+  const int k_sw0 = k_swz<HD>(pi);
+  const int v_sw = v_swz(ql);
+
+  f32x16 oacc[DB];
+#pragma unroll
+  for (int db = 0; db < DB; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[db][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+#define FAP_TILE_SYNC()                                  \
+  do {                                                   \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
+    __builtin_amdgcn_s_barrier();                        \
+    __builtin_amdgcn_sched_barrier(0);                   \
+  } while (0)
+
+  if (ntiles > 0) stage(0, 0);
+  FAP_TILE_SYNC();
+  int slot = 0;
+  for (int t = 0; t < ntiles; ++t) {
+    if (t + 1 < ntiles) stage(slot ^ 1, t + 1);
+    const char* kb = smem + slot * STAGE_BYTES;
+    const char* vb = kb + TILE_BYTES;
+    const char* klb = kb + 2 * TILE_BYTES;
+    const bool has_lo = t >= t_new0;     // block-uniform
+
+    f32x16 sacc[2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[sub][r] = 0.f;
+    // small terms first (K_hi.Q_lo, K_lo.Q_hi), the dominant K_hi.Q_hi last: the fp32 accumulator keeps the small terms' low bits
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int chunk = (ks * 2 + hh) ^ k_sw0;
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
+        const bf16x8 kf = *(const bf16x8*)(kb + k_row_off[sub] + (chunk << 4));
+        sacc[sub] = VT_MFMA_32x32x16(kf, qfl[ks], sacc[sub]);
+      }
+    }
+    if (has_lo) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int chunk = (ks * 2 + hh) ^ k_sw0;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+          const bf16x8 kl = *(const bf16x8*)(klb + k_row_off[sub] + (chunk << 4));
+          sacc[sub] = VT_MFMA_32x32x16(kl, qf[ks], sacc[sub]);
+        }
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int chunk = (ks * 2 + hh) ^ k_sw0;
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
+        const bf16x8 kf = *(const bf16x8*)(kb + k_row_off[sub] + (chunk << 4));
+        sacc[sub] = VT_MFMA_32x32x16(kf, qf[ks], sacc[sub]);
+      }
+    }
+
+    const int key0 = t * 64;
+    const bool need_mask = (key0 + 64 > sq.kv_len) || (CAUSAL && (key0 + 63 > past + q0 + wave * 32));
+    if (need_mask) {
+      asm volatile("" ::: "memory");
+      const int lim = CAUSAL ? min(sq.kv_len - 1, past + qrow) : (sq.kv_len - 1);
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = key0 + sub * 32 + 16 * hh + r;
+          if (key > lim) sacc[sub][r] = -INFINITY;
+        }
+    }
+    float mx = fmaxf(sacc[0][0], sacc[1][0]);
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = __builtin_fmaxf(__builtin_fmaxf(mx, sacc[0][r]), sacc[1][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_tile = mx * scale_log2e;
+    if (__builtin_amdgcn_ballot_w64(m_tile > m_run + RESCALE_THR) != 0) {
+      const float m_new = fmaxf(m_run, m_tile);
+      const float alpha = (m_new == -INFINITY) ? 1.f : fast_exp2(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+    }
+    const float m_safe = (m_run == -INFINITY) ? 0.f : m_run;
+    f16x8 pf[2][2];
+    float psum = 0.f;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = fast_exp2(__builtin_fmaf(sacc[sub][r], scale_log2e, P_BIAS - m_safe));
+        psum += e;
+        sacc[sub][r] = e;
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        u32x4 w;
+        w.x = pack_f16x2(sacc[sub][8 * j + 0], sacc[sub][8 * j + 1]);
+        w.y = pack_f16x2(sacc[sub][8 * j + 2], sacc[sub][8 * j + 3]);
+        w.z = pack_f16x2(sacc[sub][8 * j + 4], sacc[sub][8 * j + 5]);
+        w.w = pack_f16x2(sacc[sub][8 * j + 6], sacc[sub][8 * j + 7]);
+        pf[sub][j] = __builtin_bit_cast(f16x8, w);
+      }
+    }
+    l_run += psum;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int chunk = (sub * 4 + 2 * hh + j) ^ v_sw;
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+          const f16x8 vf = *(const f16x8*)(vb + (db * 32 + ql) * 128 + (chunk << 4));
+          oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[sub][j], oacc[db], 0, 0, 0);
+        }
+      }
+    FAP_TILE_SYNC();
+    slot ^= 1;
+  }
+#undef FAP_TILE_SYNC
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = (l_tot > 0.f) ? 1.f / l_tot : 0.f;
+  if (qrow < sq.q_len) {
+    bf16_t* op = O + (size_t)(sq.q_row0 + qrow) * ldo + head * HD + 4 * hh;
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x2 o;
+        o.x = pack_op2(oacc[db][4 * g + 0] * inv, oacc[db][4 * g + 1] * inv);
+        o.y = pack_op2(oacc[db][4 * g + 2] * inv, oacc[db][4 * g + 3] * inv);
+        *(u32x2*)(op + db * 32 + 8 * g) = o;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // kv_tiles_kernel: one block per (64-position tile, head, sequence). Handles the NEW tokens of the sequence
 // (positions past .. kv_len-1) that fall into the tile:
 //   K tile [64][HD]: row = position & 63   (rotary applied when ROPE)
@@ -406,6 +639,127 @@ __global__ __launch_bounds__(256) void kv_tiles_kernel(bf16_t* __restrict__ qkv,
     const bool any_new = (pos0 < p_hi) && (pos0 + 8 > p_lo);
     if (!full && !any_new) continue;
     float vals[8];   // bf16 -> fp16 (exact in fp16's normal range, saturating): the V^T pages hold fp16, see vt_common.h
+#pragma unroll
+    for (int j = 0; j < 8; ++j) vals[j] = vt_clamp_f16(op_to_f32(vs[kc * 8 + j][d]));
+    uint16_t* dst = vt + d * 64 + kc * 8;
+    u32x4 w;
+    w.x = pack_f16x2(vals[0], vals[1]);
+    w.y = pack_f16x2(vals[2], vals[3]);
+    w.z = pack_f16x2(vals[4], vals[5]);
+    w.w = pack_f16x2(vals[6], vals[7]);
+    if (full) {
+      *(u32x4*)dst = w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int pos = pos0 + j;
+        if (pos >= p_lo && pos < p_hi) dst[j] = (uint16_t)((w[j >> 1] >> (16 * (j & 1))) & 0xffffu);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// kv_tiles_precise_kernel (vt_llama_model.precise_qk): the same job as kv_tiles_kernel<HD, true> for a q / k projection that
+// arrives in FP32 (qk32 [rows][2 * heads * HD]: q columns, then k columns): the rotary embedding is applied in fp32 and q / k are
+// rounded ONCE, each to an operand PAIR (hi = op(v), lo = op(v - f32(hi))):
+//   q_hi -> the q columns of the fused qkv buffer (where the attention kernel reads Q), q_lo -> qlo [rows][heads * HD]
+//   k_hi -> the K page (what decode steps and later passes see: the ordinary cache), k_lo -> klo, a per-pass workspace of
+//           [sequence][new tile][head][64][HD] (zero rows where the tile holds no new key)
+// V rows go to the V^T pages exactly as in kv_tiles_kernel. flash_attn_kernel<..., PREC = true> consumes the pairs.
+// ------------------------------------------------------------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(256) void kv_tiles_precise_kernel(const float* __restrict__ qk32, bf16_t* __restrict__ qkv, int ldqkv,
+                                                               int q_col0, int v_col0, bf16_t* __restrict__ qlo,
+                                                               bf16_t* __restrict__ Kt, bf16_t* __restrict__ Vt, bf16_t* __restrict__ klo,
+                                                               const int* __restrict__ tile_table, const VtAttnSeq* __restrict__ seqs,
+                                                               int heads, const float* __restrict__ rope_cos,
+                                                               const float* __restrict__ rope_sin, const int* __restrict__ positions) {
+  constexpr int CH = HD / 8;
+  __shared__ __attribute__((aligned(16))) bf16_t vs[64][HD + 8];
+  const VtAttnSeq sq = seqs[blockIdx.z];
+  const int past = sq.kv_len - sq.q_len;
+  const int t = (past >> 6) + blockIdx.x;
+  if (t * 64 >= sq.kv_len) return;
+  const int head = blockIdx.y;
+  const int H = heads * HD;
+  const int p_lo = max(past, t * 64), p_hi = min(sq.kv_len, t * 64 + 64);
+  const bool fresh = (t * 64 >= past);
+  const size_t toff = ((size_t)tile_table[sq.table_off + t] * heads + head) * 64 * HD;
+  bf16_t* kt = Kt + toff;
+  bf16_t* vt = Vt + toff;
+  bf16_t* kl = klo + (((size_t)blockIdx.z * gridDim.x + blockIdx.x) * heads + head) * 64 * HD;
+
+  for (int it = threadIdx.x; it < 64 * (CH / 2); it += 256) {
+    const int r = it / (CH / 2), c = it % (CH / 2);
+    const int pos = t * 64 + r;
+    u32x4 k_h_lo = {0u, 0u, 0u, 0u}, k_h_hi = k_h_lo, k_l_lo = k_h_lo, k_l_hi = k_h_lo;
+    const bool is_new = pos >= p_lo && pos < p_hi;
+    if (is_new) {
+      const int row = sq.q_row0 + (pos - past);
+      const int rp = positions[row];
+      const float* cs = rope_cos + (size_t)rp * (HD / 2) + c * 8;
+      const float* sn = rope_sin + (size_t)rp * (HD / 2) + c * 8;
+      const float* qs = qk32 + (size_t)row * (2 * H) + head * HD;
+      const float* ks = qs + H;
+      u32x4 q_h_lo, q_h_hi, q_l_lo, q_l_hi;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const float c0 = cs[2 * w], c1 = cs[2 * w + 1], s0 = sn[2 * w], s1 = sn[2 * w + 1];
+        {
+          const float a0 = ks[c * 8 + 2 * w], a1 = ks[c * 8 + 2 * w + 1];
+          const float b0 = ks[HD / 2 + c * 8 + 2 * w], b1 = ks[HD / 2 + c * 8 + 2 * w + 1];
+          const float lo0 = rope_lo(a0, b0, c0, s0), lo1 = rope_lo(a1, b1, c1, s1);
+          const float hi0 = rope_hi(a0, b0, c0, s0), hi1 = rope_hi(a1, b1, c1, s1);
+          k_h_lo[w] = pack_op2(lo0, lo1);
+          k_h_hi[w] = pack_op2(hi0, hi1);
+          k_l_lo[w] = pack_op2(lo0 - oplo_to_f32(k_h_lo[w]), lo1 - ophi_to_f32(k_h_lo[w]));
+          k_l_hi[w] = pack_op2(hi0 - oplo_to_f32(k_h_hi[w]), hi1 - ophi_to_f32(k_h_hi[w]));
+        }
+        {
+          const float a0 = qs[c * 8 + 2 * w], a1 = qs[c * 8 + 2 * w + 1];
+          const float b0 = qs[HD / 2 + c * 8 + 2 * w], b1 = qs[HD / 2 + c * 8 + 2 * w + 1];
+          const float lo0 = rope_lo(a0, b0, c0, s0), lo1 = rope_lo(a1, b1, c1, s1);
+          const float hi0 = rope_hi(a0, b0, c0, s0), hi1 = rope_hi(a1, b1, c1, s1);
+          q_h_lo[w] = pack_op2(lo0, lo1);
+          q_h_hi[w] = pack_op2(hi0, hi1);
+          q_l_lo[w] = pack_op2(lo0 - oplo_to_f32(q_h_lo[w]), lo1 - ophi_to_f32(q_h_lo[w]));
+          q_l_hi[w] = pack_op2(hi0 - oplo_to_f32(q_h_hi[w]), hi1 - ophi_to_f32(q_h_hi[w]));
+        }
+      }
+      bf16_t* qp = qkv + (size_t)row * ldqkv + q_col0 + head * HD;
+      *(u32x4*)(qp + c * 8) = q_h_lo;
+      *(u32x4*)(qp + HD / 2 + c * 8) = q_h_hi;
+      bf16_t* qlp = qlo + (size_t)row * H + head * HD;
+      *(u32x4*)(qlp + c * 8) = q_l_lo;
+      *(u32x4*)(qlp + HD / 2 + c * 8) = q_l_hi;
+    }
+    if (is_new || (fresh && pos >= p_hi)) {
+      *(u32x4*)(kt + r * HD + c * 8) = k_h_lo;
+      *(u32x4*)(kt + r * HD + HD / 2 + c * 8) = k_h_hi;
+    }
+    *(u32x4*)(kl + r * HD + c * 8) = k_l_lo;              // the workspace tile is written completely: zeros where no new key sits
+    *(u32x4*)(kl + r * HD + HD / 2 + c * 8) = k_l_hi;
+  }
+
+  for (int it = threadIdx.x; it < 64 * CH; it += 256) {
+    const int r = it / CH, c = it % CH;
+    const int pos = t * 64 + r;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (pos >= p_lo && pos < p_hi) {
+      const int row = sq.q_row0 + (pos - past);
+      v = *(const u32x4*)(qkv + (size_t)row * ldqkv + v_col0 + head * HD + c * 8);
+    }
+    *(u32x4*)(&vs[r][c * 8]) = v;
+  }
+  __syncthreads();
+  for (int it = threadIdx.x; it < HD * 8; it += 256) {
+    const int d = it >> 3, kc = it & 7;
+    const int pos0 = t * 64 + kc * 8;
+    const bool full = fresh || (pos0 >= p_lo && pos0 + 8 <= p_hi);
+    const bool any_new = (pos0 < p_hi) && (pos0 + 8 > p_lo);
+    if (!full && !any_new) continue;
+    float vals[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) vals[j] = vt_clamp_f16(op_to_f32(vs[kc * 8 + j][d]));
     uint16_t* dst = vt + d * 64 + kc * 8;
@@ -1053,6 +1407,49 @@ int vt_kv_tiles_launch(bf16_t* qkv, int ldqkv, int q_col0, int k_col0, int v_col
     if (rope) hipLaunchKernelGGL((kv_tiles_kernel<128, true>), grid, block, 0, s, qkv, ldqkv, q_col0, k_col0, v_col0, Kt, Vt, tile_table, seqs, heads, rope_cos, rope_sin, positions);
     else hipLaunchKernelGGL((kv_tiles_kernel<128, false>), grid, block, 0, s, qkv, ldqkv, q_col0, k_col0, v_col0, Kt, Vt, tile_table, seqs, heads, rope_cos, rope_sin, positions);
   }
+  VT_LAUNCH_CHECK();
+  return VT_OK;
+}
+
+int vt_kv_tiles_precise_launch(const float* qk32, bf16_t* qkv, int ldqkv, int q_col0, int v_col0, bf16_t* qlo, bf16_t* Kt, bf16_t* Vt,
+                               bf16_t* klo, const int* tile_table, const VtAttnSeq* seqs, int nseq, int max_new_tiles, int heads, int HD,
+                               const float* rope_cos, const float* rope_sin, const int* positions, hipStream_t s) {
+  VT_REQUIRE(qk32 && qkv && qlo && Kt && Vt && klo && tile_table && seqs && rope_cos && rope_sin && positions, "vt_kv_tiles_precise: null pointer");
+  VT_REQUIRE(HD == 128, "vt_kv_tiles_precise: head_dim %d unsupported (128)", HD);
+  VT_REQUIRE(ldqkv % 8 == 0 && q_col0 % 8 == 0 && v_col0 % 8 == 0, "vt_kv_tiles_precise: misaligned columns");
+  dim3 grid(max_new_tiles, heads, nseq), block(256);
+  hipLaunchKernelGGL((kv_tiles_precise_kernel<128>), grid, block, 0, s, qk32, qkv, ldqkv, q_col0, v_col0, qlo, Kt, Vt, klo, tile_table, seqs,
+                     heads, rope_cos, rope_sin, positions);
+  VT_LAUNCH_CHECK();
+  return VT_OK;
+}
+
+int vt_flash_attn_precise_launch(const bf16_t* Q, int ldq, const bf16_t* Qlo, int ldqlo, const bf16_t* Kt, const bf16_t* Klo,
+                                 int klo_tiles_per_seq, const bf16_t* Vt, const int* tile_table, const VtAttnSeq* seqs, int nseq,
+                                 int max_q_len, bf16_t* O, int ldo, int heads, int HD, int causal, float scale, hipStream_t s) {
+  VT_REQUIRE(Q && Qlo && Kt && Klo && Vt && tile_table && seqs && O, "vt_flash_attn_precise: null pointer");
+  VT_REQUIRE(HD == 128, "vt_flash_attn_precise: head_dim %d unsupported (128)", HD);
+  VT_REQUIRE(nseq > 0 && max_q_len > 0 && heads > 0 && klo_tiles_per_seq > 0, "vt_flash_attn_precise: empty problem");
+  VT_REQUIRE(ldq % 8 == 0 && ldqlo % 8 == 0 && ldo % 4 == 0, "vt_flash_attn_precise: ldq %% 8, ldqlo %% 8 and ldo %% 4 must be 0");
+  const float sl2 = scale * 1.4426950408889634f;
+  VtProfScope prof(VT_PROF_FLASH_ATTN, 0.0, s);
+  constexpr int smem = 2 * 3 * 64 * 128 * 2;
+  int dev = 0;
+  VT_HIP(hipGetDevice(&dev));
+  VT_REQUIRE(dev >= 0 && dev < 64, "vt_flash_attn_precise: device ordinal %d", dev);
+  dim3 grid(heads, cdiv(max_q_len, 128), nseq), block(256);
+#define VT_FAP(CV)                                                                                             \
+  do {                                                                                                         \
+    auto kern = flash_attn_precise_kernel<CV>;                                                                 \
+    static std::atomic<unsigned long long> done{0};                                                            \
+    if (!((done.load(std::memory_order_relaxed) >> dev) & 1ull)) {                                             \
+      VT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));        \
+      done.fetch_or(1ull << dev, std::memory_order_relaxed);                                                   \
+    }                                                                                                          \
+    hipLaunchKernelGGL(kern, grid, block, smem, s, Q, ldq, Qlo, ldqlo, Kt, Klo, klo_tiles_per_seq, Vt, tile_table, seqs, O, ldo, heads, sl2); \
+  } while (0)
+  if (causal) VT_FAP(true); else VT_FAP(false);
+#undef VT_FAP
   VT_LAUNCH_CHECK();
   return VT_OK;
 }

@@ -105,6 +105,45 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
   }
 }
 
+// precise_qk mode (vt_llama_model.precise_qk): the norm output as an operand PAIR -- y = op(x_n) and y_lo = op(x_n - f32(y)) -- so that
+// the q / k projections can run as A_hi.W^T + A_lo.W^T (16 + 16 mantissa bits of the A operand instead of 11 / 8)
+template <int NCH>
+__global__ __launch_bounds__(256) void rmsnorm_hilo_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           bf16_t* __restrict__ y, bf16_t* __restrict__ ylo, int rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + (size_t)row * D;
+  f32x4 v[NCH];
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (lane + i * 64) * 4;
+    if (c < D) {
+      v[i] = *(const f32x4*)(xr + c);
+      sq += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+    } else {
+      v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (lane + i * 64) * 4;
+    if (c < D) {
+      const f32x4 g = *(const f32x4*)(w + c);
+      const float a0 = v[i][0] * rstd * g[0], a1 = v[i][1] * rstd * g[1], a2 = v[i][2] * rstd * g[2], a3 = v[i][3] * rstd * g[3];
+      u32x2 hi, lo;
+      hi.x = pack_op2(a0, a1);
+      hi.y = pack_op2(a2, a3);
+      lo.x = pack_op2(a0 - oplo_to_f32(hi.x), a1 - ophi_to_f32(hi.x));
+      lo.y = pack_op2(a2 - oplo_to_f32(hi.y), a3 - ophi_to_f32(hi.y));
+      *(u32x2*)(y + (size_t)row * D + c) = hi;
+      *(u32x2*)(ylo + (size_t)row * D + c) = lo;
+    }
+  }
+}
+
 // many rows (prefill): persistent waves, each walking rows w, w + stride, ...; the NEXT row's 16-byte loads are issued before the
 // current row is reduced and stored, so on the whole chip the read stream of one row overlaps the write stream of the previous
 // one (the one-row-per-wave kernel above runs as two chip-wide phases: every wave reads, then every wave writes).
@@ -294,6 +333,15 @@ int vt_rmsnorm_launch(const float* x, const int* idx, const float* w, bf16_t* y,
   }
   dim3 grid(cdiv(rows, 4));
   VT_NORM_DISPATCH(rmsnorm_kernel, D, x, idx, w, y, rows, D, eps);
+  VT_LAUNCH_CHECK();
+  return VT_OK;
+}
+
+int vt_rmsnorm_hilo_launch(const float* x, const float* w, bf16_t* y, bf16_t* ylo, int rows, int D, float eps, hipStream_t s) {
+  VT_REQUIRE(x && w && y && ylo, "vt_rmsnorm_hilo: null pointer");
+  VT_REQUIRE(rows > 0 && D > 0 && D % 4 == 0 && D <= 4096, "vt_rmsnorm_hilo: D=%d must be a multiple of 4, <= 4096", D);
+  dim3 grid(cdiv(rows, 4));
+  VT_NORM_DISPATCH(rmsnorm_hilo_kernel, D, x, w, y, ylo, rows, D, eps);
   VT_LAUNCH_CHECK();
   return VT_OK;
 }

@@ -420,6 +420,7 @@ class PackedLlama:
         m.layers = C.cast(self.layers, C.POINTER(_lib.VtLlamaLayer))
         m.prefill_norm_fold = int(bool(cfg.get("prefill_norm_fold", False)))
         m.qkv_fuse = int(bool(cfg.get("qkv_fuse", False)))
+        m.precise_qk = int(bool(cfg.get("precise_qk", False)))
         self.model = m
         self.ws = Workspace(dev)
 
@@ -427,6 +428,15 @@ class PackedLlama:
         """Prefill: rotary + K / V^T page writes inside the QKV GEMM's epilogue instead of the separate vt_kv_tiles pass
         (vt_llama_model.qkv_fuse; bit-identical, measured slower at the benchmark shape: default off)."""
         self.model.qkv_fuse = int(bool(on))
+
+    def set_precise_qk(self, on: bool) -> None:
+        """Prefills carry q / k (and the norm output that feeds their projection) as hi + lo operand pairs: the attention scores see
+        ~2^-20 of operand rounding instead of 2^-12 (fp16) / 2^-9 (bf16) (vt_llama_model.precise_qk; include/vitron_hip.h). The
+        fp16 build's full-depth logits move from 1.3e-3 to below 1e-3 of the reference's fp32 output; costs ~10 % of
+        the prefill time. head_dim 128 only; decode steps are unchanged. Default off."""
+        if on and self.hd != 128:
+            raise _lib.VitronHipError(f"precise_qk needs head_dim 128 (got {self.hd})")
+        self.model.precise_qk = int(bool(on))
 
     def set_prefill_norm_fold(self, on: bool) -> None:
         """RMSNorm folded into the prefill tile GEMMs (vt_llama_model.prefill_norm_fold; measured neutral, default off)."""
