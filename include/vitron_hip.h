@@ -287,6 +287,13 @@ typedef struct vt_vit_layer {
   const float* b1;
   const uint16_t* w2; /* fc2 [D][I] */
   const float* b2;
+  /* temporal MLP -- the IMAGE tower's add_time_attn variant only (reference image/modeling_image.py:83-84,129-134: after the temporal
+     attention, x += temporal_mlp(temporal_layer_norm2(x))); all NULL for the video tower (video/modeling_video.py has no such block) */
+  const float *t_ln2_g, *t_ln2_b;
+  const uint16_t* t_w1;
+  const float* t_b1;
+  const uint16_t* t_w2;
+  const float* t_b2;
 } vt_vit_layer;
 
 typedef struct vt_vit_model {
@@ -347,6 +354,10 @@ typedef struct vt_llama_model {
                                    the softmax amplifies: fp16 full-depth logits 1.3e-3 -> below 1e-3 of the reference's fp32.
                                    Costs two extra GEMM launches, +2 MFMAs per score k-step and the workspace for the pairs; the K pages hold
                                    K_hi (decode steps and later passes are unchanged). Default 0. */
+  float* hidden_trace;          /* optional DEVICE buffer fp32 [num_layers][rows][H]: when non-NULL every layer's INPUT residual stream is
+                                   copied there (entry 0 = the input embeddings) -- what `output_hidden_states=True` of the reference's
+                                   LlamaModel collects before each decoder layer (llava_llama.py:69, transformers 4.31 LlamaModel.forward).
+                                   NULL (default): nothing is copied. */
 } vt_llama_model;
 
 /* KV pool: k  [num_layers][num_pages][heads][64][head_dim]   (K rows, rotary applied)

@@ -145,6 +145,15 @@ def vit_forward(sd: SD, cfg: dict, pixels: torch.Tensor, num_layers: Optional[in
             h = clip_attention(h, sd, p + "temporal_attn.", heads, emulate_bf16, round_p=False)  # temporal kernel keeps P in fp32
             h = _lin(h, sd[p + "temporal_attn.out_proj.weight"], sd[p + "temporal_attn.out_proj.bias"])
             x = res + h.view(B, N, T, D).transpose(1, 2).reshape(B * T, N, D)  # :127
+            if p + "temporal_mlp.fc1.weight" in sd:
+                # the IMAGE tower's add_time_attn variant only (image/modeling_image.py:83-84,129-134): a row-wise MLP behind the temporal
+                # attention (the '(b t) n d -> (b n) t d' rearrangement around it does not change a row-wise operation)
+                res = x
+                h = _r(F.layer_norm(x, (D,), sd[p + "temporal_layer_norm2.weight"].float(), sd[p + "temporal_layer_norm2.bias"].float(), eps),
+                       emulate_bf16)
+                h = _lin(h, sd[p + "temporal_mlp.fc1.weight"], sd[p + "temporal_mlp.fc1.bias"])
+                h = _r(F.gelu(h) if act == "gelu" else quick_gelu(h), emulate_bf16)
+                x = res + _lin(h, sd[p + "temporal_mlp.fc2.weight"], sd[p + "temporal_mlp.fc2.bias"])
         res = x  # spatial attention :136-146
         h = _r(F.layer_norm(x, (D,), sd[p + "layer_norm1.weight"].float(), sd[p + "layer_norm1.bias"].float(), eps), emulate_bf16)
         h = clip_attention(h, sd, p + "self_attn.", heads, emulate_bf16)

@@ -18,6 +18,11 @@ VIT_VIDEO_B = dict(hidden_size=128, intermediate_size=192, num_hidden_layers=2, 
                    image_size=70, hidden_act="quick_gelu", layer_norm_eps=1e-5, add_time_attn=True, num_frames=8)
 VIT_IMAGE_B = dict(VIT_VIDEO_B, add_time_attn=False, num_frames=1)
 VIT_B_CASES = {"video_b": (VIT_VIDEO_B, (1, 3, 8, 70, 70)), "image_b": (VIT_IMAGE_B, (2, 3, 70, 70))}
+# third pinned tower shape (round 5): the IMAGE tower file's add_time_attn variant -- temporal attention AND a temporal MLP per layer
+# (reference image/modeling_image.py:74-84,105-134) -- on 4-frame clips and in its degenerate num_frames = 1 form (no embedding add)
+VIT_IMAGE_TMLP = dict(VIT_VIDEO, temporal_mlp=True)
+VIT_IMAGE_TMLP1 = dict(VIT_VIDEO, temporal_mlp=True, num_frames=1)
+VIT_TMLP_CASES = {"tmlp_t4": (VIT_IMAGE_TMLP, (2, 3, 4, 56, 56)), "tmlp_t1": (VIT_IMAGE_TMLP1, (3, 3, 56, 56))}
 MM_HIDDEN = 128
 # F1 branches: the plain HF-CLIP image tower (reference clip_encoder.py) -- CLIPVisionConfig defaults
 # (quick_gelu), a 4 x 4 patch grid -- and an mlp3x_gelu projector (multimodal_projector/builder.py:39-46)

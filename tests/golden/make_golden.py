@@ -32,8 +32,9 @@ def f32(sd):
 
 
 def build_ref_vit(ns, cfg, sd):
-    # video tower: video/modeling_video.py; image tower: image/modeling_image.py (no 'b t n c' view of hidden states)
-    if cfg["add_time_attn"]:
+    # video tower: video/modeling_video.py; image tower: image/modeling_image.py (no 'b t n c' view of hidden states; its add_time_attn
+    # variant -- cfg["temporal_mlp"] -- has a temporal MLP behind the temporal attention)
+    if cfg["add_time_attn"] and not cfg.get("temporal_mlp", False):
         cv, mv = ns.configuration_video, ns.modeling_video
     else:
         cv, mv = ns.configuration_image, ns.modeling_image
@@ -79,6 +80,23 @@ def gen_vit_b(ns):
             out[f"{name}_hidden_{i}"] = h.reshape(-1, h.shape[-2], h.shape[-1]).numpy().astype(np.float32)
     np.savez_compressed(os.path.join(OUT, "vit_b.npz"), **out)
     print("vit_b.npz", {k: getattr(v, "shape", v) for k, v in out.items()})
+
+
+def gen_vit_tmlp(ns):
+    """The IMAGE tower file's CLIPVisionTransformer with add_time_attn = True (temporal attention + temporal MLP per layer)."""
+    out = {}
+    for name, (cfg, shape) in cases.VIT_TMLP_CASES.items():
+        sd = synth.vit_state(cfg, synth.make_generator(cases.SEED_VIT + 2), **cases.VIT_INIT)
+        m = build_ref_vit(ns, cfg, sd)
+        assert hasattr(m.encoder.layers[0], "temporal_mlp")
+        x = cases.pixels(shape, cases.SEED_PIX + 2)
+        with torch.no_grad():
+            hs = m(x, output_hidden_states=True).hidden_states
+        out[f"{name}_checksum"] = np.float64(synth.checksum(sd))
+        for i, h in enumerate(hs):
+            out[f"{name}_hidden_{i}"] = h.reshape(-1, h.shape[-2], h.shape[-1]).numpy()
+    np.savez_compressed(os.path.join(OUT, "vit_tmlp.npz"), **out)
+    print("vit_tmlp.npz", {k: getattr(v, "shape", v) for k, v in out.items()})
 
 
 def gen_region_projector(ns):
@@ -570,6 +588,9 @@ if __name__ == "__main__":
     if "--fullwidth-only" in sys.argv:
         gen_fullwidth(ns)
         sys.exit(0)
+    if "--vit-tmlp-only" in sys.argv:
+        gen_vit_tmlp(ns)
+        sys.exit(0)
     if "--fullwidth-224-only" in sys.argv:
         gen_fullwidth_224(ns)
         sys.exit(0)
@@ -586,6 +607,7 @@ if __name__ == "__main__":
     gen_output_parser()
     gen_vit(ns)
     gen_vit_b(ns)
+    gen_vit_tmlp(ns)
     gen_region_projector(ns)
     gen_glue(ns)
     gen_glue_random(ns)

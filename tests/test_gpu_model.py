@@ -113,6 +113,32 @@ def test_vit_tower_second_shape(dev, name):
         assert feats.shape == ((1, 8, 25, 128) if name == "video_b" else (2, 25, 128))
 
 
+@pytest.mark.parametrize("name", list(cases.VIT_TMLP_CASES))
+def test_vit_image_tower_with_time_attention_and_temporal_mlp(dev, name):
+    """The IMAGE tower file's add_time_attn variant (reference image/modeling_image.py:74-84,105-134: temporal attention AND a temporal
+    MLP in every layer) through the tower wrapper -- 4-frame clips, and num_frames = 1 (the embedding add is skipped, the block
+    degenerates to out_proj(v_proj(LN(x))) + MLP): all layers against the reference's hidden states and the emulating oracle."""
+    from types import SimpleNamespace
+    from vitron_amd.engine import PackedVit
+    from vitron_amd.model.multimodal_encoder.languagebind import LanguageBindImageTower
+    g = np.load(os.path.join(G, "vit_tmlp.npz"))
+    cfg, shape = cases.VIT_TMLP_CASES[name]
+    sd = synth.vit_state(cfg, synth.make_generator(cases.SEED_VIT + 2), **cases.VIT_INIT)
+    x = cases.pixels(shape, cases.SEED_PIX + 2)
+    for sel in (-1, -2):
+        vit = PackedVit(sd, cfg, dev, select_layer=sel)
+        feats, hidden = vit.forward(x.to(dev).bfloat16(), return_hidden=True)
+        nl = vit.run_layers
+        emu = O.vit_forward(f32(sd), cfg, x, nl, emulate_bf16=True)
+        ref = torch.as_tensor(g[f"{name}_hidden_{nl}"])
+        assert rel_l2(hidden, emu) <= 5e-3, (sel, rel_l2(hidden, emu), "vs emulating oracle")
+        assert rel_l2(hidden, ref) <= 1.4 * TOL_FP32 and no_worse_than_emulation(hidden, emu, ref), (sel, rel_l2(hidden, ref), "vs reference fp32")   # two more storage points per layer than the video tower
+    tower = LanguageBindImageTower("tmlp/LanguageBind_Image", SimpleNamespace(mm_vision_select_layer=-2), delay_load=True)
+    tower.load_state(cfg, sd, dev)                                  # (round 4 refused these weights with NotImplementedError)
+    f = tower(x.to(dev).bfloat16())
+    assert f.shape[-2:] == (16, 128) and rel_l2(f.reshape(-1, 128), feats.reshape(-1, 128)) == 0.0
+
+
 def test_projector_and_region(dev, model):
     g = np.load(os.path.join(G, "region_projector.npz"))
     st = _states()
@@ -730,3 +756,36 @@ def test_multimodal_glue_random_layouts_vs_reference(dev, model):
     finally:
         model.config.tokenizer_model_max_length = None
         model.config.tokenizer_padding_side = "right"
+
+
+@pytest.mark.gpu
+def test_output_hidden_states_and_attentions(dev, model):
+    """forward(output_hidden_states=True) (reference llava_llama.py:69 -> transformers 4.31 LlamaModel.forward): num_layers + 1 tensors
+    [B, S, H] -- the stream in front of every decoder layer (entry 0 = the spliced embeddings), then the final-normed output of the last
+    layer -- on a right-padded batch (zeros at the padding rows), against the oracle layer by layer. output_attentions=True is refused
+    explicitly (the flash kernels never materialise the probabilities)."""
+    case = cases.glue_cases()["batch_pad"]
+    ids, am = case["input_ids"].to(dev), case["attention_mask"].to(dev)
+    images = [im.to(dev).bfloat16() for im in case["images"]]
+    out = model(input_ids=ids, attention_mask=am, images=images, regions=case["regions"], use_cache=False, output_hidden_states=True)
+    L = cases.LLM["num_hidden_layers"]
+    hs = out.hidden_states
+    assert isinstance(hs, tuple) and len(hs) == L + 1
+    w = {k: f32(v) for k, v in _states().items()}
+    e, mask, pos = O.multimodal_prepare(w, CFGS, case["input_ids"], case["attention_mask"], case["images"], case["regions"], emulate_bf16=True)
+    valid = mask.bool()
+    assert all(tuple(h.shape) == tuple(e.shape) for h in hs)
+    assert all(float(h.float().cpu()[~valid].abs().max()) == 0.0 for h in hs)               # padding rows: zeros
+    with torch.no_grad():
+        for l in range(L):
+            _, _, h = O.llama_forward(w["llama"], cases.LLM, e, pos, mask, None, True, num_layers=l, return_hidden=True)
+            d = rel_l2(hs[l].float().cpu()[valid], h[valid])
+            assert d <= (6e-3 if l == 0 else TOL_DEEP), (l, d)
+        _, _, h = O.llama_forward(w["llama"], cases.LLM, e, pos, mask, None, True, return_hidden=True)
+        final = O.bf16_round(O.rmsnorm(h, w["llama"]["model.norm.weight"], cases.LLM["rms_norm_eps"]))
+        assert rel_l2(hs[L].float().cpu()[valid], final[valid]) <= TOL_DEEP
+    assert hs[L].dtype == model.dtype and hs[0].dtype == torch.float32
+    plain = model(input_ids=ids, attention_mask=am, images=images, regions=case["regions"], use_cache=False)
+    assert plain.hidden_states is None and torch.equal(plain.logits, out.logits)            # the trace changes nothing
+    with pytest.raises(NotImplementedError):
+        model(input_ids=ids, attention_mask=am, images=images, regions=case["regions"], use_cache=False, output_attentions=True)

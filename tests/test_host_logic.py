@@ -524,12 +524,13 @@ def test_tower_and_projector_factories_pick_the_reference_branches(tmp_path):
             build_video_tower(SimpleNamespace(mm_video_tower=bad))
     with pytest.raises(ValueError):      # LanguageBind towers only know 'patch' (languagebind/__init__.py:96-104)
         build_image_tower(SimpleNamespace(mm_image_tower="x/LanguageBind_Image", mm_vision_select_feature="cls_patch"), delay_load=True)
-    # the image tower's add_time_attn branch (modeling_image.py:74-84: temporal attention + temporal_mlp) is NOT built: loud error
+    # the image tower's add_time_attn branch (modeling_image.py:74-84: temporal attention + temporal_mlp) is accepted since round 5
+    # (packed by PackedVit, run by vt_vit_forward: tests/test_gpu_model.py::test_vit_image_tower_with_time_attention_and_temporal_mlp)
     it = build_image_tower(SimpleNamespace(image_tower="x/LanguageBind_Image"), delay_load=True)
-    with pytest.raises(NotImplementedError, match="temporal_mlp"):
-        it.load_state({"hidden_size": 128, "num_attention_heads": 2, "patch_size": 14, "intermediate_size": 256, "image_size": 56,
-                       "num_hidden_layers": 2, "add_time_attn": True},
-                      {"encoder.layers.0.temporal_mlp.fc1.weight": torch.zeros(256, 128)})
+    it.load_state({"hidden_size": 128, "num_attention_heads": 2, "patch_size": 14, "intermediate_size": 256, "image_size": 56,
+                   "num_hidden_layers": 2, "add_time_attn": True},
+                  {"encoder.layers.0.temporal_mlp.fc1.weight": torch.zeros(256, 128)})
+    assert it.is_loaded and it.config.add_time_attn
     c = SimpleNamespace(mm_hidden_size=1024, hidden_size=4096)
     for name, depth in (("linear", 1), ("mlp2x_gelu", 2), ("mlp3x_gelu", 3), ("mlp5x_gelu", 5)):
         c.mm_projector_type = name

@@ -74,6 +74,21 @@ def test_vit_hidden_states_second_shape(name):
         assert rel(h, g[f"{name}_hidden_{nl}"]) <= 1e-5, nl
 
 
+@pytest.mark.parametrize("name", list(cases.VIT_TMLP_CASES))
+def test_vit_hidden_states_image_tower_with_time_attention(name):
+    """The IMAGE tower file's add_time_attn variant (temporal attention + temporal MLP per layer, image/modeling_image.py:74-84,
+    105-134) on 4-frame clips and in its num_frames = 1 form: every hidden state of the reference's module (tests/golden/vit_tmlp.npz)."""
+    g = np.load(os.path.join(G, "vit_tmlp.npz"))
+    cfg, shape = cases.VIT_TMLP_CASES[name]
+    sd = synth.vit_state(cfg, synth.make_generator(cases.SEED_VIT + 2), **cases.VIT_INIT)
+    assert synth.checksum(sd) == pytest.approx(float(g[f"{name}_checksum"]), rel=1e-12)
+    assert any("temporal_mlp.fc1" in k for k in sd)
+    x = cases.pixels(shape, cases.SEED_PIX + 2)
+    for nl in range(cfg["num_hidden_layers"] + 1):
+        h = O.vit_forward(f32(sd), cfg, x, num_layers=nl)
+        assert rel(h, g[f"{name}_hidden_{nl}"]) <= 1e-5, nl
+
+
 @pytest.mark.parametrize("tag", list(cases.REGION_CASES))
 def test_region_extractor(tag):
     g = np.load(os.path.join(G, "region_projector.npz"))

@@ -42,7 +42,8 @@ class VtRegionWeights(C.Structure):
 class VtVitLayer(C.Structure):
     _fields_ = [(n, vp) for n in (
         "t_ln_g", "t_ln_b", "t_embed", "t_wqkv", "t_bqkv", "t_wo", "t_bo",
-        "ln1_g", "ln1_b", "wqkv", "bqkv", "wo", "bo", "ln2_g", "ln2_b", "w1", "b1", "w2", "b2")]
+        "ln1_g", "ln1_b", "wqkv", "bqkv", "wo", "bo", "ln2_g", "ln2_b", "w1", "b1", "w2", "b2",
+        "t_ln2_g", "t_ln2_b", "t_w1", "t_b1", "t_w2", "t_b2")]
 
 
 class VtVitModel(C.Structure):
@@ -61,7 +62,7 @@ class VtLlamaModel(C.Structure):
     _fields_ = [("hidden", C.c_int), ("heads", C.c_int), ("head_dim", C.c_int), ("intermediate", C.c_int),
                 ("num_layers", C.c_int), ("vocab", C.c_int), ("rms_eps", C.c_float), ("final_norm", vp),
                 ("lm_head", vp), ("rope_cos", vp), ("rope_sin", vp), ("rope_len", C.c_int),
-                ("layers", C.POINTER(VtLlamaLayer)), ("prefill_norm_fold", C.c_int), ("qkv_fuse", C.c_int), ("precise_qk", C.c_int)]
+                ("layers", C.POINTER(VtLlamaLayer)), ("prefill_norm_fold", C.c_int), ("qkv_fuse", C.c_int), ("precise_qk", C.c_int), ("hidden_trace", vp)]
 
 
 class VtKvCache(C.Structure):

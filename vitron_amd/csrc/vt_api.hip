@@ -421,6 +421,12 @@ int vt_vit_forward(const vt_vit_model* m, const void* pixels, int pix_dtype, int
       VT_TRY(vt_gemm_launch(w.y, D, L.t_wqkv, D, w.qkv, 3 * D, L.t_bqkv, R, 3 * D, D, VT_EPI_BF16, AUTO, s));
       VT_TRY(vt_attn_temporal_launch(w.qkv, w.att, B, T, N, heads, s));
       VT_TRY(vt_gemm_launch(w.att, D, L.t_wo, D, w.x, D, L.t_bo, R, D, D, VT_EPI_F32_RESID, AUTO, s));
+      if (L.t_w1) {   // image tower's add_time_attn variant: x += temporal_mlp(temporal_layer_norm2(x)) (image/modeling_image.py:129-134)
+        VT_REQUIRE(L.t_ln2_g && L.t_ln2_b && L.t_w2 && L.t_b1 && L.t_b2, "vt_vit_forward: layer %d has a temporal MLP with missing tensors", l);
+        VT_TRY(vt_layernorm_launch(w.x, nullptr, 0, 0, L.t_ln2_g, L.t_ln2_b, w.y, R, D, m->ln_eps, s));
+        VT_TRY(vt_gemm_launch(w.y, D, L.t_w1, D, w.h, I, L.t_b1, R, I, D, act_epi, AUTO, s));
+        VT_TRY(vt_gemm_resid_launch(w.h, I, L.t_w2, I, w.x, D, L.t_b2, R, D, I, 0, w.splitk, w.splitk_bytes, s));
+      }
     }
     // spatial attention
     VT_TRY(vt_layernorm_launch(w.x, nullptr, 0, 0, L.ln1_g, L.ln1_b, w.y, R, D, m->ln_eps, s));
@@ -544,6 +550,8 @@ int vt_llama_forward(const vt_llama_model* m, const vt_kv_cache* kv, const uint1
   if (fuse_qkv) VT_TRY(vt_row_slot_launch((const VtAttnSeq*)seq_desc, nseq, max_q_len, tile_table, w.row_slot, s));
   for (int l = 0; l < m->num_layers; ++l) {
     const vt_llama_layer& L = m->layers[l];
+    if (m->hidden_trace)
+      VT_HIP(hipMemcpyAsync(m->hidden_trace + (size_t)l * rows * H, w.x, (size_t)rows * H * 4, hipMemcpyDeviceToDevice, s));
     bf16_t* kt = kv->k + l * layer_stride;
     bf16_t* vt = kv->vt + l * layer_stride;
     if (fold_norm) {

@@ -155,6 +155,15 @@ class PackedVit:
                 L.t_wqkv, L.t_bqkv = w.data_ptr(), b.data_ptr()
                 L.t_wo = keep(_bf(sd[p + "temporal_attn.out_proj.weight"], dev)).data_ptr()
                 L.t_bo = keep(_f32(sd[p + "temporal_attn.out_proj.bias"], dev)).data_ptr()
+                if p + "temporal_mlp.fc1.weight" in sd:
+                    # the IMAGE tower's add_time_attn variant (reference image/modeling_image.py:83-84,129-134): a temporal MLP behind the
+                    # temporal attention; the video tower's layers (video/modeling_video.py) have none
+                    L.t_ln2_g = keep(_f32(sd[p + "temporal_layer_norm2.weight"], dev)).data_ptr()
+                    L.t_ln2_b = keep(_f32(sd[p + "temporal_layer_norm2.bias"], dev)).data_ptr()
+                    L.t_w1 = keep(_bf(sd[p + "temporal_mlp.fc1.weight"], dev)).data_ptr()
+                    L.t_b1 = keep(_f32(sd[p + "temporal_mlp.fc1.bias"], dev)).data_ptr()
+                    L.t_w2 = keep(_bf(sd[p + "temporal_mlp.fc2.weight"], dev)).data_ptr()
+                    L.t_b2 = keep(_f32(sd[p + "temporal_mlp.fc2.bias"], dev)).data_ptr()
             L.ln1_g = keep(_f32(sd[p + "layer_norm1.weight"], dev)).data_ptr()
             L.ln1_b = keep(_f32(sd[p + "layer_norm1.bias"], dev)).data_ptr()
             w, b = fuse_qkv(p + "self_attn.")
@@ -477,10 +486,12 @@ class SequenceState:
 
 def llama_forward(llama: PackedLlama, kv: PagedKVCache, seqs: Sequence[SequenceState], embeds: torch.Tensor,
                   q_lens: Sequence[int], positions: Optional[torch.Tensor] = None, logit_rows: Optional[Sequence[int]] = None,
-                  return_hidden: bool = False):
+                  return_hidden: bool = False, return_all_hidden: bool = False):
     """One decoder pass over packed rows. embeds (operand dtype) [sum(q_lens), H]: the new tokens of every sequence, sequence by
     sequence. Appends their K/V to the cache, returns fp32 logits for `logit_rows` (default: last row of each
-    sequence). positions default to cache position (length + i). Prefill and decode are the same call."""
+    sequence). positions default to cache position (length + i). Prefill and decode are the same call.
+    return_hidden: also the fp32 residual stream behind the last layer [rows, H]; return_all_hidden: also the stream in front of
+    every layer, fp32 [L, rows, H] (vt_llama_model.hidden_trace) -- returns (logits, hidden, trace)."""
     lib = llama.lib
     dev = llama.device
     rows = int(sum(q_lens))
@@ -515,22 +526,34 @@ def llama_forward(llama: PackedLlama, kv: PagedKVCache, seqs: Sequence[SequenceS
     n_logit = len(logit_rows)
     lr_t = torch.tensor(list(logit_rows), dtype=torch.int32, device=dev) if n_logit else None
     logits = torch.empty((n_logit, llama.V_pad), dtype=torch.float32, device=dev) if n_logit else None
-    hidden = torch.empty((rows, llama.H), dtype=torch.float32, device=dev) if return_hidden else None
+    hidden = torch.empty((rows, llama.H), dtype=torch.float32, device=dev) if (return_hidden or return_all_hidden) else None
+    trace = torch.empty((llama.L, rows, llama.H), dtype=torch.float32, device=dev) if return_all_hidden else None
     max_kv = max(d[2] for d in desc)
     ws = llama.ws.get(lib.vt_llama_workspace_bytes(C.byref(llama.model), rows, n_logit, len(desc), max_kv))
-    _lib.check(lib.vt_llama_forward(C.byref(llama.model), C.byref(kv.struct), embeds.data_ptr(), rows, pos_t.data_ptr(),
-                                    desc_t.data_ptr(), len(desc), int(max(q_lens)), int(max_new_tiles), int(max_kv), table_t.data_ptr(),
-                                    None if lr_t is None else lr_t.data_ptr(), n_logit,
-                                    None if logits is None else logits.data_ptr(),
-                                    None if hidden is None else hidden.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
-               "vt_llama_forward", lib)
+    llama.model.hidden_trace = trace.data_ptr() if trace is not None else None
+    try:
+        _llama_call(lib, llama, kv, embeds, rows, pos_t, desc_t, len(desc), int(max(q_lens)), int(max_new_tiles), int(max_kv), table_t, lr_t,
+                    n_logit, logits, hidden, ws)
+    finally:
+        llama.model.hidden_trace = None
     for s, q in zip(seqs, q_lens):
         s.length += q
     if logits is not None and llama.V_pad != llama.V:
         logits = logits[:, :llama.V]               # rows keep the padded stride; the kernels take (V, row stride)
+    if return_all_hidden:
+        return logits, hidden, trace
     if return_hidden:
         return logits, hidden
     return logits
+
+
+def _llama_call(lib, llama, kv, embeds, rows, pos_t, desc_t, nseq, max_q, max_new_tiles, max_kv, table_t, lr_t, n_logit, logits, hidden, ws):
+    _lib.check(lib.vt_llama_forward(C.byref(llama.model), C.byref(kv.struct), embeds.data_ptr(), rows, pos_t.data_ptr(),
+                                    desc_t.data_ptr(), nseq, max_q, max_new_tiles, max_kv, table_t.data_ptr(),
+                                    None if lr_t is None else lr_t.data_ptr(), n_logit,
+                                    None if logits is None else logits.data_ptr(),
+                                    None if hidden is None else hidden.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+               "vt_llama_forward", lib)
 
 
 class DecodeState:

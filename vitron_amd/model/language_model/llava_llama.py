@@ -326,13 +326,32 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
             # (inputs_embeds of another float dtype are legal here: the gather kernel moves rows in the model's operand dtype)
             flat = ops.embed_splice(flat.to(llama.dtype).contiguous(), None, None, torch.stack([torch.zeros_like(rowsel), rowsel], 1).contiguous())
         rows = flat.shape[0]
-        logits_p, hidden = llama_forward(llama, past.kv, seqs, flat, lens, logit_rows=list(range(rows)), return_hidden=True)
-        if len(idx) != B * S:
-            logits = torch.zeros((B * S, llama.V), dtype=torch.float32, device=flat.device)
-            logits.index_copy_(0, torch.tensor(idx, device=flat.device), logits_p.contiguous())
+        if output_attentions:
+            # (the reference's eager LlamaAttention returns the [B, heads, S, S] probabilities of every layer; the flash kernels never
+            # materialise them -- refuse instead of returning None silently)
+            raise NotImplementedError("output_attentions=True: the attention probabilities are never materialised by the HIP flash-attention kernels")
+        trace = None
+        if output_hidden_states:
+            logits_p, hidden, trace = llama_forward(llama, past.kv, seqs, flat, lens, logit_rows=list(range(rows)), return_all_hidden=True)
         else:
-            logits = logits_p.contiguous()
-        logits = logits.view(B, S, llama.V)
+            logits_p, hidden = llama_forward(llama, past.kv, seqs, flat, lens, logit_rows=list(range(rows)), return_hidden=True)
+        sel = torch.tensor(idx, device=flat.device) if len(idx) != B * S else None
+
+        def unpack(t):       # packed rows [rows, D] -> the caller's padded [B, S, D] (zeros at the padding rows)
+            if sel is None:
+                return t.contiguous().view(B, S, t.shape[-1])
+            full = torch.zeros((B * S, t.shape[-1]), dtype=t.dtype, device=t.device)
+            full.index_copy_(0, sel, t.contiguous())
+            return full.view(B, S, t.shape[-1])
+
+        logits = unpack(logits_p)
+        all_hidden = None
+        if output_hidden_states:
+            # transformers 4.31 LlamaModel.forward: the stream in front of every decoder layer (entry 0 = inputs_embeds), then the
+            # FINAL-NORMED output of the last layer -- num_layers + 1 tensors [B, S, H]; fp32 here (the residual stream is fp32), the
+            # last one in the operand dtype (it is the lm_head's operand)
+            final = ops.rmsnorm(hidden, llama.final_norm, float(llama.model.rms_eps), dtype=llama.dtype)
+            all_hidden = tuple(unpack(trace[l]) for l in range(trace.shape[0])) + (unpack(final),)
         loss = None
         if labels is not None:  # shifted cross entropy, ignore_index -100 (LlamaForCausalLM.forward)
             # one row per (sample, position < S-1): position j scores label j+1; the last position of every sample scores nothing
@@ -342,8 +361,7 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
         if not use_cache and past_key_values is None:
             past.release()
             past = None
-        return CausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=past,
-                                      hidden_states=(hidden.view(-1, H),) if output_hidden_states else None, attentions=None)
+        return CausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=past, hidden_states=all_hidden, attentions=None)
 
     __call__ = forward
 

@@ -85,12 +85,9 @@ class _Tower:
     def load_state(self, config, state_dict, device=None):
         """Attach weights in the reference's CLIPVisionTransformer naming (peft LoRA adapters are merged)."""
         self.cfg_only = config if isinstance(config, VisionConfig) else VisionConfig.from_dict(dict(config))
-        if any(".temporal_mlp." in k for k in state_dict):
-            # the IMAGE tower's add_time_attn branch (reference image/modeling_image.py:74-84,105-134: temporal attention AND a
-            # temporal MLP per layer) -- LanguageBind_Image ships add_time_attn = false and Vitron never enables it; the video
-            # tower's branch (video/modeling_video.py, temporal attention only) is the one built here
-            raise NotImplementedError("LanguageBind image tower with add_time_attn (temporal_mlp weights) is not supported: "
-                                      "Vitron's image tower runs without it; use the video tower for clips")
+        # (an IMAGE tower checkpoint with add_time_attn carries temporal_mlp.* / temporal_layer_norm2.* per layer -- reference
+        # image/modeling_image.py:74-84,105-134; PackedVit packs them and vt_vit_forward runs the extra block. LanguageBind_Image ships
+        # add_time_attn = false, so this is the uncommon branch.)
         self._sd = state_dict
         self.is_loaded = True
         if device is not None:
