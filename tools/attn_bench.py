@@ -89,6 +89,18 @@ if __name__ == "__main__" and os.environ.get("ATTN_BENCH_KERNELS"):
             run(5120, 32, 128, 8, True)
     ops.flash_attn_select(0)
     sys.exit(0)
+if __name__ == "__main__" and os.environ.get("ATTN_BENCH_SHAPES"):
+    # A/B of the head_dim-128 prefill kernels on chosen sequence lengths: ATTN_BENCH_SHAPES=768,1088,2560 ATTN_BENCH_SEL=1,2,5 (round 5:
+    # the reference-native 224 px shapes S = 768 / 2560 against the automatic choice's threshold)
+    _lib.load()
+    for rep in range(2):
+        for k in [int(x) for x in os.environ.get("ATTN_BENCH_SEL", "1,2,5").split(",")]:
+            ops.flash_attn_select(k)
+            print(f"# kernel {k} (pass {rep})", flush=True)
+            for S_ in [int(x) for x in os.environ["ATTN_BENCH_SHAPES"].split(",")]:
+                run(S_, 32, 128, 1, True)
+    ops.flash_attn_select(0)
+    sys.exit(0)
 if __name__ == "__main__" and os.environ.get("ATTN_BENCH_ONLY_C3"):
     _lib.load(ablations=True)
     run(5120, 32, 128, 1, True)

@@ -8,10 +8,13 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-LEAN="--no-cpu-baseline --decode-steps 0 --c4-steps 0 --c2-reps 0 --no-empirical-peaks --fp16-ab-steps 0"
+LEAN="--no-cpu-baseline --decode-steps 0 --c4-steps 0 --c2-reps 0 --reps-224 0 --no-empirical-peaks --fp16-ab-steps 0"
 timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $O/bench_stats -- python $R/bench.py --steps 5 --warmup 2 $LEAN > $O/bench_under_rocprof.json 2> $O/bench_stats.err
 # the C5 decode flow (4 x (image + box) prefill + 256 greedy steps at batch 4) and C2 under the same tool
 timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $O/decode_stats -- python $R/tools/decode_bench.py 256 > $O/decode_under_rocprof.json 2> $O/decode_stats.err
+# the reference-native 224 px shapes (round 5): C3-224 (S = 2560) and C2-224 (S = 768) alone, 3 warm-up + 10 timed steps each
+timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $O/c3_224_stats -- python $R/tools/prefill_bench.py clip 224 10 > $O/c3_224_under_rocprof.json 2> $O/c3_224_stats.err
+timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $O/c2_224_stats -- python $R/tools/prefill_bench.py image 224 10 > $O/c2_224_under_rocprof.json 2> $O/c2_224_stats.err
 # flash attention (S = 5120 causal, 32 heads x 128): SQ counters, two passes of 8
 A="python $R/tools/one_attn.py"
 timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_COEXEC_CYCLES -f csv -d $O/pmc_attn_a -- $A > /dev/null 2> $O/pmc_attn_a.err
