@@ -226,6 +226,12 @@ int vt_sample_top_p(const float* logits, int rows, int V, int ldl, float tempera
  * reference vitron/model/multimodal_projector/builder.py:33-51, called at llava_arch.py:175,186
  * ---------------------------------------------------------------------------------------------------------- */
 size_t vt_projector_workspace_bytes(int M, int Dh);
+/* precise level 2 (mlp2x_gelu only): features in and embeddings out as operand pairs (x + x_lo, out + out_lo: hi = op(v), lo = op(v - hi)),
+ * both Linear layers as A_hi.W^T + A_lo.W^T in fp32, GELU on the fp32 value. reference multimodal_projector/builder.py:40-46 */
+size_t vt_projector_precise_workspace_bytes(int M, int Dh, int Dout);
+int vt_projector_forward_precise(const uint16_t* x, const uint16_t* x_lo, int M, int Din, const uint16_t* w1, const float* b1, int Dh,
+                                 const uint16_t* w2, const float* b2, int Dout, uint16_t* out, uint16_t* out_lo, void* workspace,
+                                 size_t workspace_bytes, void* stream);
 int vt_projector_forward(const uint16_t* x, int M, int Din, const uint16_t* w1, const float* b1, int Dh,
                          const uint16_t* w2, const float* b2, int Dout, uint16_t* out, void* workspace,
                          size_t workspace_bytes, void* stream);
@@ -309,6 +315,10 @@ typedef struct vt_vit_model {
   const float* pos;        /* [G*G+1][D] */
   const float *pre_ln_g, *pre_ln_b;
   const vt_vit_layer* layers; /* host array [num_layers] */
+  int precise;             /* 2: precise level 2 -- the MLP's two GEMM operands (layer_norm2 output, activation output) travel as operand
+                              pairs (hi + lo), every product as two launches accumulating in fp32; with out_feats_lo the selected patch
+                              tokens leave as a pair too. 0 (default): standard. */
+  uint16_t* out_feats_lo;  /* optional DEVICE buffer [B*T*G*G][D]: the low half of out_feats (precise == 2 only) */
 } vt_vit_model;
 
 size_t vt_vit_workspace_bytes(const vt_vit_model* m, int B, int T);
@@ -347,13 +357,20 @@ typedef struct vt_llama_model {
   int qkv_fuse;                 /* 1: prefills write rotated q / K pages / V^T pages from the QKV projection's epilogue instead of the
                                    separate vt_kv_tiles pass. Bit-identical results; measured 20 us per launch SLOWER at S = 5120 (the
                                    epilogue of a one-workgroup-per-CU kernel overlaps with nothing: 455 vs 386 + 48.5 us): default 0. */
-  int precise_qk;               /* 1 (head_dim 128): PREFILLS carry everything that reaches the softmax's argument as operand PAIRS
+  int precise_qk;               /* 2: precise level 2 -- level 1 below plus EVERY other GEMM A operand of a prefill as a pair (v projection,
+                                   attention output -> o_proj, post-attention norm -> gate/up with the SwiGLU as its own fp32 -> pair pass,
+                                   SwiGLU output -> down_proj, final norm -> lm_head when more than 64 rows are asked for): each product runs
+                                   as two launches accumulating in fp32. A verification mode: ~2x the GEMM work.
+                                   1 (head_dim 128): PREFILLS carry everything that reaches the softmax's argument as operand PAIRS
                                    (hi + lo, 2 x 16 bit): the input-norm output feeds the q / k projection as A_hi.W^T + A_lo.W^T into fp32,
                                    the rotary embedding runs in fp32, and the attention scores are K_hi.(Q_hi + Q_lo)^T + K_lo.Q_hi^T -- so the
                                    scores see ~2^-20 of operand rounding instead of 2^-12 (fp16) / 2^-9 (bf16). Removes the five storage points
                                    the softmax amplifies: fp16 full-depth logits 1.3e-3 -> below 1e-3 of the reference's fp32.
                                    Costs two extra GEMM launches, +2 MFMAs per score k-step and the workspace for the pairs; the K pages hold
                                    K_hi (decode steps and later passes are unchanged). Default 0. */
+  const uint16_t* embeds_lo;    /* optional DEVICE buffer [rows][H] in the operand format: the LOW half of the input embeddings when the caller
+                                   carries them as a pair (precise level 2: the projector's output is not rounded to 16 bits on its way into the
+                                   residual stream); added to x_embeds in fp32. NULL (default): x_embeds alone. */
   float* hidden_trace;          /* optional DEVICE buffer fp32 [num_layers][rows][H]: when non-NULL every layer's INPUT residual stream is
                                    copied there (entry 0 = the input embeddings) -- what `output_hidden_states=True` of the reference's
                                    LlamaModel collects before each decoder layer (llava_llama.py:69, transformers 4.31 LlamaModel.forward).

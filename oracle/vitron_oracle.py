@@ -374,7 +374,9 @@ def llama_forward(sd: SD, cfg: dict, inputs_embeds: torch.Tensor, position_ids: 
                   precise_qk: bool = False):
     """LlamaModel + lm_head. inputs_embeds [B,S,H]; attention_mask [B, past+S] (1 = attend) or None;
     past = list of (k,v) per layer, each [B,heads,Sp,hd]. Returns (logits [B,S,V] fp32, new_past[, hidden]).
-    precise_qk (with an emulation mode): the storage points of the kernels' precise_qk prefill -- the input-norm output reaches the
+    precise_qk = 2 (with an emulation mode): precise level 2 -- every GEMM A operand is an operand pair (norm outputs, attention output,
+    SwiGLU output, final norm; v is computed from the pair and stored once).
+    precise_qk = 1 / True (with an emulation mode): the storage points of the kernels' precise_qk prefill -- the input-norm output reaches the
     q / k projection as an operand pair, q / k stay fp32 through the rotary embedding and are stored once, as pairs; v, P, V^T and
     everything behind the attention are stored as usual. (The K_lo.Q_lo term the kernel drops is 2^-22 of a score: not modelled.)"""
     B, S, H = inputs_embeds.shape
@@ -401,12 +403,13 @@ def llama_forward(sd: SD, cfg: dict, inputs_embeds: torch.Tensor, position_ids: 
     new_past = []
     for l in range(L):
         p = f"model.layers.{l}."
+        full = bool(emulate_bf16) and int(precise_qk) >= 2          # level 2: every GEMM A operand is a pair
         if precise_qk and emulate_bf16:
             hn = rmsnorm(x, sd[p + "input_layernorm.weight"], eps)
             h, hp = _r(hn, emulate_bf16), _pair(hn, emulate_bf16)
             q = _lin(hp, sd[p + "self_attn.q_proj.weight"]).view(B, S, heads, hd).transpose(1, 2)
             k = _lin(hp, sd[p + "self_attn.k_proj.weight"]).view(B, S, heads, hd).transpose(1, 2)
-            v = _r(_lin(h, sd[p + "self_attn.v_proj.weight"]), emulate_bf16).view(B, S, heads, hd).transpose(1, 2)
+            v = _r(_lin(hp if full else h, sd[p + "self_attn.v_proj.weight"]), emulate_bf16).view(B, S, heads, hd).transpose(1, 2)
             q = _pair(_rope(q, cos, sin), emulate_bf16)
             k = _pair(_rope(k, cos, sin), emulate_bf16)
         else:
@@ -429,15 +432,17 @@ def llama_forward(sd: SD, cfg: dict, inputs_embeds: torch.Tensor, position_ids: 
             o = (fp16_round(pr) @ fp16_store(v)) / pr.sum(-1, keepdim=True)
         else:
             o = torch.softmax(s, dim=-1, dtype=torch.float32) @ v
-        o = _r(o.transpose(1, 2).reshape(B, S, H), emulate_bf16)
+        st = (lambda t: _pair(t, emulate_bf16)) if full else (lambda t: _r(t, emulate_bf16))
+        o = st(o.transpose(1, 2).reshape(B, S, H))
         x = x + _lin(o, sd[p + "self_attn.o_proj.weight"])
-        h = _r(rmsnorm(x, sd[p + "post_attention_layernorm.weight"], eps), emulate_bf16)
+        h = st(rmsnorm(x, sd[p + "post_attention_layernorm.weight"], eps))
         g = _lin(h, sd[p + "mlp.gate_proj.weight"])
         u = _lin(h, sd[p + "mlp.up_proj.weight"])
-        a = _r(F.silu(g) * u, emulate_bf16)
+        a = st(F.silu(g) * u)
         x = x + _lin(a, sd[p + "mlp.down_proj.weight"])
     hidden = x
-    xn = _r(rmsnorm(x, sd["model.norm.weight"], eps), emulate_bf16)
+    full = bool(emulate_bf16) and int(precise_qk) >= 2
+    xn = _pair(rmsnorm(x, sd["model.norm.weight"], eps), emulate_bf16) if full else _r(rmsnorm(x, sd["model.norm.weight"], eps), emulate_bf16)
     logits = _lin(xn, sd["lm_head.weight"]).float()
     if return_hidden:
         return logits, new_past, hidden

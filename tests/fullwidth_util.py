@@ -90,7 +90,7 @@ def oracle_llama(name, emulate, precise_qk=False):
     session: the prefill and the decode parity tests compare against the same passes (each ~1 min of host time at the 7B width)."""
     from oracle import vitron_oracle as O
     emulate = emulate if isinstance(emulate, str) else bool(emulate)
-    key = (name, emulate, bool(precise_qk))
+    key = (name, emulate, int(precise_qk))
     if key not in _ORACLE_CACHE:
         cfg, sd, x = llama_case(name)
         with torch.no_grad():

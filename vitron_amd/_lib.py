@@ -51,7 +51,7 @@ class VtVitModel(C.Structure):
                 ("intermediate", C.c_int), ("num_layers", C.c_int), ("num_frames", C.c_int),
                 ("add_time_attn", C.c_int), ("act", C.c_int), ("ln_eps", C.c_float), ("k_pad", C.c_int),
                 ("w_patch", vp), ("cls", vp), ("pos", vp), ("pre_ln_g", vp), ("pre_ln_b", vp),
-                ("layers", C.POINTER(VtVitLayer))]
+                ("layers", C.POINTER(VtVitLayer)), ("precise", C.c_int), ("out_feats_lo", vp)]
 
 
 class VtLlamaLayer(C.Structure):
@@ -62,7 +62,7 @@ class VtLlamaModel(C.Structure):
     _fields_ = [("hidden", C.c_int), ("heads", C.c_int), ("head_dim", C.c_int), ("intermediate", C.c_int),
                 ("num_layers", C.c_int), ("vocab", C.c_int), ("rms_eps", C.c_float), ("final_norm", vp),
                 ("lm_head", vp), ("rope_cos", vp), ("rope_sin", vp), ("rope_len", C.c_int),
-                ("layers", C.POINTER(VtLlamaLayer)), ("prefill_norm_fold", C.c_int), ("qkv_fuse", C.c_int), ("precise_qk", C.c_int), ("hidden_trace", vp)]
+                ("layers", C.POINTER(VtLlamaLayer)), ("prefill_norm_fold", C.c_int), ("qkv_fuse", C.c_int), ("precise_qk", C.c_int), ("embeds_lo", vp), ("hidden_trace", vp)]
 
 
 class VtKvCache(C.Structure):
@@ -97,6 +97,8 @@ SIGNATURES = {
     "vt_sample_top_p": (_i, [vp, _i, _i, _i, _f, _i, _f, C.c_uint64, C.c_uint64, vp, vp, vp]),
     "vt_projector_workspace_bytes": (_sz, [_i, _i]),
     "vt_projector_forward": (_i, [vp, _i, _i, vp, vp, _i, vp, vp, _i, vp, vp, _sz, vp]),
+    "vt_projector_precise_workspace_bytes": (_sz, [_i, _i, _i]),
+    "vt_projector_forward_precise": (_i, [vp, vp, _i, _i, vp, vp, _i, vp, vp, _i, vp, vp, vp, _sz, vp]),
     "vt_region_workspace_bytes": (_sz, [_i, _i, _i]),
     "vt_region_forward": (_i, [C.POINTER(VtRegionWeights), vp, vp, vp, _i, _i, _i, vp, vp, vp, vp, _sz, vp]),
     "vt_vit_workspace_bytes": (_sz, [C.POINTER(VtVitModel), _i, _i]),

@@ -309,6 +309,37 @@ int vt_projector_forward(const uint16_t* x, int M, int Din, const uint16_t* w1, 
   return VT_OK;
 }
 
+// precise level 2: the mlp2x_gelu projector on operand pairs -- x (+ x_lo) in, out (+ out_lo) out; both Linear layers as two launches
+// accumulating in fp32, the GELU as an fp32 -> pair pass; the output leaves as a pair so that the decoder's residual stream starts from the
+// fp32 value (vt_llama_model.embeds_lo)
+size_t vt_projector_precise_workspace_bytes(int M, int Dh, int Dout) {
+  return align_up((size_t)M * Dh * 4, 256) + 2 * align_up((size_t)M * Dh * 2, 256) + align_up((size_t)M * Dout * 4, 256) + 256;
+}
+
+int vt_projector_forward_precise(const uint16_t* x, const uint16_t* x_lo, int M, int Din, const uint16_t* w1, const float* b1, int Dh,
+                                 const uint16_t* w2, const float* b2, int Dout, uint16_t* out, uint16_t* out_lo, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  VT_REQUIRE(x && x_lo && w1 && w2 && out && out_lo && M > 0, "vt_projector_forward_precise: null pointer / empty input (mlp2x_gelu only)");
+  hipStream_t s = S(stream);
+  Carver ws(workspace, workspace_bytes);
+  float* h32 = (float*)ws.take((size_t)M * Dh * 4);
+  bf16_t* h = (bf16_t*)ws.take((size_t)M * Dh * 2);
+  bf16_t* hlo = (bf16_t*)ws.take((size_t)M * Dh * 2);
+  float* o32 = (float*)ws.take((size_t)M * Dout * 4);
+  if (!workspace || !ws.ok()) {
+    vt_set_error("vt_projector_forward_precise: workspace too small (%zu < %zu)", workspace_bytes, ws.off);
+    return VT_ERR_WORKSPACE;
+  }
+  const int AUTO = VT_GEMM_CFG_AUTO;
+  VT_TRY(vt_gemm_launch(x, Din, w1, Din, h32, Dh, b1, M, Dh, Din, VT_EPI_F32, AUTO, s));
+  VT_TRY(vt_gemm_resid_launch(x_lo, Din, w1, Din, h32, Dh, nullptr, M, Dh, Din, 0, nullptr, 0, s));
+  VT_TRY(vt_act_pair_launch(h32, Dh, h, hlo, M, Dh, 0, s));
+  VT_TRY(vt_gemm_launch(h, Dh, w2, Dh, o32, Dout, b2, M, Dout, Dh, VT_EPI_F32, AUTO, s));
+  VT_TRY(vt_gemm_resid_launch(hlo, Dh, w2, Dh, o32, Dout, nullptr, M, Dout, Dh, 0, nullptr, 0, s));
+  VT_TRY(vt_f32_to_pair_launch(o32, out, out_lo, (size_t)M, 0, Dout, s));
+  return VT_OK;
+}
+
 // ---- region_extractor ------------------------------------------------------------------------------------------------
 size_t vt_region_workspace_bytes(int B, int in_dim, int out_dim) {
   size_t n = 0;
@@ -356,6 +387,9 @@ struct VitWs {
   int *seq_desc, *tile_table;
   float* splitk;   // split-K partial products (single images: the N = 1024 projections cover a fraction of the chip)
   size_t splitk_bytes;
+  // precise level 2: the MLP's two operands as pairs (low halves) and fc1's fp32 output
+  bf16_t *ylo, *hlo;
+  float* h32;
   size_t total;
 };
 VitWs vit_carve(const vt_vit_model* m, int B, int T, void* p, size_t n) {
@@ -377,6 +411,13 @@ VitWs vit_carve(const vt_vit_model* m, int B, int T, void* p, size_t n) {
   w.tile_table = (int*)ws.take((size_t)F * ntiles * 4);
   w.splitk_bytes = (size_t)8 * R * D * 4 <= ((size_t)64 << 20) ? (size_t)8 * R * D * 4 : 0;   // only worth it for a few frames
   w.splitk = w.splitk_bytes ? (float*)ws.take(w.splitk_bytes) : nullptr;
+  w.ylo = w.hlo = nullptr;
+  w.h32 = nullptr;
+  if (m->precise >= 2) {
+    w.ylo = (bf16_t*)ws.take((size_t)R * D * 2);
+    w.hlo = (bf16_t*)ws.take((size_t)R * I * 2);
+    w.h32 = (float*)ws.take((size_t)R * I * 4);
+  }
   w.total = ws.off + 256;
   return w;
 }
@@ -437,9 +478,25 @@ int vt_vit_forward(const vt_vit_model* m, const void* pixels, int pix_dtype, int
                                 heads, 64, 0, 1.0f, s));
     VT_TRY(vt_gemm_launch(w.att, D, L.wo, D, w.x, D, L.bo, R, D, D, VT_EPI_F32_RESID, AUTO, s));
     // MLP
+    if (m->precise >= 2) {
+      // precise level 2 (layer_norm2 -> fc1 and GELU -> fc2 carry half of the tower's distance from fp32): both operands as
+      // pairs, every product as two launches accumulating in fp32, the activation as its own fp32 -> pair pass
+      VT_TRY(vt_layernorm_hilo_launch(w.x, L.ln2_g, L.ln2_b, w.y, w.ylo, R, D, m->ln_eps, s));
+      VT_TRY(vt_gemm_launch(w.y, D, L.w1, D, w.h32, I, L.b1, R, I, D, VT_EPI_F32, AUTO, s));
+      VT_TRY(vt_gemm_resid_launch(w.ylo, D, L.w1, D, w.h32, I, nullptr, R, I, D, 0, w.splitk, w.splitk_bytes, s));
+      VT_TRY(vt_act_pair_launch(w.h32, I, w.h, w.hlo, R, I, m->act == VT_ACT_QUICK_GELU ? 1 : 0, s));
+      VT_TRY(vt_gemm_resid_launch(w.h, I, L.w2, I, w.x, D, L.b2, R, D, I, 0, w.splitk, w.splitk_bytes, s));
+      VT_TRY(vt_gemm_resid_launch(w.hlo, I, L.w2, I, w.x, D, nullptr, R, D, I, 0, w.splitk, w.splitk_bytes, s));
+      continue;
+    }
     VT_TRY(vt_layernorm_launch(w.x, nullptr, 0, 0, L.ln2_g, L.ln2_b, w.y, R, D, m->ln_eps, s));
     VT_TRY(vt_gemm_launch(w.y, D, L.w1, D, w.h, I, L.b1, R, I, D, act_epi, AUTO, s));
     VT_TRY(vt_gemm_resid_launch(w.h, I, L.w2, I, w.x, D, L.b2, R, D, I, 0, w.splitk, w.splitk_bytes, s));
+  }
+  if (m->precise >= 2 && m->out_feats_lo) {   // the patch tokens of the selected hidden state as a pair (the projector's operand)
+    VT_TRY(vt_f32_to_pair_launch(w.x, out_feats, m->out_feats_lo, (size_t)F * G2, G2, D, s));
+    if (out_hidden) VT_HIP(hipMemcpyAsync(out_hidden, w.x, (size_t)R * D * 4, hipMemcpyDeviceToDevice, s));
+    return VT_OK;
   }
   VT_TRY(vt_drop_cls_launch(w.x, out_feats, F, G2, D, s));
   if (out_hidden) VT_HIP(hipMemcpyAsync(out_hidden, w.x, (size_t)R * D * 4, hipMemcpyDeviceToDevice, s));
@@ -460,8 +517,11 @@ struct LlamaWs {
   int* row_slot;        // prefill: cache slot of every new row (fused QKV epilogue)
   // precise_qk prefills: the low half of the norm output, the fp32 q | k projection, the low halves of rotated q and of the new keys
   bf16_t *ylo, *qlo, *klo;
-  float* qk32;
+  float* qk32;          // level 1: [rows][2H] (q | k); level 2: [rows][3H] (q | k | v)
   int klo_tiles;        // K_lo tiles per sequence
+  // precise level 2 (every GEMM A operand a pair): low halves of the attention output, the SwiGLU output and the final norm; fp32 gate/up
+  bf16_t *attlo, *hlo, *ynlo;
+  float* gu32;
   size_t total;
 };
 LlamaWs llama_carve(const vt_llama_model* m, int rows, int n_logit, int nseq, int max_kv_len, void* p, size_t n) {
@@ -486,13 +546,22 @@ LlamaWs llama_carve(const vt_llama_model* m, int rows, int n_logit, int nseq, in
   w.ylo = w.qlo = w.klo = nullptr;
   w.qk32 = nullptr;
   w.klo_tiles = 0;
-  if (m->precise_qk == 1 && m->head_dim == 128 && rows > 1) {   // (sized whenever the mode is on: the query does not know max_q_len)
+  w.attlo = w.hlo = w.ynlo = nullptr;
+  w.gu32 = nullptr;
+  if (m->precise_qk >= 1 && m->head_dim == 128 && rows > 1) {   // (sized whenever the mode is on: the query does not know max_q_len)
+    const bool full = m->precise_qk >= 2;
     w.ylo = (bf16_t*)ws.take((size_t)rows * H * 2);
     w.qlo = (bf16_t*)ws.take((size_t)rows * H * 2);
-    w.qk32 = (float*)ws.take((size_t)rows * 2 * H * 4);
+    w.qk32 = (float*)ws.take((size_t)rows * (full ? 3 : 2) * H * 4);
     // a sequence of q rows touches at most rows / 64 + 2 tiles; every sequence gets the same number of slots
     w.klo_tiles = rows / 64 + 2;
     w.klo = (bf16_t*)ws.take((size_t)(nseq > 0 ? nseq : 1) * w.klo_tiles * H * 64 * 2);
+    if (full) {
+      w.attlo = (bf16_t*)ws.take((size_t)rows * H * 2);
+      w.hlo = (bf16_t*)ws.take((size_t)rows * I * 2);
+      w.ynlo = (bf16_t*)ws.take((size_t)(n_logit > 0 ? n_logit : 1) * H * 2);
+      w.gu32 = (float*)ws.take((size_t)rows * 2 * I * 4);
+    }
   }
   w.total = ws.off + 256;
   return w;
@@ -527,6 +596,7 @@ int vt_llama_forward(const vt_llama_model* m, const vt_kv_cache* kv, const uint1
   const size_t layer_stride = (size_t)kv->num_pages * heads * 64 * HD;
 
   VT_TRY(vt_bf16_to_f32_launch(x_embeds, w.x, (size_t)rows * H, s));
+  if (m->embeds_lo) VT_TRY(vt_add_op_to_f32_launch(w.x, m->embeds_lo, (size_t)rows * H, s));   // the input embeddings as a pair (precise level 2)
   // Decode steps (<= 16 rows, one new token per sequence): every GEMM is the weight-streaming kernel and RMSNorm is folded
   // into them -- the residual GEMMs (o_proj, down_proj) emit bf16(x .* w_next) plus per-block sums of x^2, the GEMMs that
   // follow (gate_up, next layer's qkv) scale their rows by rstd. Only the first norm of layer 0 and the final norm stay
@@ -546,7 +616,8 @@ int vt_llama_forward(const vt_llama_model* m, const vt_kv_cache* kv, const uint1
   // writes rotated q / K pages / V^T pages itself (no vt_kv_tiles pass). Bit-identical, measured slower: default off
   const bool fuse_qkv = max_q_len > 1 && !fold_tile && m->qkv_fuse == 1 && vt_gemm_qkv_fused_supported(rows, H, HD);
   // opt-in (vt_llama_model.precise_qk): prefills carry q and k as operand pairs through the QKV projection and the attention scores
-  const bool precise = max_q_len > 1 && !fold_norm && m->precise_qk == 1 && HD == 128 && w.qk32 != nullptr && max_new_tiles <= w.klo_tiles;
+  const bool precise = max_q_len > 1 && !fold_norm && m->precise_qk >= 1 && HD == 128 && w.qk32 != nullptr && max_new_tiles <= w.klo_tiles;
+  const bool precise2 = precise && m->precise_qk >= 2 && w.gu32 != nullptr;
   if (fuse_qkv) VT_TRY(vt_row_slot_launch((const VtAttnSeq*)seq_desc, nseq, max_q_len, tile_table, w.row_slot, s));
   for (int l = 0; l < m->num_layers; ++l) {
     const vt_llama_layer& L = m->layers[l];
@@ -588,17 +659,37 @@ int vt_llama_forward(const vt_llama_model* m, const vt_kv_cache* kv, const uint1
     // (opt-in, see above).
     VtGemmNormFuse cons_t;
     cons_t.row_scale = w.rstd;
+    if (precise2) {
+      // precise level 2: EVERY GEMM A operand is a pair (hi + lo), each product as two launches accumulating in fp32: the q | k | v
+      // projection into fp32, o_proj / down_proj as two residual launches, gate/up into fp32 with the SwiGLU (pair out) as its own pass
+      VT_TRY(vt_rmsnorm_hilo_launch(w.x, nullptr, L.rms1, w.y, w.ylo, rows, H, m->rms_eps, s));
+      VT_TRY(vt_gemm_launch(w.y, H, L.wqkv, H, w.qk32, 3 * H, nullptr, rows, 3 * H, H, VT_EPI_F32, AUTO, s));
+      VT_TRY(vt_gemm_resid_launch(w.ylo, H, L.wqkv, H, w.qk32, 3 * H, nullptr, rows, 3 * H, H, 0, w.splitk, w.splitk_bytes, s));
+      VT_TRY(vt_kv_tiles_precise_launch(w.qk32, 3 * H, 1, w.qkv, 3 * H, 0, 2 * H, w.qlo, kt, vt, w.klo, tile_table, (const VtAttnSeq*)seq_desc, nseq,
+                                        max_new_tiles, heads, HD, m->rope_cos, m->rope_sin, positions, s));
+      VT_TRY(vt_flash_attn_precise_launch(w.qkv, 3 * H, w.qlo, H, kt, w.klo, max_new_tiles, vt, tile_table, (const VtAttnSeq*)seq_desc, nseq,
+                                          max_q_len, w.att, H, w.attlo, heads, HD, 1, scale, s));
+      VT_TRY(vt_gemm_resid_launch(w.att, H, L.wo, H, w.x, H, nullptr, rows, H, H, 0, w.splitk, w.splitk_bytes, s));
+      VT_TRY(vt_gemm_resid_launch(w.attlo, H, L.wo, H, w.x, H, nullptr, rows, H, H, 0, w.splitk, w.splitk_bytes, s));
+      VT_TRY(vt_rmsnorm_hilo_launch(w.x, nullptr, L.rms2, w.y, w.ylo, rows, H, m->rms_eps, s));
+      VT_TRY(vt_gemm_launch(w.y, H, L.wgu, H, w.gu32, 2 * I, nullptr, rows, 2 * I, H, VT_EPI_F32, AUTO, s));
+      VT_TRY(vt_gemm_resid_launch(w.ylo, H, L.wgu, H, w.gu32, 2 * I, nullptr, rows, 2 * I, H, 0, w.splitk, w.splitk_bytes, s));
+      VT_TRY(vt_act_pair_launch(w.gu32, 2 * I, w.h, w.hlo, rows, I, 2, s));
+      VT_TRY(vt_gemm_resid_launch(w.h, I, L.wdown, I, w.x, H, nullptr, rows, H, I, 0, w.splitk, w.splitk_bytes, s));
+      VT_TRY(vt_gemm_resid_launch(w.hlo, I, L.wdown, I, w.x, H, nullptr, rows, H, I, 0, w.splitk, w.splitk_bytes, s));
+      continue;
+    }
     if (precise) {
       // precise_qk: the q / k projection as A_hi.W^T + A_lo.W^T into fp32 (two tile GEMMs, the second accumulating), v as usual;
       // rotary in fp32, q / k rounded once into operand pairs; attention on K_hi.(Q_hi + Q_lo)^T + K_lo.Q_hi^T
-      VT_TRY(vt_rmsnorm_hilo_launch(w.x, L.rms1, w.y, w.ylo, rows, H, m->rms_eps, s));
+      VT_TRY(vt_rmsnorm_hilo_launch(w.x, nullptr, L.rms1, w.y, w.ylo, rows, H, m->rms_eps, s));
       VT_TRY(vt_gemm_launch(w.y, H, L.wqkv, H, w.qk32, 2 * H, nullptr, rows, 2 * H, H, VT_EPI_F32, AUTO, s));
       VT_TRY(vt_gemm_resid_launch(w.ylo, H, L.wqkv, H, w.qk32, 2 * H, nullptr, rows, 2 * H, H, 0, w.splitk, w.splitk_bytes, s));
       VT_TRY(vt_gemm_launch(w.y, H, L.wqkv + (size_t)2 * H * H, H, w.qkv + 2 * H, 3 * H, nullptr, rows, H, H, VT_EPI_BF16, AUTO, s));
-      VT_TRY(vt_kv_tiles_precise_launch(w.qk32, w.qkv, 3 * H, 0, 2 * H, w.qlo, kt, vt, w.klo, tile_table, (const VtAttnSeq*)seq_desc, nseq,
+      VT_TRY(vt_kv_tiles_precise_launch(w.qk32, 2 * H, 0, w.qkv, 3 * H, 0, 2 * H, w.qlo, kt, vt, w.klo, tile_table, (const VtAttnSeq*)seq_desc, nseq,
                                         max_new_tiles, heads, HD, m->rope_cos, m->rope_sin, positions, s));
       VT_TRY(vt_flash_attn_precise_launch(w.qkv, 3 * H, w.qlo, H, kt, w.klo, max_new_tiles, vt, tile_table, (const VtAttnSeq*)seq_desc, nseq,
-                                          max_q_len, w.att, H, heads, HD, 1, scale, s));
+                                          max_q_len, w.att, H, nullptr, heads, HD, 1, scale, s));
       VT_TRY(vt_gemm_resid_launch(w.att, H, L.wo, H, w.x, H, nullptr, rows, H, H, 0, w.splitk, w.splitk_bytes, s));
       VT_TRY(vt_rmsnorm_launch(w.x, nullptr, L.rms2, w.y, rows, H, m->rms_eps, s));
       VT_TRY(vt_gemm_launch(w.y, H, L.wgu, H, w.h, I, nullptr, rows, 2 * I, H, VT_EPI_SWIGLU_BF16, AUTO, s));
@@ -658,7 +749,11 @@ int vt_llama_forward(const vt_llama_model* m, const vt_kv_cache* kv, const uint1
     VT_TRY(vt_gemm_resid_launch(w.h, I, L.wdown, I, w.x, H, nullptr, rows, H, I, 0, w.splitk, w.splitk_bytes, s));
   }
   if (out_hidden) VT_HIP(hipMemcpyAsync(out_hidden, w.x, (size_t)rows * H * 4, hipMemcpyDeviceToDevice, s));
-  if (n_logit_rows > 0) {
+  if (n_logit_rows > 0 && precise2 && n_logit_rows > 64) {   // level 2: the lm_head's operand as a pair too (tile GEMMs: more than 64 rows)
+    VT_TRY(vt_rmsnorm_hilo_launch(w.x, logit_rows, m->final_norm, w.yn, w.ynlo, n_logit_rows, H, m->rms_eps, s));
+    VT_TRY(vt_gemm_launch(w.yn, H, m->lm_head, H, logits, m->vocab, nullptr, n_logit_rows, m->vocab, H, VT_EPI_F32, AUTO, s));
+    VT_TRY(vt_gemm_resid_launch(w.ynlo, H, m->lm_head, H, logits, m->vocab, nullptr, n_logit_rows, m->vocab, H, 0, w.splitk, w.splitk_bytes, s));
+  } else if (n_logit_rows > 0) {
     VT_TRY(vt_rmsnorm_launch(w.x, logit_rows, m->final_norm, w.yn, n_logit_rows, H, m->rms_eps, s));
     VT_TRY(vt_gemm_launch(w.yn, H, m->lm_head, H, logits, m->vocab, nullptr, n_logit_rows, m->vocab, H, VT_EPI_F32, AUTO, s));
   }

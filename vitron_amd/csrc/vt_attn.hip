@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256, 1) void flash_attn_precise_kernel(const bf16_t
                                                                     const bf16_t* __restrict__ Klo, int klo_tiles_per_seq,
                                                                     const bf16_t* __restrict__ Vt, const int* __restrict__ tile_table,
                                                                     const VtAttnSeq* __restrict__ seqs, bf16_t* __restrict__ O, int ldo,
-                                                                    int heads, float scale_log2e) {
+                                                                    bf16_t* __restrict__ Olo, int heads, float scale_log2e) {
   constexpr int HD = 128, NWAVES = 4;
   constexpr int KS = HD / 16, DB = HD / 32, KROW = HD * 2, TILE_BYTES = 64 * HD * 2, STAGE_BYTES = 3 * TILE_BYTES;
   constexpr int PIECES = TILE_BYTES / 1024, PPW = PIECES / NWAVES, QBLK = 32 * NWAVES;
@@ -532,10 +532,17 @@ __global__ __launch_bounds__(256, 1) void flash_attn_precise_kernel(const bf16_t
     for (int db = 0; db < DB; ++db)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
+        const float a0 = oacc[db][4 * g + 0] * inv, a1 = oacc[db][4 * g + 1] * inv, a2 = oacc[db][4 * g + 2] * inv, a3 = oacc[db][4 * g + 3] * inv;
         u32x2 o;
-        o.x = pack_op2(oacc[db][4 * g + 0] * inv, oacc[db][4 * g + 1] * inv);
-        o.y = pack_op2(oacc[db][4 * g + 2] * inv, oacc[db][4 * g + 3] * inv);
+        o.x = pack_op2(a0, a1);
+        o.y = pack_op2(a2, a3);
         *(u32x2*)(op + db * 32 + 8 * g) = o;
+        if (Olo) {   // level 2: the attention output as an operand pair (o_proj's A operand)
+          u32x2 l;
+          l.x = pack_op2(a0 - oplo_to_f32(o.x), a1 - ophi_to_f32(o.x));
+          l.y = pack_op2(a2 - oplo_to_f32(o.y), a3 - ophi_to_f32(o.y));
+          *(u32x2*)(Olo + (size_t)(sq.q_row0 + qrow) * ldo + head * HD + 4 * hh + db * 32 + 8 * g) = l;
+        }
       }
   }
 }
@@ -669,7 +676,8 @@ __global__ __launch_bounds__(256) void kv_tiles_kernel(bf16_t* __restrict__ qkv,
 // V rows go to the V^T pages exactly as in kv_tiles_kernel. flash_attn_kernel<..., PREC = true> consumes the pairs.
 // ------------------------------------------------------------------------------------------------------------------
 template <int HD>
-__global__ __launch_bounds__(256) void kv_tiles_precise_kernel(const float* __restrict__ qk32, bf16_t* __restrict__ qkv, int ldqkv,
+__global__ __launch_bounds__(256) void kv_tiles_precise_kernel(const float* __restrict__ qk32, int ld32, int v_f32,
+                                                               bf16_t* __restrict__ qkv, int ldqkv,
                                                                int q_col0, int v_col0, bf16_t* __restrict__ qlo,
                                                                bf16_t* __restrict__ Kt, bf16_t* __restrict__ Vt, bf16_t* __restrict__ klo,
                                                                const int* __restrict__ tile_table, const VtAttnSeq* __restrict__ seqs,
@@ -700,7 +708,7 @@ __global__ __launch_bounds__(256) void kv_tiles_precise_kernel(const float* __re
       const int rp = positions[row];
       const float* cs = rope_cos + (size_t)rp * (HD / 2) + c * 8;
       const float* sn = rope_sin + (size_t)rp * (HD / 2) + c * 8;
-      const float* qs = qk32 + (size_t)row * (2 * H) + head * HD;
+      const float* qs = qk32 + (size_t)row * ld32 + head * HD;
       const float* ks = qs + H;
       u32x4 q_h_lo, q_h_hi, q_l_lo, q_l_hi;
 #pragma unroll
@@ -748,7 +756,16 @@ __global__ __launch_bounds__(256) void kv_tiles_precise_kernel(const float* __re
     u32x4 v = {0u, 0u, 0u, 0u};
     if (pos >= p_lo && pos < p_hi) {
       const int row = sq.q_row0 + (pos - past);
-      v = *(const u32x4*)(qkv + (size_t)row * ldqkv + v_col0 + head * HD + c * 8);
+      if (v_f32) {   // level 2: v arrives in fp32 behind q | k (one rounding, here)
+        const float* vp = qk32 + (size_t)row * ld32 + 2 * H + head * HD + c * 8;
+        const f32x4 a = *(const f32x4*)vp, b = *(const f32x4*)(vp + 4);
+        v.x = pack_op2(a[0], a[1]);
+        v.y = pack_op2(a[2], a[3]);
+        v.z = pack_op2(b[0], b[1]);
+        v.w = pack_op2(b[2], b[3]);
+      } else {
+        v = *(const u32x4*)(qkv + (size_t)row * ldqkv + v_col0 + head * HD + c * 8);
+      }
     }
     *(u32x4*)(&vs[r][c * 8]) = v;
   }
@@ -1411,14 +1428,15 @@ int vt_kv_tiles_launch(bf16_t* qkv, int ldqkv, int q_col0, int k_col0, int v_col
   return VT_OK;
 }
 
-int vt_kv_tiles_precise_launch(const float* qk32, bf16_t* qkv, int ldqkv, int q_col0, int v_col0, bf16_t* qlo, bf16_t* Kt, bf16_t* Vt,
+int vt_kv_tiles_precise_launch(const float* qk32, int ld32, int v_f32, bf16_t* qkv, int ldqkv, int q_col0, int v_col0, bf16_t* qlo, bf16_t* Kt, bf16_t* Vt,
                                bf16_t* klo, const int* tile_table, const VtAttnSeq* seqs, int nseq, int max_new_tiles, int heads, int HD,
                                const float* rope_cos, const float* rope_sin, const int* positions, hipStream_t s) {
   VT_REQUIRE(qk32 && qkv && qlo && Kt && Vt && klo && tile_table && seqs && rope_cos && rope_sin && positions, "vt_kv_tiles_precise: null pointer");
   VT_REQUIRE(HD == 128, "vt_kv_tiles_precise: head_dim %d unsupported (128)", HD);
   VT_REQUIRE(ldqkv % 8 == 0 && q_col0 % 8 == 0 && v_col0 % 8 == 0, "vt_kv_tiles_precise: misaligned columns");
   dim3 grid(max_new_tiles, heads, nseq), block(256);
-  hipLaunchKernelGGL((kv_tiles_precise_kernel<128>), grid, block, 0, s, qk32, qkv, ldqkv, q_col0, v_col0, qlo, Kt, Vt, klo, tile_table, seqs,
+  VT_REQUIRE(ld32 >= (v_f32 ? 3 : 2) * heads * HD && ld32 % 4 == 0, "vt_kv_tiles_precise: ld32 %d too small", ld32);
+  hipLaunchKernelGGL((kv_tiles_precise_kernel<128>), grid, block, 0, s, qk32, ld32, v_f32, qkv, ldqkv, q_col0, v_col0, qlo, Kt, Vt, klo, tile_table, seqs,
                      heads, rope_cos, rope_sin, positions);
   VT_LAUNCH_CHECK();
   return VT_OK;
@@ -1426,7 +1444,7 @@ int vt_kv_tiles_precise_launch(const float* qk32, bf16_t* qkv, int ldqkv, int q_
 
 int vt_flash_attn_precise_launch(const bf16_t* Q, int ldq, const bf16_t* Qlo, int ldqlo, const bf16_t* Kt, const bf16_t* Klo,
                                  int klo_tiles_per_seq, const bf16_t* Vt, const int* tile_table, const VtAttnSeq* seqs, int nseq,
-                                 int max_q_len, bf16_t* O, int ldo, int heads, int HD, int causal, float scale, hipStream_t s) {
+                                 int max_q_len, bf16_t* O, int ldo, bf16_t* Olo, int heads, int HD, int causal, float scale, hipStream_t s) {
   VT_REQUIRE(Q && Qlo && Kt && Klo && Vt && tile_table && seqs && O, "vt_flash_attn_precise: null pointer");
   VT_REQUIRE(HD == 128, "vt_flash_attn_precise: head_dim %d unsupported (128)", HD);
   VT_REQUIRE(nseq > 0 && max_q_len > 0 && heads > 0 && klo_tiles_per_seq > 0, "vt_flash_attn_precise: empty problem");
@@ -1446,7 +1464,7 @@ int vt_flash_attn_precise_launch(const bf16_t* Q, int ldq, const bf16_t* Qlo, in
       VT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));        \
       done.fetch_or(1ull << dev, std::memory_order_relaxed);                                                   \
     }                                                                                                          \
-    hipLaunchKernelGGL(kern, grid, block, smem, s, Q, ldq, Qlo, ldqlo, Kt, Klo, klo_tiles_per_seq, Vt, tile_table, seqs, O, ldo, heads, sl2); \
+    hipLaunchKernelGGL(kern, grid, block, smem, s, Q, ldq, Qlo, ldqlo, Kt, Klo, klo_tiles_per_seq, Vt, tile_table, seqs, O, ldo, Olo, heads, sl2); \
   } while (0)
   if (causal) VT_FAP(true); else VT_FAP(false);
 #undef VT_FAP

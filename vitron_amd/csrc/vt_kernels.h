@@ -94,8 +94,15 @@ int vt_layernorm_launch(float* x, const float* temb, int T, int tokens_per_frame
                         const float* beta, bf16_t* y, int rows, int D, float eps, hipStream_t s);
 int vt_rmsnorm_launch(const float* x, const int* idx, const float* w, bf16_t* y, int rows, int D, float eps,
                       hipStream_t s);
-// precise_qk: y = op(x_n), ylo = op(x_n - f32(y))
-int vt_rmsnorm_hilo_launch(const float* x, const float* w, bf16_t* y, bf16_t* ylo, int rows, int D, float eps, hipStream_t s);
+// precise modes (operand pairs: hi = op(v), lo = op(v - f32(hi))). RMSNorm / LayerNorm with a pair output; an activation (0 erf-GELU,
+// 1 quick-GELU, 2 SwiGLU on 16-interleaved gate/up columns) over an fp32 GEMM output with a pair output; fp32 rows -> pair (optionally
+// dropping the CLS row of every frame); fp32 += f32(op16)
+int vt_rmsnorm_hilo_launch(const float* x, const int* idx, const float* w, bf16_t* y, bf16_t* ylo, int rows, int D, float eps, hipStream_t s);
+int vt_layernorm_hilo_launch(const float* x, const float* gamma, const float* beta, bf16_t* y, bf16_t* ylo, int rows, int D, float eps,
+                             hipStream_t s);
+int vt_act_pair_launch(const float* in, int ldin, bf16_t* hi, bf16_t* lo, int rows, int Nout, int mode, hipStream_t s);
+int vt_f32_to_pair_launch(const float* x, bf16_t* hi, bf16_t* lo, size_t out_rows, int G2, int D, hipStream_t s);
+int vt_add_op_to_f32_launch(float* dst, const bf16_t* a, size_t n, hipStream_t s);
 int vt_rowscale_finalize_launch(const float* partials, int np, int ldp, int rows, float inv_dim, float eps, float* out, hipStream_t s);
 int vt_gather_f32_to_bf16_launch(const float* in, const int* idx, bf16_t* out, int rows, int D, hipStream_t s);
 int vt_bf16_to_f32_launch(const bf16_t* in, float* out, size_t n, hipStream_t s);
@@ -132,12 +139,12 @@ int vt_kv_tiles_launch(bf16_t* qkv, int ldqkv, int q_col0, int k_col0, int v_col
                        const float* rope_cos, const float* rope_sin, const int* positions, hipStream_t s);
 // precise_qk (vt_llama_model.precise_qk): fp32 q / k in, rotary in fp32, q and k written as operand pairs (hi + lo); the matching
 // attention kernel computes K_hi.(Q_hi + Q_lo)^T + K_lo.Q_hi^T
-int vt_kv_tiles_precise_launch(const float* qk32, bf16_t* qkv, int ldqkv, int q_col0, int v_col0, bf16_t* qlo, bf16_t* Kt, bf16_t* Vt,
+int vt_kv_tiles_precise_launch(const float* qk32, int ld32, int v_f32, bf16_t* qkv, int ldqkv, int q_col0, int v_col0, bf16_t* qlo, bf16_t* Kt, bf16_t* Vt,
                                bf16_t* klo, const int* tile_table, const VtAttnSeq* seqs, int nseq, int max_new_tiles, int heads, int HD,
                                const float* rope_cos, const float* rope_sin, const int* positions, hipStream_t s);
 int vt_flash_attn_precise_launch(const bf16_t* Q, int ldq, const bf16_t* Qlo, int ldqlo, const bf16_t* Kt, const bf16_t* Klo,
                                  int klo_tiles_per_seq, const bf16_t* Vt, const int* tile_table, const VtAttnSeq* seqs, int nseq,
-                                 int max_q_len, bf16_t* O, int ldo, int heads, int HD, int causal, float scale, hipStream_t s);
+                                 int max_q_len, bf16_t* O, int ldo, bf16_t* Olo, int heads, int HD, int causal, float scale, hipStream_t s);
 size_t vt_attn_decode_scratch_bytes(int nseq, int heads, int HD, int max_kv_len);
 int vt_attn_decode_fused_launch(const bf16_t* qkv, int ldqkv, int q_col0, int k_col0, int v_col0, bf16_t* Kt, bf16_t* Vt,
                                 const int* tile_table, const VtAttnSeq* seqs, int nseq, bf16_t* O, int ldo, int heads, int HD,

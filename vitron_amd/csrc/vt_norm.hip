@@ -108,12 +108,13 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
 // precise_qk mode (vt_llama_model.precise_qk): the norm output as an operand PAIR -- y = op(x_n) and y_lo = op(x_n - f32(y)) -- so that
 // the q / k projections can run as A_hi.W^T + A_lo.W^T (16 + 16 mantissa bits of the A operand instead of 11 / 8)
 template <int NCH>
-__global__ __launch_bounds__(256) void rmsnorm_hilo_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                           bf16_t* __restrict__ y, bf16_t* __restrict__ ylo, int rows, int D, float eps) {
+__global__ __launch_bounds__(256) void rmsnorm_hilo_kernel(const float* __restrict__ x, const int* __restrict__ idx,
+                                                           const float* __restrict__ w, bf16_t* __restrict__ y,
+                                                           bf16_t* __restrict__ ylo, int rows, int D, float eps) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= rows) return;
-  const float* xr = x + (size_t)row * D;
+  const float* xr = x + (size_t)(idx ? idx[row] : row) * D;
   f32x4 v[NCH];
   float sq = 0.f;
 #pragma unroll
@@ -142,6 +143,109 @@ __global__ __launch_bounds__(256) void rmsnorm_hilo_kernel(const float* __restri
       *(u32x2*)(ylo + (size_t)row * D + c) = lo;
     }
   }
+}
+
+// ---- precise (pair-operand) mode, level 2: the remaining producers of GEMM A operands as pairs (hi = op(v), lo = op(v - f32(hi))) ----
+__device__ __forceinline__ void store_pair4(bf16_t* hi_p, bf16_t* lo_p, float a0, float a1, float a2, float a3) {
+  u32x2 hi, lo;
+  hi.x = pack_op2(a0, a1);
+  hi.y = pack_op2(a2, a3);
+  lo.x = pack_op2(a0 - oplo_to_f32(hi.x), a1 - ophi_to_f32(hi.x));
+  lo.y = pack_op2(a2 - oplo_to_f32(hi.y), a3 - ophi_to_f32(hi.y));
+  *(u32x2*)hi_p = hi;
+  *(u32x2*)lo_p = lo;
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void layernorm_hilo_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                             bf16_t* __restrict__ ylo, int rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + (size_t)row * D;
+  f32x4 v[NCH];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (lane + i * 64) * 4;
+    v[i] = (c < D) ? *(const f32x4*)(xr + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+  }
+  const float mean = wave_sum(sum) / (float)D;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (lane + i * 64) * 4;
+    if (c < D) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float d = v[i][r] - mean;
+        sq += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (lane + i * 64) * 4;
+    if (c < D) {
+      const f32x4 g = *(const f32x4*)(gamma + c);
+      const f32x4 b = *(const f32x4*)(beta + c);
+      store_pair4(y + (size_t)row * D + c, ylo + (size_t)row * D + c, (v[i][0] - mean) * rstd * g[0] + b[0],
+                  (v[i][1] - mean) * rstd * g[1] + b[1], (v[i][2] - mean) * rstd * g[2] + b[2], (v[i][3] - mean) * rstd * g[3] + b[3]);
+    }
+  }
+}
+
+// activation on an fp32 GEMM output -> operand pair. MODE 0: exact-erf GELU, 1: quick-GELU (in [rows][N] -> out [rows][N]);
+// MODE 2: SwiGLU on the gate/up projection whose COLUMNS are interleaved in blocks of 16 (engine.interleave_gate_up: gate[16b..16b+15]
+// at columns 32b..32b+15, up[...] at 32b+16..32b+31): in [rows][2 * Nout] -> out [rows][Nout], out[c] = silu(gate[c]) * up[c]
+template <int MODE>
+__global__ void act_pair_kernel(const float* __restrict__ in, int ldin, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, int rows, int Nout) {
+  const int per_row = Nout >> 2;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)rows * per_row) return;
+  const size_t r = i / per_row;
+  const int c = (int)(i % per_row) * 4;
+  float a[4];
+  if (MODE == 2) {
+    const int col = (c >> 4) * 32 + (c & 15);
+    const f32x4 g = *(const f32x4*)(in + r * ldin + col);
+    const f32x4 u = *(const f32x4*)(in + r * ldin + col + 16);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[k] = g[k] / (1.0f + __expf(-g[k])) * u[k];
+  } else {
+    const f32x4 v = *(const f32x4*)(in + r * ldin + c);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[k] = (MODE == 0) ? vt_gelu_erf(v[k]) : v[k] / (1.0f + __expf(-1.702f * v[k]));
+  }
+  store_pair4(hi + r * Nout + c, lo + r * Nout + c, a[0], a[1], a[2], a[3]);
+}
+
+// fp32 [rows][D] -> operand pair; with G2 > 0 the CLS row of every (G2 + 1)-row frame is dropped (feature_select of the towers)
+__global__ void f32_to_pair_kernel(const float* __restrict__ x, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, size_t out_rows, int G2, int D) {
+  const int per_row = D >> 2;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= out_rows * per_row) return;
+  const size_t r = i / per_row;
+  const int c = (int)(i % per_row) * 4;
+  const size_t src = G2 > 0 ? (r / G2) * (G2 + 1) + 1 + (r % G2) : r;
+  const f32x4 v = *(const f32x4*)(x + src * D + c);
+  store_pair4(hi + r * D + c, lo + r * D + c, v[0], v[1], v[2], v[3]);
+}
+
+// dst fp32 += f32(a) for an operand-format a (the low half of an embedding pair joining the residual stream)
+__global__ void add_op_to_f32_kernel(float* __restrict__ dst, const bf16_t* __restrict__ a, size_t n4) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const u32x2 w = *(const u32x2*)(a + i * 4);
+  f32x4 v = *(const f32x4*)(dst + i * 4);
+  v[0] += oplo_to_f32(w.x);
+  v[1] += ophi_to_f32(w.x);
+  v[2] += oplo_to_f32(w.y);
+  v[3] += ophi_to_f32(w.y);
+  *(f32x4*)(dst + i * 4) = v;
 }
 
 // many rows (prefill): persistent waves, each walking rows w, w + stride, ...; the NEXT row's 16-byte loads are issued before the
@@ -337,11 +441,50 @@ int vt_rmsnorm_launch(const float* x, const int* idx, const float* w, bf16_t* y,
   return VT_OK;
 }
 
-int vt_rmsnorm_hilo_launch(const float* x, const float* w, bf16_t* y, bf16_t* ylo, int rows, int D, float eps, hipStream_t s) {
+int vt_rmsnorm_hilo_launch(const float* x, const int* idx, const float* w, bf16_t* y, bf16_t* ylo, int rows, int D, float eps, hipStream_t s) {
   VT_REQUIRE(x && w && y && ylo, "vt_rmsnorm_hilo: null pointer");
   VT_REQUIRE(rows > 0 && D > 0 && D % 4 == 0 && D <= 4096, "vt_rmsnorm_hilo: D=%d must be a multiple of 4, <= 4096", D);
   dim3 grid(cdiv(rows, 4));
-  VT_NORM_DISPATCH(rmsnorm_hilo_kernel, D, x, w, y, ylo, rows, D, eps);
+  VT_NORM_DISPATCH(rmsnorm_hilo_kernel, D, x, idx, w, y, ylo, rows, D, eps);
+  VT_LAUNCH_CHECK();
+  return VT_OK;
+}
+
+int vt_layernorm_hilo_launch(const float* x, const float* gamma, const float* beta, bf16_t* y, bf16_t* ylo, int rows, int D, float eps,
+                             hipStream_t s) {
+  VT_REQUIRE(x && gamma && beta && y && ylo, "vt_layernorm_hilo: null pointer");
+  VT_REQUIRE(rows > 0 && D > 0 && D % 4 == 0 && D <= 4096, "vt_layernorm_hilo: D=%d must be a multiple of 4, <= 4096", D);
+  dim3 grid(cdiv(rows, 4));
+  VT_NORM_DISPATCH(layernorm_hilo_kernel, D, x, gamma, beta, y, ylo, rows, D, eps);
+  VT_LAUNCH_CHECK();
+  return VT_OK;
+}
+
+int vt_act_pair_launch(const float* in, int ldin, bf16_t* hi, bf16_t* lo, int rows, int Nout, int mode, hipStream_t s) {
+  VT_REQUIRE(in && hi && lo && rows > 0 && Nout > 0, "vt_act_pair: bad arguments");
+  VT_REQUIRE(mode >= 0 && mode <= 2 && (Nout % (mode == 2 ? 16 : 4)) == 0 && (ldin % 4) == 0, "vt_act_pair: mode %d, Nout %d, ldin %d", mode, Nout, ldin);
+  const size_t n = (size_t)rows * (Nout / 4);
+  const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  if (mode == 0) hipLaunchKernelGGL(act_pair_kernel<0>, grid, block, 0, s, in, ldin, hi, lo, rows, Nout);
+  else if (mode == 1) hipLaunchKernelGGL(act_pair_kernel<1>, grid, block, 0, s, in, ldin, hi, lo, rows, Nout);
+  else hipLaunchKernelGGL(act_pair_kernel<2>, grid, block, 0, s, in, ldin, hi, lo, rows, Nout);
+  VT_LAUNCH_CHECK();
+  return VT_OK;
+}
+
+int vt_f32_to_pair_launch(const float* x, bf16_t* hi, bf16_t* lo, size_t out_rows, int G2, int D, hipStream_t s) {
+  VT_REQUIRE(x && hi && lo && out_rows > 0 && D % 4 == 0 && G2 >= 0, "vt_f32_to_pair: bad arguments");
+  const size_t n = out_rows * (D / 4);
+  hipLaunchKernelGGL(f32_to_pair_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, hi, lo, out_rows, G2, D);
+  VT_LAUNCH_CHECK();
+  return VT_OK;
+}
+
+int vt_add_op_to_f32_launch(float* dst, const bf16_t* a, size_t n, hipStream_t s) {
+  VT_REQUIRE(dst && a && n % 4 == 0, "vt_add_op_to_f32: n must be a multiple of 4");
+  const size_t n4 = n / 4;
+  if (!n4) return VT_OK;
+  hipLaunchKernelGGL(add_op_to_f32_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, dst, a, n4);
   VT_LAUNCH_CHECK();
   return VT_OK;
 }

@@ -90,6 +90,18 @@ class Workspace:
 
 
 # =====================================================================================================================
+def pair_lo(t):
+    """The LOW half that travels with a tensor in precise level 2 (operand pairs: value = f32(t) + f32(pair_lo(t))); None otherwise."""
+    return getattr(t, "_vt_lo", None)
+
+
+def with_lo(t, lo):
+    """Attach the low half of an operand pair to its high half (a plain attribute: views / copies made by the caller drop it)."""
+    if lo is not None:
+        t._vt_lo = lo
+    return t
+
+
 class PackedVit:
     """LanguageBind CLIP vision transformer in kernel layout (vt_vit_model)."""
 
@@ -188,8 +200,13 @@ class PackedVit:
         m.w_patch, m.cls, m.pos = self.w_patch.data_ptr(), self.cls.data_ptr(), self.pos.data_ptr()
         m.pre_ln_g, m.pre_ln_b = self.pre_g.data_ptr(), self.pre_b.data_ptr()
         m.layers = C.cast(self.layers, C.POINTER(_lib.VtVitLayer))
+        m.precise = int(cfg.get("precise", 0))
         self.model = m
         self.ws = Workspace(dev)
+
+    def set_precise(self, level: int) -> None:
+        """2: the MLP's operands and the output features as operand pairs (vt_vit_model.precise; include/vitron_hip.h); 0: standard."""
+        self.model.precise = 2 if int(level) >= 2 else 0
 
     def forward(self, pixels: torch.Tensor, return_hidden: bool = False):
         """pixels [B,3,H,W] or [B,3,T,H,W] (operand dtype or fp32, on device) -> patch features [B(,T),G*G,D] in the operand
@@ -212,12 +229,19 @@ class PackedVit:
         G2 = self.G * self.G
         out = torch.empty((B * T * G2, self.D), device=self.device, dtype=self.dtype)
         hidden = torch.empty((B * T * (G2 + 1), self.D), device=self.device, dtype=torch.float32) if return_hidden else None
+        out_lo = torch.empty_like(out) if self.model.precise >= 2 else None      # precise level 2: the features leave as an operand pair
+        self.model.out_feats_lo = out_lo.data_ptr() if out_lo is not None else None
         nbytes = lib.vt_vit_workspace_bytes(C.byref(self.model), B, T)
         ws = self.ws.get(nbytes)
-        _lib.check(lib.vt_vit_forward(C.byref(self.model), pixels.data_ptr(), dt, B, T, int(video), out.data_ptr(),
-                                      None if hidden is None else hidden.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
-                   "vt_vit_forward", lib)
+        try:
+            _lib.check(lib.vt_vit_forward(C.byref(self.model), pixels.data_ptr(), dt, B, T, int(video), out.data_ptr(),
+                                          None if hidden is None else hidden.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+                       "vt_vit_forward", lib)
+        finally:
+            self.model.out_feats_lo = None
         feats = out.view(B, T, G2, self.D) if video else out.view(B, G2, self.D)
+        if out_lo is not None:
+            with_lo(feats, out_lo.view(feats.shape))
         if return_hidden:
             return feats, hidden.view(B * T, G2 + 1, self.D)
         return feats
@@ -258,8 +282,19 @@ class PackedProjector:
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         lib = self.lib
         shp = x.shape
+        x_lo = pair_lo(x)
         x2 = x.reshape(-1, shp[-1]).to(self.dtype).contiguous()
         M = x2.shape[0]
+        if x_lo is not None and len(self.layers) == 2:
+            # precise level 2: features arrive as an operand pair -> both Linear layers on pairs, the embeddings leave as a pair
+            lo2 = x_lo.reshape(-1, shp[-1]).to(self.dtype).contiguous()
+            out = torch.empty((M, self.dout), device=self.device, dtype=self.dtype)
+            out_lo = torch.empty_like(out)
+            ws = self.ws.get(lib.vt_projector_precise_workspace_bytes(M, self.dh, self.dout))
+            _lib.check(lib.vt_projector_forward_precise(x2.data_ptr(), lo2.data_ptr(), M, self.din, self.w1.data_ptr(), self.b1.data_ptr(), self.dh,
+                                                        self.w2.data_ptr(), self.b2.data_ptr(), self.dout, out.data_ptr(), out_lo.data_ptr(),
+                                                        ws.data_ptr(), ws.numel(), _stream()), "vt_projector_forward_precise", lib)
+            return with_lo(out.view(*shp[:-1], self.dout), out_lo.view(*shp[:-1], self.dout))
         if len(self.layers) > 2:
             from . import ops
             h = x2
@@ -429,7 +464,7 @@ class PackedLlama:
         m.layers = C.cast(self.layers, C.POINTER(_lib.VtLlamaLayer))
         m.prefill_norm_fold = int(bool(cfg.get("prefill_norm_fold", False)))
         m.qkv_fuse = int(bool(cfg.get("qkv_fuse", False)))
-        m.precise_qk = int(bool(cfg.get("precise_qk", False)))
+        m.precise_qk = max(int(cfg.get("precise", 0) or 0), int(bool(cfg.get("precise_qk", False))))
         self.model = m
         self.ws = Workspace(dev)
 
@@ -437,6 +472,16 @@ class PackedLlama:
         """Prefill: rotary + K / V^T page writes inside the QKV GEMM's epilogue instead of the separate vt_kv_tiles pass
         (vt_llama_model.qkv_fuse; bit-identical, measured slower at the benchmark shape: default off)."""
         self.model.qkv_fuse = int(bool(on))
+
+    def set_precise(self, level: int) -> None:
+        """0: standard; 1: precise_qk (below); 2: EVERY GEMM A operand of a prefill as an operand pair -- a verification mode at about
+        twice the GEMM work that takes the fp16 build's full-depth logits below 1e-3 of the reference's fp32 (vt_llama_model.precise_qk = 2)."""
+        level = int(level)
+        if level not in (0, 1, 2):
+            raise _lib.VitronHipError(f"precise level must be 0, 1 or 2, got {level}")
+        if level and self.hd != 128:
+            raise _lib.VitronHipError(f"precise modes need head_dim 128 (got {self.hd})")
+        self.model.precise_qk = level
 
     def set_precise_qk(self, on: bool) -> None:
         """Prefills carry q / k (and the norm output that feeds their projection) as hi + lo operand pairs: the attention scores see
@@ -486,18 +531,25 @@ class SequenceState:
 
 def llama_forward(llama: PackedLlama, kv: PagedKVCache, seqs: Sequence[SequenceState], embeds: torch.Tensor,
                   q_lens: Sequence[int], positions: Optional[torch.Tensor] = None, logit_rows: Optional[Sequence[int]] = None,
-                  return_hidden: bool = False, return_all_hidden: bool = False):
+                  return_hidden: bool = False, return_all_hidden: bool = False, embeds_lo: Optional[torch.Tensor] = None):
     """One decoder pass over packed rows. embeds (operand dtype) [sum(q_lens), H]: the new tokens of every sequence, sequence by
     sequence. Appends their K/V to the cache, returns fp32 logits for `logit_rows` (default: last row of each
     sequence). positions default to cache position (length + i). Prefill and decode are the same call.
     return_hidden: also the fp32 residual stream behind the last layer [rows, H]; return_all_hidden: also the stream in front of
-    every layer, fp32 [L, rows, H] (vt_llama_model.hidden_trace) -- returns (logits, hidden, trace)."""
+    every layer, fp32 [L, rows, H] (vt_llama_model.hidden_trace) -- returns (logits, hidden, trace).
+    embeds_lo (precise level 2): the low half of `embeds` when the caller carries them as an operand pair (same shape and dtype)."""
     lib = llama.lib
     dev = llama.device
     rows = int(sum(q_lens))
     if embeds.shape[0] != rows or embeds.shape[1] != llama.H:
         raise _lib.VitronHipError(f"llama_forward: embeds {tuple(embeds.shape)} vs rows={rows}, H={llama.H}")
+    if embeds_lo is None:
+        embeds_lo = pair_lo(embeds)
     embeds = embeds.to(llama.dtype).contiguous()
+    if embeds_lo is not None:
+        if tuple(embeds_lo.shape) != tuple(embeds.shape):
+            raise _lib.VitronHipError(f"llama_forward: embeds_lo {tuple(embeds_lo.shape)} vs embeds {tuple(embeds.shape)}")
+        embeds_lo = embeds_lo.to(llama.dtype).contiguous()
     desc, table, pos_host = [], [], []
     row0 = 0
     max_new_tiles = 1
@@ -531,11 +583,13 @@ def llama_forward(llama: PackedLlama, kv: PagedKVCache, seqs: Sequence[SequenceS
     max_kv = max(d[2] for d in desc)
     ws = llama.ws.get(lib.vt_llama_workspace_bytes(C.byref(llama.model), rows, n_logit, len(desc), max_kv))
     llama.model.hidden_trace = trace.data_ptr() if trace is not None else None
+    llama.model.embeds_lo = embeds_lo.data_ptr() if embeds_lo is not None else None
     try:
         _llama_call(lib, llama, kv, embeds, rows, pos_t, desc_t, len(desc), int(max(q_lens)), int(max_new_tiles), int(max_kv), table_t, lr_t,
                     n_logit, logits, hidden, ws)
     finally:
         llama.model.hidden_trace = None
+        llama.model.embeds_lo = None
     for s, q in zip(seqs, q_lens):
         s.length += q
     if logits is not None and llama.V_pad != llama.V:

@@ -14,7 +14,7 @@ from typing import List, Optional
 import torch
 
 from ... import _lib, ops, synth
-from ...engine import DecodeState, PackedLlama, PagedKVCache, SequenceState, llama_forward
+from ...engine import DecodeState, PackedLlama, PagedKVCache, SequenceState, llama_forward, pair_lo
 from ..llava_arch import LlavaMetaForCausalLM, LlavaMetaModel
 from ..multimodal_encoder.builder import build_image_tower, build_video_tower
 from ..multimodal_projector.builder import build_vision_projector
@@ -258,6 +258,24 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
                 self.resize_token_embeddings(n)
         return self.to(device)
 
+    # ---- precision modes -----------------------------------------------------------------------------------------
+    def set_precise(self, level: int):
+        """0: standard. 1: precise_qk -- prefills carry q / k (and the norm output behind their projection) as hi + lo operand pairs.
+        2: a VERIFICATION mode -- every GEMM A operand of a prefill travels as an operand pair, from the towers' MLPs and the projector
+        (whose output enters the decoder's fp32 residual stream unrounded) through all decoder GEMMs to the lm_head: about twice the
+        GEMM work, and the fp16 build's full-depth logits end below north_star's 1e-3 of the reference's fp32 output (DESIGN.md 4,
+        tests/test_gpu_parity_fulldepth.py). Needs the weights on the GPU (call after .to(device)); decode steps are unchanged."""
+        level = int(level)
+        llama = self.model.llama
+        if llama is None:
+            raise RuntimeError("set_precise: move the model to the GPU first (.to(device))")
+        llama.set_precise(level)
+        self.precise_level = level
+        for tower in (self.get_image_tower(), self.get_video_tower()):
+            if tower is not None and getattr(tower, "packed", None) is not None and hasattr(tower.packed, "set_precise"):
+                tower.packed.set_precise(level)
+        return self
+
     # ---- KV pool ----------------------------------------------------------------------------------------------
     def reset_prefix_cache(self):
         """Drop the kept conversation (KV pages go back to the pool) and the encoded-image cache."""
@@ -321,10 +339,16 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
             idx = list(range(B * S))
             past.padded_len += S
         flat = inputs_embeds.reshape(B * S, H)
+        flat_lo = pair_lo(inputs_embeds)                 # precise level 2: the embeddings came out of the splice as an operand pair
+        if flat_lo is not None:
+            flat_lo = flat_lo.reshape(B * S, H)
         if len(idx) != B * S:   # pack the valid rows (padding never enters the decoder): a row gather by the splice kernel
             rowsel = torch.tensor(idx, dtype=torch.int32, device=flat.device)
+            gather = torch.stack([torch.zeros_like(rowsel), rowsel], 1).contiguous()
             # (inputs_embeds of another float dtype are legal here: the gather kernel moves rows in the model's operand dtype)
-            flat = ops.embed_splice(flat.to(llama.dtype).contiguous(), None, None, torch.stack([torch.zeros_like(rowsel), rowsel], 1).contiguous())
+            flat = ops.embed_splice(flat.to(llama.dtype).contiguous(), None, None, gather)
+            if flat_lo is not None:
+                flat_lo = ops.embed_splice(flat_lo.to(llama.dtype).contiguous(), None, None, gather)
         rows = flat.shape[0]
         if output_attentions:
             # (the reference's eager LlamaAttention returns the [B, heads, S, S] probabilities of every layer; the flash kernels never
@@ -332,9 +356,10 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
             raise NotImplementedError("output_attentions=True: the attention probabilities are never materialised by the HIP flash-attention kernels")
         trace = None
         if output_hidden_states:
-            logits_p, hidden, trace = llama_forward(llama, past.kv, seqs, flat, lens, logit_rows=list(range(rows)), return_all_hidden=True)
+            logits_p, hidden, trace = llama_forward(llama, past.kv, seqs, flat, lens, logit_rows=list(range(rows)), return_all_hidden=True,
+                                                    embeds_lo=flat_lo)
         else:
-            logits_p, hidden = llama_forward(llama, past.kv, seqs, flat, lens, logit_rows=list(range(rows)), return_hidden=True)
+            logits_p, hidden = llama_forward(llama, past.kv, seqs, flat, lens, logit_rows=list(range(rows)), return_hidden=True, embeds_lo=flat_lo)
         sel = torch.tensor(idx, device=flat.device) if len(idx) != B * S else None
 
         def unpack(t):       # packed rows [rows, D] -> the caller's padded [B, S, D] (zeros at the padding rows)

@@ -13,6 +13,7 @@ import numpy as np
 import torch
 
 from .. import ops
+from ..engine import pair_lo, with_lo
 from ..constants import IGNORE_INDEX, IMAGE_TOKEN_INDEX, OBJS_TOKEN_INDEX
 
 KIND_TOKEN, KIND_VISUAL, KIND_REGION, KIND_ZERO = 0, 1, 2, 3
@@ -270,8 +271,11 @@ class LlavaMetaForCausalLM:
 
         # ---- device side: towers -> region extractor -> projector -> gather/splice ------------------------------------------
         vis_chunks: List[torch.Tensor] = []
+        lo_chunks: List[Optional[torch.Tensor]] = []       # precise level 2: the low halves of the projected visual tokens (operand pairs)
         region_buf = None
         self._last_row_sig = None
+        if feature_cache is not None and getattr(self, "precise_level", 0) >= 2:
+            feature_cache = None                           # the cache holds 16-bit features: a verification pass encodes afresh
         if feature_cache is not None:
             vis_chunks, region_buf = self._encode_with_cache(images, image_idx, video_idx, regions if use_regions else None,
                                                              feature_cache, plan, blocks)
@@ -281,15 +285,24 @@ class LlavaMetaForCausalLM:
                 rb = [regions[i] for i in image_idx] if use_regions else None         # :241
                 feats, region_buf = self.encode_images(batch, rb)
                 vis_chunks.append(feats.reshape(-1, feats.shape[-1]))
+                lo_chunks.append(None if pair_lo(feats) is None else pair_lo(feats).reshape(-1, feats.shape[-1]))
                 region_buf = region_buf.reshape(-1, region_buf.shape[-1]) if use_regions else None
             if video_idx:
                 batch = torch.stack([images[i] for i in video_idx]).to(dev)
                 feats = self.encode_videos(batch)                                     # [b, T, P, H]
                 vis_chunks.append(feats.reshape(-1, feats.shape[-1]))
+                lo_chunks.append(None if pair_lo(feats) is None else pair_lo(feats).reshape(-1, feats.shape[-1]))
         vis = torch.cat(vis_chunks, 0) if len(vis_chunks) > 1 else vis_chunks[0]
         if vis.shape[0] != nvis:
             raise RuntimeError(f"visual token count mismatch: planned {nvis}, encoded {vis.shape[0]}")
         embeds = ops.embed_splice(self.get_model().embed_tokens_weight, vis.contiguous(), region_buf, plan_t).view(B, S, -1)
+        if any(l is not None for l in lo_chunks):
+            # the same gather over the LOW halves: token and region rows are exact 16-bit values (low half zero -- a one-row zero table: the
+            # splice kernel returns a zero row for every index outside its table), visual rows bring the projector's low half
+            vis_lo = torch.cat([l if l is not None else torch.zeros_like(v) for l, v in zip(lo_chunks, vis_chunks)], 0)
+            zero_row = torch.zeros((1, embeds.shape[-1]), dtype=embeds.dtype, device=embeds.device)
+            zero_reg = None if region_buf is None else torch.zeros_like(region_buf)
+            with_lo(embeds, ops.embed_splice(zero_row, vis_lo.contiguous(), zero_reg, plan_t).view(B, S, -1))
         ids_host = ids_host.tolist()
         am_host = None if am_host is None else am_host.tolist()
         mask, pos = mask.tolist(), pos.tolist()
