@@ -761,11 +761,25 @@ def fp16_ab_report(args, dev, model_bf16, step_bf16, ids, ids_host, clip_bf16, v
         arms["fp16"].append(ms)
         l16_ = out[1]
     d = float((l16_.double() - lb.double()).norm() / lb.double().norm())
+    # the fp16 build's precise modes on the same workload (round 5): precise_qk = q / k path as operand pairs; precise2 = the verification
+    # mode (every GEMM A operand a pair: full-depth logits 4.5e-4 from the reference's fp32, tests/test_gpu_parity_fulldepth.py)
+    f16_mean = sum(arms["fp16"]) / len(arms["fp16"])
+    precise = {}
+    for level, tag in ((1, "precise_qk"), (2, "precise2")):
+        m16.set_precise(level)
+        try:
+            step16()
+            ms, out_p = timed(step16, max(2, K // 2))
+        finally:
+            m16.set_precise(0)
+        precise[tag] = {"ms_per_step": ms, "over_fp16": ms / f16_mean,
+                        "last_position_logits_rel_l2_vs_fp16_standard": float((out_p[1].double() - l16_.double()).norm() / l16_.double().norm())}
     rep = {"what": "same workload, same seed, same box: bf16 build vs fp16-operand build, arms alternated, wall clock per step",
            "steps_per_arm": K, "ms_per_step_bf16": arms["bf16"], "ms_per_step_fp16": arms["fp16"],
-           "fp16_over_bf16": (sum(arms["fp16"]) / len(arms["fp16"])) / (sum(arms["bf16"]) / len(arms["bf16"])),
+           "fp16_over_bf16": f16_mean / (sum(arms["bf16"]) / len(arms["bf16"])),
            "last_position_logits_rel_l2_fp16_vs_bf16": d, "greedy_token_equal": bool(int(out[0][0]) == int(ops.argmax(lb)[0])),
-           "note": "parity of each build against the reference: profiles/r4_parity_*.json (tests/test_gpu_parity_fulldepth.py)"}
+           "fp16_precise_modes": precise,
+           "note": "parity of each build / mode against the reference: profiles/r5_parity_fulldepth*.json (tests/test_gpu_parity_fulldepth.py)"}
     del m16, l16
     torch.cuda.empty_cache()
     return rep

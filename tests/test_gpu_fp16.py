@@ -390,3 +390,52 @@ def test_fp16_load_pretrained_model_defaults_to_the_references_dtype(dev, tmp_pa
     a = m(input_ids=ids, images=[im.to(dev).to(F16) for im in case["images"]], regions=case["regions"], use_cache=False).logits
     b = mb(input_ids=ids, images=[im.to(dev).bfloat16() for im in case["images"]], regions=case["regions"], use_cache=False).logits
     assert rel_l2(a, b) <= 2.6e-2          # TOL_DEEP of tests/test_gpu_model.py: the bf16 chain's own distance from fp32 at these widths
+
+
+def test_precise_modes_on_the_tiny_model_forward_and_generate():
+    """model.set_precise(1 | 2) through the reference-shaped surface at the tiny golden widths (fp16 build): forward() on an image +
+    region prompt and on a clip moves TOWARDS the oracle's fp32 logits with every level (level 2: towers' MLPs, projector, spliced
+    embeddings and every decoder GEMM on operand pairs), generate() runs its prefill in the mode and returns the standard ids."""
+    from oracle import vitron_oracle as O
+    from tests.golden import cases
+    from tests.util import rel_l2
+    from vitron_amd import synth
+    from vitron_amd.engine import pair_lo
+    from vitron_amd.model import LlavaConfig, LlavaLlamaForCausalLM
+    dev = torch.device("cuda:0")
+    init = dict(w_std=0.02)
+    st = {"image_tower": synth.vit_state(cases.VIT_IMAGE, synth.make_generator(cases.SEED_VIT), **init),
+          "video_tower": synth.vit_state(cases.VIT_VIDEO, synth.make_generator(cases.SEED_VIT), **init),
+          "projector": synth.projector_state(cases.MM_HIDDEN, cases.LLM["hidden_size"], synth.make_generator(cases.SEED_PROJ), **init),
+          "region": synth.region_state(cases.MM_HIDDEN, cases.LLM["hidden_size"], synth.make_generator(cases.SEED_REGION), **init),
+          "llama": synth.llama_state(cases.LLM, synth.make_generator(cases.SEED_LLM), **init)}
+    model = LlavaLlamaForCausalLM(LlavaConfig(**cases.LLM, mm_hidden_size=cases.MM_HIDDEN, mm_image_tower="p/LanguageBind_Image",
+                                              mm_video_tower="p/LanguageBind_Video_merge", kv_prefix_reuse=False))
+    model.get_image_tower().load_state(cases.VIT_IMAGE, st["image_tower"])
+    model.get_video_tower().load_state(cases.VIT_VIDEO, st["video_tower"])
+    sd = dict(st["llama"])
+    sd.update({"model.mm_projector." + k: v for k, v in st["projector"].items()})
+    sd.update({"model.region_extractor." + k: v for k, v in st["region"].items()})
+    model.load_state_dict(sd)
+    model.to(dev, dtype=torch.float16)
+    w = {k: {n: t.float() for n, t in v.items()} for k, v in st.items()}
+    cfgs = {"image": cases.VIT_IMAGE, "video": cases.VIT_VIDEO, "llama": cases.LLM}
+    for name in ("image_region", "video"):
+        case = cases.glue_cases()[name]
+        ids = case["input_ids"].to(dev)
+        images = [im.to(dev).half() for im in case["images"]]
+        ref32 = O.multimodal_forward(w, cfgs, case["input_ids"], None, case["images"], case["regions"])[0]
+        dist, toks = {}, {}
+        for level in (0, 1, 2):
+            model.set_precise(level)
+            try:
+                (_, _, _, _, embeds, _) = model.prepare_inputs_labels_for_multimodal(ids, None, None, None, None, images, case["regions"])
+                assert (pair_lo(embeds) is not None) == (level == 2)
+                out = model(input_ids=ids, images=images, regions=case["regions"], use_cache=False)
+                dist[level] = rel_l2(out.logits.float().cpu(), ref32)
+                toks[level] = model.generate(ids, images=images, regions=case["regions"], do_sample=False, max_new_tokens=4, eos_token_id=-1)[0, -4:].tolist()
+            finally:
+                model.set_precise(0)
+        print(f"[fp16-precise-tiny] {name}: logits vs fp32 standard {dist[0]:.3e} precise_qk {dist[1]:.3e} precise2 {dist[2]:.3e}", flush=True)
+        assert dist[2] <= 0.6 * dist[0] and dist[2] <= 3e-4 and dist[1] <= 1.05 * dist[0], dist
+        assert toks[1] == toks[0] and toks[2] == toks[0], toks

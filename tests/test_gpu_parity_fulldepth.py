@@ -53,7 +53,9 @@ BOUNDS["fp16-precise"] = dict(BOUNDS["fp16"])
 # precise level 2 (round 5): EVERY GEMM A operand of the prefill an operand pair, from the towers' MLPs through the projector (whose output
 # enters the residual stream unrounded) to the lm_head -- the verification mode in which north_star's 1e-3 against the reference's fp32
 # logits is ASSERTED at full depth (what is left: the attention paths' single fp16 stores -- V^T, P, the towers' q / k / v / attention output)
-BOUNDS["fp16-precise2"] = dict(embeds=3.0e-4, last=1.0e-3, rows=1.0e-3, proj=1.0e-3, top1=0.997, top5=0.996)
+# measured (profiles/r5_parity_fulldepth_precise.json): embeddings 0.7e-4 (image tower) / 1.9e-4 (video tower), logits over all rows 4.3e-4 .. 4.7e-4,
+# last position 1.0e-4 .. 3.5e-4, top-1 99.9 .. 100 %; bounds = x 1.5, all inside north_star's 1e-3
+BOUNDS["fp16-precise2"] = dict(embeds=3.0e-4, last=7.0e-4, rows=7.0e-4, proj=7.0e-4, top1=0.997, top5=0.997)
 ID_TOL = {"bf16": 1.6e-2, "fp16": 2.4e-3}      # logits distance that sets the noise bound of the id comparison (= BOUNDS[op]["last"])
 REPORT = {}
 

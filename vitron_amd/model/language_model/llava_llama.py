@@ -452,9 +452,15 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
         lens = [sum(r) for r in mask_host]
         idx = [b * S + j for b in range(B) for j in range(S) if mask_host[b][j]]
         flat = embeds.reshape(B * S, H)
+        flat_lo = pair_lo(embeds)                        # precise level 2: the spliced embeddings are an operand pair
+        if flat_lo is not None:
+            flat_lo = flat_lo.reshape(B * S, H)
         if len(idx) != B * S:
             rowsel = torch.tensor(idx, dtype=torch.int32, device=dev)
-            flat = ops.embed_splice(flat.to(llama.dtype).contiguous(), None, None, torch.stack([torch.zeros_like(rowsel), rowsel], 1).contiguous())
+            gather = torch.stack([torch.zeros_like(rowsel), rowsel], 1).contiguous()
+            flat = ops.embed_splice(flat.to(llama.dtype).contiguous(), None, None, gather)
+            if flat_lo is not None:
+                flat_lo = ops.embed_splice(flat_lo.to(llama.dtype).contiguous(), None, None, gather)
         seqs = [SequenceState() for _ in range(B)]
         # ---- multi-turn KV reuse (batch 1): keep the pages of the longest common whole-page prefix of the last call ------------
         sig = None
@@ -492,6 +498,7 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
                                     "prefill_rows": int(sum(lens) - kept), "tower_items": self.last_tower_items}
         if kept:
             flat, lens = flat[kept:], [lens[0] - kept]
+            flat_lo = None if flat_lo is None else flat_lo[kept:]
         # ---- decode loop: device-resident step state, the next pass is enqueued before the host has seen the token it consumes
         L0 = input_ids.shape[1]
         out_host = torch.empty((B, L0 + max_new_tokens), dtype=torch.long)
@@ -500,7 +507,7 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
         all_logits = []
         state = None
         try:   # (the prefill is inside: pages it took before a failure go back to the pool / the kept prefix below)
-            logits = llama_forward(llama, self.kv, seqs, flat, lens)         # [B, V]: last position of every sequence
+            logits = llama_forward(llama, self.kv, seqs, flat, lens, embeds_lo=flat_lo)     # [B, V]: last position of every sequence
             for step in range(max_new_tokens):
                 if return_logits:
                     all_logits.append(logits.clone())
