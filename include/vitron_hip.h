@@ -101,6 +101,9 @@ int vt_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, void* C
  * number of leading rows it covers (the remaining rows are planned again, as a GEMM of their own). Introspection for tests and
  * tools; no reference counterpart (torch.nn.Linear hides cuBLAS's heuristics the same way). */
 int vt_gemm_plan_query(int M, int N, int K, int epi, int* cfg, int* rows_first);
+/* the same with the column split of round 5: *cols_first > 0 means columns [0, *cols_first) run on *cfg (whole rounds of 256-row tiles) and the
+ * remaining columns are planned again (a few row blocks x many column tiles that spill just over whole rounds: 768 x 22016) */
+int vt_gemm_plan_query2(int M, int N, int K, int epi, int* cfg, int* rows_first, int* cols_first);
 
 /* y_bf16[rows][D] = LayerNorm(x_f32) * gamma + beta. If temb != NULL first x[row] += temb[(row / tokens_per_frame) % T]
  * (written back): the video tower's temporal_embedding add (reference modeling_video.py:110-114) fused with

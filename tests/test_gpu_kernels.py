@@ -687,3 +687,38 @@ def test_mfma_probe_counts_what_it_claims(dev, op):
         _lib.check(lib.vt_probe_mfma(a.data_ptr(), a.data_ptr(), out.data_ptr(), iters, torch.cuda.current_stream().cuda_stream), "vt_probe_mfma", lib)
         torch.cuda.synchronize()
         assert torch.equal(out, torch.full_like(out, 64 * 2 * 64 * iters)), (iters, out[:4].tolist())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("epi_name", ["SWIGLU_BF16", "BF16", "F32_RESID", "F32"])
+def test_gemm_column_split_plan_is_bit_identical(epi_name):
+    """Round 5's column split (a few row blocks x many column tiles that spill just over whole rounds: 768 x 22016 = 258 tiles of 256 rows):
+    the AUTO plan runs 85 column tiles on whole rounds of big tiles and plans the 256-column tail again -- weights, bias and output of the
+    tail are offset views of the same GEMM, so the result must equal the single-grid launch bit for bit (also for the SwiGLU epilogue,
+    whose output has one column per gate / up pair)."""
+    from vitron_amd import _lib, ops
+    _lib.load()
+    dev = torch.device("cuda:0")
+    M, N, K = 768, 22016, 4096
+    epi = getattr(ops, "EPI_" + epi_name)
+    cfg, rows, cols = ops.gemm_plan_cols(M, N, K, epi)
+    assert cols == 85 * 256 and rows == 0 and cfg == _lib.CFG_256x256_W4
+    g = torch.Generator(device=dev).manual_seed(5)
+    a = torch.randn((M, K), generator=g, device=dev).bfloat16()
+    w = (torch.randn((N, K), generator=g, device=dev) * 0.02).bfloat16()
+    bias = None if epi_name == "SWIGLU_BF16" else torch.randn((N,), generator=g, device=dev)
+    base = torch.randn((M, N), generator=g, device=dev) if epi_name == "F32_RESID" else None
+    got = ops.gemm(a, w, bias, epi, out=None if base is None else base.clone())
+    ref = ops.gemm(a, w, bias, epi, out=None if base is None else base.clone(), cfg=_lib.CFG_256x256_W4)
+    assert got.shape == ref.shape and torch.equal(got, ref)
+    # and against fp32 on the same operands (the tail columns in particular)
+    f = a.float() @ w.float().t()
+    if bias is not None:
+        f = f + bias
+    if epi_name == "SWIGLU_BF16":
+        f3 = f.view(M, N // 32, 2, 16)
+        f = (torch.nn.functional.silu(f3[:, :, 0]) * f3[:, :, 1]).reshape(M, N // 2)
+    if base is not None:
+        f = f + base
+    tail = slice((cols // 2) if epi_name == "SWIGLU_BF16" else cols, None)
+    assert float((got.float()[:, tail] - f[:, tail]).norm() / f[:, tail].norm()) <= 3e-3

@@ -481,9 +481,20 @@ def test_gemm_planner_fills_whole_rounds_of_the_chip():
     assert ops.gemm_plan(4616, 1024, 4096, ops.EPI_F32_RESID) == (W4R, 0)
     assert ops.gemm_plan(1088, 12288, 4096, ops.EPI_BF16) == (W4_224, 0)                # 240 big tiles, one round: 5 x 224 rows pad 1088 to 1120, not 1280
     assert ops.gemm_plan(1088, 22016, 4096, ops.EPI_SWIGLU_BF16) == (W4_224, 0)         # 430 tiles, two rounds, each 7/8 as long
-    # ... and ONLY where they pad fewer rows than 256-row tiles do (the price was measured at 1088 / 4616 rows only): a multiple of 256
-    # stays on the 256-row tile even where the round count would tie (2048 x 8192: 256 tiles of 256 rows, not 320 of 224 with 9 % padding)
-    assert ops.gemm_plan(2048, 8192, 4096, ops.EPI_BF16) == (W4, 0) and ops.gemm_plan(2048, 12288, 4096, ops.EPI_BF16) == (W4, 0)
+    # ... also on multiples of 256 since round 5 measured them (profiles/r5_gemm_cfg_224px.jsonl: the reference-native 224 px shapes): where
+    # the ROUND COUNT ties, the shorter tile wins (2048 x 12288: 384 tiles of 256 rows = 2 rounds, 480 of 224 rows = 2 rounds x 7/8); where
+    # 256-row tiles fill exactly one round they stay (2048 x 8192)
+    assert ops.gemm_plan(2048, 8192, 4096, ops.EPI_BF16) == (W4, 0) and ops.gemm_plan(2048, 12288, 4096, ops.EPI_BF16) == (W4_224, 0)
+    # the 224 px shapes (S = 768 / 2560, 2056 tower rows): decoder residual GEMMs at 2560 rows on 192 tiles of 224 rows instead of two rounds
+    # of the ring kernel (207 vs 233 us at K = 11008); ONE round of 128x128 tiles where the grid fits it (video tower qkv, projector);
+    # 768 x 22016 (258 tiles of 256 rows: two rounds for 1.008 rounds of work) as a COLUMN split -- 85 column tiles on whole rounds of big
+    # tiles, the 256-column tail planned again; the single-round ring choices of rounds 2-4 unchanged
+    assert ops.gemm_plan(2560, 4096, 11008, ops.EPI_F32_RESID) == (W4_224, 0) and ops.gemm_plan(2560, 4096, 4096, ops.EPI_F32_RESID) == (W4_224, 0)
+    assert ops.gemm_plan(768, 12288, 4096, ops.EPI_BF16) == (W4_224, 0)
+    assert ops.gemm_plan(2056, 3072, 1024, ops.EPI_BF16) == (_lib.CFG_128x128, 0) and ops.gemm_plan(2048, 4096, 4096, ops.EPI_BF16) == (_lib.CFG_128x128, 0)
+    assert ops.gemm_plan_cols(768, 22016, 4096, ops.EPI_SWIGLU_BF16) == (W4, 0, 85 * 256)
+    assert ops.gemm_plan_cols(256, 22016 - 85 * 256, 4096, ops.EPI_SWIGLU_BF16)[2] == 0 and ops.gemm_plan_cols(5120, 22016, 4096, ops.EPI_SWIGLU_BF16) == (W4, 0, 0)
+    assert ops.gemm_plan(768, 4096, 4096, ops.EPI_F32_RESID) == (W4R, 0) and ops.gemm_plan(768, 4096, 11008, ops.EPI_F32_RESID) == (W4R, 0)
     assert ops.gemm_plan(1088, 4096, 4096 + 128, ops.EPI_F32_RESID)[0] in small         # the ring walks K in steps of 256
     # K not a multiple of 128 (no big-tile kernel) and the weight-streaming range
     assert ops.gemm_plan(4096, 4096, 4096 + 64, ops.EPI_BF16)[0] in small

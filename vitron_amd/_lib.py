@@ -83,6 +83,7 @@ SIGNATURES = {
     "vt_attn_decode_scratch_bytes": (_sz, [_i, _i, _i, _i]),
     "vt_attn_decode": (_i, [vp, _i, vp, vp, vp, vp, _i, vp, _i, _i, _i, _f, _i, vp, _sz, vp]),
     "vt_gemm_plan_query": (_i, [_i, _i, _i, _i, vp, vp]),
+    "vt_gemm_plan_query2": (_i, [_i, _i, _i, _i, vp, vp, vp]),
     "vt_gemm_bf16_resid_splitk": (_i, [vp, _i, vp, _i, vp, _i, vp, _i, _i, _i, _i, vp, _sz, vp]),
     "vt_attn_decode_fused": (_i, [vp, _i, _i, _i, _i, vp, vp, vp, vp, _i, vp, _i, _i, _i, _f, vp, vp, vp, vp]),
     "vt_kv_tiles": (_i, [vp, _i, _i, _i, _i, vp, vp, vp, vp, _i, _i, _i, _i, vp, vp, vp, vp]),

@@ -181,6 +181,9 @@ int vt_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, void* C
 }
 
 int vt_gemm_plan_query(int M, int N, int K, int epi, int* cfg, int* rows_first) { return vt_gemm_plan_describe(M, N, K, epi, cfg, rows_first); }
+int vt_gemm_plan_query2(int M, int N, int K, int epi, int* cfg, int* rows_first, int* cols_first) {
+  return vt_gemm_plan_describe(M, N, K, epi, cfg, rows_first, cols_first);
+}
 
 int vt_layernorm(float* x, const float* temb, int T, int tokens_per_frame, const float* gamma, const float* beta,
                  uint16_t* y, int rows, int D, float eps, void* stream) {

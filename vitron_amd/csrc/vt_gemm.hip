@@ -763,6 +763,7 @@ int vt_gemm_pick_cfg(int M, int N, int K) {
 struct VtGemmPlan {
   int cfg;
   int M1;
+  int N1 = 0;   // > 0: COLUMNS [0, N1) go to cfg (whole rounds of big tiles), the remaining columns are planned again (round 5)
 };
 
 static bool vt_epi_plain(int epi) { return epi == VT_EPI_BF16 || epi == VT_EPI_F32_RESID || epi == VT_EPI_F32 || epi == VT_EPI_SWIGLU_BF16; }
@@ -797,18 +798,36 @@ static double vt_gemm_plan_cost(int M, int N, int K, int epi, const VtGemmNormFu
     // Only where it PADS FEWER ROWS than the 256-row tile (1088 -> 1120 vs 1280; 4616 -> 4704 vs 4864): the 0.875 x 1.02 price was
     // measured on exactly those shapes (profiles/r3_gemm_tile224_ab.jsonl). A multiple of 256 (2048 rows: 160 tiles instead of 128,
     // 9 % padding) would otherwise switch kernels on an extrapolated model -- unmeasured shapes stay on the 256-row tile.
-    const bool pads_less = (long)cdiv(M, 224) * 224 < (long)cdiv(M, 256) * 256;
-    if (pads_less && t224 >= 128 && c224 < best) {   // (under half a round the small tiles' finer grid is as good: not measured, left alone)
+    // Round 5 measured the multiples of 256 the guard above used to exclude (profiles/r5_gemm_cfg_224px.jsonl, the reference-native 224 px
+    // shapes): 2560 x 4096 x 11008 207 us on 192 tiles of 224 rows vs 233 on the ring kernel's 512 and 244 on 160 of 256 rows; 2560 x 4096 x 4096
+    // 87 vs 92 vs 99; 768 x 12288 x 4096 80 vs 88 vs 94; 2048 x 4096 x 4096 72 vs 80 vs 85 -- the round model holds there too (a round of
+    // 224-row tiles IS 7/8 as long whatever the padding), so the candidate is priced for every M.
+    if (t224 >= 128 && c224 < best) {   // (under half a round the small tiles' finer grid is as good: not measured, left alone)
       best = c224;
       *plan = VtGemmPlan{VT_GEMM_CFG_224x256_W4, 0};
     }
     // (a grid under half a round with a short K loop stays on small tiles: 577 x 3072 x 1024, 96 tiles, 281 vs 339 TFLOP/s)
     const long t160 = cdiv(M, 160) * (long)cdiv(N, 128);
     if ((K % 256) == 0 && (t160 >= 128 || K >= 4096)) {
-      const double c160 = (double)((t160 + 255) / 256) * 0.42;
+      // (round 5: every round AFTER the first costs 0.49, not 0.42 -- 2560 x 4096 x 4096, 512 tiles = two rounds: 92 us against 95 per round
+      // of 256-row tiles; one round, 768 x 4096 x 4096: 43 us. The single-round price, and with it every choice of rounds 2-4, is unchanged)
+      const long r160 = (t160 + 255) / 256;
+      const double c160 = (double)r160 * 0.42 + (double)(r160 - 1) * 0.07;
       if (c160 < best) {
         best = c160;
         *plan = VtGemmPlan{VT_GEMM_CFG_160x128_W4, 0};
+      }
+    }
+    // ONE round of 128x128 tiles (two 64-KiB workgroups per CU = 512 slots): where the grid fits that single round and covers at least half
+    // of it, it beats a part-filled round of big tiles and two rounds of the ring kernel (round 5, profiles/r5_gemm_cfg_224px.jsonl:
+    // 2048 x 4096 x 4096 67 us vs 72 on 224-row tiles / 80 on the ring; 2056 x 3072 x 1024 20.8 vs 22.9 / 25.2; 2048 x 4096 x 1024 + GELU
+    // 23.4 vs 29.6 / 29.3; two rounds lose everywhere: 2560 x 4096 x 4096 125 vs 87). Priced at 0.70 of a big round (0.80 on a short K loop).
+    const long t128 = (long)cdiv(M, 128) * cdiv(N, 128);
+    if (t128 >= 256 && t128 <= 512) {
+      const double c128 = K >= 2048 ? 0.70 : 0.80;
+      if (c128 < best) {
+        best = c128;
+        *plan = VtGemmPlan{VT_GEMM_CFG_128x128, 0};
       }
     }
   }
@@ -830,6 +849,25 @@ static double vt_gemm_plan_cost(int M, int N, int K, int epi, const VtGemmNormFu
       }
     }
   }
+  // Column split (round 5): a few row blocks x many column tiles that spill just over whole rounds (768 x 22016: 3 x 86 = 258 tiles of 256
+  // rows, two rounds for 1.008 rounds of work) -- the columns that fill WHOLE rounds go to the 256-row tiles, the remaining columns are planned
+  // again (measured: 21504 columns 107 us + 512 columns on the ring 30 us = 137 against 158 for the best single grid).
+  if (allow_split && !nf && K >= 2048 && vt_epi_plain(epi)) {
+    const long rb = cdiv(M, 256);
+    const long whole = ((long)rb * tiles_n) / 256;          // whole rounds the grid contains
+    if (whole >= 1 && rb <= 256) {
+      const long n1_tiles = whole * 256 / rb;                // column tiles that fit those rounds
+      const long N1 = n1_tiles * 256;
+      if (n1_tiles >= 1 && N1 < N && N - N1 <= 2048) {       // only a SMALL tail is worth a second launch
+        VtGemmPlan rest;
+        const double c = (double)whole + vt_gemm_plan_cost(M, N - (int)N1, K, epi, nf, &rest, false) + 0.02;
+        if (c < best - 0.05) {
+          best = c;
+          *plan = VtGemmPlan{VT_GEMM_CFG_256x256_W4, 0, (int)N1};
+        }
+      }
+    }
+  }
   return best;
 }
 
@@ -839,8 +877,9 @@ static VtGemmPlan vt_gemm_plan(int M, int N, int K, int epi, const VtGemmNormFus
   return plan;
 }
 
-int vt_gemm_plan_describe(int M, int N, int K, int epi, int* cfg, int* rows_first) {
+int vt_gemm_plan_describe(int M, int N, int K, int epi, int* cfg, int* rows_first, int* cols_first) {
   VT_REQUIRE(M > 0 && N > 0 && K > 0 && cfg && rows_first, "vt_gemm_plan_query: bad arguments");
+  if (cols_first) *cols_first = 0;
   if (M <= 64 || (K % 64) != 0) {   // the weight-streaming kernels / the ragged-K fallback, not a tile configuration
     *cfg = VT_GEMM_CFG_SKINNY;
     *rows_first = 0;
@@ -849,6 +888,7 @@ int vt_gemm_plan_describe(int M, int N, int K, int epi, int* cfg, int* rows_firs
   const VtGemmPlan plan = vt_gemm_plan(M, N, K, epi, nullptr);
   *cfg = plan.cfg;
   *rows_first = plan.M1;
+  if (cols_first) *cols_first = plan.N1;
   return VT_OK;
 }
 
@@ -901,6 +941,13 @@ int vt_gemm_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, 
       // remaining rows again (small tiles fill the CUs at any size). Both launches are plain row ranges of the same GEMM.
       const VtGemmPlan plan = vt_gemm_plan(M, N, K, epi, nf);
       cfg = plan.cfg;
+      if (plan.N1 > 0) {   // column split: whole rounds of big tiles over the first N1 columns, the tail columns planned again
+        const size_t esz = (epi == VT_EPI_F32 || epi == VT_EPI_F32_RESID) ? 4 : 2;
+        const size_t c_off = (epi == VT_EPI_SWIGLU_BF16 ? plan.N1 / 2 : plan.N1) * esz;     // SwiGLU: one output column per gate/up pair
+        VT_TRY(vt_gemm_launch(A, lda, W, ldw, C, ldc, bias, M, plan.N1, K, epi, plan.cfg, s, nullptr));
+        return vt_gemm_launch(A, lda, W + (size_t)plan.N1 * ldw, ldw, (char*)C + c_off, ldc, bias ? bias + plan.N1 : nullptr, M, N - plan.N1, K,
+                              epi, VT_GEMM_CFG_AUTO, s, nullptr);
+      }
       if (plan.M1 > 0) {
         const size_t esz = (epi == VT_EPI_F32 || epi == VT_EPI_F32_RESID) ? 4 : 2;
         VT_TRY(vt_gemm_launch(A, lda, W, ldw, C, ldc, bias, plan.M1, N, K, epi, plan.cfg, s, nf));

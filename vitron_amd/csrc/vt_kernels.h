@@ -14,7 +14,7 @@ struct VtAttnSeq {  // device-side view of one row of seq_desc (int32 x 4)
 
 // ---- vt_gemm.hip ----------------------------------------------------------------------------------
 int vt_gemm_pick_cfg(int M, int N, int K);
-int vt_gemm_plan_describe(int M, int N, int K, int epi, int* cfg, int* rows_first);   // vt_gemm.hip: the planner's verdict, no launch
+int vt_gemm_plan_describe(int M, int N, int K, int epi, int* cfg, int* rows_first, int* cols_first = nullptr);   // vt_gemm.hip: the planner's verdict, no launch
 struct VtGemmNormFuse;
 int vt_gemm_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, const float* bias,
                    int M, int N, int K, int epi, int cfg, hipStream_t s,

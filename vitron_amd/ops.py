@@ -50,6 +50,15 @@ def gemm_plan(M: int, N: int, K: int, epi: int = EPI_BF16):
     return cfg.value, rows.value
 
 
+def gemm_plan_cols(M: int, N: int, K: int, epi: int = EPI_BF16):
+    """(cfg, rows_first, cols_first) of the dispatcher's plan (vt_gemm_plan_query2): cols_first > 0 = the column split of round 5."""
+    import ctypes
+    lib = _lib.load_any()
+    cfg, rows, cols = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    _lib.check(lib.vt_gemm_plan_query2(M, N, K, epi, ctypes.byref(cfg), ctypes.byref(rows), ctypes.byref(cols)), "vt_gemm_plan_query2", lib)
+    return cfg.value, rows.value, cols.value
+
+
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, epi: int = EPI_BF16,
          out: Optional[torch.Tensor] = None, cfg: int = CFG_AUTO, row_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out = epi(row_scale[:, None] * (a[M,K] @ w[N,K]^T) + bias). EPI_F32_RESID accumulates into `out` (fp32, required)."""
