@@ -1028,16 +1028,27 @@ int vt_gemm_skinny_norm_launch(const bf16_t* A, int lda, const bf16_t* W, int ld
 int vt_gemm_resid_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, float* C, int ldc, const float* bias, int M, int N,
                          int K, int ksplit, float* partials, size_t partial_bytes, hipStream_t s, const VtGemmNormFuse* nf) {
   int ks = ksplit;
+  // K splits that fill one round of the chip with 256x256 tiles: floor(256 / tiles), bounded by the K loop and by 8
+  const int sk_tiles = cdiv(M, 256) * cdiv(N, 256);
+  const int sk_cand = std::min(std::min(256 / std::max(sk_tiles, 1), (K >> 7) / 2), 8);
+  const bool sk_room = partials && (N % 4) == 0 && partial_bytes >= (size_t)std::max(sk_cand, 1) * M * N * sizeof(float);
   if (ks == 0 && M > 64 && vt_gemm_p8_supported(M, N, K)) {
-    // a 160x128 grid that covers at least half the chip beats the two-pass split-K (1088 x 4096 x 11008: 1077 vs 724 TFLOP/s)
+    // A 160x128 grid that covers at least half the chip beats the two-pass split-K on a SHORT K loop (768 x 4096 x 4096: 45 vs 47 us at 5
+    // splits). On a LONG one (down_proj, K = 11008) with COLD weights -- what every layer of a prefill sees -- the split that fills the chip
+    // wins once it has 3 or more parts (round 5, weights rotated over > 600 MB: 512 rows 88 -> 62 us at 8 splits, 640: 112 -> 70 (5),
+    // 768: 114 -> 84 (5), 896: 106 -> 83 (4), 1088: 112 -> 97 (3); round 2's 1077 vs 724 TFLOP/s at 1088 rows was measured on warm weights)
+    const bool long_k_split = !nf && sk_room && K >= 8192 && sk_cand >= 3 && (long)sk_tiles * sk_cand >= 192;
     const VtGemmPlan plan = vt_gemm_plan(M, N, K, VT_EPI_F32_RESID, nf);
-    if (plan.M1 == 0 && plan.cfg == VT_GEMM_CFG_160x128_W4 && (long)cdiv(M, 160) * cdiv(N, 128) >= 128)
+    if (!long_k_split && plan.M1 == 0 && plan.cfg == VT_GEMM_CFG_160x128_W4 && (long)cdiv(M, 160) * cdiv(N, 128) >= 128)
       return vt_gemm_launch(A, lda, W, ldw, C, ldc, bias, M, N, K, VT_EPI_F32_RESID, plan.cfg, s, nf);
   }
   if (ks == 0 && partials && M > 64 && vt_gemm_p8_supported(M, N, K) && (N % 4) == 0) {
-    const int tiles = cdiv(M, 256) * cdiv(N, 256);
-    const int cand = std::min(std::min(256 / std::max(tiles, 1), (K >> 7) / 2), 8);
-    if (tiles <= 128 && cand >= 2 && (long)tiles * cand >= 128 && vt_gemm_splitk_pays(M, N, K, cand) &&
+    const int tiles = sk_tiles;
+    const int cand = sk_cand;
+    // (>= 128 work items; a handful of rows x N = 1024 with a long K loop -- one image's fc2: 257 x 1024 x 4096, 8 tiles -- pays from 64:
+    //  40 -> 27 us at 8 splits, 514 rows 38 -> 27)
+    const long need = (K >= 4096 && cand >= 8 && N <= 1024) ? 64 : 128;
+    if (tiles <= 128 && cand >= 2 && (long)tiles * cand >= need && vt_gemm_splitk_pays(M, N, K, cand) &&
         partial_bytes >= (size_t)cand * M * N * sizeof(float))
       ks = cand;
     if (ks == 0) {
