@@ -25,9 +25,10 @@ def f32(sd):
     return {k: v.float() for k, v in sd.items()}
 
 
-def build_vit(ns, cfg: dict, sd):
-    """The reference's CLIPVisionTransformer for a tower config (video file when add_time_attn, image file otherwise)."""
-    if cfg["add_time_attn"]:
+def build_vit(ns, cfg: dict, sd, image_file: bool = False):
+    """The reference's CLIPVisionTransformer for a tower config (video file when add_time_attn, image file otherwise; image_file=True
+    forces the image file's class -- its add_time_attn variant carries a temporal MLP per layer, image/modeling_image.py:83-84)."""
+    if cfg["add_time_attn"] and not image_file:
         cv, mv = ns.configuration_video, ns.modeling_video
     else:
         cv, mv = ns.configuration_image, ns.modeling_image

@@ -34,20 +34,10 @@ def f32(sd):
 def build_ref_vit(ns, cfg, sd):
     # video tower: video/modeling_video.py; image tower: image/modeling_image.py (no 'b t n c' view of hidden states; its add_time_attn
     # variant -- cfg["temporal_mlp"] -- has a temporal MLP behind the temporal attention)
-    if cfg["add_time_attn"] and not cfg.get("temporal_mlp", False):
-        cv, mv = ns.configuration_video, ns.modeling_video
-    else:
-        cv, mv = ns.configuration_image, ns.modeling_image
-    c = cv.CLIPVisionConfig(hidden_size=cfg["hidden_size"], intermediate_size=cfg["intermediate_size"],
-                            num_hidden_layers=cfg["num_hidden_layers"], num_attention_heads=cfg["num_attention_heads"],
-                            image_size=cfg["image_size"], patch_size=cfg["patch_size"], hidden_act=cfg["hidden_act"],
-                            layer_norm_eps=cfg["layer_norm_eps"], add_time_attn=cfg["add_time_attn"],
-                            num_frames=cfg["num_frames"])
-    m = mv.CLIPVisionTransformer(c).eval()
-    missing, unexpected = m.load_state_dict(f32(sd), strict=False)
-    assert not unexpected, unexpected
-    assert all("position_ids" in k for k in missing), missing
-    return m
+    from oracle import ref_model
+    if cfg["add_time_attn"] and cfg.get("temporal_mlp", False):
+        return ref_model.build_vit(ns, cfg, sd, image_file=True)
+    return ref_model.build_vit(ns, cfg, sd)
 
 
 def gen_vit(ns):

@@ -33,15 +33,13 @@ import json
 import os
 import sys
 import time
-import types
 
 import numpy as np
 import torch
-import torch.nn as nn
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-from oracle import ref_shim  # noqa: E402
+from oracle import ref_model, ref_shim  # noqa: E402
 from tests.golden import cases, make_golden  # noqa: E402
 from vitron_amd import synth  # noqa: E402
 
@@ -120,22 +118,9 @@ def c3_weights(device="cpu"):
 
 
 def _attach_tower(ns, model, name):
-    lb = sys.modules["vitron.model.multimodal_encoder.languagebind"]
+    """The case's tower (image or video), the projector and the RegionExtractor on the reference's model (oracle/ref_model.py)."""
     vcfg, vsd, psd, rsd = case_weights(name)
-    video = vcfg["add_time_attn"]
-    cls, attr = (lb.LanguageBindVideoTower, "video_tower") if video else (lb.LanguageBindImageTower, "image_tower")
-    t = cls.__new__(cls)
-    nn.Module.__init__(t)
-    t.is_loaded, t.select_layer, t.select_feature = True, -2, "patch"
-    setattr(t, attr, make_golden.build_ref_vit(ns, vcfg, vsd))
-    model.model.video_tower = t if video else None
-    model.model.image_tower = None if video else t
-    pcfg = types.SimpleNamespace(mm_projector_type="mlp2x_gelu", mm_hidden_size=1024, hidden_size=4096)
-    model.model.mm_projector = ns.projector_builder.build_vision_projector(pcfg).eval()
-    model.model.mm_projector.load_state_dict(make_golden.f32(psd))
-    # the reference builds RegionExtractor(mm_hidden, hidden) with its default 224 canvas (region_extractor/builder.py:5, layer.py:60)
-    model.model.region_extractor = ns.region_layer.RegionExtractor(1024, 4096).eval()
-    model.model.region_extractor.load_state_dict(make_golden.f32(rsd))
+    ref_model.attach(ns, model, vcfg, vsd, psd, rsd)
 
 
 def _run_prefill_case(model, name):
@@ -211,31 +196,11 @@ def main(argv):
     names = [a for a in argv if a in CASES] or ["c3_224", "c2", "c2_224", "c5", "c5_224"]
     torch.set_num_threads(os.cpu_count() or 8)
     ns = ref_shim.install()
-    ll = ns.llava_llama
     t0 = time.time()
     lsd = llama_weights()
     print(f"weights: {time.time() - t0:.0f}s", flush=True)
-    c = synth.VICUNA_7B
-    cfg = ll.LlavaConfig(hidden_size=c["hidden_size"], intermediate_size=c["intermediate_size"], num_hidden_layers=c["num_hidden_layers"],
-                         num_attention_heads=c["num_attention_heads"], num_key_value_heads=c["num_attention_heads"],
-                         vocab_size=c["vocab_size"], rms_norm_eps=c["rms_norm_eps"], max_position_embeddings=8192,
-                         rope_theta=c["rope_theta"], tie_word_embeddings=False)
-    cfg._attn_implementation = "eager"
-    cfg.pretraining_tp = 1
-    try:
-        from transformers.modeling_utils import no_init_weights
-        init_ctx = no_init_weights()
-    except Exception:  # noqa: BLE001
-        init_ctx = contextlib.nullcontext()
-    with contextlib.redirect_stdout(io.StringIO()), init_ctx:
-        model = ll.LlavaLlamaForCausalLM(cfg).eval()
-    params = dict(model.named_parameters())
-    with torch.no_grad():
-        for k in list(lsd):
-            params[k].copy_(lsd.pop(k).float())
+    model = ref_model.build_decoder(ns, synth.VICUNA_7B, lsd)
     table = model.get_model().embed_tokens.weight.detach()
-    model.config.tokenizer_model_max_length = None
-    model.config.tokenizer_padding_side = "right"
     print(f"decoder built: {time.time() - t0:.0f}s", flush=True)
     rep_path = os.path.join(ROOT, "profiles", "r2_cpu_reference.json" if names == ["c3"] else "r5_cpu_reference.json")
     rep = {}
