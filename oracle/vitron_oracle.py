@@ -451,7 +451,7 @@ def llama_forward(sd: SD, cfg: dict, inputs_embeds: torch.Tensor, position_ids: 
 
 def greedy_generate(sd: SD, cfg: dict, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor,
                     position_ids: torch.Tensor, max_new_tokens: int, emulate_bf16: bool = False,
-                    eos_token_id: Optional[int] = None, ids_mask: Optional[torch.Tensor] = None):
+                    eos_token_id: Optional[int] = None, ids_mask: Optional[torch.Tensor] = None, return_logits: bool = False):
     """Greedy GenerationMixin loop with Vitron's decode-step fix-up (reference llava_arch.py:196-205): on every
     step the mask is extended to past_len+1 and position_ids = sum(mask) - 1. Returns [B, <=max_new_tokens] ids.
 
@@ -466,12 +466,14 @@ def greedy_generate(sd: SD, cfg: dict, inputs_embeds: torch.Tensor, attention_ma
     logits, past = llama_forward(sd, cfg, inputs_embeds, position_ids, attention_mask, None, emulate_bf16)
     if ids_mask is None:
         last = attention_mask.long().sum(1) - 1  # right padding: last valid position
-        nxt = logits[torch.arange(B), last].argmax(-1)
+        row = logits[torch.arange(B), last]
         mask = attention_mask.clone()
     else:
-        nxt = logits[:, -1].argmax(-1)
+        row = logits[:, -1]
         mask = ids_mask.clone()
+    nxt = row.argmax(-1)
     out = [nxt]
+    rows = [row]
     finished = torch.zeros(B, dtype=torch.bool)
     for _ in range(max_new_tokens - 1):
         if eos_token_id is not None:
@@ -484,6 +486,9 @@ def greedy_generate(sd: SD, cfg: dict, inputs_embeds: torch.Tensor, attention_ma
         logits, past = llama_forward(sd, cfg, embed[nxt].unsqueeze(1), pos, mask, past, emulate_bf16)
         nxt = logits[:, -1].argmax(-1)
         out.append(nxt)
+        rows.append(logits[:, -1])
+    if return_logits:   # (ids [B, steps], the logits row every id was the arg-max of [B, steps, V])
+        return torch.stack(out, dim=1), torch.stack(rows, dim=1)
     return torch.stack(out, dim=1)
 
 

@@ -323,6 +323,52 @@ def test_batched_generate_rows_are_the_batch1_rows_of_the_reference(dev, model, 
     print("batched generate vs the reference:", report)
 
 
+def test_padded_batch_generate_reproduces_the_references_batch_ids(dev, model, record_property):
+    """generate(padded_batch=True) (round 5): the ids the REFERENCE's own B > 1 generate() returns for the right-padded
+    `batch_pad` case (tests/golden/greedy_batch.npz: transformers 4.31's loop restated over the reference's forward) -- first token of the
+    shorter sample read from its last PAD row, pad rows attended by every later step, the rows that share an index with the ids-length
+    mask's zeros masked. Compared id by id up to the first step a flip is legitimate (the fp32 oracle's top-2 margin at that step inside
+    the bf16 noise of the row); the default packed path must keep returning the batch-1 rows."""
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "greedy_batch.npz"))
+    case = cases.glue_cases()["batch_pad"]
+    ids, am = case["input_ids"].to(dev), case["attention_mask"].to(dev)
+    images = [im.to(dev).bfloat16() for im in case["images"]]
+    want = G["batch_pad_padded_ids"]
+    n_new = int(want.shape[1])
+    out, step_logits = model.generate(ids, images=images, regions=case["regions"], attention_mask=am, do_sample=False, max_new_tokens=n_new,
+                                      eos_token_id=-1, return_logits=True, padded_batch=True)
+    new = out[:, ids.shape[1]:].cpu()
+    stats = model.last_generate_stats["padded_batch"]
+    lengths = G["batch_pad_spliced_lengths"].tolist()
+    shorter, longest = int(np.argmin(lengths)), int(np.argmax(lengths))
+    assert stats["pad_rows"] == {shorter: max(lengths) - min(lengths)} and stats["masked_rows"] == {shorter: ids.shape[1] - int(am[shorter].sum())}
+    # the fp32 oracle's padded-batch loop: the same ids as the reference (tests/test_oracle_golden.py) and the margins behind them
+    w = {k: f32(v) for k, v in _states().items()}
+    e, mask, pos = O.multimodal_prepare(w, CFGS, case["input_ids"], case["attention_mask"], case["images"], case["regions"])
+    o_ids, o_rows = O.greedy_generate(w["llama"], cases.LLM, e, mask.long(), pos, n_new, ids_mask=case["attention_mask"].long(), return_logits=True)
+    assert o_ids.tolist() == want.tolist()
+    report = {}
+    for b in range(ids.shape[0]):
+        got = new[b].tolist()
+        agree = next((t for t in range(n_new) if got[t] != int(want[b][t])), n_new)
+        worst = max(rel_l2(step_logits[t][b].float().cpu(), o_rows[b, t]) for t in range(agree + (agree < n_new)))
+        if agree < n_new:           # a flip is allowed only where the reference's own margin is within the bf16 noise of the row
+            top2 = o_rows[b, agree].topk(2).values
+            assert float(top2[0] - top2[1]) < 3e-2 * float(o_rows[b, agree].pow(2).mean().sqrt()), (b, agree, got, want[b].tolist())
+        assert worst <= 1.1e-1, (b, worst)                                   # TOL_TINY_LOGITS of the decode parity tests
+        report[f"sample{b}_ids_equal_to_reference_padded_batch"] = agree
+        report[f"sample{b}_worst_step_logits_vs_oracle"] = round(worst, 5)
+    assert report[f"sample{shorter}_ids_equal_to_reference_padded_batch"] >= 1          # the first token comes from the pad row, as in the reference
+    alone_short = G[f"batch_pad_alone{shorter}_ids"].tolist()
+    assert new[shorter].tolist() != alone_short                                       # ... and differs from the packed / batch-1 result
+    packed = model.generate(ids, images=images, regions=case["regions"], attention_mask=am, do_sample=False, max_new_tokens=n_new, eos_token_id=-1)
+    assert packed[shorter, ids.shape[1]:].tolist()[:1] == alone_short[:1]
+    model.reset_prefix_cache()
+    assert len(model.kv.free) == model.kv.num_pages                                    # every page (pads, compaction copies) returned
+    record_property("padded_batch_generate_vs_reference", report)
+    print("padded-batch generate vs the reference:", report)
+
+
 def test_decode_matches_prefill(dev, model):
     from vitron_amd.engine import PagedKVCache, SequenceState, llama_forward
     llama = model.get_model().llama

@@ -439,6 +439,7 @@ class PackedLlama:
         self.rope_len = int(rope_len or max(cfg.get("max_position_embeddings", 4096), 8192))
         self.rope_cos, self.rope_sin = rope_tables(self.hd, self.rope_len, float(cfg.get("rope_theta", 10000.0)), dev)
         self.layers = (_lib.VtLlamaLayer * self.L)()
+        self.layer_tensors: List[dict] = []
         for l in range(self.L):
             p = f"model.layers.{l}."
             Ly = self.layers[l]
@@ -448,14 +449,15 @@ class PackedLlama:
             for name, shp in want.items():
                 if tuple(sd[p + name + ".weight"].shape) != shp:
                     raise _lib.VitronHipError(f"PackedLlama: {p}{name}.weight is {tuple(sd[p + name + '.weight'].shape)}, config says {shp}")
-            Ly.rms1 = keep(_f32(sd[p + "input_layernorm.weight"], dev)).data_ptr()
-            Ly.rms2 = keep(_f32(sd[p + "post_attention_layernorm.weight"], dev)).data_ptr()
-            wqkv = torch.cat([_bf(sd[p + "self_attn.q_proj.weight"], dev), _bf(sd[p + "self_attn.k_proj.weight"], dev),
-                              _bf(sd[p + "self_attn.v_proj.weight"], dev)], 0)
-            Ly.wqkv = keep(wqkv).data_ptr()
-            Ly.wo = keep(_bf(sd[p + "self_attn.o_proj.weight"], dev)).data_ptr()
-            Ly.wgu = keep(interleave_gate_up(_bf(sd[p + "mlp.gate_proj.weight"], dev), _bf(sd[p + "mlp.up_proj.weight"], dev)).contiguous()).data_ptr()
-            Ly.wdown = keep(_bf(sd[p + "mlp.down_proj.weight"], dev)).data_ptr()
+            t = {"rms1": keep(_f32(sd[p + "input_layernorm.weight"], dev)), "rms2": keep(_f32(sd[p + "post_attention_layernorm.weight"], dev)),
+                 "wqkv": keep(torch.cat([_bf(sd[p + "self_attn.q_proj.weight"], dev), _bf(sd[p + "self_attn.k_proj.weight"], dev),
+                                         _bf(sd[p + "self_attn.v_proj.weight"], dev)], 0)),
+                 "wo": keep(_bf(sd[p + "self_attn.o_proj.weight"], dev)),
+                 "wgu": keep(interleave_gate_up(_bf(sd[p + "mlp.gate_proj.weight"], dev), _bf(sd[p + "mlp.up_proj.weight"], dev)).contiguous()),
+                 "wdown": keep(_bf(sd[p + "mlp.down_proj.weight"], dev))}
+            self.layer_tensors.append(t)      # the packed tensors by name (engine.padded_batch_fixup runs single rows through the primitive ops)
+            Ly.rms1, Ly.rms2 = t["rms1"].data_ptr(), t["rms2"].data_ptr()
+            Ly.wqkv, Ly.wo, Ly.wgu, Ly.wdown = t["wqkv"].data_ptr(), t["wo"].data_ptr(), t["wgu"].data_ptr(), t["wdown"].data_ptr()
         m = _lib.VtLlamaModel()
         m.hidden, m.heads, m.head_dim, m.intermediate, m.num_layers, m.vocab = H, heads, self.hd, self.I, self.L, self.V_pad
         m.rms_eps = float(cfg.get("rms_norm_eps", 1e-5))
@@ -608,6 +610,89 @@ def _llama_call(lib, llama, kv, embeds, rows, pos_t, desc_t, nseq, max_q, max_ne
                                     None if logits is None else logits.data_ptr(),
                                     None if hidden is None else hidden.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
                "vt_llama_forward", lib)
+
+
+def padded_batch_fixup(llama: PackedLlama, kv: PagedKVCache, seqs: Sequence[SequenceState], padded_len: int,
+                       ids_valid: Sequence[int], ids_len: int) -> dict:
+    """Turn the packed prefill of a RIGHT-padded batch into the state the REFERENCE's padded-batch generate() decodes from
+    (`generate(..., padded_batch=True)`; reference llava_arch.py:196-205 + transformers 4.31 GenerationMixin, restated step by step in
+    tests/golden/make_golden._padded_batch_greedy_hf431 and pinned by tests/golden/greedy_batch.npz):
+
+      * the reference prefills the spliced batch padded to `padded_len` rows: a pad row (zero embedding, position 0) attends the sample's
+        VALID keys only -- not itself, not the other pads -- and its K / V land in the cache like any row's. All pad rows of a sample are
+        identical, so ONE row per sample is run here through the primitive operators (RMSNorm, weight-streaming GEMMs, single-query
+        attention over the cache without append), layer by layer, and its K / V are written to the cache rows [valid, padded_len);
+      * the first token of a sample shorter than the longest is read from its LAST PAD ROW (`logits[:, -1]`) -> returned as `pad_logits`;
+      * every decode step attends the whole cache EXCEPT the rows [ids_valid[b], ids_len) -- the zeros of the ids-length mask, which the
+        fix-up aligns with whatever spliced rows share their index -- at position (rows attended) - 1. That hole never changes, so the
+        cache is COMPACTED once (rows before and behind the hole gathered into fresh pages: K rows carry their rotary position with
+        them) and the ordinary decode kernels run on it: position = compacted length + step, exactly the reference's.
+
+    seqs: the sequences after the packed prefill (length = valid spliced rows). Returns {"pad_logits": {b: fp32 [V]}, "holes": {b: n}}."""
+    from . import ops
+    dev, H, heads, hd, dt = llama.device, llama.H, llama.heads, llama.hd, llama.dtype
+    B = len(seqs)
+    valid = [s.length for s in seqs]
+    pads = [b for b in range(B) if valid[b] < padded_len]
+    kview = kv.k.view(llama.L, kv.num_pages, heads, PAGE_TOKENS, hd)
+    vview = kv.vt.view(llama.L, kv.num_pages, heads, hd, PAGE_TOKENS)
+    pad_logits = {}
+    if pads:
+        eps = float(llama.model.rms_eps)
+        for b in pads:                                                    # pages for the pad rows
+            need = (padded_len + PAGE_TOKENS - 1) // PAGE_TOKENS
+            if need > len(seqs[b].pages):
+                seqs[b].pages += kv.alloc(need - len(seqs[b].pages))
+        table, desc_q, desc_w, rep = [], [], [], []
+        row0 = 0
+        for i, b in enumerate(pads):
+            npad = padded_len - valid[b]
+            desc_q.append([i, 1, valid[b], len(table)])                   # the pad row's attention: the VALID keys only
+            desc_w.append([row0, npad, padded_len, len(table)])           # its K / V as "new tokens" [valid, padded_len)
+            table += seqs[b].pages
+            rep += [i] * npad
+            row0 += npad
+        table_t = torch.tensor(table, dtype=torch.int32, device=dev)
+        desc_q_t = torch.tensor(desc_q, dtype=torch.int32, device=dev)
+        desc_w_t = torch.tensor(desc_w, dtype=torch.int32, device=dev)
+        rep_t = torch.tensor(rep, dtype=torch.long, device=dev)
+        max_kv = max(valid[b] for b in pads)
+        max_new_tiles = max((padded_len - 1) // PAGE_TOKENS - valid[b] // PAGE_TOKENS + 1 for b in pads)
+        x = torch.zeros((len(pads), H), dtype=torch.float32, device=dev)  # the zero embedding of a pad row (llava_arch.py:520-533)
+        lstride = kv.num_pages * heads * PAGE_TOKENS * hd
+        for l, t in enumerate(llama.layer_tensors):
+            k_l, vt_l = kv.k[l * lstride:(l + 1) * lstride], kv.vt[l * lstride:(l + 1) * lstride]
+            y = ops.rmsnorm(x, t["rms1"], eps, dtype=dt)
+            qkv = ops.gemm(y, t["wqkv"], None, ops.EPI_BF16)             # position 0: the rotary embedding is the identity
+            att = ops.attn_decode(qkv[:, :H], k_l, vt_l, table_t, desc_q_t, heads, hd, 1.0 / math.sqrt(hd), max_kv)
+            ops.kv_tiles(qkv.index_select(0, rep_t).contiguous(), 0, H, 2 * H, k_l, vt_l, table_t, desc_w_t, max_new_tiles, heads, hd)
+            x = ops.gemm(att, t["wo"], None, ops.EPI_F32_RESID, out=x)
+            h = ops.gemm(ops.rmsnorm(x, t["rms2"], eps, dtype=dt), t["wgu"], None, ops.EPI_SWIGLU_BF16)
+            x = ops.gemm(h, t["wdown"], None, ops.EPI_F32_RESID, out=x)
+        lg = ops.gemm(ops.rmsnorm(x, llama.final_norm, eps, dtype=dt), llama.lm_head, None, ops.EPI_F32)[:, :llama.V]
+        for i, b in enumerate(pads):
+            pad_logits[b] = lg[i]
+            seqs[b].length = padded_len
+    holes = {}
+    for b in range(B):
+        lo, hi = int(ids_valid[b]), min(int(ids_len), seqs[b].length)
+        if hi <= lo:
+            continue
+        keep = list(range(0, lo)) + list(range(hi, seqs[b].length))
+        old = seqs[b].pages
+        new = kv.alloc((len(keep) + PAGE_TOKENS - 1) // PAGE_TOKENS + 1)
+        kview[:, new] = 0
+        vview[:, new] = 0
+        src = torch.tensor(keep, dtype=torch.long, device=dev)
+        dst = torch.arange(len(keep), dtype=torch.long, device=dev)
+        oldp, newp = torch.tensor(old, dtype=torch.long, device=dev), torch.tensor(new, dtype=torch.long, device=dev)
+        sp, ss, dp, ds = oldp[src // PAGE_TOKENS], src % PAGE_TOKENS, newp[dst // PAGE_TOKENS], dst % PAGE_TOKENS
+        kview[:, dp, :, ds, :] = kview[:, sp, :, ss, :]                    # (row moves, no arithmetic: K rows carry their rotation)
+        vview[:, dp, :, :, ds] = vview[:, sp, :, :, ss]
+        kv.release(old)
+        seqs[b].pages, seqs[b].length = new, len(keep)
+        holes[b] = hi - lo
+    return {"pad_logits": pad_logits, "holes": holes}
 
 
 class DecodeState:

@@ -411,7 +411,12 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
     def generate(self, input_ids=None, images=None, regions=None, attention_mask=None, do_sample=False,
                  temperature=1.0, top_p=1.0, top_k=None, max_new_tokens=None, max_length=None, use_cache=True,
                  stopping_criteria=None, eos_token_id=None, pad_token_id=None, num_beams=1, seed=None,
-                 return_logits=False, **kwargs):
+                 return_logits=False, padded_batch=False, **kwargs):
+        """padded_batch=True (B > 1, right padding): reproduce what the REFERENCE's batched generate() returns -- transformers 4.31 reads the
+        first token of every sample from the last COLUMN of the padded logits (a pad row for the shorter samples) and the decode-step
+        fix-up (llava_arch.py:196-205) attends the pad rows of the spliced batch while masking the rows that share an index with the
+        ids-length mask's zeros (engine.padded_batch_fixup; pinned by tests/golden/greedy_batch.npz). Default False: sequences are packed
+        and every sample gets the ids the reference returns for it ALONE."""
         if num_beams != 1:
             raise NotImplementedError("beam search is not implemented (the reference entry points sample or go greedy)")
         dev = self.device
@@ -487,7 +492,17 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
                 self._prefix = None
         elif self._prefix is not None:
             self.reset_prefix_cache()
+        pad_mode = bool(padded_batch) and B > 1
+        if pad_mode:
+            if getattr(self.config, "tokenizer_padding_side", "right") != "right":
+                raise NotImplementedError("generate(padded_batch=True) reproduces the reference's RIGHT-padded batches only")
+            am_rows = attention_mask.to(torch.int32).tolist() if attention_mask is not None else [[1] * input_ids.shape[1]] * B
+            if any(any(a < b_ for a, b_ in zip(r, r[1:])) for r in am_rows):
+                raise NotImplementedError("generate(padded_batch=True): attention_mask must be right-padded (ones, then zeros)")
+            ids_valid = [sum(r) for r in am_rows]
         need = sum((l + max_new_tokens + 63) // 64 + 1 for l in lens) - kept // 64
+        if pad_mode:     # pad rows join the cache, and the compaction needs a second set of pages for a moment
+            need = sum(2 * ((S + 63) // 64 + 2) + (max_new_tokens + 63) // 64 + 1 for _ in lens)
         if self.kv is None or len(self.kv.free) < need:
             if kept:                                                          # cannot grow the pool around live pages: start over
                 self.kv.release(seqs[0].pages)
@@ -508,6 +523,13 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
         state = None
         try:   # (the prefill is inside: pages it took before a failure go back to the pool / the kept prefix below)
             logits = llama_forward(llama, self.kv, seqs, flat, lens, embeds_lo=flat_lo)     # [B, V]: last position of every sequence
+            if pad_mode:
+                from ...engine import padded_batch_fixup
+                fix = padded_batch_fixup(llama, self.kv, seqs, S, ids_valid, input_ids.shape[1])
+                logits = logits.clone()
+                for b, lg in fix["pad_logits"].items():       # shorter samples: the first token comes from their last PAD row
+                    logits[b] = lg
+                self.last_generate_stats["padded_batch"] = {"pad_rows": {b: S - lens[b] for b in fix["pad_logits"]}, "masked_rows": fix["holes"]}
             for step in range(max_new_tokens):
                 if return_logits:
                     all_logits.append(logits.clone())
