@@ -323,7 +323,8 @@ def test_batched_generate_rows_are_the_batch1_rows_of_the_reference(dev, model, 
     print("batched generate vs the reference:", report)
 
 
-def test_padded_batch_generate_reproduces_the_references_batch_ids(dev, model, record_property):
+@pytest.mark.parametrize("op", ["bf16", "fp16"])
+def test_padded_batch_generate_reproduces_the_references_batch_ids(dev, model, record_property, op):
     """generate(padded_batch=True) (round 5): the ids the REFERENCE's own B > 1 generate() returns for the right-padded
     `batch_pad` case (tests/golden/greedy_batch.npz: transformers 4.31's loop restated over the reference's forward) -- first token of the
     shorter sample read from its last PAD row, pad rows attended by every later step, the rows that share an index with the ids-length
@@ -332,7 +333,21 @@ def test_padded_batch_generate_reproduces_the_references_batch_ids(dev, model, r
     G = np.load(os.path.join(os.path.dirname(__file__), "golden", "greedy_batch.npz"))
     case = cases.glue_cases()["batch_pad"]
     ids, am = case["input_ids"].to(dev), case["attention_mask"].to(dev)
-    images = [im.to(dev).bfloat16() for im in case["images"]]
+    odt = torch.bfloat16
+    if op == "fp16":                       # the reference's inference dtype: a fresh model of the same weights in the fp16-operand build
+        from vitron_amd.model import LlavaConfig, LlavaLlamaForCausalLM
+        st = _states()
+        model = LlavaLlamaForCausalLM(LlavaConfig(**cases.LLM, mm_hidden_size=cases.MM_HIDDEN, mm_image_tower="golden/LanguageBind_Image",
+                                                  mm_video_tower="golden/LanguageBind_Video_merge"))
+        model.get_image_tower().load_state(cases.VIT_IMAGE, st["image_tower"])
+        model.get_video_tower().load_state(cases.VIT_VIDEO, st["video_tower"])
+        sd = dict(st["llama"])
+        sd.update({"model.mm_projector." + k: v for k, v in st["projector"].items()})
+        sd.update({"model.region_extractor." + k: v for k, v in st["region"].items()})
+        model.load_state_dict(sd)
+        model.to(dev, dtype=torch.float16)
+        odt = torch.float16
+    images = [im.to(dev).to(odt) for im in case["images"]]
     want = G["batch_pad_padded_ids"]
     n_new = int(want.shape[1])
     out, step_logits = model.generate(ids, images=images, regions=case["regions"], attention_mask=am, do_sample=False, max_new_tokens=n_new,
@@ -358,15 +373,18 @@ def test_padded_batch_generate_reproduces_the_references_batch_ids(dev, model, r
         assert worst <= 1.1e-1, (b, worst)                                   # TOL_TINY_LOGITS of the decode parity tests
         report[f"sample{b}_ids_equal_to_reference_padded_batch"] = agree
         report[f"sample{b}_worst_step_logits_vs_oracle"] = round(worst, 5)
-    assert report[f"sample{shorter}_ids_equal_to_reference_padded_batch"] >= 1          # the first token comes from the pad row, as in the reference
+    # the first token comes from the pad row, as in the reference; the fp16 build (the reference's inference dtype) returns the reference's
+    # padded-batch ids exactly (measured: 12 of 12 on both samples; bf16: 7 / 6 until a step whose margin is inside the noise)
+    assert report[f"sample{shorter}_ids_equal_to_reference_padded_batch"] >= (1 if op == "bf16" else n_new)
+    assert op == "bf16" or report[f"sample{longest}_ids_equal_to_reference_padded_batch"] == n_new
     alone_short = G[f"batch_pad_alone{shorter}_ids"].tolist()
     assert new[shorter].tolist() != alone_short                                       # ... and differs from the packed / batch-1 result
     packed = model.generate(ids, images=images, regions=case["regions"], attention_mask=am, do_sample=False, max_new_tokens=n_new, eos_token_id=-1)
     assert packed[shorter, ids.shape[1]:].tolist()[:1] == alone_short[:1]
     model.reset_prefix_cache()
     assert len(model.kv.free) == model.kv.num_pages                                    # every page (pads, compaction copies) returned
-    record_property("padded_batch_generate_vs_reference", report)
-    print("padded-batch generate vs the reference:", report)
+    record_property(f"padded_batch_generate_vs_reference_{op}", report)
+    print(f"padded-batch generate vs the reference [{op}]:", report)
 
 
 def test_decode_matches_prefill(dev, model):
