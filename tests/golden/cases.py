@@ -230,3 +230,32 @@ ACCEPTANCE_USER_TURNS = {
     "image_region": " <image>\n<objs> What is in this region?",
     "video": " ".join(["<image>"] * 4) + "\nWhy is this video funny?",
 }
+
+
+# ---- pre-processing pins (round 5): synthetic decoded pictures / clips for the reference's own processors (preproc_ref.npz) -------------
+# name -> (frames, H, W): portrait, landscape, already 224 x 224 (Resize returns its input), an up-scale, a long side that lands on
+# int(224 * 500 / 333) = 336; clips: landscape with more frames than are sampled, portrait with exactly 8, FEWER frames than are sampled
+# (np.linspace(..., dtype=int) repeats indices) on a square up-scale
+PREPROC_IMAGES = {"portrait": (1, 300, 200), "landscape": (1, 240, 320), "identity": (1, 224, 224), "upscale": (1, 97, 131),
+                  "long336": (1, 333, 500)}
+PREPROC_CLIPS = {"clip_landscape": (20, 120, 200), "clip_portrait": (8, 150, 100), "clip_short": (5, 64, 64)}
+PREPROC_SEED = 9100
+PREPROC_IMG_STRIDE, PREPROC_CLIP_STRIDE = 3, 6      # the fixture keeps every n-th pixel of an output (+ float64 sums over all of them)
+
+
+def preproc_frames(shape, seed):
+    """Smooth + noisy uint8 frames [F,H,W,3] (structure at several scales, so that resampling errors show)."""
+    g = torch.Generator().manual_seed(seed)
+    F_, H, W = shape
+    yy, xx = torch.meshgrid(torch.linspace(0, 3.0, H), torch.linspace(0, 5.0, W), indexing="ij")
+    base = 127 + 90 * torch.sin(yy[None] * 2.1 + torch.arange(F_)[:, None, None]) * torch.cos(xx[None] * 1.3)
+    img = base[..., None] + torch.randn((F_, H, W, 3), generator=g) * 25 + torch.tensor([0.0, 12.0, -9.0])
+    return img.clamp(0, 255).to(torch.uint8)
+
+
+def preproc_inputs():
+    """name -> uint8 [F,H,W,3] for every pre-processing case, in a fixed order."""
+    out = {}
+    for i, (name, shp) in enumerate({**PREPROC_IMAGES, **PREPROC_CLIPS}.items()):
+        out[name] = preproc_frames(shp, PREPROC_SEED + i)
+    return out

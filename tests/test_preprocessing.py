@@ -77,3 +77,71 @@ def test_oracle_preprocess_on_the_references_example_images_is_frozen():
         assert np.allclose(got["probe_values"], c["probe_values"], atol=2e-5) and np.allclose(got["video_probe_values"], c["video_probe_values"], atol=2e-5)
         assert abs(got["checksum"] - c["checksum"]) <= 1e-6 * c["checksum"] and abs(got["video_checksum"] - c["video_checksum"]) <= 1e-6 * c["video_checksum"]
         assert np.allclose(got["mean"], c["mean"], atol=1e-5) and np.allclose(got["std"], c["std"], atol=1e-5)
+
+
+# ---- the reference's OWN processors (tests/golden/preproc_ref.npz; generator: make_golden_preproc.py::gen_ref) ------------------------
+def _ref_cases():
+    """(name, frames uint8 [F,H,W,3], flip or None for pictures, fixture entries) for every case of the fixture."""
+    import os
+
+    from tests.golden import cases
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "preproc_ref.npz"))
+    inputs = cases.preproc_inputs()
+    out = []
+    for n in cases.PREPROC_IMAGES:
+        assert float(inputs[n].double().sum()) == float(gold[n + "_in_checksum"]), "the seeded inputs drifted from the fixture's"
+        out.append((n, inputs[n], None, gold[n + "_sub"], gold[n + "_sums"], None, cases.PREPROC_IMG_STRIDE))
+    for n in cases.PREPROC_CLIPS:
+        assert float(inputs[n].double().sum()) == float(gold[n + "_in_checksum"])
+        for tag in ("keep", "flip"):
+            if f"{n}_{tag}_sub" in gold.files:
+                out.append((n, inputs[n], tag == "flip", gold[f"{n}_{tag}_sub"], gold[f"{n}_{tag}_sums"], gold[f"{n}_{tag}_idx"],
+                            cases.PREPROC_CLIP_STRIDE))
+    return out
+
+
+def _against_fixture(y, sub, sums, stride, tol):
+    y = y.float()
+    assert float((y[..., ::stride, ::stride] - torch.from_numpy(sub)).abs().max()) <= tol
+    yd = y.double().reshape(3, -1)
+    got = torch.stack([yd.sum(1), yd.abs().sum(1), (yd * yd).sum(1)], 1).numpy()
+    # (all pixels, not only the kept ones: sums of |.| and of squares within tol relative; the signed sum within tol per pixel)
+    assert np.all(np.abs(got[:, 1:] - sums[:, 1:]) <= 2 * tol * sums[:, 1:] + 1e-9)
+    assert np.all(np.abs(got[:, 0] - sums[:, 0]) <= tol * yd.shape[1])
+
+
+def test_oracle_preprocess_matches_the_references_own_processors():
+    """The oracle's restatement (and the product's frame sampling rule) against the reference's LanguageBindImageProcessor /
+    LanguageBindVideoProcessor code, run unmodified over restated torchvision 0.15.2 / pytorchvideo 0.1.5 / decord / cv2 primitives
+    (oracle/ref_preproc.py): transform order, the hard-wired 224, constants, x / 255, layout permutes, BGR -> RGB, the frames
+    np.linspace picks (more, exactly, fewer frames than sampled), both outcomes of the inference-time random flip."""
+    from vitron_amd.processing import sample_frame_indices
+    seen_repeat = False
+    for name, fr, flip, sub, sums, idx, stride in _ref_cases():
+        if flip is None:
+            y = O.preprocess_image(fr[0], 224)
+        else:
+            mine = sample_frame_indices(fr.shape[0], 8)
+            assert mine.tolist() == idx.tolist(), name
+            seen_repeat |= len(set(idx.tolist())) < 8
+            y = O.preprocess_video(fr[torch.from_numpy(mine)], 224, flip)
+        _against_fixture(y, sub, sums, stride, 2e-6)
+    assert seen_repeat          # the fixture holds a clip with fewer frames than are sampled
+
+
+@pytest.mark.gpu
+def test_gpu_preprocess_matches_the_references_own_processors():
+    """vt_preprocess through the product's processors (same entry points app.py uses) against the same fixture: fp32 output within 2e-4
+    (fp32 tap weights in another summation order), 16-bit output within its rounding."""
+    from vitron_amd.processing import LanguageBindImageProcessor, LanguageBindVideoProcessor
+    ip = LanguageBindImageProcessor(image_size=224, dtype=torch.float32)
+    for name, fr, flip, sub, sums, idx, stride in _ref_cases():
+        if flip is None:
+            y = ip.preprocess([fr[0].numpy()], return_tensors="pt")["pixel_values"][0]
+            y16 = LanguageBindImageProcessor(image_size=224).preprocess([fr[0].numpy()], return_tensors="pt")["pixel_values"][0]
+        else:
+            y = LanguageBindVideoProcessor(image_size=224, num_frames=8, dtype=torch.float32, flip=flip)(fr)["pixel_values"][0]
+            y16 = LanguageBindVideoProcessor(image_size=224, num_frames=8, flip=flip)(fr)["pixel_values"][0]
+        assert y.dtype == torch.float32 and y16.dtype == torch.bfloat16
+        _against_fixture(y.cpu(), sub, sums, stride, 2e-4)
+        assert float((y16.float().cpu()[..., ::stride, ::stride] - torch.from_numpy(sub)).abs().max()) <= 2e-2
