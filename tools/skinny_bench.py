@@ -11,7 +11,9 @@ from vitron_amd import _lib, ops  # noqa: E402
 
 
 def main():
-    _lib.load()
+    # SKINNY_ABL=1 VT_SKINNY_VARIANT=<waves * 100 + ring slots>: the test library's other (waves, ring) shapes of the LDS-DMA kernel
+    abl = os.environ.get("SKINNY_ABL") == "1"
+    _lib.load(ablations=abl)
     dev = torch.device("cuda:0")
     shapes = [("qkv", 12288, 4096, ops.EPI_BF16), ("o_proj", 4096, 4096, ops.EPI_F32_RESID),
               ("gate_up", 22016, 4096, ops.EPI_SWIGLU_BF16), ("down", 4096, 11008, ops.EPI_F32_RESID),
@@ -25,7 +27,9 @@ def main():
             n_out = N // 2 if epi == ops.EPI_SWIGLU_BF16 else N
             out = torch.zeros((M, n_out), device=dev, dtype=torch.float32 if epi in (ops.EPI_F32, ops.EPI_F32_RESID) else torch.bfloat16)
             row = {"shape": name, "M": M, "N": N, "K": K}
-            for label, cfg in (("auto", 0), ("dma_ring", 1), ("tile_64x128", 5)):
+            if abl:
+                row["variant"] = os.environ.get("VT_SKINNY_VARIANT", "0")
+            for label, cfg in ((("auto", 0),) if abl else (("auto", 0), ("dma_ring", 1), ("tile_64x128", 5))):
                 for w in ws:
                     ops.gemm(a, w, None, epi, out=out, cfg=cfg)
                 torch.cuda.synchronize()

@@ -703,6 +703,21 @@ int launch_skinny(const GemmP& p, hipStream_t s, bool reg_operands) {
   // measured on MI355X (tools/skinny_bench.py): 4 waves x 4-slot rings beat 8x4, 4x8 and 2x8 on every decode shape
   if (p.M > 16) return launch_skinny_dma32<EPI>(p, s);   // 17..32 rows (K % 64 == 0 checked by the caller)
   if (reg_operands || (p.K % 64) != 0) return launch_skinny_mfma<EPI>(p, s);
+#ifdef VT_ABLATIONS   // VT_SKINNY_VARIANT=<waves * 100 + ring slots> tools/skinny_bench.py (test library): other (waves, ring) shapes, M <= 8
+  {
+    static const int variant = getenv("VT_SKINNY_VARIANT") ? atoi(getenv("VT_SKINNY_VARIANT")) : 0;
+    constexpr int NTv = (EPI == VT_EPI_SWIGLU_BF16) ? 2 : 1;
+    if (variant && p.M <= 8) {
+#define VT_SKV(NW, RR)                                                                               \
+  if (variant == NW * 100 + RR) {                                                                    \
+    if constexpr (NW * RR * (NTv * 2 + 1) * 1024 + 1024 + NW * NTv * 1024 <= 160 * 1024)             \
+      return launch_skinny_dma_cfg<EPI, 1, NW, RR>(p, s);                                            \
+  }
+      VT_SKV(8, 4) VT_SKV(4, 8) VT_SKV(2, 4) VT_SKV(2, 8) VT_SKV(8, 8) VT_SKV(3, 4) VT_SKV(6, 4) VT_SKV(4, 16) VT_SKV(2, 16)
+#undef VT_SKV
+    }
+  }
+#endif
   if (p.M <= 8) return launch_skinny_dma_cfg<EPI, 1, 4, 4>(p, s);
   return launch_skinny_dma_cfg<EPI, 2, 4, 4>(p, s);
 }
