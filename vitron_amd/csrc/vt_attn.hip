@@ -759,10 +759,11 @@ __global__ __launch_bounds__(256) void kv_tiles_precise_kernel(const float* __re
       if (v_f32) {   // level 2: v arrives in fp32 behind q | k (one rounding, here)
         const float* vp = qk32 + (size_t)row * ld32 + 2 * H + head * HD + c * 8;
         const f32x4 a = *(const f32x4*)vp, b = *(const f32x4*)(vp + 4);
-        v.x = pack_op2(a[0], a[1]);
-        v.y = pack_op2(a[2], a[3]);
-        v.z = pack_op2(b[0], b[1]);
-        v.w = pack_op2(b[2], b[3]);
+        // straight into the pages' fp16 (both operand builds: the bf16 build would otherwise round v to 8 bits first)
+        v.x = pack_f16x2(vt_clamp_f16(a[0]), vt_clamp_f16(a[1]));
+        v.y = pack_f16x2(vt_clamp_f16(a[2]), vt_clamp_f16(a[3]));
+        v.z = pack_f16x2(vt_clamp_f16(b[0]), vt_clamp_f16(b[1]));
+        v.w = pack_f16x2(vt_clamp_f16(b[2]), vt_clamp_f16(b[3]));
       } else {
         v = *(const u32x4*)(qkv + (size_t)row * ldqkv + v_col0 + head * HD + c * 8);
       }
@@ -776,15 +777,20 @@ __global__ __launch_bounds__(256) void kv_tiles_precise_kernel(const float* __re
     const bool full = fresh || (pos0 >= p_lo && pos0 + 8 <= p_hi);
     const bool any_new = (pos0 < p_hi) && (pos0 + 8 > p_lo);
     if (!full && !any_new) continue;
-    float vals[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) vals[j] = vt_clamp_f16(op_to_f32(vs[kc * 8 + j][d]));
     uint16_t* dst = vt + d * 64 + kc * 8;
     u32x4 w;
-    w.x = pack_f16x2(vals[0], vals[1]);
-    w.y = pack_f16x2(vals[2], vals[3]);
-    w.z = pack_f16x2(vals[4], vals[5]);
-    w.w = pack_f16x2(vals[6], vals[7]);
+    if (v_f32) {   // the staging buffer already holds fp16
+#pragma unroll
+      for (int q = 0; q < 4; ++q) w[q] = (uint32_t)vs[kc * 8 + 2 * q][d] | ((uint32_t)vs[kc * 8 + 2 * q + 1][d] << 16);
+    } else {
+      float vals[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) vals[j] = vt_clamp_f16(op_to_f32(vs[kc * 8 + j][d]));
+      w.x = pack_f16x2(vals[0], vals[1]);
+      w.y = pack_f16x2(vals[2], vals[3]);
+      w.z = pack_f16x2(vals[4], vals[5]);
+      w.w = pack_f16x2(vals[6], vals[7]);
+    }
     if (full) {
       *(u32x4*)dst = w;
     } else {
