@@ -318,9 +318,12 @@ typedef struct vt_vit_model {
   const float* pos;        /* [G*G+1][D] */
   const float *pre_ln_g, *pre_ln_b;
   const vt_vit_layer* layers; /* host array [num_layers] */
-  int precise;             /* 2: precise level 2 -- the MLP's two GEMM operands (layer_norm2 output, activation output) travel as operand
-                              pairs (hi + lo), every product as two launches accumulating in fp32; with out_feats_lo the selected patch
-                              tokens leave as a pair too. 0 (default): standard. */
+  int precise;             /* 2: precise level 2 -- EVERY GEMM A operand of the tower travels as an operand pair (hi + lo), every product as
+                              two launches accumulating in fp32: the norm outputs, q and k through the attention scores (the decoder's
+                              precise kernels at head_dim 64; v goes from fp32 straight into the V^T tiles' fp16), the attention outputs,
+                              the temporal attention in fp32, the activation outputs; with out_feats_lo the selected patch tokens leave
+                              as a pair too. The hidden state is then within ~1e-5 of fp32 in both operand builds. 0 (default):
+                              standard. */
   uint16_t* out_feats_lo;  /* optional DEVICE buffer [B*T*G*G][D]: the low half of out_feats (precise == 2 only) */
 } vt_vit_model;
 

@@ -186,6 +186,46 @@ def test_towers_at_vit_l_336_vs_oracle_and_reference(dev, name, op):
         assert d_f32 <= 1.25 * emu_f32 + 2e-4 and ref_rows <= 1.25 * emu_f32 + 3e-4, (nl, d_f32, ref_rows, emu_f32)
 
 
+TOWER_PRECISE_TOL = 6e-5            # towers in precise level 2 vs fp32 / the reference, BOTH builds (measured 1.0e-5 .. 2.9e-5), x 2
+
+
+@pytest.mark.parametrize("op", OPERANDS)
+@pytest.mark.parametrize("name", ["video336", "image336", "video224", "image224"])
+def test_towers_precise_level_2_vs_reference(dev, name, op):
+    """vt_vit_model.precise = 2: every GEMM A operand of the tower an operand pair -- norm outputs, q and k through the scores (the decoder's
+    precise attention kernels at head_dim 64), v from fp32 straight into the V^T tiles, attention outputs, the temporal attention in fp32,
+    GELU outputs. What is left is V^T / P in fp16 and the pairs' 2^-17 (bf16) / 2^-23 (fp16): the hidden state is within 6e-5 of the fp32
+    oracle and of the REFERENCE's stored outputs in both operand builds -- the tower no longer contributes to the end-to-end distance."""
+    from vitron_amd.engine import PackedVit, pair_lo
+    odt, _, _ = FW.operand(op)
+    g = FW.golden_of(name)
+    cfg, sd, x = FW.vit_case(name)
+    nl = cases.FW_VIT_LAYERS
+    vit = PackedVit(sd, cfg, dev, select_layer=nl, dtype=odt)
+    _, h_std = vit.forward(x.to(dev).to(odt), return_hidden=True)
+    vit.set_precise(2)
+    feats, hidden = vit.forward(x.to(dev).to(odt), return_hidden=True)
+    lo = pair_lo(feats)
+    assert lo is not None and lo.shape == feats.shape
+    hidden, h_std = hidden.float().cpu().reshape(-1, 1024), h_std.float().cpu().reshape(-1, 1024)
+    with torch.no_grad():
+        h32 = O.vit_forward(f32(sd), cfg, x, num_layers=nl).reshape(-1, 1024)
+    d_f32, std_f32 = FW.rel(hidden, h32), FW.rel(h_std, h32)
+    ref_proj, ref_rows = FW.vs_pin(hidden, g, f"vit_{name}_hidden_{nl}")
+    # the features leave as a pair whose sum is the fp32 hidden state of the patch tokens
+    N = hidden.shape[0] // (x.shape[0] * (x.shape[2] if x.dim() == 5 else 1))
+    patch = hidden.reshape(-1, N, 1024)[:, 1:].reshape(-1, 1024)
+    d_pair = FW.rel((feats.float() + lo.float()).cpu().reshape(-1, 1024), patch)
+    _note(f"vit_{name}_layers{nl}_{op}-precise2", rows=hidden.shape[0], vs_fp32=d_f32, standard_mode_vs_fp32=std_f32, vs_reference_rows=ref_rows,
+          vs_reference_proj=ref_proj, feature_pair_vs_hidden=d_pair)
+    assert d_f32 <= TOWER_PRECISE_TOL and ref_rows <= TOWER_PRECISE_TOL and ref_proj <= TOWER_PRECISE_TOL, (d_f32, ref_rows, ref_proj)
+    assert d_f32 <= 0.2 * std_f32, (d_f32, std_f32)
+    assert d_pair <= (3e-5 if op == "bf16" else 1e-6), d_pair
+    vit.set_precise(0)
+    _, h_again = vit.forward(x.to(dev).to(odt), return_hidden=True)
+    assert torch.equal(h_again.float().cpu().reshape(-1, 1024), h_std)         # back to the standard kernels, bit for bit
+
+
 @pytest.mark.parametrize("which", ["336", "224"])
 @pytest.mark.parametrize("op", OPERANDS)
 def test_projector_and_region_at_full_width_vs_oracle_and_reference(dev, op, which):

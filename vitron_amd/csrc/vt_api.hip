@@ -390,9 +390,10 @@ struct VitWs {
   int *seq_desc, *tile_table;
   float* splitk;   // split-K partial products (single images: the N = 1024 projections cover a fraction of the chip)
   size_t splitk_bytes;
-  // precise level 2: the MLP's two operands as pairs (low halves) and fc1's fp32 output
-  bf16_t *ylo, *hlo;
-  float* h32;
+  // precise level 2: the MLP's two operands as pairs (low halves) and fc1's fp32 output; the attention paths' fp32 q | k | v, the low
+  // halves of q, of the keys (one workspace tile per page) and of the attention output
+  bf16_t *ylo, *hlo, *qlo, *klo, *attlo;
+  float *h32, *qkv32;
   size_t total;
 };
 VitWs vit_carve(const vt_vit_model* m, int B, int T, void* p, size_t n) {
@@ -414,12 +415,16 @@ VitWs vit_carve(const vt_vit_model* m, int B, int T, void* p, size_t n) {
   w.tile_table = (int*)ws.take((size_t)F * ntiles * 4);
   w.splitk_bytes = (size_t)8 * R * D * 4 <= ((size_t)64 << 20) ? (size_t)8 * R * D * 4 : 0;   // only worth it for a few frames
   w.splitk = w.splitk_bytes ? (float*)ws.take(w.splitk_bytes) : nullptr;
-  w.ylo = w.hlo = nullptr;
-  w.h32 = nullptr;
+  w.ylo = w.hlo = w.qlo = w.klo = w.attlo = nullptr;
+  w.h32 = w.qkv32 = nullptr;
   if (m->precise >= 2) {
     w.ylo = (bf16_t*)ws.take((size_t)R * D * 2);
     w.hlo = (bf16_t*)ws.take((size_t)R * I * 2);
     w.h32 = (float*)ws.take((size_t)R * I * 4);
+    w.qkv32 = (float*)ws.take((size_t)R * 3 * D * 4);
+    w.qlo = (bf16_t*)ws.take((size_t)R * D * 2);
+    w.klo = (bf16_t*)ws.take((size_t)F * ntiles * 64 * D * 2);
+    w.attlo = (bf16_t*)ws.take((size_t)R * D * 2);
   }
   w.total = ws.off + 256;
   return w;
@@ -450,6 +455,7 @@ int vt_vit_forward(const vt_vit_model* m, const void* pixels, int pix_dtype, int
   const int D = m->hidden, I = m->intermediate, heads = m->heads;
   const int AUTO = VT_GEMM_CFG_AUTO;
   const int act_epi = (m->act == VT_ACT_QUICK_GELU) ? VT_EPI_BF16_QGELU : VT_EPI_BF16_GELU;
+  const bool precise = m->precise >= 2 && w.qkv32 != nullptr;
 
   // embeddings: patch GEMM (fp32 out) -> + CLS / position -> pre-LayerNorm -> fp32 residual stream x
   VT_TRY(vt_im2col_launch(pixels, pix_dtype, w.patches, B, T, m->image_size, m->image_size, m->patch, m->k_pad, video_layout, s));
@@ -459,7 +465,25 @@ int vt_vit_forward(const vt_vit_model* m, const void* pixels, int pix_dtype, int
 
   for (int l = 0; l < m->num_layers; ++l) {
     const vt_vit_layer& L = m->layers[l];
-    if (m->add_time_attn) {
+    if (m->add_time_attn && precise) {
+      // precise level 2: the norm output as a pair, q | k | v into fp32 (two launches), the T x T attention in fp32, its output as a pair
+      VT_TRY(vt_layernorm_launch(w.x, (T != 1) ? L.t_embed : nullptr, T, N, L.t_ln_g, L.t_ln_b, w.y, R, D, m->ln_eps, s));   // (adds the embedding)
+      VT_TRY(vt_layernorm_hilo_launch(w.x, L.t_ln_g, L.t_ln_b, w.y, w.ylo, R, D, m->ln_eps, s));
+      VT_TRY(vt_gemm_launch(w.y, D, L.t_wqkv, D, w.qkv32, 3 * D, L.t_bqkv, R, 3 * D, D, VT_EPI_F32, AUTO, s));
+      VT_TRY(vt_gemm_resid_launch(w.ylo, D, L.t_wqkv, D, w.qkv32, 3 * D, nullptr, R, 3 * D, D, 0, w.splitk, w.splitk_bytes, s));
+      VT_TRY(vt_attn_temporal_f32_launch(w.qkv32, 3 * D, w.att, w.attlo, B, T, N, heads, s));
+      VT_TRY(vt_gemm_resid_launch(w.att, D, L.t_wo, D, w.x, D, L.t_bo, R, D, D, 0, w.splitk, w.splitk_bytes, s));
+      VT_TRY(vt_gemm_resid_launch(w.attlo, D, L.t_wo, D, w.x, D, nullptr, R, D, D, 0, w.splitk, w.splitk_bytes, s));
+      if (L.t_w1) {   // the image tower's temporal MLP, operands as pairs like the spatial MLP below
+        VT_REQUIRE(L.t_ln2_g && L.t_ln2_b && L.t_w2 && L.t_b1 && L.t_b2, "vt_vit_forward: layer %d has a temporal MLP with missing tensors", l);
+        VT_TRY(vt_layernorm_hilo_launch(w.x, L.t_ln2_g, L.t_ln2_b, w.y, w.ylo, R, D, m->ln_eps, s));
+        VT_TRY(vt_gemm_launch(w.y, D, L.t_w1, D, w.h32, I, L.t_b1, R, I, D, VT_EPI_F32, AUTO, s));
+        VT_TRY(vt_gemm_resid_launch(w.ylo, D, L.t_w1, D, w.h32, I, nullptr, R, I, D, 0, w.splitk, w.splitk_bytes, s));
+        VT_TRY(vt_act_pair_launch(w.h32, I, w.h, w.hlo, R, I, m->act == VT_ACT_QUICK_GELU ? 1 : 0, s));
+        VT_TRY(vt_gemm_resid_launch(w.h, I, L.t_w2, I, w.x, D, L.t_b2, R, D, I, 0, w.splitk, w.splitk_bytes, s));
+        VT_TRY(vt_gemm_resid_launch(w.hlo, I, L.t_w2, I, w.x, D, nullptr, R, D, I, 0, w.splitk, w.splitk_bytes, s));
+      }
+    } else if (m->add_time_attn) {
       // x += temporal_embedding[t]; y = temporal_layer_norm1(x); temporal attention over T; x += out_proj
       VT_TRY(vt_layernorm_launch(w.x, (T != 1) ? L.t_embed : nullptr, T, N, L.t_ln_g, L.t_ln_b, w.y, R, D, m->ln_eps, s));
       VT_TRY(vt_gemm_launch(w.y, D, L.t_wqkv, D, w.qkv, 3 * D, L.t_bqkv, R, 3 * D, D, VT_EPI_BF16, AUTO, s));
@@ -473,13 +497,27 @@ int vt_vit_forward(const vt_vit_model* m, const void* pixels, int pix_dtype, int
       }
     }
     // spatial attention
-    VT_TRY(vt_layernorm_launch(w.x, nullptr, 0, 0, L.ln1_g, L.ln1_b, w.y, R, D, m->ln_eps, s));
-    VT_TRY(vt_gemm_launch(w.y, D, L.wqkv, D, w.qkv, 3 * D, L.bqkv, R, 3 * D, D, VT_EPI_BF16, AUTO, s));
-    VT_TRY(vt_kv_tiles_launch(w.qkv, 3 * D, 0, D, 2 * D, w.kt, w.vt, w.tile_table, (const VtAttnSeq*)w.seq_desc, F,
-                              cdiv(N, 64), heads, 64, nullptr, nullptr, nullptr, s));
-    VT_TRY(vt_flash_attn_launch(w.qkv, 3 * D, w.kt, w.vt, w.tile_table, (const VtAttnSeq*)w.seq_desc, F, N, w.att, D,
-                                heads, 64, 0, 1.0f, s));
-    VT_TRY(vt_gemm_launch(w.att, D, L.wo, D, w.x, D, L.bo, R, D, D, VT_EPI_F32_RESID, AUTO, s));
+    if (precise) {
+      // precise level 2: q and k as operand pairs through the scores (K_hi.(Q_hi + Q_lo)^T + K_lo.Q_hi^T), v from fp32 straight into the V^T
+      // tiles' fp16, the attention output as a pair into out_proj -- the same kernels as the decoder's precise prefill, at head_dim 64
+      VT_TRY(vt_layernorm_hilo_launch(w.x, L.ln1_g, L.ln1_b, w.y, w.ylo, R, D, m->ln_eps, s));
+      VT_TRY(vt_gemm_launch(w.y, D, L.wqkv, D, w.qkv32, 3 * D, L.bqkv, R, 3 * D, D, VT_EPI_F32, AUTO, s));
+      VT_TRY(vt_gemm_resid_launch(w.ylo, D, L.wqkv, D, w.qkv32, 3 * D, nullptr, R, 3 * D, D, 0, w.splitk, w.splitk_bytes, s));
+      VT_TRY(vt_kv_tiles_precise_launch(w.qkv32, 3 * D, 1, w.qkv, 3 * D, 0, 2 * D, w.qlo, w.kt, w.vt, w.klo, w.tile_table, (const VtAttnSeq*)w.seq_desc,
+                                        F, cdiv(N, 64), heads, 64, nullptr, nullptr, nullptr, s));
+      VT_TRY(vt_flash_attn_precise_launch(w.qkv, 3 * D, w.qlo, D, w.kt, w.klo, cdiv(N, 64), w.vt, w.tile_table, (const VtAttnSeq*)w.seq_desc, F, N,
+                                          w.att, D, w.attlo, heads, 64, 0, 1.0f, s));
+      VT_TRY(vt_gemm_resid_launch(w.att, D, L.wo, D, w.x, D, L.bo, R, D, D, 0, w.splitk, w.splitk_bytes, s));
+      VT_TRY(vt_gemm_resid_launch(w.attlo, D, L.wo, D, w.x, D, nullptr, R, D, D, 0, w.splitk, w.splitk_bytes, s));
+    } else {
+      VT_TRY(vt_layernorm_launch(w.x, nullptr, 0, 0, L.ln1_g, L.ln1_b, w.y, R, D, m->ln_eps, s));
+      VT_TRY(vt_gemm_launch(w.y, D, L.wqkv, D, w.qkv, 3 * D, L.bqkv, R, 3 * D, D, VT_EPI_BF16, AUTO, s));
+      VT_TRY(vt_kv_tiles_launch(w.qkv, 3 * D, 0, D, 2 * D, w.kt, w.vt, w.tile_table, (const VtAttnSeq*)w.seq_desc, F,
+                                cdiv(N, 64), heads, 64, nullptr, nullptr, nullptr, s));
+      VT_TRY(vt_flash_attn_launch(w.qkv, 3 * D, w.kt, w.vt, w.tile_table, (const VtAttnSeq*)w.seq_desc, F, N, w.att, D,
+                                  heads, 64, 0, 1.0f, s));
+      VT_TRY(vt_gemm_launch(w.att, D, L.wo, D, w.x, D, L.bo, R, D, D, VT_EPI_F32_RESID, AUTO, s));
+    }
     // MLP
     if (m->precise >= 2) {
       // precise level 2 (layer_norm2 -> fc1 and GELU -> fc2 carry half of the tower's distance from fp32): both operands as

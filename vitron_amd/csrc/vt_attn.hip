@@ -310,21 +310,22 @@ __global__ __launch_bounds__(64 * NWAVES, (NWAVES == 8) ? 2 : 2) void flash_attn
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// flash_attn_precise_kernel (vt_llama_model.precise_qk; head_dim 128, 4 waves x 32 query rows, 2-stage ring): flash_attn_kernel's
+// flash_attn_precise_kernel (vt_llama_model.precise_qk: head_dim 128, causal; vt_vit_model.precise: head_dim 64, the towers' spatial
+// attention; 4 waves x 32 query rows, 2-stage ring): flash_attn_kernel's
 // formulation with q and k as operand PAIRS written by kv_tiles_precise_kernel -- S^T = K_hi.(Q_hi + Q_lo)^T + K_lo.Q_hi^T, three MFMAs
 // per k step instead of one (the K_lo.Q_lo term is 2^-22 of the score and dropped): the score carries ~2^-20 of operand
 // rounding instead of 2^-12 (fp16) / 2^-9 (bf16), which is what the softmax amplifies. K_lo exists for the keys this
 // pass appended (a per-pass workspace: tile `t - (past >> 6)` of the sequence); older keys (prefix reuse, chunked prefill) have
 // K_hi only. P, V^T and the P.V MFMA are unchanged. LDS: K_hi + K_lo + V^T = 48 KiB per stage, 96 KiB: one workgroup per CU.
 // ------------------------------------------------------------------------------------------------------------------
-template <bool CAUSAL>
+template <bool CAUSAL, int HD>
 __global__ __launch_bounds__(256, 1) void flash_attn_precise_kernel(const bf16_t* __restrict__ Q, int ldq, const bf16_t* __restrict__ Qlo,
                                                                     int ldqlo, const bf16_t* __restrict__ Kt,
                                                                     const bf16_t* __restrict__ Klo, int klo_tiles_per_seq,
                                                                     const bf16_t* __restrict__ Vt, const int* __restrict__ tile_table,
                                                                     const VtAttnSeq* __restrict__ seqs, bf16_t* __restrict__ O, int ldo,
                                                                     bf16_t* __restrict__ Olo, int heads, float scale_log2e) {
-  constexpr int HD = 128, NWAVES = 4;
+  constexpr int NWAVES = 4;
   constexpr int KS = HD / 16, DB = HD / 32, KROW = HD * 2, TILE_BYTES = 64 * HD * 2, STAGE_BYTES = 3 * TILE_BYTES;
   constexpr int PIECES = TILE_BYTES / 1024, PPW = PIECES / NWAVES, QBLK = 32 * NWAVES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -705,7 +706,8 @@ __global__ __launch_bounds__(256) void kv_tiles_precise_kernel(const float* __re
     const bool is_new = pos >= p_lo && pos < p_hi;
     if (is_new) {
       const int row = sq.q_row0 + (pos - past);
-      const int rp = positions[row];
+      const bool rope = rope_cos != nullptr;     // the towers have no rotary embedding: identity (a * 1 - b * 0 is exact)
+      const int rp = rope ? positions[row] : 0;
       const float* cs = rope_cos + (size_t)rp * (HD / 2) + c * 8;
       const float* sn = rope_sin + (size_t)rp * (HD / 2) + c * 8;
       const float* qs = qk32 + (size_t)row * ld32 + head * HD;
@@ -713,7 +715,7 @@ __global__ __launch_bounds__(256) void kv_tiles_precise_kernel(const float* __re
       u32x4 q_h_lo, q_h_hi, q_l_lo, q_l_hi;
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
-        const float c0 = cs[2 * w], c1 = cs[2 * w + 1], s0 = sn[2 * w], s1 = sn[2 * w + 1];
+        const float c0 = rope ? cs[2 * w] : 1.f, c1 = rope ? cs[2 * w + 1] : 1.f, s0 = rope ? sn[2 * w] : 0.f, s1 = rope ? sn[2 * w + 1] : 0.f;
         {
           const float a0 = ks[c * 8 + 2 * w], a1 = ks[c * 8 + 2 * w + 1];
           const float b0 = ks[HD / 2 + c * 8 + 2 * w], b1 = ks[HD / 2 + c * 8 + 2 * w + 1];
@@ -1268,6 +1270,52 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(const bf16_t* __rest
   }
 }
 
+// precise level 2 (vt_vit_model.precise): the same attention on the fp32 q | k | v of the pair projection, everything in fp32, the output
+// as an operand pair (out_proj's A operand); one lane per head dim like the generic kernel (a verification mode: speed is not the point)
+template <int T>
+__global__ __launch_bounds__(256) void attn_temporal_f32_kernel(const float* __restrict__ qkv, int ld, bf16_t* __restrict__ out,
+                                                                bf16_t* __restrict__ out_lo, int B, int N, int heads) {
+  const int D = heads * 64;
+  const int lane = threadIdx.x & 63;
+  const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long total = (long)B * N * heads;
+  if (wid >= total) return;
+  const int head = (int)(wid % heads);
+  const long bn = wid / heads;
+  const int n = (int)(bn % N), b = (int)(bn / N);
+  float q[T], k[T], v[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const size_t row = ((size_t)b * T + t) * N + n;
+    const float* p = qkv + row * (size_t)ld + head * 64 + lane;
+    q[t] = p[0];
+    k[t] = p[D];
+    v[t] = p[2 * D];
+  }
+#pragma unroll
+  for (int t1 = 0; t1 < T; ++t1) {
+    float s[T];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t2 = 0; t2 < T; ++t2) {
+      s[t2] = wave_sum(q[t1] * k[t2]);
+      mx = fmaxf(mx, s[t2]);
+    }
+    float den = 0.f, acc = 0.f;
+#pragma unroll
+    for (int t2 = 0; t2 < T; ++t2) {
+      const float p = __expf(s[t2] - mx);
+      den += p;
+      acc += p * v[t2];
+    }
+    const size_t row = ((size_t)b * T + t1) * N + n;
+    const float o = acc / den;
+    const bf16_t hi = f32_to_op(o);
+    out[row * (size_t)D + head * 64 + lane] = hi;
+    out_lo[row * (size_t)D + head * 64 + lane] = f32_to_op(o - op_to_f32(hi));
+  }
+}
+
 // T == 8 (the LanguageBind video tower): one wave per (clip, position, head) with 16-byte accesses only.
 //   load  : lane (t = lane>>3, c = lane&7) fetches the 16-B chunk c of frame t's q, k and v head rows (8 lanes = one 128-B row)
 //           into a per-wave LDS image (rows padded to 144 B: conflict-free for the reads below),
@@ -1437,13 +1485,18 @@ int vt_kv_tiles_launch(bf16_t* qkv, int ldqkv, int q_col0, int k_col0, int v_col
 int vt_kv_tiles_precise_launch(const float* qk32, int ld32, int v_f32, bf16_t* qkv, int ldqkv, int q_col0, int v_col0, bf16_t* qlo, bf16_t* Kt, bf16_t* Vt,
                                bf16_t* klo, const int* tile_table, const VtAttnSeq* seqs, int nseq, int max_new_tiles, int heads, int HD,
                                const float* rope_cos, const float* rope_sin, const int* positions, hipStream_t s) {
-  VT_REQUIRE(qk32 && qkv && qlo && Kt && Vt && klo && tile_table && seqs && rope_cos && rope_sin && positions, "vt_kv_tiles_precise: null pointer");
-  VT_REQUIRE(HD == 128, "vt_kv_tiles_precise: head_dim %d unsupported (128)", HD);
+  VT_REQUIRE(qk32 && qkv && qlo && Kt && Vt && klo && tile_table && seqs, "vt_kv_tiles_precise: null pointer");
+  if (rope_cos) VT_REQUIRE(rope_sin && positions, "vt_kv_tiles_precise: rope needs sin table and positions");
+  VT_REQUIRE(HD == 128 || HD == 64, "vt_kv_tiles_precise: head_dim %d unsupported (64, 128)", HD);
   VT_REQUIRE(ldqkv % 8 == 0 && q_col0 % 8 == 0 && v_col0 % 8 == 0, "vt_kv_tiles_precise: misaligned columns");
   dim3 grid(max_new_tiles, heads, nseq), block(256);
   VT_REQUIRE(ld32 >= (v_f32 ? 3 : 2) * heads * HD && ld32 % 4 == 0, "vt_kv_tiles_precise: ld32 %d too small", ld32);
-  hipLaunchKernelGGL((kv_tiles_precise_kernel<128>), grid, block, 0, s, qk32, ld32, v_f32, qkv, ldqkv, q_col0, v_col0, qlo, Kt, Vt, klo, tile_table, seqs,
-                     heads, rope_cos, rope_sin, positions);
+  if (HD == 128)
+    hipLaunchKernelGGL((kv_tiles_precise_kernel<128>), grid, block, 0, s, qk32, ld32, v_f32, qkv, ldqkv, q_col0, v_col0, qlo, Kt, Vt, klo, tile_table, seqs,
+                       heads, rope_cos, rope_sin, positions);
+  else
+    hipLaunchKernelGGL((kv_tiles_precise_kernel<64>), grid, block, 0, s, qk32, ld32, v_f32, qkv, ldqkv, q_col0, v_col0, qlo, Kt, Vt, klo, tile_table, seqs,
+                       heads, rope_cos, rope_sin, positions);
   VT_LAUNCH_CHECK();
   return VT_OK;
 }
@@ -1452,19 +1505,19 @@ int vt_flash_attn_precise_launch(const bf16_t* Q, int ldq, const bf16_t* Qlo, in
                                  int klo_tiles_per_seq, const bf16_t* Vt, const int* tile_table, const VtAttnSeq* seqs, int nseq,
                                  int max_q_len, bf16_t* O, int ldo, bf16_t* Olo, int heads, int HD, int causal, float scale, hipStream_t s) {
   VT_REQUIRE(Q && Qlo && Kt && Klo && Vt && tile_table && seqs && O, "vt_flash_attn_precise: null pointer");
-  VT_REQUIRE(HD == 128, "vt_flash_attn_precise: head_dim %d unsupported (128)", HD);
+  VT_REQUIRE(HD == 128 || HD == 64, "vt_flash_attn_precise: head_dim %d unsupported (64, 128)", HD);
   VT_REQUIRE(nseq > 0 && max_q_len > 0 && heads > 0 && klo_tiles_per_seq > 0, "vt_flash_attn_precise: empty problem");
   VT_REQUIRE(ldq % 8 == 0 && ldqlo % 8 == 0 && ldo % 4 == 0, "vt_flash_attn_precise: ldq %% 8, ldqlo %% 8 and ldo %% 4 must be 0");
   const float sl2 = scale * 1.4426950408889634f;
   VtProfScope prof(VT_PROF_FLASH_ATTN, 0.0, s);
-  constexpr int smem = 2 * 3 * 64 * 128 * 2;
+  const int smem = 2 * 3 * 64 * HD * 2;
   int dev = 0;
   VT_HIP(hipGetDevice(&dev));
   VT_REQUIRE(dev >= 0 && dev < 64, "vt_flash_attn_precise: device ordinal %d", dev);
   dim3 grid(heads, cdiv(max_q_len, 128), nseq), block(256);
-#define VT_FAP(CV)                                                                                             \
+#define VT_FAP(CV, HDV)                                                                                        \
   do {                                                                                                         \
-    auto kern = flash_attn_precise_kernel<CV>;                                                                 \
+    auto kern = flash_attn_precise_kernel<CV, HDV>;                                                            \
     static std::atomic<unsigned long long> done{0};                                                            \
     if (!((done.load(std::memory_order_relaxed) >> dev) & 1ull)) {                                             \
       VT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));        \
@@ -1472,7 +1525,11 @@ int vt_flash_attn_precise_launch(const bf16_t* Q, int ldq, const bf16_t* Qlo, in
     }                                                                                                          \
     hipLaunchKernelGGL(kern, grid, block, smem, s, Q, ldq, Qlo, ldqlo, Kt, Klo, klo_tiles_per_seq, Vt, tile_table, seqs, O, ldo, Olo, heads, sl2); \
   } while (0)
-  if (causal) VT_FAP(true); else VT_FAP(false);
+  if (HD == 128) {
+    if (causal) VT_FAP(true, 128); else VT_FAP(false, 128);
+  } else {
+    if (causal) VT_FAP(true, 64); else VT_FAP(false, 64);
+  }
 #undef VT_FAP
   VT_LAUNCH_CHECK();
   return VT_OK;
@@ -1533,6 +1590,21 @@ int vt_attn_decode_fused_launch(const bf16_t* qkv, int ldqkv, int q_col0, int k_
     if (rope_cos) VT_ADF(128, true); else VT_ADF(128, false);
   }
 #undef VT_ADF
+  VT_LAUNCH_CHECK();
+  return VT_OK;
+}
+
+int vt_attn_temporal_f32_launch(const float* qkv, int ld, bf16_t* out, bf16_t* out_lo, int B, int T, int N, int heads, hipStream_t s) {
+  VT_REQUIRE(qkv && out && out_lo, "vt_attn_temporal_f32: null pointer");
+  VT_REQUIRE(T >= 1 && T <= 8, "vt_attn_temporal_f32: T=%d unsupported (1..8)", T);
+  VT_REQUIRE(ld >= 3 * heads * 64, "vt_attn_temporal_f32: ld %d too small", ld);
+  const long total = (long)B * N * heads;
+  dim3 grid((unsigned)((total + 3) / 4)), block(256);
+  switch (T) {
+#define VT_TC(TV) case TV: hipLaunchKernelGGL((attn_temporal_f32_kernel<TV>), grid, block, 0, s, qkv, ld, out, out_lo, B, N, heads); break;
+    VT_TC(1) VT_TC(2) VT_TC(3) VT_TC(4) VT_TC(5) VT_TC(6) VT_TC(7) VT_TC(8)
+#undef VT_TC
+  }
   VT_LAUNCH_CHECK();
   return VT_OK;
 }

@@ -153,6 +153,8 @@ int vt_attn_decode_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf16
                           const VtAttnSeq* seqs, int nseq, bf16_t* O, int ldo, int heads, int HD, float scale,
                           int max_kv_len, float* scratch, size_t scratch_bytes, hipStream_t s);
 int vt_attn_temporal_launch(const bf16_t* qkv, bf16_t* out, int B, int T, int N, int heads, hipStream_t s);
+// precise level 2 of the towers: the temporal attention on fp32 q | k | v rows (row stride ld), output as an operand pair
+int vt_attn_temporal_f32_launch(const float* qkv, int ld, bf16_t* out, bf16_t* out_lo, int B, int T, int N, int heads, hipStream_t s);
 
 // ---- vt_region.hip --------------------------------------------------------------------------------
 // cell mask / count / masked mean per (box, 64-channel slab); optionally also LocationEncoder layer 0:

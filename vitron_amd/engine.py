@@ -205,7 +205,8 @@ class PackedVit:
         self.ws = Workspace(dev)
 
     def set_precise(self, level: int) -> None:
-        """2: the MLP's operands and the output features as operand pairs (vt_vit_model.precise; include/vitron_hip.h); 0: standard."""
+        """2: every GEMM A operand of the tower (norm outputs, q / k through the scores, attention and activation outputs) and the output
+        features as operand pairs, the temporal attention in fp32 (vt_vit_model.precise; include/vitron_hip.h); 0: standard."""
         self.model.precise = 2 if int(level) >= 2 else 0
 
     def forward(self, pixels: torch.Tensor, return_hidden: bool = False):
