@@ -86,14 +86,22 @@ def quick_gelu(x):  # transformers ACT2FN['quick_gelu']
     return x * torch.sigmoid(1.702 * x)
 
 
-def clip_attention(x, sd: SD, prefix: str, heads: int, emulate: bool, round_p: bool = True):
+def clip_attention(x, sd: SD, prefix: str, heads: int, emulate: bool, round_p: bool = True, precise: int = 0):
     """transformers-4.31 CLIPAttention.forward: q = q_proj(x)*hd^-0.5, bmm, softmax,
-    bmm, out_proj -- no masks on the vision path (reference modeling_video.py:652-657 passes None)."""
+    bmm, out_proj -- no masks on the vision path (reference modeling_video.py:652-657 passes None).
+    precise = 2 (with an emulation mode): the storage points of vt_vit_model.precise = 2 -- q and k reach the scores as operand PAIRS, v
+    goes from fp32 straight into the V^T tiles' fp16, the output leaves as a pair; the temporal attention (round_p False) runs on the
+    fp32 q | k | v and only its output is stored (as a pair)."""
     B, N, D = x.shape
     hd = D // heads
-    q = _r(_lin(x, sd[prefix + "q_proj.weight"], sd[prefix + "q_proj.bias"]), emulate) * (hd ** -0.5)
-    k = _r(_lin(x, sd[prefix + "k_proj.weight"], sd[prefix + "k_proj.bias"]), emulate)
-    v = _r(_lin(x, sd[prefix + "v_proj.weight"], sd[prefix + "v_proj.bias"]), emulate)
+    pairs = bool(emulate) and int(precise) >= 2
+    st = (lambda t: _pair(t, emulate)) if pairs else (lambda t: _r(t, emulate))
+    qkv_st = (lambda t: t) if (pairs and not round_p) else st
+    q = qkv_st(_lin(x, sd[prefix + "q_proj.weight"], sd[prefix + "q_proj.bias"])) * (hd ** -0.5)
+    k = qkv_st(_lin(x, sd[prefix + "k_proj.weight"], sd[prefix + "k_proj.bias"]))
+    v = _lin(x, sd[prefix + "v_proj.weight"], sd[prefix + "v_proj.bias"])
+    if not pairs:
+        v = _r(v, emulate)
     q = q.view(B, N, heads, hd).transpose(1, 2)
     k = k.view(B, N, heads, hd).transpose(1, 2)
     v = v.view(B, N, heads, hd).transpose(1, 2)
@@ -104,14 +112,18 @@ def clip_attention(x, sd: SD, prefix: str, heads: int, emulate: bool, round_p: b
     else:
         o = torch.softmax(s, dim=-1) @ v
     o = o.transpose(1, 2).reshape(B, N, D)
-    return _r(o, emulate)  # out_proj is applied by the caller (its output goes straight into the fp32 residual)
+    return st(o)  # out_proj is applied by the caller (its output goes straight into the fp32 residual)
 
 
-def vit_forward(sd: SD, cfg: dict, pixels: torch.Tensor, num_layers: Optional[int] = None, emulate_bf16: bool = False):
+def vit_forward(sd: SD, cfg: dict, pixels: torch.Tensor, num_layers: Optional[int] = None, emulate_bf16: bool = False, precise: int = 0):
     """CLIPVisionTransformer.forward + CLIPEncoderLayer.forward of the reference:
       vitron/model/multimodal_encoder/languagebind/video/modeling_video.py:610-675 and :65-158
     pixels: [B,3,H,W] (image) or [B,3,T,H,W] (video). Returns the hidden state after `num_layers` encoder
-    layers as [B*T, N, D] fp32 (hidden_states[num_layers] in HF numbering; select_layer=-2 <=> L-1 layers)."""
+    layers as [B*T, N, D] fp32 (hidden_states[num_layers] in HF numbering; select_layer=-2 <=> L-1 layers).
+    precise = 2 (with an emulation mode): the storage points of the kernels' precise level 2 (vt_vit_model.precise) -- every GEMM A operand
+    an operand pair instead of one 16-bit value."""
+    pairs = bool(emulate_bf16) and int(precise) >= 2
+    _st = (lambda t: _pair(t, emulate_bf16)) if pairs else (lambda t: _r(t, emulate_bf16))
     D, heads, P = cfg["hidden_size"], cfg["num_attention_heads"], cfg["patch_size"]
     L = cfg["num_hidden_layers"] if num_layers is None else num_layers
     eps = cfg.get("layer_norm_eps", 1e-5)
@@ -140,29 +152,28 @@ def vit_forward(sd: SD, cfg: dict, pixels: torch.Tensor, num_layers: Optional[in
                 x = (x.view(B, T, N, D) + sd[p + "temporal_embedding"].float()[:, :t, None, :]).view(B * T, N, D)
             res = x  # :117
             h = x.view(B, T, N, D).transpose(1, 2).reshape(B * N, T, D)  # '(b t) n d -> (b n) t d'
-            h = _r(F.layer_norm(h, (D,), sd[p + "temporal_layer_norm1.weight"].float(),
-                                sd[p + "temporal_layer_norm1.bias"].float(), eps), emulate_bf16)
-            h = clip_attention(h, sd, p + "temporal_attn.", heads, emulate_bf16, round_p=False)  # temporal kernel keeps P in fp32
+            h = _st(F.layer_norm(h, (D,), sd[p + "temporal_layer_norm1.weight"].float(),
+                                 sd[p + "temporal_layer_norm1.bias"].float(), eps))
+            h = clip_attention(h, sd, p + "temporal_attn.", heads, emulate_bf16, round_p=False, precise=precise)  # temporal kernel keeps P in fp32
             h = _lin(h, sd[p + "temporal_attn.out_proj.weight"], sd[p + "temporal_attn.out_proj.bias"])
             x = res + h.view(B, N, T, D).transpose(1, 2).reshape(B * T, N, D)  # :127
             if p + "temporal_mlp.fc1.weight" in sd:
                 # the IMAGE tower's add_time_attn variant only (image/modeling_image.py:83-84,129-134): a row-wise MLP behind the temporal
                 # attention (the '(b t) n d -> (b n) t d' rearrangement around it does not change a row-wise operation)
                 res = x
-                h = _r(F.layer_norm(x, (D,), sd[p + "temporal_layer_norm2.weight"].float(), sd[p + "temporal_layer_norm2.bias"].float(), eps),
-                       emulate_bf16)
+                h = _st(F.layer_norm(x, (D,), sd[p + "temporal_layer_norm2.weight"].float(), sd[p + "temporal_layer_norm2.bias"].float(), eps))
                 h = _lin(h, sd[p + "temporal_mlp.fc1.weight"], sd[p + "temporal_mlp.fc1.bias"])
-                h = _r(F.gelu(h) if act == "gelu" else quick_gelu(h), emulate_bf16)
+                h = _st(F.gelu(h) if act == "gelu" else quick_gelu(h))
                 x = res + _lin(h, sd[p + "temporal_mlp.fc2.weight"], sd[p + "temporal_mlp.fc2.bias"])
         res = x  # spatial attention :136-146
-        h = _r(F.layer_norm(x, (D,), sd[p + "layer_norm1.weight"].float(), sd[p + "layer_norm1.bias"].float(), eps), emulate_bf16)
-        h = clip_attention(h, sd, p + "self_attn.", heads, emulate_bf16)
+        h = _st(F.layer_norm(x, (D,), sd[p + "layer_norm1.weight"].float(), sd[p + "layer_norm1.bias"].float(), eps))
+        h = clip_attention(h, sd, p + "self_attn.", heads, emulate_bf16, precise=precise)
         x = res + _lin(h, sd[p + "self_attn.out_proj.weight"], sd[p + "self_attn.out_proj.bias"])
         res = x  # MLP :148-151 (CLIPMLP: fc2(act(fc1(x))))
-        h = _r(F.layer_norm(x, (D,), sd[p + "layer_norm2.weight"].float(), sd[p + "layer_norm2.bias"].float(), eps), emulate_bf16)
+        h = _st(F.layer_norm(x, (D,), sd[p + "layer_norm2.weight"].float(), sd[p + "layer_norm2.bias"].float(), eps))
         h = _lin(h, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"])
         h = F.gelu(h) if act == "gelu" else quick_gelu(h)
-        h = _r(h, emulate_bf16)
+        h = _st(h)
         x = res + _lin(h, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
     return x
 

@@ -197,7 +197,7 @@ def test_towers_precise_level_2_vs_reference(dev, name, op):
     GELU outputs. What is left is V^T / P in fp16 and the pairs' 2^-17 (bf16) / 2^-23 (fp16): the hidden state is within 6e-5 of the fp32
     oracle and of the REFERENCE's stored outputs in both operand builds -- the tower no longer contributes to the end-to-end distance."""
     from vitron_amd.engine import PackedVit, pair_lo
-    odt, _, _ = FW.operand(op)
+    odt, emu, _ = FW.operand(op)
     g = FW.golden_of(name)
     cfg, sd, x = FW.vit_case(name)
     nl = cases.FW_VIT_LAYERS
@@ -210,8 +210,10 @@ def test_towers_precise_level_2_vs_reference(dev, name, op):
     hidden, h_std = hidden.float().cpu().reshape(-1, 1024), h_std.float().cpu().reshape(-1, 1024)
     with torch.no_grad():
         h32 = O.vit_forward(f32(sd), cfg, x, num_layers=nl).reshape(-1, 1024)
-    d_f32, std_f32 = FW.rel(hidden, h32), FW.rel(h_std, h32)
+        hem = O.vit_forward(f32(sd), cfg, x, num_layers=nl, emulate_bf16=emu, precise=2).reshape(-1, 1024)
+    d_f32, std_f32, d_emu = FW.rel(hidden, h32), FW.rel(h_std, h32), FW.rel(hidden, hem)
     ref_proj, ref_rows = FW.vs_pin(hidden, g, f"vit_{name}_hidden_{nl}")
+    assert d_emu <= 3e-5, d_emu                  # against the oracle's emulation of the mode's own storage points
     # the features leave as a pair whose sum is the fp32 hidden state of the patch tokens
     N = hidden.shape[0] // (x.shape[0] * (x.shape[2] if x.dim() == 5 else 1))
     patch = hidden.reshape(-1, N, 1024)[:, 1:].reshape(-1, 1024)

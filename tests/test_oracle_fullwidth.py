@@ -143,3 +143,24 @@ def test_storage_emulation_is_defined_only_up_to_rounding_flips():
     assert d32 <= 2e-5                      # the arithmetic itself is smooth (amplification ~20)
     assert 1.0e-3 <= dbf <= 8.6e-3          # bf16: the same size as HIP vs emulation (4.1e-3 .. 5.7e-3), inside that test's bound
     assert 2.0e-4 <= d16 <= 2.4e-3          # fp16: 8x finer stores, 4x smaller flips; the GPU test's fp16 bounds sit above it
+
+
+@pytest.mark.parametrize("name", ["video224", "image224"])
+def test_oracle_towers_precise_level_2_emulation(name):
+    """The oracle's emulation of the storage points of vt_vit_model.precise = 2 (every GEMM A operand an operand pair, q / k pairs through
+    the scores, v from fp32 into fp16 tiles, the temporal attention in fp32) at ViT-L width: 1.1e-5 from fp32 and from the REFERENCE's stored
+    outputs in both operand formats, against 1.5e-3 (bf16) / 1.9e-4 (fp16) for the standard storage points -- what
+    tests/test_gpu_parity_fullwidth.py::test_towers_precise_level_2_vs_reference then measures on the GPU."""
+    g = FW.golden_of(name)
+    cfg, sd, x = FW.vit_case(name)
+    nl = cases.FW_VIT_LAYERS
+    with torch.no_grad():
+        h32 = O.vit_forward(f32(sd), cfg, x, num_layers=nl).reshape(-1, 1024)
+        for emu in (True, "fp16"):
+            hs = O.vit_forward(f32(sd), cfg, x, num_layers=nl, emulate_bf16=emu).reshape(-1, 1024)
+            hp = O.vit_forward(f32(sd), cfg, x, num_layers=nl, emulate_bf16=emu, precise=2).reshape(-1, 1024)
+            dp, dr = FW.vs_pin(hp, g, f"vit_{name}_hidden_{nl}")
+            assert FW.rel(hp, h32) <= 3e-5 and dp <= 3e-5 and dr <= 3e-5, (emu, FW.rel(hp, h32), dp, dr)
+            assert FW.rel(hp, h32) <= 0.1 * FW.rel(hs, h32), (emu, FW.rel(hp, h32), FW.rel(hs, h32))
+        # without an emulation mode the argument changes nothing
+        assert torch.equal(O.vit_forward(f32(sd), cfg, x, num_layers=nl, precise=2).reshape(-1, 1024), h32)
