@@ -719,7 +719,7 @@ def fp16_ab_report(args, dev, model_bf16, step_bf16, ids, ids_host, clip_bf16, v
     import torch
 
     from vitron_amd import ops, synth
-    from vitron_amd.engine import SequenceState, llama_forward
+    from vitron_amd.engine import SequenceState, llama_forward, pair_lo
     from vitron_amd.model import LlavaConfig, LlavaLlamaForCausalLM
 
     G = args.image_size // 14
@@ -735,7 +735,8 @@ def fp16_ab_report(args, dev, model_bf16, step_bf16, ids, ids_host, clip_bf16, v
     def step16():
         (_, _, _, _, embeds, _) = m16.prepare_inputs_labels_for_multimodal(ids, None, None, None, None, [clip16], None, input_ids_host=ids_host)
         seq = SequenceState()
-        logits = llama_forward(l16, m16.kv, [seq], embeds[0], [embeds.shape[1]])
+        lo = pair_lo(embeds)                      # precise level 2: the spliced embeddings are an operand pair
+        logits = llama_forward(l16, m16.kv, [seq], embeds[0], [embeds.shape[1]], embeds_lo=None if lo is None else lo[0])
         tok = ops.argmax(logits)
         m16.kv.release(seq.pages)
         return tok, logits
@@ -774,11 +775,24 @@ def fp16_ab_report(args, dev, model_bf16, step_bf16, ids, ids_host, clip_bf16, v
             m16.set_precise(0)
         precise[tag] = {"ms_per_step": ms, "over_fp16": ms / f16_mean,
                         "last_position_logits_rel_l2_vs_fp16_standard": float((out_p[1].double() - l16_.double()).norm() / l16_.double().norm())}
+        lp16 = out_p[1]
+    # the bf16 (benchmark) build in the verification mode: two libraries compiled from the same sources for different operand formats,
+    # 1.2e-2 apart in the standard mode, must land on the same logits (each is ~4e-4 from the reference's fp32 at full depth)
+    bf16_mean = sum(arms["bf16"]) / len(arms["bf16"])
+    model_bf16.set_precise(2)
+    try:
+        step_bf16()
+        ms, out_b = timed(step_bf16, max(2, K // 2))
+    finally:
+        model_bf16.set_precise(0)
+    bf16_p2 = {"ms_per_step": ms, "over_bf16": ms / bf16_mean,
+               "last_position_logits_rel_l2_vs_fp16_precise2": float((out_b[2].double() - lp16.double()).norm() / lp16.double().norm()),
+               "last_position_logits_rel_l2_vs_bf16_standard": float((out_b[2].double() - lb.double()).norm() / lb.double().norm())}
     rep = {"what": "same workload, same seed, same box: bf16 build vs fp16-operand build, arms alternated, wall clock per step",
            "steps_per_arm": K, "ms_per_step_bf16": arms["bf16"], "ms_per_step_fp16": arms["fp16"],
            "fp16_over_bf16": f16_mean / (sum(arms["bf16"]) / len(arms["bf16"])),
            "last_position_logits_rel_l2_fp16_vs_bf16": d, "greedy_token_equal": bool(int(out[0][0]) == int(ops.argmax(lb)[0])),
-           "fp16_precise_modes": precise,
+           "fp16_precise_modes": precise, "bf16_precise2": bf16_p2,
            "note": "parity of each build / mode against the reference: profiles/r5_parity_fulldepth*.json (tests/test_gpu_parity_fulldepth.py)"}
     del m16, l16
     torch.cuda.empty_cache()
@@ -979,7 +993,7 @@ def main():
         dist.init_process_group(backend="nccl", device_id=dev)
 
     from vitron_amd import _lib, ops, synth
-    from vitron_amd.engine import SequenceState, llama_forward
+    from vitron_amd.engine import SequenceState, llama_forward, pair_lo
     from vitron_amd.model import LlavaConfig, LlavaLlamaForCausalLM
 
     _lib.load(operand=args.dtype)
@@ -1025,7 +1039,8 @@ def main():
         (_, _, _, _, embeds, _) = model.prepare_inputs_labels_for_multimodal(ids, None, None, None, None, [clip], None,
                                                                              input_ids_host=ids_host)
         seq = SequenceState()
-        logits = llama_forward(llama, model.kv, [seq], embeds[0], [embeds.shape[1]])
+        lo = pair_lo(embeds)                      # (only in the verification mode of the fp16_ab report: operand pairs)
+        logits = llama_forward(llama, model.kv, [seq], embeds[0], [embeds.shape[1]], embeds_lo=None if lo is None else lo[0])
         tok = ops.argmax(logits)
         model.kv.release(seq.pages)
         for g in pending:

@@ -365,7 +365,7 @@ typedef struct vt_llama_model {
                                    epilogue of a one-workgroup-per-CU kernel overlaps with nothing: 455 vs 386 + 48.5 us): default 0. */
   int precise_qk;               /* 2: precise level 2 -- level 1 below plus EVERY other GEMM A operand of a prefill as a pair (v projection,
                                    attention output -> o_proj, post-attention norm -> gate/up with the SwiGLU as its own fp32 -> pair pass,
-                                   SwiGLU output -> down_proj, final norm -> lm_head when more than 64 rows are asked for): each product runs
+                                   SwiGLU output -> down_proj, final norm -> lm_head): each product runs
                                    as two launches accumulating in fp32. A verification mode: ~2x the GEMM work.
                                    1 (head_dim 128): PREFILLS carry everything that reaches the softmax's argument as operand PAIRS
                                    (hi + lo, 2 x 16 bit): the input-norm output feeds the q / k projection as A_hi.W^T + A_lo.W^T into fp32,

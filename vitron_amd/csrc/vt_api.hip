@@ -790,7 +790,7 @@ int vt_llama_forward(const vt_llama_model* m, const vt_kv_cache* kv, const uint1
     VT_TRY(vt_gemm_resid_launch(w.h, I, L.wdown, I, w.x, H, nullptr, rows, H, I, 0, w.splitk, w.splitk_bytes, s));
   }
   if (out_hidden) VT_HIP(hipMemcpyAsync(out_hidden, w.x, (size_t)rows * H * 4, hipMemcpyDeviceToDevice, s));
-  if (n_logit_rows > 0 && precise2 && n_logit_rows > 64) {   // level 2: the lm_head's operand as a pair too (tile GEMMs: more than 64 rows)
+  if (n_logit_rows > 0 && precise2) {   // level 2: the lm_head's operand as a pair too (any number of rows: a last-position-only call included)
     VT_TRY(vt_rmsnorm_hilo_launch(w.x, logit_rows, m->final_norm, w.yn, w.ynlo, n_logit_rows, H, m->rms_eps, s));
     VT_TRY(vt_gemm_launch(w.yn, H, m->lm_head, H, logits, m->vocab, nullptr, n_logit_rows, m->vocab, H, VT_EPI_F32, AUTO, s));
     VT_TRY(vt_gemm_resid_launch(w.ynlo, H, m->lm_head, H, logits, m->vocab, nullptr, n_logit_rows, m->vocab, H, 0, w.splitk, w.splitk_bytes, s));
