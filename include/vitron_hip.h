@@ -75,7 +75,8 @@ enum { VT_ACT_GELU = 0, VT_ACT_QUICK_GELU = 1 };
 
 #define VT_PAGE_TOKENS 64 /* tokens per KV-cache page == keys per attention tile */
 
-int vt_version(void);
+#define VT_ABI_VERSION 112
+int vt_version(void); /* == VT_ABI_VERSION of the header the library was built from */
 /* operand format of THIS library (see Conventions): every uint16_t tensor argument carries these bits */
 enum { VT_OPERAND_BF16 = 0, VT_OPERAND_FP16 = 1 };
 int vt_operand_format(void);
@@ -113,6 +114,29 @@ int vt_layernorm(float* x, const float* temb, int T, int tokens_per_frame, const
 
 /* y_bf16[r] = w * x[idx ? idx[r] : r] * rsqrt(mean(x^2) + eps) : transformers-4.31 LlamaRMSNorm. */
 int vt_rmsnorm(const float* x, const int* idx, const float* w, uint16_t* y, int rows, int D, float eps, void* stream);
+
+/* ---- precise level 3: the rounding remainder of a GEMM's A operand on the MX-FP4 pipe (no reference counterpart: the reference computes
+ * every Linear in ONE 16-bit format, vitron/model/builder.py:47; north_star's 1e-3 against its fp32 CPU path is what these serve) ----------
+ * A Linear of level 3 is  C = epi(A.W^T + (A4 2^ea).(W4 2^ew)^T + bias): A = op16(v) against the 16-bit weights on the 16-bit MFMA, plus
+ * A4 = the MX-FP4 image (OCP e2m1 elements, power-of-two block scales) of lo = v - f32(A) against the weights' MX-FP4 image on
+ * v_mfma_scale_f32_16x16x128_f8f6f4, in ONE launch and one fp32 accumulator.
+ *   W4   uint8 [N][K/2]: element k of row n in byte k/2 (even k in bits 3:0);  wexp uint8 [N]: one biased (e8m0) exponent per row
+ *   A4   uint8 [M][K/2]: same element order;  aexp uint8 [vt_mx4_aexp_bytes(M, K)]: one biased exponent per row and 32 consecutive k, at
+ *        aexp[((m / 64) * (K / 32) + kb) * 64 + (m % 16) * 4 + (m % 64) / 16]  (the order the GEMM's lanes fetch them; rows padded to 256)
+ * Quantisation: scale 2^e with the smallest e for which the block's largest magnitude is <= 6, elements to the nearest e2m1 value
+ * {0, .5, 1, 1.5, 2, 3, 4, 6}, ties to the even mantissa (oracle/vitron_oracle.py mx4_quant restates it; tests compare bit for bit). */
+size_t vt_mx4_aexp_bytes(int M, int K);
+/* weights (K % 8 == 0) */
+int vt_mx4_quant_weights(const uint16_t* W, int ldw, int N, int K, uint8_t* W4, uint8_t* wexp, void* stream);
+/* a 16-bit remainder lo [M][K] (the second output of the precise level 2 operators), K % 32 == 0 */
+int vt_mx4_quant_lo(const uint16_t* lo, int ld, int M, int K, uint8_t* A4, uint8_t* aexp, void* stream);
+/* vt_rmsnorm with the level 3 operand out: y = op16(v), (A4, aexp) = MX-FP4 image of v - f32(y); D % 256 == 0 */
+int vt_rmsnorm_mx(const float* x, const int* idx, const float* w, uint16_t* y, uint8_t* A4, uint8_t* aexp, int rows, int D, float eps,
+                  void* stream);
+/* the GEMM: 256 x 256 tiles of the four-wave kernel, K % 128 == 0, K >= 256, N % 4 == 0; epi = VT_EPI_BF16 / _GELU / _QGELU / F32_RESID /
+ * F32 / SWIGLU_BF16 */
+int vt_gemm_mx(const uint16_t* A, int lda, const uint8_t* A4, const uint8_t* aexp, const uint16_t* W, int ldw, const uint8_t* W4,
+               const uint8_t* wexp, void* C, int ldc, const float* bias, int M, int N, int K, int epi, void* stream);
 
 /* Attention over 64-key tiles. seq_desc: device int32 [nseq][4] = {q_row0, q_len, kv_len, table_off};
  * tile_table: device int32, tile_table[table_off + t] = index of the sequence's t-th K / V^T tile.

@@ -79,6 +79,61 @@ def _lin(x, w, b=None):
     return F.linear(x, w.float(), None if b is None else b.float())
 
 
+# ---- MX-FP4 (OCP e2m1 elements, e8m0 power-of-two block scales): the low halves of precise level 3's operand pairs ------------------
+# Restates what the kernels do (vitron_amd/csrc/vt_mx4.hip, vt_gemm8x.hip), not anything in the reference: the reference computes in one
+# format throughout (vitron/model/builder.py:47). v_mfma_scale_f32_16x16x128_f8f6f4 multiplies 4-bit elements {0, .5, 1, 1.5, 2, 3, 4, 6}
+# x sign and applies 2^(E - 127) per 32-element block of each operand (tools/mx_probe.hip pins layout and scale semantics on the GPU).
+MX4_BLOCK = 32
+
+
+def mx4_exponent(amax: torch.Tensor) -> torch.Tensor:
+    """Unbiased power-of-two scale exponent e of a block whose largest magnitude is amax: the smallest e with amax / 2^e <= 6, i.e.
+    amax / 2^e in (3, 6] -- nothing is clipped. From the fp32 fields, exactly as the kernels do it: floor(log2 amax) - 2, plus one when
+    the mantissa exceeds 1.5. Clamped to the e8m0 range [-127, 127]; amax = 0 gives -127 (every element quantises to 0 anyway)."""
+    bits = amax.float().contiguous().view(torch.int32)
+    ex = ((bits >> 23) & 0xFF) - 127
+    e = ex - 2 + ((bits & 0x7FFFFF) > 0x400000).to(torch.int32)
+    return e.clamp(-127, 127)
+
+
+def mx4_round(x: torch.Tensor) -> torch.Tensor:
+    """|x| <= 6 (already divided by the block scale) to the nearest e2m1 value, ties to the even mantissa: rint at a step of .5 below 2,
+    1 below 4, 2 above (the e2m1 codes with mantissa bit 0 are 0, 1, 2, 4: rint's ties-to-even lands on exactly those)."""
+    a = x.abs()
+    q = torch.where(a < 2.0, torch.round(a * 2.0) * 0.5, torch.where(a < 4.0, torch.round(a), torch.round(a * 0.5) * 2.0))
+    return torch.copysign(q.clamp(max=6.0), x)
+
+
+def mx4_codes(q: torch.Tensor) -> torch.Tensor:
+    """e2m1 values -> 4-bit codes (bit 3 = sign; -0 keeps its sign bit like the hardware conversion would)."""
+    a = q.abs()
+    c = torch.where(a <= 2.0, a * 2.0, torch.where(a <= 4.0, a + 2.0, torch.full_like(a, 7.0))).to(torch.int32)
+    return c | (torch.signbit(q).to(torch.int32) << 3)
+
+
+def mx4_quant(x: torch.Tensor, block: Optional[int] = MX4_BLOCK):
+    """x [..., K] -> (dequantised fp32 image, e2m1 values, unbiased exponents [..., K / block]). block = None: ONE scale per row (the
+    weights' format: `w4_scale` per output feature); block = 32: the activations' low halves (a scale per 32 consecutive k)."""
+    x = x.float()
+    K = x.shape[-1]
+    b = K if block is None else block
+    xb = x.reshape(*x.shape[:-1], K // b, b)
+    e = mx4_exponent(xb.abs().amax(-1))
+    sc = torch.ldexp(torch.ones_like(e, dtype=torch.float32), e).unsqueeze(-1)
+    q = mx4_round(xb / sc)
+    return (q * sc).reshape(x.shape), q.reshape(x.shape), e
+
+
+def _lin_mx(x, w, emulate, w4=None):
+    """A GEMM of precise level 3: A = hi + lo with hi = store(x) on the 16-bit MFMA against the 16-bit weights and lo = x - hi in MX-FP4
+    (block 32) against the weights' MX-FP4 image (one scale per output feature), both accumulated in fp32."""
+    hi = _r(x, emulate)
+    lo4 = mx4_quant(x - hi, MX4_BLOCK)[0]
+    if w4 is None:
+        w4 = mx4_quant(w.float(), None)[0]
+    return F.linear(hi, w.float()) + F.linear(lo4, w4)
+
+
 # =====================================================================================================================
 # ViT tower (image: add_time_attn=False, T=1; video: add_time_attn=True, T=num_frames)
 # =====================================================================================================================
@@ -385,6 +440,9 @@ def llama_forward(sd: SD, cfg: dict, inputs_embeds: torch.Tensor, position_ids: 
                   precise_qk: bool = False):
     """LlamaModel + lm_head. inputs_embeds [B,S,H]; attention_mask [B, past+S] (1 = attend) or None;
     past = list of (k,v) per layer, each [B,heads,Sp,hd]. Returns (logits [B,S,V] fp32, new_past[, hidden]).
+    precise_qk = 3 (with an emulation mode): precise level 3 -- every decoder GEMM's A operand is hi (the 16-bit store) plus an MX-FP4 low half
+    multiplied with the weights' MX-FP4 image (_lin_mx); q / k / v / P / V^T are stored as in the standard mode; the lm_head's operand is a
+    16-bit pair as in level 2.
     precise_qk = 2 (with an emulation mode): precise level 2 -- every GEMM A operand is an operand pair (norm outputs, attention output,
     SwiGLU output, final norm; v is computed from the pair and stored once).
     precise_qk = 1 / True (with an emulation mode): the storage points of the kernels' precise_qk prefill -- the input-norm output reaches the
@@ -414,8 +472,17 @@ def llama_forward(sd: SD, cfg: dict, inputs_embeds: torch.Tensor, position_ids: 
     new_past = []
     for l in range(L):
         p = f"model.layers.{l}."
-        full = bool(emulate_bf16) and int(precise_qk) >= 2          # level 2: every GEMM A operand is a pair
-        if precise_qk and emulate_bf16:
+        full = bool(emulate_bf16) and int(precise_qk) == 2          # level 2: every GEMM A operand is a pair
+        mx = bool(emulate_bf16) and int(precise_qk) == 3            # level 3: every GEMM A operand is hi + an MX-FP4 low half
+        if mx:
+            hn = rmsnorm(x, sd[p + "input_layernorm.weight"], eps)
+            lin = lambda t, name: _lin_mx(t, sd[p + name], emulate_bf16)
+            q = _r(lin(hn, "self_attn.q_proj.weight"), emulate_bf16).view(B, S, heads, hd).transpose(1, 2)
+            k = _r(lin(hn, "self_attn.k_proj.weight"), emulate_bf16).view(B, S, heads, hd).transpose(1, 2)
+            v = _r(lin(hn, "self_attn.v_proj.weight"), emulate_bf16).view(B, S, heads, hd).transpose(1, 2)
+            q = _r(_rope(q, cos, sin), emulate_bf16)
+            k = _r(_rope(k, cos, sin), emulate_bf16)
+        elif precise_qk and emulate_bf16:
             hn = rmsnorm(x, sd[p + "input_layernorm.weight"], eps)
             h, hp = _r(hn, emulate_bf16), _pair(hn, emulate_bf16)
             q = _lin(hp, sd[p + "self_attn.q_proj.weight"]).view(B, S, heads, hd).transpose(1, 2)
@@ -443,6 +510,12 @@ def llama_forward(sd: SD, cfg: dict, inputs_embeds: torch.Tensor, position_ids: 
             o = (fp16_round(pr) @ fp16_store(v)) / pr.sum(-1, keepdim=True)
         else:
             o = torch.softmax(s, dim=-1, dtype=torch.float32) @ v
+        if mx:
+            x = x + lin(o.transpose(1, 2).reshape(B, S, H), "self_attn.o_proj.weight")
+            hn = rmsnorm(x, sd[p + "post_attention_layernorm.weight"], eps)
+            a = F.silu(lin(hn, "mlp.gate_proj.weight")) * lin(hn, "mlp.up_proj.weight")
+            x = x + lin(a, "mlp.down_proj.weight")
+            continue
         st = (lambda t: _pair(t, emulate_bf16)) if full else (lambda t: _r(t, emulate_bf16))
         o = st(o.transpose(1, 2).reshape(B, S, H))
         x = x + _lin(o, sd[p + "self_attn.o_proj.weight"])
@@ -452,7 +525,7 @@ def llama_forward(sd: SD, cfg: dict, inputs_embeds: torch.Tensor, position_ids: 
         a = st(F.silu(g) * u)
         x = x + _lin(a, sd[p + "mlp.down_proj.weight"])
     hidden = x
-    full = bool(emulate_bf16) and int(precise_qk) >= 2
+    full = bool(emulate_bf16) and int(precise_qk) >= 2     # the lm_head's operand is a 16-bit pair in level 3 too
     xn = _pair(rmsnorm(x, sd["model.norm.weight"], eps), emulate_bf16) if full else _r(rmsnorm(x, sd["model.norm.weight"], eps), emulate_bf16)
     logits = _lin(xn, sd["lm_head.weight"]).float()
     if return_hidden:

@@ -18,6 +18,7 @@ PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = PKG_DIR / "libvitron_hip.so"
 LIB_PATHS = {"bf16": LIB_PATH, "fp16": PKG_DIR / "libvitron_hip_f16.so"}
 OPERAND_BF16, OPERAND_FP16 = 0, 1
+ABI_VERSION = 112   # == VT_ABI_VERSION of include/vitron_hip.h; load() refuses a library that reports anything else
 
 # ---- enums (mirror include/vitron_hip.h) ---------------------------------------------------------------------
 EPI_BF16, EPI_BF16_GELU, EPI_BF16_QGELU, EPI_BF16_RELU, EPI_F32_RESID, EPI_F32, EPI_SWIGLU_BF16 = range(7)
@@ -111,6 +112,11 @@ SIGNATURES = {
     "vt_profile_end": (_i, [C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "vt_probe_mfma": (_i, [vp, vp, vp, _i, vp]),
     "vt_flash_attn_block_order": (_i, [_i, _i, _i, _i, C.POINTER(C.c_int), _i]),
+    "vt_mx4_aexp_bytes": (_sz, [_i, _i]),
+    "vt_mx4_quant_weights": (_i, [vp, _i, _i, _i, vp, vp, vp]),
+    "vt_mx4_quant_lo": (_i, [vp, _i, _i, _i, vp, vp, vp]),
+    "vt_rmsnorm_mx": (_i, [vp, vp, vp, vp, vp, vp, _i, _i, _f, vp]),
+    "vt_gemm_mx": (_i, [vp, _i, vp, vp, vp, _i, vp, vp, vp, _i, vp, _i, _i, _i, _i, vp]),
 }
 PROF_CLASSES = ("gemm_tile", "flash_attn", "gemm_skinny", "attn_decode")
 
@@ -201,6 +207,9 @@ def load(build_if_needed: bool = True, ablations: bool = False, operand=None):
     import torch  # noqa: F401
     lib = _bind(C.CDLL(str(path)))
     want = OPERAND_FP16 if op == "fp16" else OPERAND_BF16
+    if lib.vt_version() != ABI_VERSION:
+        raise VitronHipError(f"{path.name} reports ABI {lib.vt_version()}, this package binds ABI {ABI_VERSION}: rebuild it "
+                             "(python -m vitron_amd.build)")
     if lib.vt_operand_format() != want:
         raise VitronHipError(f"{path.name} reports operand format {lib.vt_operand_format()}, expected {want} ({op})")
     _libs[op] = lib

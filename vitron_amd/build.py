@@ -26,7 +26,7 @@ F16_LIB_PATH = PKG_DIR / "libvitron_hip_f16.so"
 # results by construction) and their environment switches. Only tools/ load it (vitron_amd._lib.load(ablations=True)); the
 # product library above contains none of that code.
 ABL_LIB_PATH = PKG_DIR / "libvitron_hip_abl.so"
-SOURCES = ["vt_api.hip", "vt_gemm.hip", "vt_gemm8.hip", "vt_norm.hip", "vt_attn.hip", "vt_attn_w4.hip", "vt_vit.hip", "vt_region.hip", "vt_llama.hip", "vt_preproc.hip"]
+SOURCES = ["vt_api.hip", "vt_gemm.hip", "vt_gemm8.hip", "vt_mx4.hip", "vt_norm.hip", "vt_attn.hip", "vt_attn_w4.hip", "vt_vit.hip", "vt_region.hip", "vt_llama.hip", "vt_preproc.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
          "-Wno-unused-but-set-variable", "-Wno-unused-variable"]

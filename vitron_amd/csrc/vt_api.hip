@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 extern "C" {
 
-int vt_version(void) { return 111; }
+int vt_version(void) { return VT_ABI_VERSION; }
 
 int vt_operand_format(void) { return VT_OPERAND_F16 ? VT_OPERAND_FP16 : VT_OPERAND_BF16; }
 
@@ -226,6 +226,21 @@ int vt_attn_decode(const uint16_t* Q, int ldq, const uint16_t* k_tiles, const ui
                    int max_kv_len, void* scratch, size_t scratch_bytes, void* stream) {
   return vt_attn_decode_launch(Q, ldq, k_tiles, vt_tiles, tile_table, (const VtAttnSeq*)seq_desc, nseq, O, ldo, heads,
                                head_dim, scale, max_kv_len, (float*)scratch, scratch_bytes, S(stream));
+}
+
+int vt_mx4_quant_weights(const uint16_t* W, int ldw, int N, int K, uint8_t* W4, uint8_t* wexp, void* stream) {
+  return vt_mx4_quant_weights_launch(W, ldw, N, K, W4, wexp, S(stream));
+}
+int vt_mx4_quant_lo(const uint16_t* lo, int ld, int M, int K, uint8_t* A4, uint8_t* aexp, void* stream) {
+  return vt_mx4_quant_lo_launch(lo, ld, M, K, A4, aexp, S(stream));
+}
+int vt_rmsnorm_mx(const float* x, const int* idx, const float* w, uint16_t* y, uint8_t* A4, uint8_t* aexp, int rows, int D, float eps,
+                  void* stream) {
+  return vt_rmsnorm_mx_launch(x, idx, w, y, A4, aexp, rows, D, eps, S(stream));
+}
+int vt_gemm_mx(const uint16_t* A, int lda, const uint8_t* A4, const uint8_t* aexp, const uint16_t* W, int ldw, const uint8_t* W4,
+               const uint8_t* wexp, void* C, int ldc, const float* bias, int M, int N, int K, int epi, void* stream) {
+  return vt_gemm_mx_launch(A, lda, A4, aexp, W, ldw, W4, wexp, C, ldc, bias, M, N, K, epi, 1, 0, S(stream));
 }
 
 int vt_gemm_bf16_resid_splitk(const uint16_t* A, int lda, const uint16_t* W, int ldw, float* C, int ldc, const float* bias,

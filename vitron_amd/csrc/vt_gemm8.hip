@@ -1004,6 +1004,8 @@ int launch_w4(const GemmP8& p, hipStream_t s) {
   return VT_OK;
 }
 
+#include "vt_gemm8x.inc"   // gemm_w4x_kernel: the same tile with the MX-FP4 product of precise level 3 folded in
+
 // ------------------------------------------------------------------------------------------------------------------
 // gemm_w4r_kernel: the four-wave kernel on a SMALL tile, 160x128x64 (four waves of 80x64: 20 accumulator quads), for GEMMs whose
 // big-tile grid would cover a fraction of the chip and whose 64x128 small-tile grid quantises badly -- the ViT's N = 1024
@@ -1636,5 +1638,29 @@ int vt_gemm_p8_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* 
     case VT_EPI_F32: return launch_p8<VT_EPI_F32>(p, s);
     case VT_EPI_SWIGLU_BF16: return launch_p8<VT_EPI_SWIGLU_BF16>(p, s);
     default: vt_set_error("vt_gemm(p8): unknown epilogue %d", epi); return VT_ERR_ARG;
+  }
+}
+
+// precise level 3: C = epi(A.W^T + (A4 2^ea).(W4 2^ew)^T) on 256x256 tiles (vt_gemm8x.inc). M, N arbitrary (edges clamped / masked as in the
+// base kernel), K % 128 == 0 and K >= 256; aexp must cover ceil(M / 256) * 256 rows (vt_mx4_aexp_bytes). ksplit > 1: EPI F32 only, split s
+// of every tile writes slab s (C + s * slab elements).
+int vt_gemm_mx_launch(const bf16_t* A, int lda, const uint8_t* A4, const uint8_t* aexp, const bf16_t* W, int ldw, const uint8_t* W4,
+                      const uint8_t* wexp, void* C, int ldc, const float* bias, int M, int N, int K, int epi, int ksplit, size_t slab,
+                      hipStream_t s) {
+  VT_REQUIRE(A && A4 && aexp && W && W4 && wexp && C, "vt_gemm_mx: null pointer");
+  VT_REQUIRE(M > 0 && N > 0 && (K % 128) == 0 && K >= 256 && (N % 4) == 0, "vt_gemm_mx: needs K %% 128 == 0, K >= 256, N %% 4 == 0 (K=%d N=%d)", K, N);
+  VT_REQUIRE((lda % 8) == 0 && (ldw % 8) == 0 && (((size_t)A4 | (size_t)W4) & 15) == 0, "vt_gemm_mx: misaligned operands");
+  VT_REQUIRE(ksplit <= 1 || (epi == VT_EPI_F32 && (K / 128) >= 2 * ksplit), "vt_gemm_mx: split-K needs the fp32 epilogue and >= 2 K pairs per split");
+  GemmP8 p{A, W, C, bias, M, N, K, lda, ldw, ldc, std::max(ksplit, 1), slab, VtGemmNormFuse{}};
+  const GemmMx x{A4, aexp, W4, wexp};
+  VtProfScope prof(VT_PROF_GEMM_TILE, 2.0 * (double)M * (double)N * (double)K, s);
+  switch (epi) {
+    case VT_EPI_BF16: return launch_w4x<VT_EPI_BF16>(p, x, s);
+    case VT_EPI_BF16_GELU: return launch_w4x<VT_EPI_BF16_GELU>(p, x, s);
+    case VT_EPI_BF16_QGELU: return launch_w4x<VT_EPI_BF16_QGELU>(p, x, s);
+    case VT_EPI_F32_RESID: return launch_w4x<VT_EPI_F32_RESID>(p, x, s);
+    case VT_EPI_F32: return launch_w4x<VT_EPI_F32>(p, x, s);
+    case VT_EPI_SWIGLU_BF16: return launch_w4x<VT_EPI_SWIGLU_BF16>(p, x, s);
+    default: vt_set_error("vt_gemm_mx: epilogue %d not instantiated", epi); return VT_ERR_ARG;
   }
 }

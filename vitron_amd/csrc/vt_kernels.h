@@ -89,6 +89,17 @@ bool vt_gemm_norm_fold_supported(int M, int N, int K);
 int vt_gemm_rp_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, const float* bias, int M,
                       int N, int K, int epi, hipStream_t s);
 
+// ---- vt_mx4.hip / vt_gemm8x.inc: precise level 3 (16-bit product + MX-FP4 product of the rounding remainder, one accumulator) -------------
+// W4 [N][K/2] + wexp[N] (one e8m0 exponent per output feature); A4 [M][K/2] + aexp (one exponent per row and 32 k, in the order the
+// GEMM's lanes fetch them; vt_mx4_aexp_bytes(M, K) bytes -- include/vitron_hip.h -- rows padded to whole 256-row tiles)
+int vt_mx4_quant_weights_launch(const bf16_t* W, int ldw, int N, int K, uint8_t* W4, uint8_t* wexp, hipStream_t s);
+int vt_mx4_quant_lo_launch(const bf16_t* lo, int ld, int M, int K, uint8_t* A4, uint8_t* aexp, hipStream_t s);
+int vt_rmsnorm_mx_launch(const float* x, const int* idx, const float* w, bf16_t* y, uint8_t* A4, uint8_t* aexp, int rows, int D, float eps,
+                         hipStream_t s);
+int vt_gemm_mx_launch(const bf16_t* A, int lda, const uint8_t* A4, const uint8_t* aexp, const bf16_t* W, int ldw, const uint8_t* W4,
+                      const uint8_t* wexp, void* C, int ldc, const float* bias, int M, int N, int K, int epi, int ksplit, size_t slab,
+                      hipStream_t s);
+
 // ---- vt_norm.hip ----------------------------------------------------------------------------------
 int vt_layernorm_launch(float* x, const float* temb, int T, int tokens_per_frame, const float* gamma,
                         const float* beta, bf16_t* y, int rows, int D, float eps, hipStream_t s);

@@ -307,3 +307,71 @@ def cross_entropy(logits: torch.Tensor, labels: torch.Tensor, ignore_index: int 
     _lib.check(lib.vt_cross_entropy(_p(logits), rows, V, logits.stride(0), _p(lab), int(ignore_index), _p(nll), _p(loss), _stream()),
                "vt_cross_entropy", lib)
     return loss[0]
+
+
+# ---- precise level 3: MX-FP4 images of the rounding remainders (include/vitron_hip.h "precise level 3") ---------------------------------
+def mx4_aexp_bytes(M: int, K: int) -> int:
+    return int(_lib.load_any().vt_mx4_aexp_bytes(M, K))
+
+
+def mx4_quant_weights(w: torch.Tensor):
+    """(W4 uint8 [N][K/2], wexp uint8 [N]) of a 16-bit weight matrix [N][K]."""
+    lib, dt = _op16(w, "mx4_quant_weights.w")
+    _chk(w, dt, "mx4_quant_weights.w")
+    N, K = w.shape
+    w4 = torch.empty((N, K // 2), device=w.device, dtype=torch.uint8)
+    wexp = torch.empty((N,), device=w.device, dtype=torch.uint8)
+    _lib.check(lib.vt_mx4_quant_weights(_p(w), K, N, K, _p(w4), _p(wexp), _stream()), "vt_mx4_quant_weights", lib)
+    return w4, wexp
+
+
+def mx4_quant_lo(lo: torch.Tensor):
+    """(A4 uint8 [M][K/2], aexp uint8 [mx4_aexp_bytes(M, K)]) of a 16-bit remainder [M][K]."""
+    lib, dt = _op16(lo, "mx4_quant_lo.lo")
+    _chk(lo, dt, "mx4_quant_lo.lo")
+    M, K = lo.shape
+    a4 = torch.empty((M, K // 2), device=lo.device, dtype=torch.uint8)
+    aexp = torch.zeros((mx4_aexp_bytes(M, K),), device=lo.device, dtype=torch.uint8)
+    _lib.check(lib.vt_mx4_quant_lo(_p(lo), K, M, K, _p(a4), _p(aexp), _stream()), "vt_mx4_quant_lo", lib)
+    return a4, aexp
+
+
+def rmsnorm_mx(x: torch.Tensor, w: torch.Tensor, eps: float, dtype: torch.dtype, idx: Optional[torch.Tensor] = None):
+    """(y op16 [rows][D], A4, aexp): RMSNorm with the level 3 operand out."""
+    _chk(x, torch.float32, "rmsnorm_mx.x")
+    _chk(w, torch.float32, "rmsnorm_mx.w")
+    lib = _lib.load(operand=_lib.operand_of(dtype))
+    rows = x.shape[0] if idx is None else idx.shape[0]
+    D = x.shape[1]
+    y = torch.empty((rows, D), device=x.device, dtype=dtype)
+    a4 = torch.empty((rows, D // 2), device=x.device, dtype=torch.uint8)
+    aexp = torch.zeros((mx4_aexp_bytes(rows, D),), device=x.device, dtype=torch.uint8)
+    _lib.check(lib.vt_rmsnorm_mx(_p(x), _p(idx), _p(w), _p(y), _p(a4), _p(aexp), rows, D, eps, _stream()), "vt_rmsnorm_mx", lib)
+    return y, a4, aexp
+
+
+def gemm_mx(a: torch.Tensor, a4: torch.Tensor, aexp: torch.Tensor, w: torch.Tensor, w4: torch.Tensor, wexp: torch.Tensor,
+            bias: Optional[torch.Tensor] = None, epi: int = EPI_BF16, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = epi(a @ w^T + (a4 2^aexp) @ (w4 2^wexp)^T + bias) in one launch (vt_gemm_mx)."""
+    lib, dt = _op16(a, "gemm_mx.a")
+    _chk(a, dt, "gemm_mx.a")
+    _chk(w, dt, "gemm_mx.w")
+    for t, n in ((a4, "a4"), (aexp, "aexp"), (w4, "w4"), (wexp, "wexp")):
+        _chk(t, torch.uint8, "gemm_mx." + n)
+    M, K = a.shape
+    N = w.shape[0]
+    if w.shape[1] != K or tuple(a4.shape) != (M, K // 2) or tuple(w4.shape) != (N, K // 2) or wexp.numel() != N or \
+            aexp.numel() < mx4_aexp_bytes(M, K):
+        raise _lib.VitronHipError("gemm_mx: operand shapes do not match")
+    if bias is not None:
+        _chk(bias, torch.float32, "gemm_mx.bias")
+    n_out = N // 2 if epi == EPI_SWIGLU_BF16 else N
+    odt = torch.float32 if epi in (EPI_F32, EPI_F32_RESID) else dt
+    if out is None:
+        if epi == EPI_F32_RESID:
+            raise _lib.VitronHipError("gemm_mx: EPI_F32_RESID needs `out` (the fp32 residual stream)")
+        out = torch.empty((M, n_out), device=a.device, dtype=odt)
+    _chk(out, odt, "gemm_mx.out")
+    _lib.check(lib.vt_gemm_mx(_p(a), K, _p(a4), _p(aexp), _p(w), K, _p(w4), _p(wexp), _p(out), out.shape[1], _p(bias), M, N, K, epi,
+                              _stream()), "vt_gemm_mx", lib)
+    return out
