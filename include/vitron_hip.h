@@ -138,6 +138,21 @@ int vt_rmsnorm_mx(const float* x, const int* idx, const float* w, uint16_t* y, u
 int vt_gemm_mx(const uint16_t* A, int lda, const uint8_t* A4, const uint8_t* aexp, const uint16_t* W, int ldw, const uint8_t* W4,
                const uint8_t* wexp, void* C, int ldc, const float* bias, int M, int N, int K, int epi, void* stream);
 
+/* gate/up of level 3: C [M][N/2] = op16(v), v = silu(gate) * up over the 16-interleaved columns, and (out4 [M][N/4], oexp) = the MX-FP4 image of
+ * v - f32(C) -- down_proj's second operand, written by the same launch. N % 128 == 0. */
+int vt_gemm_mx_swiglu(const uint16_t* A, int lda, const uint8_t* A4, const uint8_t* aexp, const uint16_t* W, int ldw, const uint8_t* W4,
+                      const uint8_t* wexp, uint16_t* C, int ldc, uint8_t* out4, uint8_t* oexp, int M, int N, int K, void* stream);
+/* x += A.W^T + A4.W4^T (o_proj, down_proj of level 3). A grid that spills a fraction of a round over whole rounds of the chip's 256
+ * multiprocessors runs its trailing row blocks as K ranges on the idle ones (fp32 partial slabs in `partials`, then an ordered reduce);
+ * partials may be NULL (one plain launch). */
+int vt_gemm_mx_resid(const uint16_t* A, int lda, const uint8_t* A4, const uint8_t* aexp, const uint16_t* W, int ldw, const uint8_t* W4,
+                     const uint8_t* wexp, float* C, int ldc, int M, int N, int K, float* partials, size_t partial_bytes, void* stream);
+/* vt_flash_attn (causal, head_dim 128, dense output: ldo == heads * 128) that also writes (O4 [rows][heads * 64], oexp) = the MX-FP4 image of
+ * the output's rounding remainder -- o_proj's second operand in level 3. */
+int vt_flash_attn_mx(const uint16_t* Q, int ldq, const uint16_t* k_tiles, const uint16_t* vt_tiles, const int* tile_table,
+                     const int* seq_desc, int nseq, int max_q_len, uint16_t* O, int ldo, uint8_t* O4, uint8_t* oexp, int heads, float scale,
+                     void* stream);
+
 /* Attention over 64-key tiles. seq_desc: device int32 [nseq][4] = {q_row0, q_len, kv_len, table_off};
  * tile_table: device int32, tile_table[table_off + t] = index of the sequence's t-th K / V^T tile.
  * K tile = [64 keys][HD] bf16, V^T tile = [HD][64 keys] holding IEEE fp16 bits (the bf16 values of the projection converted
@@ -346,9 +361,11 @@ typedef struct vt_vit_model {
                               two launches accumulating in fp32: the norm outputs, q and k through the attention scores (the decoder's
                               precise kernels at head_dim 64; v goes from fp32 straight into the V^T tiles' fp16), the attention outputs,
                               the temporal attention in fp32, the activation outputs; with out_feats_lo the selected patch tokens leave
-                              as a pair too. The hidden state is then within ~1e-5 of fp32 in both operand builds. 0 (default):
-                              standard. */
-  uint16_t* out_feats_lo;  /* optional DEVICE buffer [B*T*G*G][D]: the low half of out_feats (precise == 2 only) */
+                              as a pair too. The hidden state is then within ~1e-5 of fp32 in both operand builds.
+                              1: the MLPs' operands (layer_norm2 -> fc1, activation -> fc2: what carries the tower's distance from fp32)
+                              and out_feats as pairs, the attention paths standard -- the towers' share of the decoder's precise level 3.
+                              0 (default): standard. */
+  uint16_t* out_feats_lo;  /* optional DEVICE buffer [B*T*G*G][D]: the low half of out_feats (precise >= 1 only) */
 } vt_vit_model;
 
 size_t vt_vit_workspace_bytes(const vt_vit_model* m, int B, int T);
@@ -370,6 +387,12 @@ typedef struct vt_llama_layer {
   const float* rms2;     /* post_attention_layernorm.weight */
   const uint16_t* wgu;   /* [2I][H], rows interleaved in blocks of 16: gate | up | gate | up ... */
   const uint16_t* wdown; /* [H][I] */
+  /* precise level 3 (precise_qk = 3) only, else NULL: the MX-FP4 images of the four weight matrices (vt_mx4_quant_weights on the packed
+   * matrices above: same row order) and their per-row exponents */
+  const uint8_t* wqkv4;  const uint8_t* wqkv_e;
+  const uint8_t* wo4;    const uint8_t* wo_e;
+  const uint8_t* wgu4;   const uint8_t* wgu_e;
+  const uint8_t* wdown4; const uint8_t* wdown_e;
 } vt_llama_layer;
 
 typedef struct vt_llama_model {
@@ -387,7 +410,14 @@ typedef struct vt_llama_model {
   int qkv_fuse;                 /* 1: prefills write rotated q / K pages / V^T pages from the QKV projection's epilogue instead of the
                                    separate vt_kv_tiles pass. Bit-identical results; measured 20 us per launch SLOWER at S = 5120 (the
                                    epilogue of a one-workgroup-per-CU kernel overlaps with nothing: 455 vs 386 + 48.5 us): default 0. */
-  int precise_qk;               /* 2: precise level 2 -- level 1 below plus EVERY other GEMM A operand of a prefill as a pair (v projection,
+  int precise_qk;               /* 3: precise level 3 (head_dim 128, hidden % 256 == 0, intermediate % 128 == 0; the layers' *4 / *_e images set):
+                                   PREFILLS run every decoder Linear as ONE launch that adds, to the 16-bit product, the product of the MX-FP4
+                                   image of the A operand's rounding remainder with the weights' MX-FP4 image on the 4x-rate MX pipe (vt_gemm_mx;
+                                   RMSNorm, the attention kernels and the SwiGLU epilogue emit the remainder's image beside the 16-bit operand);
+                                   the lm_head's operand is a 16-bit pair as in level 2; q / k / v / P / V^T are stored as in the standard mode.
+                                   The mode north_star's 1e-3 is met in at ~1.25x of the standard step. A request the shapes
+                                   cannot serve is an ERROR, never a silent standard-mode pass.
+                                   2: precise level 2 -- level 1 below plus EVERY other GEMM A operand of a prefill as a pair (v projection,
                                    attention output -> o_proj, post-attention norm -> gate/up with the SwiGLU as its own fp32 -> pair pass,
                                    SwiGLU output -> down_proj, final norm -> lm_head): each product runs
                                    as two launches accumulating in fp32. A verification mode: ~2x the GEMM work.

@@ -89,11 +89,11 @@ MX4_BLOCK = 32
 def mx4_exponent(amax: torch.Tensor) -> torch.Tensor:
     """Unbiased power-of-two scale exponent e of a block whose largest magnitude is amax: the smallest e with amax / 2^e <= 6, i.e.
     amax / 2^e in (3, 6] -- nothing is clipped. From the fp32 fields, exactly as the kernels do it: floor(log2 amax) - 2, plus one when
-    the mantissa exceeds 1.5. Clamped to the e8m0 range [-127, 127]; amax = 0 gives -127 (every element quantises to 0 anyway)."""
+    the mantissa exceeds 1.5. Clamped to [-126, 127] (2^e stays a normal fp32 number); amax = 0 gives -126 (every element quantises to 0)."""
     bits = amax.float().contiguous().view(torch.int32)
     ex = ((bits >> 23) & 0xFF) - 127
     e = ex - 2 + ((bits & 0x7FFFFF) > 0x400000).to(torch.int32)
-    return e.clamp(-127, 127)
+    return e.clamp(-126, 127)
 
 
 def mx4_round(x: torch.Tensor) -> torch.Tensor:

@@ -160,3 +160,124 @@ def test_rmsnorm_mx(dev, dtype):
     # the remainder's 4-bit image carries it to ~13 % (e2m1 against a block scale); hi + image must be far closer to v than hi alone
     assert rel_l2(lo_got, lo_ref) < 0.2
     assert rel_l2(y.cpu().float() + lo_got, v) < 0.25 * rel_l2(y.cpu().float(), v)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(300, 256, 512), (700, 1408, 1024)])
+def test_gemm_mx_swiglu_operand_out(dev, dtype, M, N, K):
+    """Level 3 gate/up: the 16-bit output is the plain SwiGLU epilogue's, bit for bit; its 4-bit image restores most of what the 16-bit
+    store dropped (checked against the fp64 value of the same two products)."""
+    from oracle import vitron_oracle as O
+    from vitron_amd import ops
+    emu = "fp16" if dtype == torch.float16 else True
+    g = torch.Generator().manual_seed(N + K)
+    v = torch.randn((M, K), generator=g)
+    w = (torch.randn((N, K), generator=g) * 0.05).to(torch.bfloat16).to(dtype)
+    hi = O._r(v, emu)
+    lo = (v - hi).to(dtype)
+    a4, aexp = ops.mx4_quant_lo(lo.to(dev))
+    w4, wexp = ops.mx4_quant_weights(w.to(dev))
+    a = hi.to(dtype).to(dev)
+    h, h4, hexp = ops.gemm_mx_swiglu(a, a4, aexp, w.to(dev), w4, wexp)
+    base = ops.gemm_mx(a, a4, aexp, w.to(dev), w4, wexp, None, ops.EPI_SWIGLU_BF16)
+    assert torch.equal(h.cpu(), base.cpu())
+    y = hi.double() @ w.double().t() + O.mx4_quant(lo.float(), 32)[0].double() @ O.mx4_quant(w.float(), None)[0].double().t()
+    y4 = y.view(M, N // 32, 2, 16)
+    val = (torch.nn.functional.silu(y4[:, :, 0]) * y4[:, :, 1]).reshape(M, N // 2).float()
+    img = _deq(_unpack(h4), _aexp_rows(hexp, M, N // 2), 32)
+    rem = val - h.cpu().float()
+    assert rel_l2(img, rem) < 0.2, rel_l2(img, rem)
+    assert rel_l2(h.cpu().float() + img, val) < 0.25 * rel_l2(h.cpu().float(), val)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(5120, 4096, 512), (1300, 1024, 768), (300, 512, 1024)])
+def test_gemm_mx_resid_with_split_k_tail(dev, dtype, M, N, K):
+    """x += A.W^T + A4.W4^T with the trailing row blocks as K ranges (5120 x 4096: one round + 64 tiles x 4 ranges) == one plain launch, up to
+    the order of fp32 additions."""
+    from oracle import vitron_oracle as O
+    from vitron_amd import ops
+    emu = "fp16" if dtype == torch.float16 else True
+    g = torch.Generator().manual_seed(M + K)
+    v = torch.randn((M, K), generator=g)
+    w = (torch.randn((N, K), generator=g) * 0.05).to(torch.bfloat16).to(dtype)
+    x0 = torch.randn((M, N), generator=g)
+    hi = O._r(v, emu)
+    a4, aexp = ops.mx4_quant_lo((v - hi).to(dtype).to(dev))
+    w4, wexp = ops.mx4_quant_weights(w.to(dev))
+    a = hi.to(dtype).to(dev)
+    plain = ops.gemm_mx_resid(a, a4, aexp, w.to(dev), w4, wexp, x0.to(dev).clone())
+    part = torch.empty((256 * 256 * 256,), device=dev, dtype=torch.float32)
+    split = ops.gemm_mx_resid(a, a4, aexp, w.to(dev), w4, wexp, x0.to(dev).clone(), part)
+    one = ops.gemm_mx(a, a4, aexp, w.to(dev), w4, wexp, None, ops.EPI_F32_RESID, out=x0.to(dev).clone())
+    assert torch.equal(plain.cpu(), one.cpu())
+    assert rel_l2(split, plain) < 2e-6
+    if M <= 1300:
+        ref = x0.double() + hi.double() @ w.double().t() + O.mx4_quant((v - hi).to(dtype).float(), 32)[0].double() @ O.mx4_quant(w.float(), None)[0].double().t()
+        assert rel_l2(split, ref) < 2e-6
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("heads,lens", [(3, [600, 70]), (32, [2304])])
+def test_flash_attn_mx_operand_out(dev, dtype, heads, lens):
+    """The attention kernels' level 3 output (two-waves-per-SIMD kernel for the short problem, one-wave-per-SIMD kernel for the long one): O is the
+    standard launch's, bit for bit; with q = 0 every visible key weighs the same and v holds small integers, so the fp32 value behind O is known
+    exactly (sum / count, the kernel's own expression) and the image must be the quantiser's image of its remainder, code for code."""
+    import math
+    from oracle import vitron_oracle as O
+    from tests.test_gpu_attn_w4 import _problem
+    from vitron_amd import ops
+    op = "fp16" if dtype == torch.float16 else "bf16"
+    hd, D = 128, heads * 128
+    q, kt, vt, table, desc, kv_full = _problem(dev, dtype, heads, lens, [0] * len(lens))
+    scale = 1.0 / math.sqrt(hd)
+    o, o4, oexp = ops.flash_attn_mx(q, kt, vt, table, desc, max(lens), heads, scale)
+    base = ops.flash_attn(q, kt, vt, table, desc, max(lens), heads, hd, True, scale)
+    assert torch.equal(o.cpu(), base.cpu())
+    rows = sum(lens)
+    img = _deq(_unpack(o4), _aexp_rows(oexp, rows, D), 32)
+    assert torch.isfinite(img).all() and float(img.abs().max()) <= float(o.float().abs().max()) * (2 ** -8 if op == "bf16" else 2 ** -11) * 1.01
+    # exact case: q = 0, integer v
+    g = torch.Generator().manual_seed(9)
+    xs = []
+    for n in lens:
+        x = torch.zeros((n, 3 * D))
+        x[:, D:2 * D] = torch.randn((n, D), generator=g)
+        x[:, 2 * D:] = torch.randint(-8, 9, (n, D), generator=g).float()
+        xs.append(x.to(dev).to(dtype))
+    ntl = [(n + 63) // 64 for n in lens]
+    kt2 = torch.zeros_like(kt)
+    vt2 = torch.zeros_like(vt)
+    toff = 0
+    for i, x in enumerate(xs):
+        d = torch.tensor([[0, lens[i], lens[i], toff]], dtype=torch.int32, device=dev)
+        ops.kv_tiles(x, 0, D, 2 * D, kt2, vt2, table, d, ntl[i], heads, hd)
+        toff += ntl[i]
+    q0 = torch.cat([x[:, :D] for x in xs], 0).contiguous()
+    o, o4, oexp = ops.flash_attn_mx(q0, kt2, vt2, table, desc, max(lens), heads, scale)
+    vals = []
+    for x, n in zip(xs, lens):
+        cs = torch.cumsum(x[:, 2 * D:].float().cpu(), 0)                      # exact: small integers
+        cnt = torch.arange(1, n + 1, dtype=torch.float32)[:, None]
+        # the kernel's expression: oacc * (1 / l) with P = 2^7 on every visible key (P_BIAS): (128 sum) * (1 / (128 count)) in fp32
+        vals.append((cs * 128.0) * (1.0 / (cnt * 128.0)))
+    val = torch.cat(vals, 0)
+    emu = "fp16" if dtype == torch.float16 else True
+    hi = O._r(val, emu)
+    assert torch.equal(o.cpu().float(), hi)
+    _, qv, e = O.mx4_quant(val - hi, 32)
+    # the two-waves-per-SIMD kernel evaluates exactly this expression: exponents and codes must match one for one. The one-wave-per-SIMD kernel
+    # folds the scale into its exponent differently (its fp32 value can sit an ulp away from ours, which moves a remainder of 2^-12 of the value
+    # by 2^-12 of itself): there the images may differ where a remainder sits on a rounding boundary
+    e_got, c_got, c_ref = _aexp_rows(oexp, rows, D), _unpack(o4), O.mx4_codes(qv)
+    if heads == 3:
+        assert torch.equal(e_got, e + 127)
+        assert torch.equal(c_got & 7, c_ref & 7)                                   # (the sign of a zero code is not compared)
+        nz = (c_ref & 7) != 0
+        assert torch.equal((c_got & 8)[nz], (c_ref & 8)[nz])
+    else:
+        assert float((e_got != e + 127).float().mean()) < 2e-2
+        same_e = (e_got == e + 127).repeat_interleave(32, dim=1)
+        assert float(((c_got & 7) != (c_ref & 7))[same_e].float().mean()) < 2e-2
+        img = _deq(c_got, e_got, 32)
+        assert rel_l2(img, val - hi) < 0.2

@@ -62,6 +62,12 @@ BOUNDS["fp16-precise2"] = dict(embeds=5.0e-5, last=5.5e-4, rows=7.0e-4, proj=5.5
 # the bf16 build (the benchmark dtype) in precise level 2: one operand pair carries 16 mantissa bits, v goes straight from fp32 into the pages'
 # fp16, P is fp16 in both builds -- the same numbers as the fp16 build's (standard mode: 1.1 .. 1.3e-2), the same bounds
 BOUNDS["bf16-precise2"] = dict(BOUNDS["fp16-precise2"])
+# precise level 3 (round 6): the fp16 build with every decoder Linear of the prefill as ONE launch that adds the MX-FP4 product of the
+# A operand's rounding remainder on the 4x-rate MX pipe (towers and projector in level 2, the lm_head's operand a 16-bit pair): the mode in which
+# north_star's 1e-3 is met at ~1.25x of the standard step instead of 2.3x. The oracle's emulation (tests/parity_mx_fulldepth.py) puts c2_224 at
+# 6.1e-4 over all rows / 6.6e-4 at the last position -- q, k, V^T and P keep their single 16-bit stores; asserted inside 1e-3 with what margin there is
+# (the towers run their level 1 there: MLP operands and output features as pairs, attention paths standard -- embeddings 1.8e-4 instead of 2e-5)
+BOUNDS["fp16-precise3"] = dict(embeds=3.0e-4, last=9.5e-4, rows=9.0e-4, proj=9.0e-4, top1=0.996, top5=0.996)
 ID_TOL = {"bf16": 1.6e-2, "fp16": 2.4e-3}      # logits distance that sets the noise bound of the id comparison (= BOUNDS[op]["last"])
 REPORT = {}
 
@@ -115,17 +121,17 @@ def _load_tower(model, name, dev, odt, loaded={}):
     loaded[key] = FD.CASES[name]["image"]
 
 
-@pytest.mark.parametrize("precise", [0, 1, 2], ids=["standard", "precise_qk", "precise2"])
+@pytest.mark.parametrize("precise", [0, 1, 2, 3], ids=["standard", "precise_qk", "precise2", "precise3"])
 @pytest.mark.parametrize("name", ["c3", "c3_224", "c2", "c2_224"])
 def test_prefill_full_depth_vs_reference(full, name, precise):
     op, odt, model = full
-    if precise == 1 and op != "fp16":
-        pytest.skip("precise_qk (level 1) is asserted on the fp16 build only; level 2 on both")
+    if precise in (1, 3) and op != "fp16":
+        pytest.skip("precise_qk (level 1) and level 3 are asserted on the fp16 build (the reference's dtype) only; level 2 on both")
     dev = torch.device("cuda:0")
     _load_tower(model, name, dev, odt)          # (before set_precise: a re-packed tower starts in the standard mode)
     model.set_precise(precise)
     try:
-        _prefill_case(op + {0: "", 1: "-precise", 2: "-precise2"}[precise], odt, model, name, dev)
+        _prefill_case(op + {0: "", 1: "-precise", 2: "-precise2", 3: "-precise3"}[precise], odt, model, name, dev)
     finally:
         model.set_precise(0)
 
@@ -141,7 +147,7 @@ def _prefill_case(op, odt, model, name, dev):
     S = int(g["S"])
     assert embeds.shape[1] == S
     lo = pair_lo(embeds)                          # precise level 2: the spliced embeddings are an operand pair
-    assert (lo is not None) == op.endswith("precise2")
+    assert (lo is not None) == op.endswith(("precise2", "precise3"))
     e_val = embeds[0].float().cpu() + (lo[0].float().cpu() if lo is not None else 0.0)
     e_proj, e_rows = FW.vs_pin(e_val, g, "embeds")
     llama = model.get_model().llama

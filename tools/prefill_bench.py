@@ -1,4 +1,4 @@
-"""One prefill configuration alone, N timed repetitions: tools/prefill_bench.py {image|clip} IMAGE_SIZE [reps] [dtype] [precise_qk|precise2]
+"""One prefill configuration alone, N timed repetitions: tools/prefill_bench.py {image|clip} IMAGE_SIZE [reps] [dtype] [precise_qk|precise2|precise3]
   image 224 -> C2-224 (S = 768)    image 336 -> C2 (S = 1088)    clip 224 -> C3-224 (S = 2560)    clip 336 -> C3 (S = 5120)
 Full-work step as in bench.py (tower, projector, splice, 32 layers, last-position logits, arg-max). Used under
 rocprofv3 --kernel-trace --stats to see where each shape spends its time (profiles/r5_*_rocprofv3_kernel_stats.csv)."""
@@ -19,7 +19,7 @@ def main():
     kind, size = sys.argv[1], int(sys.argv[2])
     reps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
     op = sys.argv[4] if len(sys.argv) > 4 else "bf16"
-    precise = {"precise": 1, "precise_qk": 1, "precise2": 2}.get(sys.argv[5], 0) if len(sys.argv) > 5 else 0
+    precise = {"precise": 1, "precise_qk": 1, "precise2": 2, "precise3": 3}.get(sys.argv[5], 0) if len(sys.argv) > 5 else 0
     _lib.load(operand=op)
     odt = _lib.torch_dtype(op)
     dev = torch.device("cuda:0")

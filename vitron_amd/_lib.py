@@ -56,7 +56,8 @@ class VtVitModel(C.Structure):
 
 
 class VtLlamaLayer(C.Structure):
-    _fields_ = [(n, vp) for n in ("rms1", "wqkv", "wo", "rms2", "wgu", "wdown")]
+    _fields_ = [(n, vp) for n in ("rms1", "wqkv", "wo", "rms2", "wgu", "wdown",
+                                  "wqkv4", "wqkv_e", "wo4", "wo_e", "wgu4", "wgu_e", "wdown4", "wdown_e")]
 
 
 class VtLlamaModel(C.Structure):
@@ -117,6 +118,9 @@ SIGNATURES = {
     "vt_mx4_quant_lo": (_i, [vp, _i, _i, _i, vp, vp, vp]),
     "vt_rmsnorm_mx": (_i, [vp, vp, vp, vp, vp, vp, _i, _i, _f, vp]),
     "vt_gemm_mx": (_i, [vp, _i, vp, vp, vp, _i, vp, vp, vp, _i, vp, _i, _i, _i, _i, vp]),
+    "vt_gemm_mx_swiglu": (_i, [vp, _i, vp, vp, vp, _i, vp, vp, vp, _i, vp, vp, _i, _i, _i, vp]),
+    "vt_gemm_mx_resid": (_i, [vp, _i, vp, vp, vp, _i, vp, vp, vp, _i, _i, _i, _i, vp, _sz, vp]),
+    "vt_flash_attn_mx": (_i, [vp, _i, vp, vp, vp, vp, _i, _i, vp, _i, vp, vp, _i, _f, vp]),
 }
 PROF_CLASSES = ("gemm_tile", "flash_attn", "gemm_skinny", "attn_decode")
 

@@ -240,7 +240,23 @@ int vt_rmsnorm_mx(const float* x, const int* idx, const float* w, uint16_t* y, u
 }
 int vt_gemm_mx(const uint16_t* A, int lda, const uint8_t* A4, const uint8_t* aexp, const uint16_t* W, int ldw, const uint8_t* W4,
                const uint8_t* wexp, void* C, int ldc, const float* bias, int M, int N, int K, int epi, void* stream) {
-  return vt_gemm_mx_launch(A, lda, A4, aexp, W, ldw, W4, wexp, C, ldc, bias, M, N, K, epi, 1, 0, S(stream));
+  return vt_gemm_mx_launch(A, lda, A4, aexp, W, ldw, W4, wexp, C, ldc, bias, M, N, K, epi, 1, 0, nullptr, nullptr, S(stream));
+}
+
+int vt_gemm_mx_swiglu(const uint16_t* A, int lda, const uint8_t* A4, const uint8_t* aexp, const uint16_t* W, int ldw, const uint8_t* W4,
+                      const uint8_t* wexp, uint16_t* C, int ldc, uint8_t* out4, uint8_t* oexp, int M, int N, int K, void* stream) {
+  return vt_gemm_mx_launch(A, lda, A4, aexp, W, ldw, W4, wexp, C, ldc, nullptr, M, N, K, VT_EPI_SWIGLU_MX, 1, 0, out4, oexp, S(stream));
+}
+int vt_gemm_mx_resid(const uint16_t* A, int lda, const uint8_t* A4, const uint8_t* aexp, const uint16_t* W, int ldw, const uint8_t* W4,
+                     const uint8_t* wexp, float* C, int ldc, int M, int N, int K, float* partials, size_t partial_bytes, void* stream) {
+  return vt_gemm_mx_resid_launch(A, lda, A4, aexp, W, ldw, W4, wexp, C, ldc, M, N, K, partials, partial_bytes, S(stream));
+}
+int vt_flash_attn_mx(const uint16_t* Q, int ldq, const uint16_t* k_tiles, const uint16_t* vt_tiles, const int* tile_table,
+                     const int* seq_desc, int nseq, int max_q_len, uint16_t* O, int ldo, uint8_t* O4, uint8_t* oexp, int heads, float scale,
+                     void* stream) {
+  VT_REQUIRE(O4 && oexp, "vt_flash_attn_mx: null pointer");
+  return vt_flash_attn_launch(Q, ldq, k_tiles, vt_tiles, tile_table, (const VtAttnSeq*)seq_desc, nseq, max_q_len, O, ldo, heads, 128, 1, scale,
+                              S(stream), O4, oexp);
 }
 
 int vt_gemm_bf16_resid_splitk(const uint16_t* A, int lda, const uint16_t* W, int ldw, float* C, int ldc, const float* bias,
@@ -432,10 +448,12 @@ VitWs vit_carve(const vt_vit_model* m, int B, int T, void* p, size_t n) {
   w.splitk = w.splitk_bytes ? (float*)ws.take(w.splitk_bytes) : nullptr;
   w.ylo = w.hlo = w.qlo = w.klo = w.attlo = nullptr;
   w.h32 = w.qkv32 = nullptr;
-  if (m->precise >= 2) {
+  if (m->precise >= 1) {
     w.ylo = (bf16_t*)ws.take((size_t)R * D * 2);
     w.hlo = (bf16_t*)ws.take((size_t)R * I * 2);
     w.h32 = (float*)ws.take((size_t)R * I * 4);
+  }
+  if (m->precise >= 2) {
     w.qkv32 = (float*)ws.take((size_t)R * 3 * D * 4);
     w.qlo = (bf16_t*)ws.take((size_t)R * D * 2);
     w.klo = (bf16_t*)ws.take((size_t)F * ntiles * 64 * D * 2);
@@ -504,7 +522,15 @@ int vt_vit_forward(const vt_vit_model* m, const void* pixels, int pix_dtype, int
       VT_TRY(vt_gemm_launch(w.y, D, L.t_wqkv, D, w.qkv, 3 * D, L.t_bqkv, R, 3 * D, D, VT_EPI_BF16, AUTO, s));
       VT_TRY(vt_attn_temporal_launch(w.qkv, w.att, B, T, N, heads, s));
       VT_TRY(vt_gemm_launch(w.att, D, L.t_wo, D, w.x, D, L.t_bo, R, D, D, VT_EPI_F32_RESID, AUTO, s));
-      if (L.t_w1) {   // image tower's add_time_attn variant: x += temporal_mlp(temporal_layer_norm2(x)) (image/modeling_image.py:129-134)
+      if (L.t_w1 && m->precise >= 1) {   // (precise level 1: the temporal MLP's operands as pairs, like the spatial MLP below)
+        VT_REQUIRE(L.t_ln2_g && L.t_ln2_b && L.t_w2 && L.t_b1 && L.t_b2, "vt_vit_forward: layer %d has a temporal MLP with missing tensors", l);
+        VT_TRY(vt_layernorm_hilo_launch(w.x, L.t_ln2_g, L.t_ln2_b, w.y, w.ylo, R, D, m->ln_eps, s));
+        VT_TRY(vt_gemm_launch(w.y, D, L.t_w1, D, w.h32, I, L.t_b1, R, I, D, VT_EPI_F32, AUTO, s));
+        VT_TRY(vt_gemm_resid_launch(w.ylo, D, L.t_w1, D, w.h32, I, nullptr, R, I, D, 0, w.splitk, w.splitk_bytes, s));
+        VT_TRY(vt_act_pair_launch(w.h32, I, w.h, w.hlo, R, I, m->act == VT_ACT_QUICK_GELU ? 1 : 0, s));
+        VT_TRY(vt_gemm_resid_launch(w.h, I, L.t_w2, I, w.x, D, L.t_b2, R, D, I, 0, w.splitk, w.splitk_bytes, s));
+        VT_TRY(vt_gemm_resid_launch(w.hlo, I, L.t_w2, I, w.x, D, nullptr, R, D, I, 0, w.splitk, w.splitk_bytes, s));
+      } else if (L.t_w1) {   // image tower's add_time_attn variant: x += temporal_mlp(temporal_layer_norm2(x)) (image/modeling_image.py:129-134)
         VT_REQUIRE(L.t_ln2_g && L.t_ln2_b && L.t_w2 && L.t_b1 && L.t_b2, "vt_vit_forward: layer %d has a temporal MLP with missing tensors", l);
         VT_TRY(vt_layernorm_launch(w.x, nullptr, 0, 0, L.t_ln2_g, L.t_ln2_b, w.y, R, D, m->ln_eps, s));
         VT_TRY(vt_gemm_launch(w.y, D, L.t_w1, D, w.h, I, L.t_b1, R, I, D, act_epi, AUTO, s));
@@ -534,8 +560,8 @@ int vt_vit_forward(const vt_vit_model* m, const void* pixels, int pix_dtype, int
       VT_TRY(vt_gemm_launch(w.att, D, L.wo, D, w.x, D, L.bo, R, D, D, VT_EPI_F32_RESID, AUTO, s));
     }
     // MLP
-    if (m->precise >= 2) {
-      // precise level 2 (layer_norm2 -> fc1 and GELU -> fc2 carry half of the tower's distance from fp32): both operands as
+    if (m->precise >= 1) {
+      // precise level 1 / 2 (layer_norm2 -> fc1 and GELU -> fc2 carry half of the tower's distance from fp32): both operands as
       // pairs, every product as two launches accumulating in fp32, the activation as its own fp32 -> pair pass
       VT_TRY(vt_layernorm_hilo_launch(w.x, L.ln2_g, L.ln2_b, w.y, w.ylo, R, D, m->ln_eps, s));
       VT_TRY(vt_gemm_launch(w.y, D, L.w1, D, w.h32, I, L.b1, R, I, D, VT_EPI_F32, AUTO, s));
@@ -549,7 +575,7 @@ int vt_vit_forward(const vt_vit_model* m, const void* pixels, int pix_dtype, int
     VT_TRY(vt_gemm_launch(w.y, D, L.w1, D, w.h, I, L.b1, R, I, D, act_epi, AUTO, s));
     VT_TRY(vt_gemm_resid_launch(w.h, I, L.w2, I, w.x, D, L.b2, R, D, I, 0, w.splitk, w.splitk_bytes, s));
   }
-  if (m->precise >= 2 && m->out_feats_lo) {   // the patch tokens of the selected hidden state as a pair (the projector's operand)
+  if (m->precise >= 1 && m->out_feats_lo) {   // the patch tokens of the selected hidden state as a pair (the projector's operand)
     VT_TRY(vt_f32_to_pair_launch(w.x, out_feats, m->out_feats_lo, (size_t)F * G2, G2, D, s));
     if (out_hidden) VT_HIP(hipMemcpyAsync(out_hidden, w.x, (size_t)R * D * 4, hipMemcpyDeviceToDevice, s));
     return VT_OK;
@@ -578,6 +604,9 @@ struct LlamaWs {
   // precise level 2 (every GEMM A operand a pair): low halves of the attention output, the SwiGLU output and the final norm; fp32 gate/up
   bf16_t *attlo, *hlo, *ynlo;
   float* gu32;
+  // precise level 3: MX-FP4 images (codes + block exponents) of the rounding remainders of the norm output, the attention output and the
+  // SwiGLU output (vt_mx4.hip); ynlo above for the lm_head's pair
+  uint8_t *y4, *yexp, *att4, *attexp, *h4, *hexp;
   size_t total;
 };
 LlamaWs llama_carve(const vt_llama_model* m, int rows, int n_logit, int nseq, int max_kv_len, void* p, size_t n) {
@@ -604,7 +633,16 @@ LlamaWs llama_carve(const vt_llama_model* m, int rows, int n_logit, int nseq, in
   w.klo_tiles = 0;
   w.attlo = w.hlo = w.ynlo = nullptr;
   w.gu32 = nullptr;
-  if (m->precise_qk >= 1 && m->head_dim == 128 && rows > 1) {   // (sized whenever the mode is on: the query does not know max_q_len)
+  w.y4 = w.yexp = w.att4 = w.attexp = w.h4 = w.hexp = nullptr;
+  if (m->precise_qk == 3 && m->head_dim == 128 && rows > 1) {
+    w.y4 = (uint8_t*)ws.take((size_t)rows * (H / 2));
+    w.yexp = (uint8_t*)ws.take(vt_mx4_aexp_bytes(rows, H));
+    w.att4 = (uint8_t*)ws.take((size_t)rows * (H / 2));
+    w.attexp = (uint8_t*)ws.take(vt_mx4_aexp_bytes(rows, H));
+    w.h4 = (uint8_t*)ws.take((size_t)rows * (I / 2));
+    w.hexp = (uint8_t*)ws.take(vt_mx4_aexp_bytes(rows, I));
+    w.ynlo = (bf16_t*)ws.take((size_t)(n_logit > 0 ? n_logit : 1) * H * 2);
+  } else if (m->precise_qk >= 1 && m->head_dim == 128 && rows > 1) {   // (sized whenever the mode is on: the query does not know max_q_len)
     const bool full = m->precise_qk >= 2;
     w.ylo = (bf16_t*)ws.take((size_t)rows * H * 2);
     w.qlo = (bf16_t*)ws.take((size_t)rows * H * 2);
@@ -672,7 +710,18 @@ int vt_llama_forward(const vt_llama_model* m, const vt_kv_cache* kv, const uint1
   // writes rotated q / K pages / V^T pages itself (no vt_kv_tiles pass). Bit-identical, measured slower: default off
   const bool fuse_qkv = max_q_len > 1 && !fold_tile && m->qkv_fuse == 1 && vt_gemm_qkv_fused_supported(rows, H, HD);
   // opt-in (vt_llama_model.precise_qk): prefills carry q and k as operand pairs through the QKV projection and the attention scores
-  const bool precise = max_q_len > 1 && !fold_norm && m->precise_qk >= 1 && HD == 128 && w.qk32 != nullptr && max_new_tiles <= w.klo_tiles;
+  // precise level 3: every decoder Linear of a prefill as ONE launch with the MX-FP4 product of the A operand's remainder folded in
+  const bool precise3 = max_q_len > 1 && !fold_norm && m->precise_qk == 3;
+  if (precise3) {   // a request the shapes cannot serve is an error, never a silent standard-mode pass
+    VT_REQUIRE(HD == 128 && (H % 256) == 0 && (I % 128) == 0 && w.y4 != nullptr, "vt_llama_forward: precise level 3 needs head_dim 128, hidden %% 256 == 0, intermediate %% 128 == 0 (H=%d I=%d)", H, I);
+    for (int l = 0; l < m->num_layers; ++l) {
+      const vt_llama_layer& L = m->layers[l];
+      VT_REQUIRE(L.wqkv4 && L.wqkv_e && L.wo4 && L.wo_e && L.wgu4 && L.wgu_e && L.wdown4 && L.wdown_e, "vt_llama_forward: precise level 3 without the weights' MX-FP4 images (layer %d)", l);
+    }
+  }
+  const bool precise = !precise3 && max_q_len > 1 && !fold_norm && m->precise_qk >= 1 && HD == 128 && w.qk32 != nullptr && max_new_tiles <= w.klo_tiles;
+  if (m->precise_qk >= 1 && m->precise_qk <= 2 && max_q_len > 1 && !fold_norm)
+    VT_REQUIRE(precise, "vt_llama_forward: precise level %d was requested and cannot run here (head_dim %d, %d new tiles per sequence against %d slots)", m->precise_qk, HD, max_new_tiles, w.klo_tiles);
   const bool precise2 = precise && m->precise_qk >= 2 && w.gu32 != nullptr;
   if (fuse_qkv) VT_TRY(vt_row_slot_launch((const VtAttnSeq*)seq_desc, nseq, max_q_len, tile_table, w.row_slot, s));
   for (int l = 0; l < m->num_layers; ++l) {
@@ -715,6 +764,21 @@ int vt_llama_forward(const vt_llama_model* m, const vt_kv_cache* kv, const uint1
     // (opt-in, see above).
     VtGemmNormFuse cons_t;
     cons_t.row_scale = w.rstd;
+    if (precise3) {
+      VT_TRY(vt_rmsnorm_mx_launch(w.x, nullptr, L.rms1, w.y, w.y4, w.yexp, rows, H, m->rms_eps, s));
+      VT_TRY(vt_gemm_mx_launch(w.y, H, w.y4, w.yexp, L.wqkv, H, L.wqkv4, L.wqkv_e, w.qkv, 3 * H, nullptr, rows, 3 * H, H, VT_EPI_BF16, 1, 0, nullptr,
+                               nullptr, s));
+      VT_TRY(vt_kv_tiles_launch(w.qkv, 3 * H, 0, H, 2 * H, kt, vt, tile_table, (const VtAttnSeq*)seq_desc, nseq, max_new_tiles, heads, HD,
+                                m->rope_cos, m->rope_sin, positions, s));
+      VT_TRY(vt_flash_attn_launch(w.qkv, 3 * H, kt, vt, tile_table, (const VtAttnSeq*)seq_desc, nseq, max_q_len, w.att, H, heads, HD, 1, scale, s,
+                                  w.att4, w.attexp));
+      VT_TRY(vt_gemm_mx_resid_launch(w.att, H, w.att4, w.attexp, L.wo, H, L.wo4, L.wo_e, w.x, H, rows, H, H, w.splitk, w.splitk_bytes, s));
+      VT_TRY(vt_rmsnorm_mx_launch(w.x, nullptr, L.rms2, w.y, w.y4, w.yexp, rows, H, m->rms_eps, s));
+      VT_TRY(vt_gemm_mx_launch(w.y, H, w.y4, w.yexp, L.wgu, H, L.wgu4, L.wgu_e, w.h, I, nullptr, rows, 2 * I, H, VT_EPI_SWIGLU_MX, 1, 0, w.h4, w.hexp,
+                               s));
+      VT_TRY(vt_gemm_mx_resid_launch(w.h, I, w.h4, w.hexp, L.wdown, I, L.wdown4, L.wdown_e, w.x, H, rows, H, I, w.splitk, w.splitk_bytes, s));
+      continue;
+    }
     if (precise2) {
       // precise level 2: EVERY GEMM A operand is a pair (hi + lo), each product as two launches accumulating in fp32: the q | k | v
       // projection into fp32, o_proj / down_proj as two residual launches, gate/up into fp32 with the SwiGLU (pair out) as its own pass
@@ -805,7 +869,7 @@ int vt_llama_forward(const vt_llama_model* m, const vt_kv_cache* kv, const uint1
     VT_TRY(vt_gemm_resid_launch(w.h, I, L.wdown, I, w.x, H, nullptr, rows, H, I, 0, w.splitk, w.splitk_bytes, s));
   }
   if (out_hidden) VT_HIP(hipMemcpyAsync(out_hidden, w.x, (size_t)rows * H * 4, hipMemcpyDeviceToDevice, s));
-  if (n_logit_rows > 0 && precise2) {   // level 2: the lm_head's operand as a pair too (any number of rows: a last-position-only call included)
+  if (n_logit_rows > 0 && (precise2 || precise3)) {   // level 2: the lm_head's operand as a pair too (any number of rows: a last-position-only call included)
     VT_TRY(vt_rmsnorm_hilo_launch(w.x, logit_rows, m->final_norm, w.yn, w.ynlo, n_logit_rows, H, m->rms_eps, s));
     VT_TRY(vt_gemm_launch(w.yn, H, m->lm_head, H, logits, m->vocab, nullptr, n_logit_rows, m->vocab, H, VT_EPI_F32, AUTO, s));
     VT_TRY(vt_gemm_resid_launch(w.ynlo, H, m->lm_head, H, logits, m->vocab, nullptr, n_logit_rows, m->vocab, H, 0, w.splitk, w.splitk_bytes, s));

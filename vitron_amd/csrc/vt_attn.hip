@@ -26,6 +26,7 @@
 
 #include "vt_common.h"
 #include "vt_kernels.h"
+#include "vt_mx4.h"
 
 namespace {
 
@@ -53,13 +54,16 @@ __device__ __forceinline__ int v_swz(int d) { return (d >> 1) & 7; }
 //   <8 waves, 3 stages>  256-row blocks, 96 KiB LDS, one block per CU, two tiles of DMA lead -- long causal prefill
 // ABL (timing ablations, results are garbage): bit0 = no exp / max / sum (softmax VALU), bit1 = no MFMA;
 // experiment knobs (results correct): bit2 = s_setprio 3 around the softmax section, bit3 = s_setprio 3 around the MFMA sections
-template <int HD, bool CAUSAL, int NWAVES, int NSTAGES, int ABL = 0>
+// MXOUT (precise level 3, head_dim 128): the epilogue also writes the MX-FP4 image of the output's rounding remainder (O4 / oexp: o_proj's
+// second operand, vt_mx4.h); the other instantiations never read the two pointers.
+template <int HD, bool CAUSAL, int NWAVES, int NSTAGES, int ABL = 0, bool MXOUT = false>
 __global__ __launch_bounds__(64 * NWAVES, (NWAVES == 8) ? 2 : 2) void flash_attn_kernel(const bf16_t* __restrict__ Q, int ldq,
                                                          const bf16_t* __restrict__ Kt,
                                                          const bf16_t* __restrict__ Vt,
                                                          const int* __restrict__ tile_table,
                                                          const VtAttnSeq* __restrict__ seqs, bf16_t* __restrict__ O,
-                                                         int ldo, int heads, float scale_log2e) {
+                                                         int ldo, int heads, float scale_log2e, uint8_t* __restrict__ O4,
+                                                         uint8_t* __restrict__ oexp) {
   constexpr int KS = HD / 16;          // k-steps of the QK^T MFMA
   constexpr int DB = HD / 32;          // 32-wide d blocks of the output
   constexpr int KROW = HD * 2;         // bytes per K row
@@ -295,7 +299,29 @@ __global__ __launch_bounds__(64 * NWAVES, (NWAVES == 8) ? 2 : 2) void flash_attn
   // ---- epilogue ------------------------------------------------------------------------------------------------
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = (l_tot > 0.f) ? 1.f / l_tot : 0.f;
-  if (qrow < sq.q_len) {
+  if constexpr (MXOUT) {
+    const bool valid = qrow < sq.q_len;
+    const int m = sq.q_row0 + qrow_c;
+    bf16_t* op = O + (size_t)m * ldo + head * HD + 4 * hh;
+#pragma unroll
+    for (int db = 0; db < DB; ++db) {
+      float lo[16];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float a0 = oacc[db][4 * g + 0] * inv, a1 = oacc[db][4 * g + 1] * inv, a2 = oacc[db][4 * g + 2] * inv, a3 = oacc[db][4 * g + 3] * inv;
+        u32x2 o;
+        o.x = pack_op2(a0, a1);
+        o.y = pack_op2(a2, a3);
+        if (valid) *(u32x2*)(op + db * 32 + 8 * g) = o;
+        lo[4 * g + 0] = a0 - oplo_to_f32(o.x);
+        lo[4 * g + 1] = a1 - ophi_to_f32(o.x);
+        lo[4 * g + 2] = a2 - oplo_to_f32(o.y);
+        lo[4 * g + 3] = a3 - ophi_to_f32(o.y);
+      }
+      mx4_store_attn_block(lo, hh, valid, O4 + (size_t)m * (heads * (HD / 2)) + head * (HD / 2) + db * 16,
+                           oexp + mx4_aexp_index(m, head * DB + db, heads * DB));
+    }
+  } else if (qrow < sq.q_len) {
     bf16_t* op = O + (size_t)(sq.q_row0 + qrow) * ldo + head * HD + 4 * hh;
 #pragma unroll
     for (int db = 0; db < DB; ++db)
@@ -1399,8 +1425,10 @@ int g_vt_flash_attn_order = 1;
 
 int vt_flash_attn_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf16_t* Vt, const int* tile_table,
                          const VtAttnSeq* seqs, int nseq, int max_q_len, bf16_t* O, int ldo, int heads, int HD,
-                         int causal, float scale, hipStream_t s) {
+                         int causal, float scale, hipStream_t s, uint8_t* O4, uint8_t* oexp) {
   VT_REQUIRE(Q && Kt && Vt && tile_table && seqs && O, "vt_flash_attn: null pointer");
+  VT_REQUIRE(!O4 || (oexp && HD == 128 && causal && ldo == heads * HD && (((size_t)O4) & 7) == 0),
+             "vt_flash_attn: the level 3 operand out needs head_dim 128, a causal launch and a dense output (ldo == heads * 128)");
   VT_REQUIRE(HD == 64 || HD == 128, "vt_flash_attn: head_dim %d unsupported (64 or 128)", HD);
   VT_REQUIRE(nseq > 0 && max_q_len > 0 && heads > 0, "vt_flash_attn: empty problem");
   VT_REQUIRE(ldq % 8 == 0 && ldo % 4 == 0, "vt_flash_attn: ldq %% 8 and ldo %% 4 must be 0");
@@ -1415,7 +1443,7 @@ int vt_flash_attn_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf16_
     if (g_vt_flash_attn_kernel >= 2 || (fills && aligned)) {
       VT_REQUIRE(aligned, "vt_flash_attn: the one-wave-per-SIMD kernel stores 16-byte chunks: O 16-byte aligned, ldo %% 8 == 0");
       return vt_flash_attn_w4_launch(Q, ldq, Kt, Vt, tile_table, seqs, nseq, max_q_len, O, ldo, heads, causal, sl2,
-                                     g_vt_flash_attn_kernel == 3 ? 0 : g_vt_flash_attn_kernel == 4 ? 2 : 1, s);
+                                     g_vt_flash_attn_kernel == 3 ? 0 : g_vt_flash_attn_kernel == 4 ? 2 : 1, s, O4, oexp);
     }
   }
   // long sequences: 256-row blocks, 3-stage ring; short ones (ViT frames, small prefills): 128-row blocks
@@ -1437,9 +1465,11 @@ int vt_flash_attn_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf16_
       done = true;                                                                                             \
     }                                                                                                          \
     dim3 grid(heads, cdiv(max_q_len, 32 * NW), nseq), block(64 * NW);                                          \
-    hipLaunchKernelGGL(kern, grid, block, smem, s, Q, ldq, Kt, Vt, tile_table, seqs, O, ldo, heads, sl2);      \
+    hipLaunchKernelGGL(kern, grid, block, smem, s, Q, ldq, Kt, Vt, tile_table, seqs, O, ldo, heads, sl2, O4, oexp); \
   } while (0)
-  if (HD == 64) {
+  if (O4) {
+    VT_FA(128, true, 4, 2, 0, true);
+  } else if (HD == 64) {
     if (causal) VT_FA(64, true, 4, 2); else VT_FA(64, false, 4, 2);
 #ifdef VT_ABLATIONS
   } else if (big) {

@@ -39,6 +39,7 @@
 
 #include "vt_common.h"
 #include "vt_kernels.h"
+#include "vt_mx4.h"
 
 namespace {
 
@@ -110,11 +111,13 @@ __device__ unsigned long long g_w4_prof[4][16];
 //     tiles 0 and 1 of the NEXT block into slots 0 and 1 (where they belong), the tail fetches its tile 2 and loads its Q rows into the
 //     registers the last score MFMA has just released, and O is staged in the two slots the tail frees (K slot 3, V^T slot 3) -- the next
 //     block starts with its operands in flight or landed instead of cold. Other tile counts fall back to a cold start per block.
-template <bool CAUSAL, bool PLACED, int ABL = 0, bool PERSIST = false>
+// MXOUT (precise level 3): the epilogue also writes the MX-FP4 image of the output's rounding remainder (O4 / oexp: o_proj's second operand,
+// vt_mx4.h); the other instantiations never read the two pointers.
+template <bool CAUSAL, bool PLACED, int ABL = 0, bool PERSIST = false, bool MXOUT = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void flash_attn_w4_kernel(
     const op16_t* __restrict__ Q, int ldq, const op16_t* __restrict__ Kt, const op16_t* __restrict__ Vt,
     const int* __restrict__ tile_table, const VtAttnSeq* __restrict__ seqs, op16_t* __restrict__ O, int ldo, int heads,
-    float scale_log2e, int nqb_max, int nseq, int nx, const int* __restrict__ order) {
+    float scale_log2e, int nqb_max, int nseq, int nx, const int* __restrict__ order, uint8_t* __restrict__ O4, uint8_t* __restrict__ oexp) {
   constexpr int HD = 128, QBLK = 256, TB = 64 * HD * 2, VRING = 4 * TB;   // 16-KiB tiles; K ring then V^T ring, 4 slots each
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -605,14 +608,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       const float l_tot = lrun[rh] + __shfl_xor(lrun[rh], 32, 64);
       const float inv = (l_tot > 0.f) ? 1.f / l_tot : 0.f;
 #pragma unroll
-      for (int db = 0; db < 4; ++db)
+      for (int db = 0; db < 4; ++db) {
+        float lo[MXOUT ? 16 : 1];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
+          const float a0 = oacc[rh][db][4 * g + 0] * inv, a1 = oacc[rh][db][4 * g + 1] * inv, a2 = oacc[rh][db][4 * g + 2] * inv,
+                      a3 = oacc[rh][db][4 * g + 3] * inv;
           u32x2 o;
-          o.x = pack_op2(oacc[rh][db][4 * g + 0] * inv, oacc[rh][db][4 * g + 1] * inv);
-          o.y = pack_op2(oacc[rh][db][4 * g + 2] * inv, oacc[rh][db][4 * g + 3] * inv);
+          o.x = pack_op2(a0, a1);
+          o.y = pack_op2(a2, a3);
           *(u32x2*)(stage + ql * 256 + (((db * 4 + g) ^ (ql & 15)) << 4) + hh * 8) = o;      // d = db*32 + 8g + 4hh .. +3
+          if constexpr (MXOUT) {
+            lo[4 * g + 0] = a0 - oplo_to_f32(o.x);
+            lo[4 * g + 1] = a1 - ophi_to_f32(o.x);
+            lo[4 * g + 2] = a2 - oplo_to_f32(o.y);
+            lo[4 * g + 3] = a3 - ophi_to_f32(o.y);
+          }
         }
+        if constexpr (MXOUT) {   // the remainder's 4-bit image straight from the registers: 8 bytes per lane and block
+          const int rq = wrow0 + rh * 32 + ql;
+          const int m = sq.q_row0 + min(rq, sq.q_len - 1);
+          mx4_store_attn_block(lo, hh, rq < sq.q_len, O4 + (size_t)m * (heads * 64) + head * 64 + db * 16,
+                               oexp + mx4_aexp_index(m, head * 4 + db, heads * 4));
+        }
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the wave's own writes (the region is wave-private: no barrier)
       const int c = lane & 15, r4 = lane >> 4;               // 16-byte chunk of the row, row inside a group of 4
 #pragma unroll
@@ -779,7 +798,8 @@ bool vt_flash_attn_w4_supported(int HD, int max_q_len, int heads, int nseq) {
 
 int vt_flash_attn_w4_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf16_t* Vt, const int* tile_table, const VtAttnSeq* seqs,
                             int nseq, int max_q_len, bf16_t* O, int ldo, int heads, int causal, float scale_log2e, int placed,
-                            hipStream_t s) {
+                            hipStream_t s, uint8_t* O4, uint8_t* oexp) {
+  VT_REQUIRE(!O4 || (oexp && causal && placed == 1 && ldo == heads * 128), "vt_flash_attn_w4: the level 3 operand out runs on the placed causal kernel, dense output");
   constexpr int smem = 8 * 16384 + 16;   // K ring + V^T ring, four 16-KiB slots each (+ the persistent form's ticket words)
   const int nqb_max = cdiv(max_q_len, 256);
   // placed == 2: the persistent form -- one workgroup per CU walking the block list (kernel header)
@@ -805,7 +825,7 @@ int vt_flash_attn_w4_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf
       VT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));        \
       done.fetch_or(1ull << dev, std::memory_order_relaxed);                                                   \
     }                                                                                                          \
-    hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, Q, ldq, Kt, Vt, tile_table, seqs, O, ldo, heads, scale_log2e, nqb_max, nseq, nx, order); \
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, Q, ldq, Kt, Vt, tile_table, seqs, O, ldo, heads, scale_log2e, nqb_max, nseq, nx, order, O4, oexp); \
   } while (0)
   dim3 grid(heads, nqb_max, nseq);
   // causal launches of more than one round: the planned dispatch order (above), computed once per shape and kept on the device
@@ -873,6 +893,8 @@ int vt_flash_attn_w4_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf
   if (placed == 2) {
     grid = dim3(ngrid);
     if (causal) VT_FAW4(true, true, 0, true); else VT_FAW4(false, true, 0, true);
+  } else if (O4) {
+    VT_FAW4(true, true, 0, false, true);
   } else if (placed) {
     if (causal) VT_FAW4(true, true); else VT_FAW4(false, true);
   } else {

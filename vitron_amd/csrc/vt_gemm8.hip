@@ -37,6 +37,7 @@
 
 #include "vt_common.h"
 #include "vt_kernels.h"
+#include "vt_mx4.h"
 
 namespace {
 
@@ -1643,16 +1644,16 @@ int vt_gemm_p8_launch(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* 
 
 // precise level 3: C = epi(A.W^T + (A4 2^ea).(W4 2^ew)^T) on 256x256 tiles (vt_gemm8x.inc). M, N arbitrary (edges clamped / masked as in the
 // base kernel), K % 128 == 0 and K >= 256; aexp must cover ceil(M / 256) * 256 rows (vt_mx4_aexp_bytes). ksplit > 1: EPI F32 only, split s
-// of every tile writes slab s (C + s * slab elements).
+// of every tile writes slab s (C + s * slab elements). epi = VT_EPI_SWIGLU_MX (internal): out4 / oexp receive the output's own 4-bit image.
 int vt_gemm_mx_launch(const bf16_t* A, int lda, const uint8_t* A4, const uint8_t* aexp, const bf16_t* W, int ldw, const uint8_t* W4,
                       const uint8_t* wexp, void* C, int ldc, const float* bias, int M, int N, int K, int epi, int ksplit, size_t slab,
-                      hipStream_t s) {
+                      uint8_t* out4, uint8_t* oexp, hipStream_t s) {
   VT_REQUIRE(A && A4 && aexp && W && W4 && wexp && C, "vt_gemm_mx: null pointer");
   VT_REQUIRE(M > 0 && N > 0 && (K % 128) == 0 && K >= 256 && (N % 4) == 0, "vt_gemm_mx: needs K %% 128 == 0, K >= 256, N %% 4 == 0 (K=%d N=%d)", K, N);
   VT_REQUIRE((lda % 8) == 0 && (ldw % 8) == 0 && (((size_t)A4 | (size_t)W4) & 15) == 0, "vt_gemm_mx: misaligned operands");
   VT_REQUIRE(ksplit <= 1 || (epi == VT_EPI_F32 && (K / 128) >= 2 * ksplit), "vt_gemm_mx: split-K needs the fp32 epilogue and >= 2 K pairs per split");
   GemmP8 p{A, W, C, bias, M, N, K, lda, ldw, ldc, std::max(ksplit, 1), slab, VtGemmNormFuse{}};
-  const GemmMx x{A4, aexp, W4, wexp};
+  const GemmMx x{A4, aexp, W4, wexp, out4, oexp};
   VtProfScope prof(VT_PROF_GEMM_TILE, 2.0 * (double)M * (double)N * (double)K, s);
   switch (epi) {
     case VT_EPI_BF16: return launch_w4x<VT_EPI_BF16>(p, x, s);
@@ -1661,6 +1662,35 @@ int vt_gemm_mx_launch(const bf16_t* A, int lda, const uint8_t* A4, const uint8_t
     case VT_EPI_F32_RESID: return launch_w4x<VT_EPI_F32_RESID>(p, x, s);
     case VT_EPI_F32: return launch_w4x<VT_EPI_F32>(p, x, s);
     case VT_EPI_SWIGLU_BF16: return launch_w4x<VT_EPI_SWIGLU_BF16>(p, x, s);
+    case VT_EPI_SWIGLU_MX:
+      VT_REQUIRE(out4 && oexp && (N % 128) == 0 && (ldc % 8) == 0 && (((size_t)C | (size_t)out4) & 15) == 0 && !bias,
+                 "vt_gemm_mx: the SwiGLU epilogue with the level 3 operand out needs N %% 128 == 0, aligned outputs and no bias");
+      return launch_w4x<VT_EPI_SWIGLU_MX>(p, x, s);
     default: vt_set_error("vt_gemm_mx: epilogue %d not instantiated", epi); return VT_ERR_ARG;
   }
+}
+
+// the residual GEMMs of level 3 (x += A.W^T + A4.W4^T: o_proj, down_proj). The kernel has ONE tile height (256 rows; the 4-bit image takes the
+// LDS the 320-row tile would need), so a grid that spills a fraction of a round over whole rounds of the 256 CUs -- 5120 x 4096: 320 tiles --
+// is cut at the last whole round: the leading row blocks run as they are, the trailing ones as `ksplit` K ranges per tile on the otherwise
+// idle CUs (fp32 partial slabs + the ordered reduce of the two-pass split-K), 1.25 rounds + a reduce instead of 2.
+int vt_gemm_mx_resid_launch(const bf16_t* A, int lda, const uint8_t* A4, const uint8_t* aexp, const bf16_t* W, int ldw, const uint8_t* W4,
+                            const uint8_t* wexp, float* C, int ldc, int M, int N, int K, float* partials, size_t partial_bytes, hipStream_t s) {
+  const int tiles_m = cdiv(M, 256), tiles_n = cdiv(N, 256), total = tiles_m * tiles_n, CUS = 256;
+  const int head_rows = (total / CUS) * CUS / tiles_n;        // row blocks inside whole rounds
+  const int tail_tiles = (tiles_m - head_rows) * tiles_n;
+  int ksplit = tail_tiles > 0 ? std::min(8, CUS / tail_tiles) : 1;
+  while (ksplit > 1 && (K / 128) < 2 * ksplit) --ksplit;
+  const int m0 = head_rows * 256, mt = M - m0;
+  if (head_rows == 0 || tail_tiles == 0 || ksplit < 2 || !partials || (size_t)ksplit * mt * N * 4 > partial_bytes || (N % 4) != 0)
+    return vt_gemm_mx_launch(A, lda, A4, aexp, W, ldw, W4, wexp, C, ldc, nullptr, M, N, K, VT_EPI_F32_RESID, 1, 0, nullptr, nullptr, s);
+  VT_TRY(vt_gemm_mx_launch(A, lda, A4, aexp, W, ldw, W4, wexp, C, ldc, nullptr, m0, N, K, VT_EPI_F32_RESID, 1, 0, nullptr, nullptr, s));
+  const size_t slab = (size_t)mt * N;
+  VT_TRY(vt_gemm_mx_launch(A + (size_t)m0 * lda, lda, A4 + (size_t)m0 * (K >> 1), aexp + (size_t)(m0 >> 6) * (K >> 5) * 64, W, ldw, W4, wexp,
+                           partials, N, nullptr, mt, N, K, VT_EPI_F32, ksplit, slab, nullptr, nullptr, s));
+  const long tot4 = (long)mt * (N >> 2);
+  hipLaunchKernelGGL(splitk_reduce_resid_kernel, dim3((int)std::min<long>((tot4 + 255) / 256, 2048)), dim3(256), 0, s, partials, slab, ksplit,
+                     C + (size_t)m0 * ldc, ldc, mt, N, VtGemmNormFuse{});
+  VT_LAUNCH_CHECK();
+  return VT_OK;
 }

@@ -98,7 +98,10 @@ int vt_rmsnorm_mx_launch(const float* x, const int* idx, const float* w, bf16_t*
                          hipStream_t s);
 int vt_gemm_mx_launch(const bf16_t* A, int lda, const uint8_t* A4, const uint8_t* aexp, const bf16_t* W, int ldw, const uint8_t* W4,
                       const uint8_t* wexp, void* C, int ldc, const float* bias, int M, int N, int K, int epi, int ksplit, size_t slab,
-                      hipStream_t s);
+                      uint8_t* out4, uint8_t* oexp, hipStream_t s);
+#define VT_EPI_SWIGLU_MX 8   // internal epilogue of vt_gemm_mx_launch: SwiGLU with the level 3 operand out (C = op16(v), out4 / oexp = image of v - f32(C))
+int vt_gemm_mx_resid_launch(const bf16_t* A, int lda, const uint8_t* A4, const uint8_t* aexp, const bf16_t* W, int ldw, const uint8_t* W4,
+                            const uint8_t* wexp, float* C, int ldc, int M, int N, int K, float* partials, size_t partial_bytes, hipStream_t s);
 
 // ---- vt_norm.hip ----------------------------------------------------------------------------------
 int vt_layernorm_launch(float* x, const float* temb, int T, int tokens_per_frame, const float* gamma,
@@ -132,14 +135,14 @@ int vt_vit_attn_meta_launch(int* seq_desc, int* tile_table, int F, int N, hipStr
 // ---- vt_attn.hip ----------------------------------------------------------------------------------
 int vt_flash_attn_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf16_t* Vt, const int* tile_table,
                          const VtAttnSeq* seqs, int nseq, int max_q_len, bf16_t* O, int ldo, int heads, int HD,
-                         int causal, float scale, hipStream_t s);
+                         int causal, float scale, hipStream_t s, uint8_t* O4 = nullptr, uint8_t* oexp = nullptr);   // O4 / oexp: level 3 operand out (vt_mx4.h)
 // vt_attn_w4.hip: the one-wave-per-SIMD prefill kernel (head_dim 128, 256-row blocks). placed = 1: hand-placed sub-iterations,
 // 0: the same pipeline with its stages run one after the other (reference of the placed schedule)
 bool vt_flash_attn_w4_supported(int HD, int max_q_len, int heads, int nseq);
 std::vector<int> vt_flash_attn_w4_block_order(int heads, int nqb, int nseq, int ncu);
 int vt_flash_attn_w4_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf16_t* Vt, const int* tile_table, const VtAttnSeq* seqs,
                             int nseq, int max_q_len, bf16_t* O, int ldo, int heads, int causal, float scale_log2e, int placed,
-                            hipStream_t s);
+                            hipStream_t s, uint8_t* O4 = nullptr, uint8_t* oexp = nullptr);
 // which prefill kernel vt_flash_attn_launch runs for head_dim 128 (vt_flash_attn_select): 0 auto, 1 two-waves-per-SIMD kernel,
 // 2 one-wave-per-SIMD kernel (placed), 3 the same unplaced
 extern int g_vt_flash_attn_kernel;

@@ -16,29 +16,14 @@
 // even mantissa. tools/mx_probe.hip pins the instruction's operand layout and scale semantics on the hardware.
 #include "vt_common.h"
 #include "vt_kernels.h"
+#include "vt_mx4.h"
 
 namespace {
 
-// unbiased scale exponent of a block with largest magnitude amax: floor(log2 amax) - 2, +1 when the mantissa exceeds 1.5
-__device__ __forceinline__ int mx4_exponent(float amax) {
-  const uint32_t b = __float_as_uint(amax);
-  const int e = (int)((b >> 23) & 0xffu) - 129 + ((b & 0x7fffffu) > 0x400000u ? 1 : 0);
-  return max(-127, min(127, e));
-}
-// x already divided by the block scale (|x| <= 6 up to the exponent clamp) -> 4-bit e2m1 code, sign in bit 3
-__device__ __forceinline__ uint32_t mx4_code(float x) {
-  const float a = fminf(fabsf(x), 6.0f);
-  const float c = a < 2.0f ? rintf(a * 2.0f) : (a < 4.0f ? rintf(a) + 2.0f : rintf(a * 0.5f) + 4.0f);
-  return (uint32_t)c | ((__float_as_uint(x) >> 28) & 8u);
-}
 __device__ __forceinline__ float quad_max(float v) {   // over the 4 lanes of a quad
   v = fmaxf(v, __shfl_xor(v, 1, 64));
   return fmaxf(v, __shfl_xor(v, 2, 64));
 }
-__device__ __forceinline__ size_t aexp_index(int m, int kb, int KB) {
-  return ((size_t)(m >> 6) * KB + kb) * 64 + (m & 15) * 4 + ((m & 63) >> 4);
-}
-
 // one wave per weight row: pass 1 the row's largest magnitude, pass 2 eight elements per lane -> one dword of codes
 __global__ __launch_bounds__(256) void mx4_quant_rows_kernel(const op16_t* __restrict__ W, int ldw, int N, int K, uint8_t* __restrict__ W4,
                                                              uint8_t* __restrict__ wexp) {
@@ -54,17 +39,13 @@ __global__ __launch_bounds__(256) void mx4_quant_rows_kernel(const op16_t* __res
   }
   amax = wave_max(amax);
   const int e = mx4_exponent(amax);
+  const float sc = mx4_scale(e);
   if (lane == 0) wexp[n] = (uint8_t)(e + 127);
   uint32_t* out = (uint32_t*)(W4 + (size_t)n * (K >> 1));
   for (int k = lane * 8; k < K; k += 512) {
     const u32x4 v = *(const u32x4*)(row + k);
-    uint32_t o = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      o |= mx4_code(ldexpf(oplo_to_f32(v[j]), -e)) << (8 * j);
-      o |= mx4_code(ldexpf(ophi_to_f32(v[j]), -e)) << (8 * j + 4);
-    }
-    out[k >> 3] = o;
+    out[k >> 3] = mx4_pack8(oplo_to_f32(v[0]), ophi_to_f32(v[0]), oplo_to_f32(v[1]), ophi_to_f32(v[1]), oplo_to_f32(v[2]), ophi_to_f32(v[2]),
+                            oplo_to_f32(v[3]), ophi_to_f32(v[3]), sc);
   }
 }
 
@@ -86,63 +67,76 @@ __global__ __launch_bounds__(256) void mx4_quant_lo_kernel(const op16_t* __restr
 #pragma unroll
   for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(x[j]));
   const int e = mx4_exponent(quad_max(amax));
-  uint32_t o = 0;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) o |= mx4_code(ldexpf(x[j], -e)) << (4 * j);
-  *(uint32_t*)(A4 + (size_t)m * (K >> 1) + c * 4) = o;
-  if ((c & 3) == 0) aexp[aexp_index(m, c >> 2, K >> 5)] = (uint8_t)(e + 127);
+  *(uint32_t*)(A4 + (size_t)m * (K >> 1) + c * 4) = mx4_pack8(x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7], mx4_scale(e));
+  if ((c & 3) == 0) aexp[mx4_aexp_index(m, c >> 2, K >> 5)] = (uint8_t)(e + 127);
 }
 
 // RMSNorm (transformers-4.31 LlamaRMSNorm) with the level 3 operand out: hi = op16(v), lo = v - f32(hi) as MX-FP4.
-// One wave per row as in vt_norm.hip; a lane holds 4 consecutive columns per chunk, so 8 lanes share a 32-block.
+// A lane holds 4 consecutive columns per chunk as in vt_norm.hip, so 8 lanes share a 32-block. A wave takes the FOUR rows whose block
+// exponents share a dword of the scale array -- rows i, i + 16, i + 32, i + 48 of a 64-row group -- one after the other, and stores the
+// exponents as whole dwords (one byte store per row and block, each to a line of its own, made this kernel twice as long as vt_rmsnorm).
 template <int NCH>
 __global__ __launch_bounds__(256) void rmsnorm_mx_kernel(const float* __restrict__ x, const int* __restrict__ idx, const float* __restrict__ w,
                                                          op16_t* __restrict__ y, uint8_t* __restrict__ A4, uint8_t* __restrict__ aexp, int rows,
                                                          int D, float eps) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const float* xr = x + (size_t)(idx ? idx[row] : row) * D;
-  f32x4 v[NCH];
-  float sq = 0.f;
+  const int wv = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);   // (64-row group, row % 16)
+  const int rg = wv >> 4, i16 = wv & 15;
+  if (rg * 64 >= rows) return;
+  uint32_t eb[NCH];
 #pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int c = (lane + i * 64) * 4;
-    if (c < D) {
-      v[i] = *(const f32x4*)(xr + c);
-      sq += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
-    } else {
-      v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < NCH; ++i) eb[i] = 0u;
+#pragma unroll 1
+  for (int j = 0; j < 4; ++j) {
+    const int row = rg * 64 + j * 16 + i16;
+    if (row >= rows) break;
+    const float* xr = x + (size_t)(idx ? idx[row] : row) * D;
+    f32x4 v[NCH];
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = (lane + i * 64) * 4;
+      if (c < D) {
+        v[i] = *(const f32x4*)(xr + c);
+        sq += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+      } else {
+        v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
+    op16_t* yr = y + (size_t)row * D;
+    uint8_t* ar = A4 + (size_t)row * (D >> 1);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = (lane + i * 64) * 4;
+      if (c < D) {                                                // (D % 256 == 0: whole 8-lane groups are in or out together)
+        const f32x4 g = *(const f32x4*)(w + c);
+        float val[4], lo[4];
+        u32x2 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) val[r] = v[i][r] * rstd * g[r];
+        o.x = pack_op2(val[0], val[1]);
+        o.y = pack_op2(val[2], val[3]);
+        *(u32x2*)(yr + c) = o;
+        lo[0] = val[0] - oplo_to_f32(o.x);
+        lo[1] = val[1] - ophi_to_f32(o.x);
+        lo[2] = val[2] - oplo_to_f32(o.y);
+        lo[3] = val[3] - ophi_to_f32(o.y);
+        float amax = fmaxf(fmaxf(fabsf(lo[0]), fabsf(lo[1])), fmaxf(fabsf(lo[2]), fabsf(lo[3])));
+        amax = quad_max(amax);
+        amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+        const int e = mx4_exponent(amax);
+        *(uint16_t*)(ar + (c >> 1)) = (uint16_t)mx4_pack4(lo[0], lo[1], lo[2], lo[3], mx4_scale(e));
+        eb[i] |= (uint32_t)(e + 127) << (8 * j);
+      }
     }
   }
-  const float rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
-  op16_t* yr = y + (size_t)row * D;
-  uint8_t* ar = A4 + (size_t)row * (D >> 1);
+  if ((lane & 7) == 0) {
+    const int KB = D >> 5;
 #pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int c = (lane + i * 64) * 4;
-    if (c < D) {                                                // (D % 256 == 0: whole 8-lane groups are in or out together)
-      const f32x4 g = *(const f32x4*)(w + c);
-      float val[4], lo[4];
-      u32x2 o;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) val[r] = g[r] * (v[i][r] * rstd);
-      o.x = pack_op2(val[0], val[1]);
-      o.y = pack_op2(val[2], val[3]);
-      *(u32x2*)(yr + c) = o;
-      lo[0] = val[0] - oplo_to_f32(o.x);
-      lo[1] = val[1] - ophi_to_f32(o.x);
-      lo[2] = val[2] - oplo_to_f32(o.y);
-      lo[3] = val[3] - ophi_to_f32(o.y);
-      float amax = fmaxf(fmaxf(fabsf(lo[0]), fabsf(lo[1])), fmaxf(fabsf(lo[2]), fabsf(lo[3])));
-      amax = quad_max(amax);
-      amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
-      const int e = mx4_exponent(amax);
-      uint32_t q = 0;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) q |= mx4_code(ldexpf(lo[r], -e)) << (4 * r);
-      *(uint16_t*)(ar + (c >> 1)) = (uint16_t)q;
-      if ((lane & 7) == 0) aexp[aexp_index(row, c >> 5, D >> 5)] = (uint8_t)(e + 127);
+    for (int i = 0; i < NCH; ++i) {
+      const int c = (lane + i * 64) * 4;
+      if (c < D) *(uint32_t*)(aexp + ((size_t)rg * KB + (c >> 5)) * 64 + i16 * 4) = eb[i];
     }
   }
 }
@@ -168,7 +162,7 @@ int vt_rmsnorm_mx_launch(const float* x, const int* idx, const float* w, bf16_t*
                          hipStream_t s) {
   VT_REQUIRE(x && w && y && A4 && aexp && rows > 0, "vt_rmsnorm_mx: null pointer");
   VT_REQUIRE(D % 256 == 0 && D <= 8192, "vt_rmsnorm_mx: D = %d must be a multiple of 256, at most 8192", D);
-  const dim3 grid(cdiv(rows, 4)), block(256);
+  const dim3 grid(cdiv(rows, 64) * 4), block(256);   // a wave per (64-row group, row % 16): four rows each
   if (D <= 1024) hipLaunchKernelGGL(rmsnorm_mx_kernel<4>, grid, block, 0, s, x, idx, w, y, A4, aexp, rows, D, eps);
   else if (D <= 4096) hipLaunchKernelGGL(rmsnorm_mx_kernel<16>, grid, block, 0, s, x, idx, w, y, A4, aexp, rows, D, eps);
   else hipLaunchKernelGGL(rmsnorm_mx_kernel<32>, grid, block, 0, s, x, idx, w, y, A4, aexp, rows, D, eps);

@@ -205,9 +205,12 @@ class PackedVit:
         self.ws = Workspace(dev)
 
     def set_precise(self, level: int) -> None:
-        """2: every GEMM A operand of the tower (norm outputs, q / k through the scores, attention and activation outputs) and the output
-        features as operand pairs, the temporal attention in fp32 (vt_vit_model.precise; include/vitron_hip.h); 0: standard."""
-        self.model.precise = 2 if int(level) >= 2 else 0
+        """The MODEL's precise level -> the tower's (vt_vit_model.precise; include/vitron_hip.h). Model level 2: every GEMM A operand of the
+        tower (norm outputs, q / k through the scores, attention and activation outputs) and the output features as operand pairs, the
+        temporal attention in fp32 (tower level 2). Model level 3: the MLPs' operands and the output features as pairs, the attention
+        paths standard (tower level 1: the part of level 2 that carries the tower's distance from fp32, at half its cost). 0 / 1: standard."""
+        level = int(level)
+        self.model.precise = 2 if level == 2 else 1 if level >= 3 else 0
 
     def forward(self, pixels: torch.Tensor, return_hidden: bool = False):
         """pixels [B,3,H,W] or [B,3,T,H,W] (operand dtype or fp32, on device) -> patch features [B(,T),G*G,D] in the operand
@@ -230,7 +233,7 @@ class PackedVit:
         G2 = self.G * self.G
         out = torch.empty((B * T * G2, self.D), device=self.device, dtype=self.dtype)
         hidden = torch.empty((B * T * (G2 + 1), self.D), device=self.device, dtype=torch.float32) if return_hidden else None
-        out_lo = torch.empty_like(out) if self.model.precise >= 2 else None      # precise level 2: the features leave as an operand pair
+        out_lo = torch.empty_like(out) if self.model.precise >= 1 else None      # precise levels: the features leave as an operand pair
         self.model.out_feats_lo = out_lo.data_ptr() if out_lo is not None else None
         nbytes = lib.vt_vit_workspace_bytes(C.byref(self.model), B, T)
         ws = self.ws.get(nbytes)
@@ -478,13 +481,33 @@ class PackedLlama:
 
     def set_precise(self, level: int) -> None:
         """0: standard; 1: precise_qk (below); 2: EVERY GEMM A operand of a prefill as an operand pair -- a verification mode at about
-        twice the GEMM work that takes the fp16 build's full-depth logits below 1e-3 of the reference's fp32 (vt_llama_model.precise_qk = 2)."""
+        twice the GEMM work that takes the fp16 build's full-depth logits below 1e-3 of the reference's fp32 (vt_llama_model.precise_qk = 2);
+        3: every decoder Linear of a prefill adds the MX-FP4 product of the A operand's rounding remainder in the SAME launch (the weights'
+        MX-FP4 images are made here, once: + 1/4 of the 16-bit weight bytes) -- the same 1e-3 at ~1.25x of the standard step."""
         level = int(level)
-        if level not in (0, 1, 2):
-            raise _lib.VitronHipError(f"precise level must be 0, 1 or 2, got {level}")
+        if level not in (0, 1, 2, 3):
+            raise _lib.VitronHipError(f"precise level must be 0, 1, 2 or 3, got {level}")
         if level and self.hd != 128:
             raise _lib.VitronHipError(f"precise modes need head_dim 128 (got {self.hd})")
+        if level == 3:
+            if self.H % 256 or self.I % 128:
+                raise _lib.VitronHipError(f"precise level 3 needs hidden % 256 == 0 and intermediate % 128 == 0 (got {self.H}, {self.I})")
+            self._pack_mx4()
         self.model.precise_qk = level
+
+    def _pack_mx4(self) -> None:
+        """The weights' MX-FP4 images (vt_mx4_quant_weights on the packed matrices: gate/up keep their interleaved row order)."""
+        if getattr(self, "_mx4_done", False):
+            return
+        from . import ops
+        for l in range(self.L):
+            t, Ly = self.layer_tensors[l], self.layers[l]
+            for name in ("wqkv", "wo", "wgu", "wdown"):
+                w4, we = ops.mx4_quant_weights(t[name])
+                t[name + "4"], t[name + "_e"] = w4, we
+                setattr(Ly, name + "4", w4.data_ptr())
+                setattr(Ly, name + "_e", we.data_ptr())
+        self._mx4_done = True
 
     def set_precise_qk(self, on: bool) -> None:
         """Prefills carry q / k (and the norm output that feeds their projection) as hi + lo operand pairs: the attention scores see

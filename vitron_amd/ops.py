@@ -375,3 +375,41 @@ def gemm_mx(a: torch.Tensor, a4: torch.Tensor, aexp: torch.Tensor, w: torch.Tens
     _lib.check(lib.vt_gemm_mx(_p(a), K, _p(a4), _p(aexp), _p(w), K, _p(w4), _p(wexp), _p(out), out.shape[1], _p(bias), M, N, K, epi,
                               _stream()), "vt_gemm_mx", lib)
     return out
+
+
+def gemm_mx_swiglu(a, a4, aexp, w, w4, wexp):
+    """(h op16 [M][N/2], h4 uint8 [M][N/4], hexp): level 3 gate/up -- the SwiGLU output and the MX-FP4 image of its rounding remainder."""
+    lib, dt = _op16(a, "gemm_mx_swiglu.a")
+    M, K = a.shape
+    N = w.shape[0]
+    h = torch.empty((M, N // 2), device=a.device, dtype=dt)
+    h4 = torch.empty((M, N // 4), device=a.device, dtype=torch.uint8)
+    hexp = torch.zeros((mx4_aexp_bytes(M, N // 2),), device=a.device, dtype=torch.uint8)
+    _lib.check(lib.vt_gemm_mx_swiglu(_p(a), K, _p(a4), _p(aexp), _p(w), K, _p(w4), _p(wexp), _p(h), N // 2, _p(h4), _p(hexp), M, N, K, _stream()),
+               "vt_gemm_mx_swiglu", lib)
+    return h, h4, hexp
+
+
+def gemm_mx_resid(a, a4, aexp, w, w4, wexp, out: torch.Tensor, partials: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out (fp32 [M][N]) += a @ w^T + (a4 2^aexp) @ (w4 2^wexp)^T; `partials` (fp32 scratch) lets a grid that spills over whole rounds run
+    its trailing row blocks as K ranges (vt_gemm_mx_resid)."""
+    lib, dt = _op16(a, "gemm_mx_resid.a")
+    _chk(out, torch.float32, "gemm_mx_resid.out")
+    M, K = a.shape
+    N = w.shape[0]
+    _lib.check(lib.vt_gemm_mx_resid(_p(a), K, _p(a4), _p(aexp), _p(w), K, _p(w4), _p(wexp), _p(out), N, M, N, K, _p(partials),
+                                    0 if partials is None else partials.numel() * 4, _stream()), "vt_gemm_mx_resid", lib)
+    return out
+
+
+def flash_attn_mx(q, k_tiles, vt_tiles, tile_table, seq_desc, max_q_len: int, heads: int, scale: float):
+    """Causal head_dim-128 attention with the level 3 operand out: (O op16 [rows][heads*128], O4, oexp). q: a [rows, ldq] view whose first
+    heads*128 columns are the queries."""
+    lib, dt = _op16(q, "flash_attn_mx.q")
+    rows = q.shape[0]
+    o = torch.empty((rows, heads * 128), device=q.device, dtype=dt)
+    o4 = torch.empty((rows, heads * 64), device=q.device, dtype=torch.uint8)
+    oexp = torch.zeros((mx4_aexp_bytes(rows, heads * 128),), device=q.device, dtype=torch.uint8)
+    _lib.check(lib.vt_flash_attn_mx(_p(q), q.stride(0), _p(k_tiles), _p(vt_tiles), _p(tile_table), _p(seq_desc), seq_desc.shape[0], max_q_len,
+                                    _p(o), heads * 128, _p(o4), _p(oexp), heads, scale, _stream()), "vt_flash_attn_mx", lib)
+    return o, o4, oexp
