@@ -98,3 +98,12 @@ def oracle_llama(name, emulate, precise_qk=False):
                                        precise_qk=precise_qk)
         _ORACLE_CACHE[key] = (lg[0], h[0])
     return _ORACLE_CACHE[key]
+
+
+def vs_wide_pin(logits, g):
+    """The wider pin of the full-depth logits (round 6; tests/golden/make_golden_fulldepth.py): rel-L2 over the projections of ALL rows on 32
+    directions, and -- for the cases that hold them -- over the last 64 rows whole. (None, None) parts when the golden predates them."""
+    t = torch.as_tensor(logits).reshape(-1, logits.shape[-1]).cpu()
+    p32 = rel(t.double() @ cases.fw_directions(t.shape[-1], n=32, seed=cases.FW_SEED + 1), g["logits_proj32"]) if "logits_proj32" in g.files else None
+    tail = rel(t[-64:].float(), g["logits_tail"]) if "logits_tail" in g.files else None
+    return p32, tail

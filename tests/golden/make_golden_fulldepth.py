@@ -47,6 +47,7 @@ OUT = os.path.dirname(os.path.abspath(__file__))
 SEED = 20260926
 FRAMES, IMAGE, TEXT = 8, 336, 512
 GREEDY_STEPS = 16
+WIDE_TAIL_CASES = ("c3", "c2_224")   # cases whose pin also holds the last 64 logits rows whole (8 MB each)
 # the four boxes of C5 in the reference's 224-pixel space (whole canvas, two interior boxes, a single 2 x 2-centre hit)
 C5_BOXES = [[0, 0, 224, 224], [0, 58.9, 117.9, 117.9], [100, 20, 180, 200], [7, 7, 8, 8]]
 
@@ -143,6 +144,11 @@ def _run_prefill_case(model, name):
     lg = logits[0].float()
     out["last_logits"] = lg[-1].numpy()
     make_golden._compact(lg, "logits", out, top5=True, nrows=4)
+    # round 6: a wider pin of the logits beside the first one (whose keys keep their round-5 values bit for bit) --
+    # projections of EVERY row on 32 more directions, and for the headline case and the worst case the last 64 rows whole
+    out["logits_proj32"] = (lg.double() @ cases.fw_directions(lg.shape[-1], n=32, seed=cases.FW_SEED + 1)).numpy()
+    if name in WIDE_TAIL_CASES:
+        out["logits_tail"] = lg[-64:].numpy()
     make_golden._compact(grabbed["h"].reshape(S, -1).float(), "hidden", out)
     make_golden._compact(embeds[0].float(), "embeds", out)
     out["S"] = np.int64(S)

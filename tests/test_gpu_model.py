@@ -496,6 +496,42 @@ def test_multi_turn_reuses_towers_and_kv_prefix(dev):
 
 
 @pytest.mark.gpu
+def test_padded_batch_left_padding_and_refusals(dev, model):
+    """generate(padded_batch=True) with tokenizer_padding_side = 'left' (reference llava_arch.py:379-386): a batch whose samples carry the same
+    number of visual rows gets, per sample, the ids of the sample alone -- what the reference's loop returns there
+    (tests/test_oracle_golden.py::test_left_padded_batch_with_equal_visual_rows_is_every_sample_alone); unequal padding and text-only batches
+    are refused explicitly (never silently different ids)."""
+    from tests.test_oracle_golden import _left_padded_batch
+    case = _left_padded_batch()
+    ids, am = case["input_ids"].to(dev), case["attention_mask"].to(dev)
+    images = [im.to(dev).to(torch.bfloat16) for im in case["images"]]
+    n = 8
+    old = getattr(model.config, "tokenizer_padding_side", "right")
+    model.config.tokenizer_padding_side = "left"
+    try:
+        out = model.generate(ids, images=images, regions=case["regions"], attention_mask=am, do_sample=False, max_new_tokens=n, eos_token_id=-1,
+                             padded_batch=True)
+        for b, solo in enumerate(case["solo"]):
+            one = model.generate(torch.tensor([solo], device=dev), images=[images[b]], regions=[case["regions"][b]], do_sample=False,
+                                 max_new_tokens=n, eos_token_id=-1)
+            assert out[b, ids.shape[1]:].tolist() == one[0, len(solo):].tolist(), b
+        # unequal numbers of visual rows: the reference attends pad rows / masks real rows there -- refused
+        bad_ids = ids.clone()
+        bad_ids[1, -2] = 5          # the second sample loses its <objs> row: padding in id space != padding in the spliced space
+        with pytest.raises(NotImplementedError):
+            model.generate(bad_ids, images=images, regions=case["regions"], attention_mask=am, do_sample=False, max_new_tokens=2, padded_batch=True)
+        # a right-padded mask under the left setting
+        with pytest.raises(NotImplementedError):
+            model.generate(ids, images=images, regions=case["regions"], attention_mask=am.flip(1), do_sample=False, max_new_tokens=2, padded_batch=True)
+    finally:
+        model.config.tokenizer_padding_side = old
+    # text-only batches take another path in the reference (llava_arch.py:196 returns early): refused, in either padding mode
+    txt = torch.tensor([[1, 5, 6, 7], [1, 8, 0, 0]], device=dev)
+    with pytest.raises(NotImplementedError):
+        model.generate(txt, attention_mask=torch.tensor([[1, 1, 1, 1], [1, 1, 0, 0]], device=dev), do_sample=False, max_new_tokens=2, padded_batch=True)
+    model.reset_prefix_cache()
+
+
 def test_serving_engine_continuous_batching_matches_solo_runs(dev, model):
     """Five requests (text-only, image, image + region, video) joining a running decode batch at different steps: every
     request's greedy tokens equal the tokens `generate` produces for it alone; pages all return to the pool."""

@@ -158,6 +158,7 @@ def _prefill_case(op, odt, model, name, dev):
     model.kv.release(seq.pages)
     logits, hidden = logits.float().cpu(), hidden.float().cpu()
     l_proj, l_rows = FW.vs_pin(logits, g, "logits")
+    l_proj32, l_tail = FW.vs_wide_pin(logits, g)       # round 6: 32 more directions over all rows; the last 64 rows whole (c3, c2_224)
     h_proj, h_rows = FW.vs_pin(hidden, g, "hidden")
     last = FW.rel(logits[-1], g["last_logits"])
     top1, top5 = FW.topk_agreement(logits, g, "logits")
@@ -166,7 +167,8 @@ def _prefill_case(op, odt, model, name, dev):
            "workload": f"full depth (23 ViT layers + projector + 32 decoder layers), S = {S}, vs the reference's fp32 output",
            "visual_plus_text_embeddings_rel_l2_rows": e_rows, "embeddings_rel_l2_proj": e_proj,
            "final_hidden_rel_l2_rows": h_rows, "final_hidden_rel_l2_proj": h_proj,
-           "logits_rel_l2_rows": l_rows, "logits_rel_l2_proj": l_proj, "last_position_logits_rel_l2": last,
+           "logits_rel_l2_rows": l_rows, "logits_rel_l2_proj": l_proj, "logits_rel_l2_proj32": l_proj32, "logits_rel_l2_last_64_rows": l_tail,
+           "last_position_logits_rel_l2": last,
            "top1_agreement_all_positions": top1, "top5_overlap_all_positions": top5, "last_position_top1_equal": bool(last_top1)}
     _note(f"{name}_{op}", rep)
     out = os.environ.get("VT_PARITY_REPORT")
@@ -176,6 +178,9 @@ def _prefill_case(op, odt, model, name, dev):
     b = BOUNDS[op]
     assert e_rows <= b["embeds"] and e_proj <= b["embeds"], (e_rows, e_proj)
     assert last <= b["last"] and l_rows <= b["rows"] and h_rows <= b["rows"] and l_proj <= b["proj"] and h_proj <= b["proj"], (last, l_rows, h_rows, l_proj, h_proj)
+    assert l_proj32 is not None and l_proj32 <= b["proj"], l_proj32
+    assert l_tail is None or l_tail <= b["rows"], l_tail
+    assert (l_tail is not None) == (name in FD.WIDE_TAIL_CASES)
     assert top5 >= b["top5"] and top1 >= b["top1"], (top1, top5)
     # the greedy first token: equal wherever the reference's own top-2 margin exceeds the build's noise bound
     ll = np.sort(g["last_logits"])[::-1]

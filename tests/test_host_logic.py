@@ -16,6 +16,33 @@ G = os.path.join(os.path.dirname(__file__), "golden")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def test_mm_utils_image_helpers_match_reference_goldens():
+    """load_image_from_base64 / expand2square / process_images (reference mm_utils.py:48-77) against the reference's own functions' outputs on
+    the pictures of tests/golden/mm_images_cases.py (tests/golden/make_golden_mm_images.py)."""
+    import types
+    from tests.golden import mm_images_cases as MC
+    from vitron_amd import mm_utils
+    g = np.load(os.path.join(G, "mm_utils_images.npz"))
+    pics = [MC.picture(w, h) for w, h in MC.SIZES]
+    proc = MC.StubProcessor()
+    for i, im in enumerate(pics):
+        sq = mm_utils.expand2square(im, MC.FILL)
+        assert sq.size == (max(im.size), max(im.size)) and np.array_equal(np.asarray(sq), g[f"square_{i}"])
+        assert np.array_equal(np.asarray(mm_utils.load_image_from_base64(MC.png_base64(im))), g[f"b64_{i}"])
+    assert mm_utils.expand2square(pics[2], MC.FILL) is pics[2]                       # a square picture comes back as it is
+    pad = mm_utils.process_images(pics, proc, types.SimpleNamespace(image_aspect_ratio="pad"))
+    assert isinstance(pad, torch.Tensor) and np.array_equal(pad.numpy(), g["process_pad"])
+    assert np.array_equal(mm_utils.process_images(pics, proc, types.SimpleNamespace(image_aspect_ratio=None)).numpy(), g["process_plain"])
+    assert np.array_equal(mm_utils.process_images(pics[:2], proc, types.SimpleNamespace()).numpy(), g["process_missing_attr"])
+
+    class Ragged(MC.StubProcessor):                                                  # shapes that differ stay a list (mm_utils.py:75-76)
+        def preprocess(self, image, return_tensors=None):
+            t = self._one(image)
+            return {"pixel_values": [t[:, : min(image.size[0], 16)]]}
+    rag = mm_utils.process_images([pics[0], pics[3]], Ragged(), types.SimpleNamespace(image_aspect_ratio="pad"))
+    assert isinstance(rag, list) and len(rag) == 2
+
+
 def test_mm_utils_match_reference_goldens():
     from vitron_amd import mm_utils
     g = np.load(os.path.join(G, "mm_utils.npz"))

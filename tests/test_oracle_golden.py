@@ -220,6 +220,38 @@ def test_padded_batch_greedy_ids_against_the_reference():
     assert alone[longest].tolist() == g[f"batch_pad_alone{longest}_ids"].tolist()
 
 
+def _left_padded_batch():
+    """Two (text + image + box) samples of different text lengths, LEFT-padded in id space as a tokenizer with padding_side = 'left' hands them
+    over (zeros, then ones), each with ONE <image> and one <objs>: the padding in id space equals the padding in the spliced space."""
+    from tests.golden.cases import SEED_IDS, SEED_PIX, BOXES, _ids, pixels
+    a = [1] + _ids(1, SEED_IDS + 40) + [-200, -300] + _ids(6, SEED_IDS + 41)
+    b = [1, -200, -300] + _ids(2, SEED_IDS + 42)
+    L = max(len(a), len(b))
+    ids = torch.tensor([[0] * (L - len(a)) + a, [0] * (L - len(b)) + b])
+    am = torch.tensor([[0] * (L - len(a)) + [1] * len(a), [0] * (L - len(b)) + [1] * len(b)])
+    return dict(input_ids=ids, attention_mask=am, images=[pixels((3, 56, 56), SEED_PIX + 31), pixels((3, 56, 56), SEED_PIX + 32)],
+                regions=[BOXES[2], BOXES[0]], solo=[a, b])
+
+
+def test_left_padded_batch_with_equal_visual_rows_is_every_sample_alone():
+    """What vitron_amd.generate(padded_batch=True) relies on for tokenizer_padding_side = 'left' (reference llava_arch.py:379-386 pads the
+    spliced rows on the left; :196-205 extends the ids-length mask with ones at every decode step): when every sample carries the same
+    number of visual rows, the zeros of the ids-length mask cover exactly the sample's pad rows and sum(mask) - 1 is its own length + step, so
+    the reference's padded-batch loop returns, for every sample, the ids it returns for that sample ALONE. Shown on the oracle's restatement
+    of that loop (pinned on the reference's ids for the right-padded case above)."""
+    case = _left_padded_batch()
+    w, cfgs = oracle_weights()
+    n = 8
+    embeds, mask, pos = O.multimodal_prepare(w, cfgs, case["input_ids"], case["attention_mask"], case["images"], case["regions"], padding_side="left")
+    S = embeds.shape[1]
+    assert (S - mask.long().sum(1)).tolist() == (case["attention_mask"].shape[1] - case["attention_mask"].sum(1)).tolist()
+    padded = O.greedy_generate(w["llama"], cfgs["llama"], embeds, mask.long(), pos, n, ids_mask=case["attention_mask"].long())
+    for b, ids in enumerate(case["solo"]):
+        e1, m1, p1 = O.multimodal_prepare(w, cfgs, torch.tensor([ids]), None, [case["images"][b]], [case["regions"][b]])
+        one = O.greedy_generate(w["llama"], cfgs["llama"], e1, m1.long(), p1, n)
+        assert padded[b].tolist() == one[0].tolist(), b
+
+
 def _proj3_state():
     H = cases.LLM["hidden_size"]
     g = synth.make_generator(cases.SEED_PROJ + 3)

@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-LEAN="--no-cpu-baseline --decode-steps 0 --c4-steps 0 --c2-reps 0 --reps-224 0 --no-empirical-peaks --fp16-ab-steps 0"
+LEAN="--no-cpu-baseline --decode-steps 0 --c4-steps 0 --c2-reps 0 --reps-224 0 --no-empirical-peaks --fp16-ab-steps 0 --no-parity --no-live-traffic"
 timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $O/bench_stats -- python $R/bench.py --steps 5 --warmup 2 $LEAN > $O/bench_under_rocprof.json 2> $O/bench_stats.err
 # the C5 decode flow (4 x (image + box) prefill + 256 greedy steps at batch 4) and C2 under the same tool
 timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $O/decode_stats -- python $R/tools/decode_bench.py 256 > $O/decode_under_rocprof.json 2> $O/decode_stats.err

@@ -1459,11 +1459,7 @@ int vt_flash_attn_launch(const bf16_t* Q, int ldq, const bf16_t* Kt, const bf16_
   do {                                                                                                         \
     auto kern = flash_attn_kernel<HDV, CV, NW, NS __VA_OPT__(,) __VA_ARGS__>;                                  \
     const int smem = NS * 2 * 64 * HDV * 2;                                                                    \
-    static bool done = false;                                                                                  \
-    if (!done) {                                                                                               \
-      VT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));        \
-      done = true;                                                                                             \
-    }                                                                                                          \
+    VT_LDS_ATTR_ONCE(kern, smem);                                                                              \
     dim3 grid(heads, cdiv(max_q_len, 32 * NW), nseq), block(64 * NW);                                          \
     hipLaunchKernelGGL(kern, grid, block, smem, s, Q, ldq, Kt, Vt, tile_table, seqs, O, ldo, heads, sl2, O4, oexp); \
   } while (0)

@@ -503,12 +503,8 @@ __global__ __launch_bounds__(64 * NWAVE) void gemm_skinny_dma_kernel(GemmP p) {
 template <int BM, int BN, int WM, int WN, int EPI>
 int launch_tile(const GemmP& p, hipStream_t s) {
   constexpr int smem = 2 * (BM + BN) * 64 * 2;
-  static bool attr_done = false;  // benign race: idempotent
   auto kern = gemm_bt_kernel<BM, BN, WM, WN, EPI>;
-  if (!attr_done) {
-    VT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    attr_done = true;
-  }
+  VT_LDS_ATTR_ONCE(kern, smem);
   const int nwg = cdiv(p.M, BM) * cdiv(p.N, BN);
   hipLaunchKernelGGL(kern, dim3(nwg), dim3(64 * WM * WN), smem, s, p);
   VT_LAUNCH_CHECK();
@@ -667,11 +663,7 @@ int launch_skinny_dma32_w(const GemmP& p, hipStream_t s) {
   constexpr int smem = NWAVE * 4 * (NT * 2 + 4) * 1024;
   static_assert(smem + NWAVE * NT * 2 * 1024 <= 160 * 1024, "ring does not fit the 160 KiB LDS");
   auto kern = gemm_skinny_dma32_kernel<EPI, NWAVE, WIDE>;
-  static bool done = false;
-  if (!done) {
-    VT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    done = true;
-  }
+  VT_LDS_ATTR_ONCE(kern, smem);
   hipLaunchKernelGGL(kern, dim3(cdiv(p.N, 16 * NT)), dim3(64 * NWAVE), smem, s, p);
   VT_LAUNCH_CHECK();
   return VT_OK;
@@ -688,11 +680,7 @@ int launch_skinny_dma_cfg(const GemmP& p, hipStream_t s) {
   constexpr int smem = NWAVE * R * (NT * 2 + XI) * 1024 + ((XI == 1) ? 1024 : 0);  // + slack for the XI == 1 over-read of the last slot
   static_assert(smem + NWAVE * NT * 1024 <= 160 * 1024, "ring does not fit the 160 KiB LDS");
   auto kern = gemm_skinny_dma_kernel<EPI, XI, NWAVE, R>;
-  static bool done = false;
-  if (!done) {
-    VT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    done = true;
-  }
+  VT_LDS_ATTR_ONCE(kern, smem);
   hipLaunchKernelGGL(kern, dim3(cdiv(p.N, 16 * NT)), dim3(64 * NWAVE), smem, s, p);
   VT_LAUNCH_CHECK();
   return VT_OK;

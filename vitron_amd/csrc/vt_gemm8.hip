@@ -995,11 +995,7 @@ int launch_w4(const GemmP8& p, hipStream_t s) {
     if ((nout & 7) != 0 || (p.ldc & 7) != 0 || (((size_t)p.C) & 15) != 0) return launch_w4<EPI, MT, ABL | 64, AUX_A, AUX_B>(p, s);
   }
   auto kern = gemm_w4_kernel<EPI, MT, ABL, AUX_A, AUX_B>;
-  static bool done = false;
-  if (!done) {
-    VT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    done = true;
-  }
+  VT_LDS_ATTR_ONCE(kern, smem);
   hipLaunchKernelGGL(kern, dim3(cdiv(p.M, BM) * cdiv(p.N, 256) * (EPI == VT_EPI_F32 ? std::max(p.ksplit, 1) : 1)), dim3(256), smem, s, p);
   VT_LAUNCH_CHECK();
   return VT_OK;
@@ -1142,11 +1138,7 @@ template <int EPI>
 int launch_w4r(const GemmP8& p, hipStream_t s) {
   constexpr int smem = 4 * (160 + 128) * 128;      // 144 KiB
   auto kern = gemm_w4r_kernel<EPI>;
-  static bool done = false;
-  if (!done) {
-    VT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    done = true;
-  }
+  VT_LDS_ATTR_ONCE(kern, smem);
   hipLaunchKernelGGL(kern, dim3(cdiv(p.M, 160) * cdiv(p.N, 128)), dim3(256), smem, s, p);
   VT_LAUNCH_CHECK();
   return VT_OK;
@@ -1356,11 +1348,7 @@ template <int EPI, int VAR = 0>
 int launch_rp(const GemmP8& p, hipStream_t s) {
   constexpr int smem = 2 * 2 * 256 * 64 * 2;  // 128 KiB
   auto kern = gemm_rp_kernel<EPI, VAR>;
-  static bool done = false;
-  if (!done) {
-    VT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    done = true;
-  }
+  VT_LDS_ATTR_ONCE(kern, smem);
   const int nwg = cdiv(p.M, 256) * cdiv(p.N, 256) * (p.ksplit > 1 ? p.ksplit : 1);
   hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), smem, s, p);
   VT_LAUNCH_CHECK();
@@ -1371,11 +1359,7 @@ template <int EPI, int ABL = 0, bool P4 = false>
 int launch_p8(const GemmP8& p, hipStream_t s) {
   constexpr int smem = 2 * BUF_BYTES;  // 128 KiB
   auto kern = gemm_p8_kernel<EPI, ABL, P4>;
-  static bool done = false;
-  if (!done) {
-    VT_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    done = true;
-  }
+  VT_LDS_ATTR_ONCE(kern, smem);
   const int nwg = cdiv(p.M, 256) * cdiv(p.N, 256) * (p.ksplit > 1 ? p.ksplit : 1);
   hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), smem, s, p);
   VT_LAUNCH_CHECK();

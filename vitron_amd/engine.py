@@ -234,15 +234,13 @@ class PackedVit:
         out = torch.empty((B * T * G2, self.D), device=self.device, dtype=self.dtype)
         hidden = torch.empty((B * T * (G2 + 1), self.D), device=self.device, dtype=torch.float32) if return_hidden else None
         out_lo = torch.empty_like(out) if self.model.precise >= 1 else None      # precise levels: the features leave as an operand pair
-        self.model.out_feats_lo = out_lo.data_ptr() if out_lo is not None else None
-        nbytes = lib.vt_vit_workspace_bytes(C.byref(self.model), B, T)
+        call_model = _lib.VtVitModel.from_buffer_copy(self.model)     # per-call pointer in a copy: the shared struct stays untouched
+        call_model.out_feats_lo = out_lo.data_ptr() if out_lo is not None else None
+        nbytes = lib.vt_vit_workspace_bytes(C.byref(call_model), B, T)
         ws = self.ws.get(nbytes)
-        try:
-            _lib.check(lib.vt_vit_forward(C.byref(self.model), pixels.data_ptr(), dt, B, T, int(video), out.data_ptr(),
-                                          None if hidden is None else hidden.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
-                       "vt_vit_forward", lib)
-        finally:
-            self.model.out_feats_lo = None
+        _lib.check(lib.vt_vit_forward(C.byref(call_model), pixels.data_ptr(), dt, B, T, int(video), out.data_ptr(),
+                                      None if hidden is None else hidden.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+                   "vt_vit_forward", lib)
         feats = out.view(B, T, G2, self.D) if video else out.view(B, G2, self.D)
         if out_lo is not None:
             with_lo(feats, out_lo.view(feats.shape))
@@ -608,14 +606,13 @@ def llama_forward(llama: PackedLlama, kv: PagedKVCache, seqs: Sequence[SequenceS
     trace = torch.empty((llama.L, rows, llama.H), dtype=torch.float32, device=dev) if return_all_hidden else None
     max_kv = max(d[2] for d in desc)
     ws = llama.ws.get(lib.vt_llama_workspace_bytes(C.byref(llama.model), rows, n_logit, len(desc), max_kv))
-    llama.model.hidden_trace = trace.data_ptr() if trace is not None else None
-    llama.model.embeds_lo = embeds_lo.data_ptr() if embeds_lo is not None else None
-    try:
-        _llama_call(lib, llama, kv, embeds, rows, pos_t, desc_t, len(desc), int(max(q_lens)), int(max_new_tiles), int(max_kv), table_t, lr_t,
-                    n_logit, logits, hidden, ws)
-    finally:
-        llama.model.hidden_trace = None
-        llama.model.embeds_lo = None
+    # the per-call pointers travel in a COPY of the model struct (two threads / streams sharing one PackedLlama must not see each
+    # other's trace or lo buffer; the C call reads the struct and keeps nothing)
+    call_model = _lib.VtLlamaModel.from_buffer_copy(llama.model)
+    call_model.hidden_trace = trace.data_ptr() if trace is not None else None
+    call_model.embeds_lo = embeds_lo.data_ptr() if embeds_lo is not None else None
+    _llama_call(lib, call_model, kv, embeds, rows, pos_t, desc_t, len(desc), int(max(q_lens)), int(max_new_tiles), int(max_kv), table_t, lr_t,
+                n_logit, logits, hidden, ws)
     for s, q in zip(seqs, q_lens):
         s.length += q
     if logits is not None and llama.V_pad != llama.V:
@@ -627,8 +624,8 @@ def llama_forward(llama: PackedLlama, kv: PagedKVCache, seqs: Sequence[SequenceS
     return logits
 
 
-def _llama_call(lib, llama, kv, embeds, rows, pos_t, desc_t, nseq, max_q, max_new_tiles, max_kv, table_t, lr_t, n_logit, logits, hidden, ws):
-    _lib.check(lib.vt_llama_forward(C.byref(llama.model), C.byref(kv.struct), embeds.data_ptr(), rows, pos_t.data_ptr(),
+def _llama_call(lib, model_struct, kv, embeds, rows, pos_t, desc_t, nseq, max_q, max_new_tiles, max_kv, table_t, lr_t, n_logit, logits, hidden, ws):
+    _lib.check(lib.vt_llama_forward(C.byref(model_struct), C.byref(kv.struct), embeds.data_ptr(), rows, pos_t.data_ptr(),
                                     desc_t.data_ptr(), nseq, max_q, max_new_tiles, max_kv, table_t.data_ptr(),
                                     None if lr_t is None else lr_t.data_ptr(), n_logit,
                                     None if logits is None else logits.data_ptr(),
@@ -705,14 +702,19 @@ def padded_batch_fixup(llama: PackedLlama, kv: PagedKVCache, seqs: Sequence[Sequ
         keep = list(range(0, lo)) + list(range(hi, seqs[b].length))
         old = seqs[b].pages
         new = kv.alloc((len(keep) + PAGE_TOKENS - 1) // PAGE_TOKENS + 1)
-        kview[:, new] = 0
-        vview[:, new] = 0
-        src = torch.tensor(keep, dtype=torch.long, device=dev)
-        dst = torch.arange(len(keep), dtype=torch.long, device=dev)
-        oldp, newp = torch.tensor(old, dtype=torch.long, device=dev), torch.tensor(new, dtype=torch.long, device=dev)
-        sp, ss, dp, ds = oldp[src // PAGE_TOKENS], src % PAGE_TOKENS, newp[dst // PAGE_TOKENS], dst % PAGE_TOKENS
-        kview[:, dp, :, ds, :] = kview[:, sp, :, ss, :]                    # (row moves, no arithmetic: K rows carry their rotation)
-        vview[:, dp, :, :, ds] = vview[:, sp, :, :, ss]
+        try:     #  a failure while the rows move must hand the fresh pages back: generate() only releases seqs[*].pages
+            kview[:, new] = 0
+            vview[:, new] = 0
+            src = torch.tensor(keep, dtype=torch.long, device=dev)
+            dst = torch.arange(len(keep), dtype=torch.long, device=dev)
+            oldp, newp = torch.tensor(old, dtype=torch.long, device=dev), torch.tensor(new, dtype=torch.long, device=dev)
+            sp, ss, dp, ds = oldp[src // PAGE_TOKENS], src % PAGE_TOKENS, newp[dst // PAGE_TOKENS], dst % PAGE_TOKENS
+            for l in range(kview.shape[0]):                                 # layer by layer: the gather's temporary stays one layer's rows
+                kview[l, dp, :, ds, :] = kview[l, sp, :, ss, :]             # (row moves, no arithmetic: K rows carry their rotation)
+                vview[l, dp, :, :, ds] = vview[l, sp, :, :, ss]
+        except Exception:
+            kv.release(new)
+            raise
         kv.release(old)
         seqs[b].pages, seqs[b].length = new, len(keep)
         holes[b] = hi - lo

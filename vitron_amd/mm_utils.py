@@ -7,6 +7,41 @@ import torch
 from .constants import IMAGE_TOKEN_INDEX, OBJS_TOKEN_INDEX
 
 
+def load_image_from_base64(image):
+    """reference mm_utils.py:48-49 -- a base64 string (what the Gradio front end posts) -> PIL image."""
+    import base64
+    import io
+
+    from PIL import Image
+    return Image.open(io.BytesIO(base64.b64decode(image)))
+
+
+def expand2square(pil_img, background_color):
+    """reference mm_utils.py:51-63 -- pad the shorter side with `background_color` so that the picture sits centred on a square canvas
+    (the offset of the odd pixel goes to the far side: (long - short) // 2 in front); a square picture is returned as it is."""
+    from PIL import Image
+    w, h = pil_img.size
+    if w == h:
+        return pil_img
+    side = max(w, h)
+    canvas = Image.new(pil_img.mode, (side, side), background_color)
+    canvas.paste(pil_img, ((side - w) // 2, (side - h) // 2))
+    return canvas
+
+
+def process_images(images, image_processor, model_cfg):
+    """reference mm_utils.py:66-77 -- `image_aspect_ratio == 'pad'`: every picture squared on the processor's mean colour and run through
+    `image_processor.preprocess` on its own, stacked when the shapes agree (a list otherwise); any other setting: the processor on the
+    whole list."""
+    if getattr(model_cfg, "image_aspect_ratio", None) != "pad":
+        return image_processor(images, return_tensors="pt")["pixel_values"]
+    fill = tuple(int(c * 255) for c in image_processor.image_mean)
+    out = [image_processor.preprocess(expand2square(im, fill), return_tensors="pt")["pixel_values"][0] for im in images]
+    if all(t.shape == out[0].shape for t in out):
+        return torch.stack(out, dim=0)
+    return out
+
+
 def tokenizer_image_token(prompt, tokenizer, image_token_index=IMAGE_TOKEN_INDEX, return_tensors=None, is_first=True):
     """reference mm_utils.py:80-99 -- split on '<image>', tokenise the chunks, keep one BOS (only when is_first),
     put one sentinel between chunks."""

@@ -493,10 +493,34 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
         elif self._prefix is not None:
             self.reset_prefix_cache()
         pad_mode = bool(padded_batch) and B > 1
+        if pad_mode and not embeds_spliced:
+            # a text-only batch never reaches the reference's decode-step fix-up (llava_arch.py:196 returns early when images is
+            # None); transformers then reads a shorter sample's first token from embed(pad_token_id) at position 1 -- another behaviour than
+            # the one reproduced here (a ZERO row at position 0), so refuse instead of returning different ids silently
+            raise NotImplementedError("generate(padded_batch=True) reproduces the reference's B > 1 result for MULTIMODAL (spliced) batches; a "
+                                      "text-only batch takes another path in the reference (llava_arch.py:196-205) -- use the default packed batch")
         if pad_mode:
-            if getattr(self.config, "tokenizer_padding_side", "right") != "right":
-                raise NotImplementedError("generate(padded_batch=True) reproduces the reference's RIGHT-padded batches only")
             am_rows = attention_mask.to(torch.int32).tolist() if attention_mask is not None else [[1] * input_ids.shape[1]] * B
+            side = getattr(self.config, "tokenizer_padding_side", "right")
+            if side == "left":
+                # LEFT-padded batches (llava_arch.py:379-386): the first token comes from the last column, which is a real row; at a decode step
+                # the fix-up (:196-205) extends the ids-length mask with ones, so sample i is denied the first p_ids[i] rows of its padded cache
+                # (its padding in ID space) and gets position sum(mask) - 1. When every sample's padding in ID space equals its padding in
+                # the SPLICED space -- the same number of <image> / <objs> rows in every sample, what a batched app.py turn looks like -- those
+                # are exactly its pad rows and the position is its own length + step: the reference's ids ARE the ids each sample gets alone,
+                # i.e. the packed batch below. Any other left-padded batch attends pad rows / loses real rows in the reference; not reproduced.
+                if any(any(a > b_ for a, b_ in zip(r, r[1:])) for r in am_rows):
+                    raise NotImplementedError("generate(padded_batch=True): with tokenizer_padding_side = 'left' the attention_mask must be left-padded (zeros, then ones)")
+                p_ids = [len(r) - sum(r) for r in am_rows]
+                p_sp = [S - l for l in lens]
+                if p_ids != p_sp:
+                    raise NotImplementedError(f"generate(padded_batch=True), left-padded: the samples' padding differs between the id space {p_ids} and the "
+                                              f"spliced space {p_sp} (unequal numbers of visual rows): the reference then attends pad rows / masks real rows "
+                                              "at decode steps (llava_arch.py:196-205); not reproduced -- use the default packed batch")
+                pad_mode = False
+            elif side != "right":
+                raise NotImplementedError(f"generate(padded_batch=True): tokenizer_padding_side = {side!r}")
+        if pad_mode:
             if any(any(a < b_ for a, b_ in zip(r, r[1:])) for r in am_rows):
                 raise NotImplementedError("generate(padded_batch=True): attention_mask must be right-padded (ones, then zeros)")
             ids_valid = [sum(r) for r in am_rows]
