@@ -517,7 +517,8 @@ def test_padded_batch_left_padding_and_refusals(dev, model):
             assert out[b, ids.shape[1]:].tolist() == one[0, len(solo):].tolist(), b
         # unequal numbers of visual rows: the reference attends pad rows / masks real rows there -- refused
         bad_ids = ids.clone()
-        bad_ids[1, -2] = 5          # the second sample loses its <objs> row: padding in id space != padding in the spliced space
+        assert int(bad_ids[1, -4]) == -200
+        bad_ids[1, -4], bad_ids[1, -3] = 5, 6     # the second sample loses its <image> / <objs> rows: padding in id space != in the spliced space
         with pytest.raises(NotImplementedError):
             model.generate(bad_ids, images=images, regions=case["regions"], attention_mask=am, do_sample=False, max_new_tokens=2, padded_batch=True)
         # a right-padded mask under the left setting

@@ -72,24 +72,20 @@ __global__ __launch_bounds__(256) void mx4_quant_lo_kernel(const op16_t* __restr
 }
 
 // RMSNorm (transformers-4.31 LlamaRMSNorm) with the level 3 operand out: hi = op16(v), lo = v - f32(hi) as MX-FP4.
-// A lane holds 4 consecutive columns per chunk as in vt_norm.hip, so 8 lanes share a 32-block. A wave takes the FOUR rows whose block
-// exponents share a dword of the scale array -- rows i, i + 16, i + 32, i + 48 of a 64-row group -- one after the other, and stores the
-// exponents as whole dwords (one byte store per row and block, each to a line of its own, made this kernel twice as long as vt_rmsnorm).
+// One wave per row and 4 consecutive columns per lane and chunk as in vt_norm.hip (8 lanes share a 32-block). The four waves of a workgroup
+// take the FOUR rows whose block exponents share a dword of the scale array -- rows i, i + 16, i + 32, i + 48 of a 64-row group -- park
+// their exponent bytes in LDS and store them as whole dwords: a byte store per row and block, each to a line of its own, doubled this
+// kernel's time (41 us against vt_rmsnorm's 19 at 5120 x 4096), and a wave walking the four rows one after the other tripled it (63 us).
 template <int NCH>
 __global__ __launch_bounds__(256) void rmsnorm_mx_kernel(const float* __restrict__ x, const int* __restrict__ idx, const float* __restrict__ w,
                                                          op16_t* __restrict__ y, uint8_t* __restrict__ A4, uint8_t* __restrict__ aexp, int rows,
                                                          int D, float eps) {
-  const int lane = threadIdx.x & 63;
-  const int wv = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);   // (64-row group, row % 16)
-  const int rg = wv >> 4, i16 = wv & 15;
-  if (rg * 64 >= rows) return;
-  uint32_t eb[NCH];
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) eb[i] = 0u;
-#pragma unroll 1
-  for (int j = 0; j < 4; ++j) {
-    const int row = rg * 64 + j * 16 + i16;
-    if (row >= rows) break;
+  __shared__ __attribute__((aligned(4))) uint8_t se[NCH * 8 * 4];     // [block][row of the four]
+  const int lane = threadIdx.x & 63, j = threadIdx.x >> 6;
+  const int rg = blockIdx.x >> 4, i16 = blockIdx.x & 15;
+  const int row = rg * 64 + j * 16 + i16;
+  const int KB = D >> 5;
+  if (row < rows) {
     const float* xr = x + (size_t)(idx ? idx[row] : row) * D;
     f32x4 v[NCH];
     float sq = 0.f;
@@ -127,18 +123,14 @@ __global__ __launch_bounds__(256) void rmsnorm_mx_kernel(const float* __restrict
         amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
         const int e = mx4_exponent(amax);
         *(uint16_t*)(ar + (c >> 1)) = (uint16_t)mx4_pack4(lo[0], lo[1], lo[2], lo[3], mx4_scale(e));
-        eb[i] |= (uint32_t)(e + 127) << (8 * j);
+        if ((lane & 7) == 0) se[(c >> 5) * 4 + j] = (uint8_t)(e + 127);
       }
     }
+  } else {
+    for (int kb = lane; kb < KB; kb += 64) se[kb * 4 + j] = 0;
   }
-  if ((lane & 7) == 0) {
-    const int KB = D >> 5;
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int c = (lane + i * 64) * 4;
-      if (c < D) *(uint32_t*)(aexp + ((size_t)rg * KB + (c >> 5)) * 64 + i16 * 4) = eb[i];
-    }
-  }
+  __syncthreads();
+  if ((int)threadIdx.x < KB) *(uint32_t*)(aexp + ((size_t)rg * KB + threadIdx.x) * 64 + i16 * 4) = *(const uint32_t*)(se + threadIdx.x * 4);
 }
 
 }  // namespace
@@ -162,7 +154,7 @@ int vt_rmsnorm_mx_launch(const float* x, const int* idx, const float* w, bf16_t*
                          hipStream_t s) {
   VT_REQUIRE(x && w && y && A4 && aexp && rows > 0, "vt_rmsnorm_mx: null pointer");
   VT_REQUIRE(D % 256 == 0 && D <= 8192, "vt_rmsnorm_mx: D = %d must be a multiple of 256, at most 8192", D);
-  const dim3 grid(cdiv(rows, 64) * 4), block(256);   // a wave per (64-row group, row % 16): four rows each
+  const dim3 grid(cdiv(rows, 64) * 16), block(256);   // a workgroup per (64-row group, row % 16): its four waves take the four rows
   if (D <= 1024) hipLaunchKernelGGL(rmsnorm_mx_kernel<4>, grid, block, 0, s, x, idx, w, y, A4, aexp, rows, D, eps);
   else if (D <= 4096) hipLaunchKernelGGL(rmsnorm_mx_kernel<16>, grid, block, 0, s, x, idx, w, y, A4, aexp, rows, D, eps);
   else hipLaunchKernelGGL(rmsnorm_mx_kernel<32>, grid, block, 0, s, x, idx, w, y, A4, aexp, rows, D, eps);
