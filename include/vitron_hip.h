@@ -130,7 +130,7 @@ size_t vt_mx4_aexp_bytes(int M, int K);
 int vt_mx4_quant_weights(const uint16_t* W, int ldw, int N, int K, uint8_t* W4, uint8_t* wexp, void* stream);
 /* a 16-bit remainder lo [M][K] (the second output of the precise level 2 operators), K % 32 == 0 */
 int vt_mx4_quant_lo(const uint16_t* lo, int ld, int M, int K, uint8_t* A4, uint8_t* aexp, void* stream);
-/* vt_rmsnorm with the level 3 operand out: y = op16(v), (A4, aexp) = MX-FP4 image of v - f32(y); D % 256 == 0 */
+/* vt_rmsnorm with the level 3 operand out: y = op16(v), (A4, aexp) = MX-FP4 image of v - f32(y); D % 512 == 0 */
 int vt_rmsnorm_mx(const float* x, const int* idx, const float* w, uint16_t* y, uint8_t* A4, uint8_t* aexp, int rows, int D, float eps,
                   void* stream);
 /* the GEMM: 256 x 256 tiles of the four-wave kernel, K % 128 == 0, K >= 256, N % 4 == 0; epi = VT_EPI_BF16 / _GELU / _QGELU / F32_RESID /
@@ -142,6 +142,14 @@ int vt_gemm_mx(const uint16_t* A, int lda, const uint8_t* A4, const uint8_t* aex
  * v - f32(C) -- down_proj's second operand, written by the same launch. N % 128 == 0. */
 int vt_gemm_mx_swiglu(const uint16_t* A, int lda, const uint8_t* A4, const uint8_t* aexp, const uint16_t* W, int ldw, const uint8_t* W4,
                       const uint8_t* wexp, uint16_t* C, int ldc, uint8_t* out4, uint8_t* oexp, int M, int N, int K, void* stream);
+/* the towers' fc1 in their precise level 1: C [M][N] = op16(v), v = gelu(acc + bias) (quick = 0: erf form, 1: x sigmoid(1.702 x)), and
+ * (out4 [M][N/2], oexp) = the MX-FP4 image of v - f32(C) -- fc2's second operand. N % 64 == 0. */
+int vt_gemm_mx_gelu(const uint16_t* A, int lda, const uint8_t* A4, const uint8_t* aexp, const uint16_t* W, int ldw, const uint8_t* W4,
+                    const uint8_t* wexp, const float* bias, uint16_t* C, int ldc, uint8_t* out4, uint8_t* oexp, int M, int N, int K, int quick,
+                    void* stream);
+/* vt_layernorm (without the temporal-embedding add) with the level 3 operand out, as vt_rmsnorm_mx; D % 256 == 0 */
+int vt_layernorm_mx(const float* x, const float* gamma, const float* beta, uint16_t* y, uint8_t* A4, uint8_t* aexp, int rows, int D, float eps,
+                    void* stream);
 /* x += A.W^T + A4.W4^T (o_proj, down_proj of level 3). A grid that spills a fraction of a round over whole rounds of the chip's 256
  * multiprocessors runs its trailing row blocks as K ranges on the idle ones (fp32 partial slabs in `partials`, then an ordered reduce);
  * partials may be NULL (one plain launch). */
@@ -342,6 +350,10 @@ typedef struct vt_vit_layer {
   const float* t_b1;
   const uint16_t* t_w2;
   const float* t_b2;
+  /* precise level 1 only, else NULL: MX-FP4 images of fc1 / fc2 (vt_mx4_quant_weights) and their per-row exponents -- with them the MLP runs
+     as two launches of vt_gemm_mx's kernel (hidden % 256 == 0, intermediate % 128 == 0); without them level 1 falls back to 16-bit operand pairs */
+  const uint8_t* w14; const uint8_t* w1_e;
+  const uint8_t* w24; const uint8_t* w2_e;
 } vt_vit_layer;
 
 typedef struct vt_vit_model {
@@ -363,7 +375,9 @@ typedef struct vt_vit_model {
                               the temporal attention in fp32, the activation outputs; with out_feats_lo the selected patch tokens leave
                               as a pair too. The hidden state is then within ~1e-5 of fp32 in both operand builds.
                               1: the MLPs' operands (layer_norm2 -> fc1, activation -> fc2: what carries the tower's distance from fp32)
-                              and out_feats as pairs, the attention paths standard -- the towers' share of the decoder's precise level 3.
+                              with their rounding remainders -- as MX-FP4 images in the same launch when the layers carry w14 / w24
+                              (else as 16-bit operand pairs, two launches) -- and out_feats as a pair; the attention paths standard:
+                              the towers' share of the decoder's precise level 3.
                               0 (default): standard. */
   uint16_t* out_feats_lo;  /* optional DEVICE buffer [B*T*G*G][D]: the low half of out_feats (precise >= 1 only) */
 } vt_vit_model;
@@ -410,7 +424,7 @@ typedef struct vt_llama_model {
   int qkv_fuse;                 /* 1: prefills write rotated q / K pages / V^T pages from the QKV projection's epilogue instead of the
                                    separate vt_kv_tiles pass. Bit-identical results; measured 20 us per launch SLOWER at S = 5120 (the
                                    epilogue of a one-workgroup-per-CU kernel overlaps with nothing: 455 vs 386 + 48.5 us): default 0. */
-  int precise_qk;               /* 3: precise level 3 (head_dim 128, hidden % 256 == 0, intermediate % 128 == 0; the layers' *4 / *_e images set):
+  int precise_qk;               /* 3: precise level 3 (head_dim 128, hidden % 512 == 0, intermediate % 128 == 0; the layers' *4 / *_e images set):
                                    PREFILLS run every decoder Linear as ONE launch that adds, to the 16-bit product, the product of the MX-FP4
                                    image of the A operand's rounding remainder with the weights' MX-FP4 image on the 4x-rate MX pipe (vt_gemm_mx;
                                    RMSNorm, the attention kernels and the SwiGLU epilogue emit the remainder's image beside the 16-bit operand);

@@ -281,3 +281,40 @@ def test_flash_attn_mx_operand_out(dev, dtype, heads, lens):
         assert float(((c_got & 7) != (c_ref & 7))[same_e].float().mean()) < 2e-2
         img = _deq(c_got, e_got, 32)
         assert rel_l2(img, val - hi) < 0.2
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("quick", [False, True])
+def test_tower_mlp_on_the_mx_pipe(dev, dtype, quick):
+    """The towers' precise level 1 at ViT-L width: LayerNorm with the operand out -> fc1 + GELU with the operand out -> fc2 into the residual stream
+    (one whole-problem split-K launch pair: 76 tiles), against fp64 of the exact values -- the MLP's distance from it must be a fraction of
+    the standard 16-bit operators' on the same input."""
+    from vitron_amd import ops
+    g = torch.Generator().manual_seed(11)
+    R, D, I = 1154, 1024, 4096
+    x = torch.randn((R, D), generator=g) * 3
+    gam, bet = 1 + 0.1 * torch.randn((D,), generator=g), 0.1 * torch.randn((D,), generator=g)
+    w1 = (torch.randn((I, D), generator=g) * 0.03).to(torch.bfloat16).to(dtype)
+    w2 = (torch.randn((D, I), generator=g) * 0.02).to(torch.bfloat16).to(dtype)
+    b1, b2 = 0.1 * torch.randn((I,), generator=g), 0.1 * torch.randn((D,), generator=g)
+    xd = x.to(dev)
+    y, y4, yexp = ops.layernorm_mx(xd, gam.to(dev), bet.to(dev), 1e-5, dtype)
+    y0 = ops.layernorm(xd.clone(), gam.to(dev), bet.to(dev), 1e-5, dtype=dtype)
+    assert rel_l2(y.float().cpu(), y0.float().cpu()) < 1e-4
+    w14, w1e = ops.mx4_quant_weights(w1.to(dev))
+    w24, w2e = ops.mx4_quant_weights(w2.to(dev))
+    h, h4, hexp = ops.gemm_mx_gelu(y, y4, yexp, w1.to(dev), w14, w1e, b1.to(dev), quick)
+    part = torch.empty((256 * 256 * 64,), device=dev, dtype=torch.float32)
+    out = ops.gemm_mx_resid(h, h4, hexp, w2.to(dev), w24, w2e, xd.clone(), part)
+    # fp64 of the exact values (no rounding anywhere); the bias of fc2 is added on the host (the public resid entry takes none)
+    ln = torch.nn.functional.layer_norm(x.double(), (D,), gam.double(), bet.double(), 1e-5)
+    a = ln @ w1.double().t() + b1.double()
+    act = a * torch.sigmoid(1.702 * a) if quick else torch.nn.functional.gelu(a)
+    mlp_ref = act @ w2.double().t()
+    mlp_got = out.double().cpu() - x.double()
+    # the standard operators on the same input
+    hs = ops.gemm(y0, w1.to(dev), b1.to(dev), ops.EPI_BF16_QGELU if quick else ops.EPI_BF16_GELU)
+    std = ops.gemm(hs, w2.to(dev), None, ops.EPI_F32_RESID, out=xd.clone()).double().cpu() - x.double()
+    d_mx, d_std = rel_l2(mlp_got, mlp_ref), rel_l2(std, mlp_ref)
+    assert d_mx < 0.35 * d_std, (d_mx, d_std)
+    assert rel_l2(h.float().cpu(), hs.float().cpu()) < (3e-3 if dtype == torch.bfloat16 else 4e-4)      # the 16-bit halves agree up to an ulp of a few elements

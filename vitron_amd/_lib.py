@@ -44,7 +44,7 @@ class VtVitLayer(C.Structure):
     _fields_ = [(n, vp) for n in (
         "t_ln_g", "t_ln_b", "t_embed", "t_wqkv", "t_bqkv", "t_wo", "t_bo",
         "ln1_g", "ln1_b", "wqkv", "bqkv", "wo", "bo", "ln2_g", "ln2_b", "w1", "b1", "w2", "b2",
-        "t_ln2_g", "t_ln2_b", "t_w1", "t_b1", "t_w2", "t_b2")]
+        "t_ln2_g", "t_ln2_b", "t_w1", "t_b1", "t_w2", "t_b2", "w14", "w1_e", "w24", "w2_e")]
 
 
 class VtVitModel(C.Structure):
@@ -119,6 +119,8 @@ SIGNATURES = {
     "vt_rmsnorm_mx": (_i, [vp, vp, vp, vp, vp, vp, _i, _i, _f, vp]),
     "vt_gemm_mx": (_i, [vp, _i, vp, vp, vp, _i, vp, vp, vp, _i, vp, _i, _i, _i, _i, vp]),
     "vt_gemm_mx_swiglu": (_i, [vp, _i, vp, vp, vp, _i, vp, vp, vp, _i, vp, vp, _i, _i, _i, vp]),
+    "vt_gemm_mx_gelu": (_i, [vp, _i, vp, vp, vp, _i, vp, vp, vp, vp, _i, vp, vp, _i, _i, _i, _i, vp]),
+    "vt_layernorm_mx": (_i, [vp, vp, vp, vp, vp, vp, _i, _i, _f, vp]),
     "vt_gemm_mx_resid": (_i, [vp, _i, vp, vp, vp, _i, vp, vp, vp, _i, _i, _i, _i, vp, _sz, vp]),
     "vt_flash_attn_mx": (_i, [vp, _i, vp, vp, vp, vp, _i, _i, vp, _i, vp, vp, _i, _f, vp]),
 }

@@ -247,9 +247,19 @@ int vt_gemm_mx_swiglu(const uint16_t* A, int lda, const uint8_t* A4, const uint8
                       const uint8_t* wexp, uint16_t* C, int ldc, uint8_t* out4, uint8_t* oexp, int M, int N, int K, void* stream) {
   return vt_gemm_mx_launch(A, lda, A4, aexp, W, ldw, W4, wexp, C, ldc, nullptr, M, N, K, VT_EPI_SWIGLU_MX, 1, 0, out4, oexp, S(stream));
 }
+int vt_gemm_mx_gelu(const uint16_t* A, int lda, const uint8_t* A4, const uint8_t* aexp, const uint16_t* W, int ldw, const uint8_t* W4,
+                    const uint8_t* wexp, const float* bias, uint16_t* C, int ldc, uint8_t* out4, uint8_t* oexp, int M, int N, int K, int quick,
+                    void* stream) {
+  return vt_gemm_mx_launch(A, lda, A4, aexp, W, ldw, W4, wexp, C, ldc, bias, M, N, K, quick ? VT_EPI_QGELU_MX : VT_EPI_GELU_MX, 1, 0, out4, oexp,
+                           S(stream));
+}
+int vt_layernorm_mx(const float* x, const float* gamma, const float* beta, uint16_t* y, uint8_t* A4, uint8_t* aexp, int rows, int D, float eps,
+                    void* stream) {
+  return vt_layernorm_mx_launch(x, gamma, beta, y, A4, aexp, rows, D, eps, S(stream));
+}
 int vt_gemm_mx_resid(const uint16_t* A, int lda, const uint8_t* A4, const uint8_t* aexp, const uint16_t* W, int ldw, const uint8_t* W4,
                      const uint8_t* wexp, float* C, int ldc, int M, int N, int K, float* partials, size_t partial_bytes, void* stream) {
-  return vt_gemm_mx_resid_launch(A, lda, A4, aexp, W, ldw, W4, wexp, C, ldc, M, N, K, partials, partial_bytes, S(stream));
+  return vt_gemm_mx_resid_launch(A, lda, A4, aexp, W, ldw, W4, wexp, C, ldc, nullptr, M, N, K, partials, partial_bytes, S(stream));
 }
 int vt_flash_attn_mx(const uint16_t* Q, int ldq, const uint16_t* k_tiles, const uint16_t* vt_tiles, const int* tile_table,
                      const int* seq_desc, int nseq, int max_q_len, uint16_t* O, int ldo, uint8_t* O4, uint8_t* oexp, int heads, float scale,
@@ -425,6 +435,8 @@ struct VitWs {
   // halves of q, of the keys (one workspace tile per page) and of the attention output
   bf16_t *ylo, *hlo, *qlo, *klo, *attlo;
   float *h32, *qkv32;
+  // precise level 1 with the layers' MX-FP4 weight images: the MLP's two A operands as 16-bit value + 4-bit image of the remainder
+  uint8_t *y4, *yexp, *h4, *hexp;
   size_t total;
 };
 VitWs vit_carve(const vt_vit_model* m, int B, int T, void* p, size_t n) {
@@ -445,13 +457,27 @@ VitWs vit_carve(const vt_vit_model* m, int B, int T, void* p, size_t n) {
   w.seq_desc = (int*)ws.take((size_t)F * 4 * 4);
   w.tile_table = (int*)ws.take((size_t)F * ntiles * 4);
   w.splitk_bytes = (size_t)8 * R * D * 4 <= ((size_t)64 << 20) ? (size_t)8 * R * D * 4 : 0;   // only worth it for a few frames
+  if (m->precise == 1 && m->num_layers > 0 && m->layers[0].w14) {
+    // level 1 on the MX pipe: fc2's grid of 256 x 256 tiles covers a fraction of the chip (one clip: 19 x 4 = 76 tiles) and runs as K ranges
+    // (vt_gemm_mx_resid_launch): room for its fp32 partial slabs
+    const int tiles = cdiv(R, 256) * cdiv(D, 256);
+    const int ks = tiles * 2 <= 256 ? std::min(8, 256 / tiles) : 0;
+    w.splitk_bytes = std::max(w.splitk_bytes, (size_t)ks * R * D * 4);
+  }
   w.splitk = w.splitk_bytes ? (float*)ws.take(w.splitk_bytes) : nullptr;
   w.ylo = w.hlo = w.qlo = w.klo = w.attlo = nullptr;
   w.h32 = w.qkv32 = nullptr;
+  w.y4 = w.yexp = w.h4 = w.hexp = nullptr;
   if (m->precise >= 1) {
     w.ylo = (bf16_t*)ws.take((size_t)R * D * 2);
     w.hlo = (bf16_t*)ws.take((size_t)R * I * 2);
     w.h32 = (float*)ws.take((size_t)R * I * 4);
+  }
+  if (m->precise == 1 && m->num_layers > 0 && m->layers[0].w14) {
+    w.y4 = (uint8_t*)ws.take((size_t)R * (D / 2));
+    w.yexp = (uint8_t*)ws.take(vt_mx4_aexp_bytes(R, D));
+    w.h4 = (uint8_t*)ws.take((size_t)R * (I / 2));
+    w.hexp = (uint8_t*)ws.take(vt_mx4_aexp_bytes(R, I));
   }
   if (m->precise >= 2) {
     w.qkv32 = (float*)ws.take((size_t)R * 3 * D * 4);
@@ -560,6 +586,15 @@ int vt_vit_forward(const vt_vit_model* m, const void* pixels, int pix_dtype, int
       VT_TRY(vt_gemm_launch(w.att, D, L.wo, D, w.x, D, L.bo, R, D, D, VT_EPI_F32_RESID, AUTO, s));
     }
     // MLP
+    if (m->precise == 1 && L.w14 && L.w1_e && L.w24 && L.w2_e && w.y4) {
+      // precise level 1 with MX-FP4 weight images (the towers' share of the decoder's level 3): both MLP products as ONE launch each that adds
+      // the 4-bit product of the A operand's rounding remainder -- LayerNorm and the activation epilogue write the remainder's image
+      VT_TRY(vt_layernorm_mx_launch(w.x, L.ln2_g, L.ln2_b, w.y, w.y4, w.yexp, R, D, m->ln_eps, s));
+      VT_TRY(vt_gemm_mx_launch(w.y, D, w.y4, w.yexp, L.w1, D, L.w14, L.w1_e, w.h, I, L.b1, R, I, D,
+                               m->act == VT_ACT_QUICK_GELU ? VT_EPI_QGELU_MX : VT_EPI_GELU_MX, 1, 0, w.h4, w.hexp, s));
+      VT_TRY(vt_gemm_mx_resid_launch(w.h, I, w.h4, w.hexp, L.w2, I, L.w24, L.w2_e, w.x, D, L.b2, R, D, I, w.splitk, w.splitk_bytes, s));
+      continue;
+    }
     if (m->precise >= 1) {
       // precise level 1 / 2 (layer_norm2 -> fc1 and GELU -> fc2 carry half of the tower's distance from fp32): both operands as
       // pairs, every product as two launches accumulating in fp32, the activation as its own fp32 -> pair pass
@@ -713,7 +748,7 @@ int vt_llama_forward(const vt_llama_model* m, const vt_kv_cache* kv, const uint1
   // precise level 3: every decoder Linear of a prefill as ONE launch with the MX-FP4 product of the A operand's remainder folded in
   const bool precise3 = max_q_len > 1 && !fold_norm && m->precise_qk == 3;
   if (precise3) {   // a request the shapes cannot serve is an error, never a silent standard-mode pass
-    VT_REQUIRE(HD == 128 && (H % 256) == 0 && (I % 128) == 0 && w.y4 != nullptr, "vt_llama_forward: precise level 3 needs head_dim 128, hidden %% 256 == 0, intermediate %% 128 == 0 (H=%d I=%d)", H, I);
+    VT_REQUIRE(HD == 128 && (H % 512) == 0 && (I % 128) == 0 && w.y4 != nullptr, "vt_llama_forward: precise level 3 needs head_dim 128, hidden %% 512 == 0, intermediate %% 128 == 0 (H=%d I=%d)", H, I);
     for (int l = 0; l < m->num_layers; ++l) {
       const vt_llama_layer& L = m->layers[l];
       VT_REQUIRE(L.wqkv4 && L.wqkv_e && L.wo4 && L.wo_e && L.wgu4 && L.wgu_e && L.wdown4 && L.wdown_e, "vt_llama_forward: precise level 3 without the weights' MX-FP4 images (layer %d)", l);
@@ -772,11 +807,11 @@ int vt_llama_forward(const vt_llama_model* m, const vt_kv_cache* kv, const uint1
                                 m->rope_cos, m->rope_sin, positions, s));
       VT_TRY(vt_flash_attn_launch(w.qkv, 3 * H, kt, vt, tile_table, (const VtAttnSeq*)seq_desc, nseq, max_q_len, w.att, H, heads, HD, 1, scale, s,
                                   w.att4, w.attexp));
-      VT_TRY(vt_gemm_mx_resid_launch(w.att, H, w.att4, w.attexp, L.wo, H, L.wo4, L.wo_e, w.x, H, rows, H, H, w.splitk, w.splitk_bytes, s));
+      VT_TRY(vt_gemm_mx_resid_launch(w.att, H, w.att4, w.attexp, L.wo, H, L.wo4, L.wo_e, w.x, H, nullptr, rows, H, H, w.splitk, w.splitk_bytes, s));
       VT_TRY(vt_rmsnorm_mx_launch(w.x, nullptr, L.rms2, w.y, w.y4, w.yexp, rows, H, m->rms_eps, s));
       VT_TRY(vt_gemm_mx_launch(w.y, H, w.y4, w.yexp, L.wgu, H, L.wgu4, L.wgu_e, w.h, I, nullptr, rows, 2 * I, H, VT_EPI_SWIGLU_MX, 1, 0, w.h4, w.hexp,
                                s));
-      VT_TRY(vt_gemm_mx_resid_launch(w.h, I, w.h4, w.hexp, L.wdown, I, L.wdown4, L.wdown_e, w.x, H, rows, H, I, w.splitk, w.splitk_bytes, s));
+      VT_TRY(vt_gemm_mx_resid_launch(w.h, I, w.h4, w.hexp, L.wdown, I, L.wdown4, L.wdown_e, w.x, H, nullptr, rows, H, I, w.splitk, w.splitk_bytes, s));
       continue;
     }
     if (precise2) {

@@ -1650,6 +1650,11 @@ int vt_gemm_mx_launch(const bf16_t* A, int lda, const uint8_t* A4, const uint8_t
       VT_REQUIRE(out4 && oexp && (N % 128) == 0 && (ldc % 8) == 0 && (((size_t)C | (size_t)out4) & 15) == 0 && !bias,
                  "vt_gemm_mx: the SwiGLU epilogue with the level 3 operand out needs N %% 128 == 0, aligned outputs and no bias");
       return launch_w4x<VT_EPI_SWIGLU_MX>(p, x, s);
+    case VT_EPI_GELU_MX:
+    case VT_EPI_QGELU_MX:
+      VT_REQUIRE(out4 && oexp && (N % 64) == 0 && (ldc % 8) == 0 && (((size_t)C | (size_t)out4) & 15) == 0,
+                 "vt_gemm_mx: the GELU epilogues with the level 3 operand out need N %% 64 == 0 and aligned outputs");
+      return epi == VT_EPI_GELU_MX ? launch_w4x<VT_EPI_GELU_MX>(p, x, s) : launch_w4x<VT_EPI_QGELU_MX>(p, x, s);
     default: vt_set_error("vt_gemm_mx: epilogue %d not instantiated", epi); return VT_ERR_ARG;
   }
 }
@@ -1659,19 +1664,23 @@ int vt_gemm_mx_launch(const bf16_t* A, int lda, const uint8_t* A4, const uint8_t
 // is cut at the last whole round: the leading row blocks run as they are, the trailing ones as `ksplit` K ranges per tile on the otherwise
 // idle CUs (fp32 partial slabs + the ordered reduce of the two-pass split-K), 1.25 rounds + a reduce instead of 2.
 int vt_gemm_mx_resid_launch(const bf16_t* A, int lda, const uint8_t* A4, const uint8_t* aexp, const bf16_t* W, int ldw, const uint8_t* W4,
-                            const uint8_t* wexp, float* C, int ldc, int M, int N, int K, float* partials, size_t partial_bytes, hipStream_t s) {
+                            const uint8_t* wexp, float* C, int ldc, const float* bias, int M, int N, int K, float* partials, size_t partial_bytes,
+                            hipStream_t s) {
   const int tiles_m = cdiv(M, 256), tiles_n = cdiv(N, 256), total = tiles_m * tiles_n, CUS = 256;
-  const int head_rows = (total / CUS) * CUS / tiles_n;        // row blocks inside whole rounds
+  int head_rows = (total / CUS) * CUS / tiles_n;              // row blocks inside whole rounds
+  // a grid of at most half a round (the towers' fc2: 4616 x 1024 = 76 tiles) has no head: the whole problem runs as K ranges
+  if (total * 2 <= CUS) head_rows = 0;
   const int tail_tiles = (tiles_m - head_rows) * tiles_n;
   int ksplit = tail_tiles > 0 ? std::min(8, CUS / tail_tiles) : 1;
   while (ksplit > 1 && (K / 128) < 2 * ksplit) --ksplit;
   const int m0 = head_rows * 256, mt = M - m0;
-  if (head_rows == 0 || tail_tiles == 0 || ksplit < 2 || !partials || (size_t)ksplit * mt * N * 4 > partial_bytes || (N % 4) != 0)
-    return vt_gemm_mx_launch(A, lda, A4, aexp, W, ldw, W4, wexp, C, ldc, nullptr, M, N, K, VT_EPI_F32_RESID, 1, 0, nullptr, nullptr, s);
-  VT_TRY(vt_gemm_mx_launch(A, lda, A4, aexp, W, ldw, W4, wexp, C, ldc, nullptr, m0, N, K, VT_EPI_F32_RESID, 1, 0, nullptr, nullptr, s));
+  if (tail_tiles == 0 || ksplit < 2 || !partials || (size_t)ksplit * mt * N * 4 > partial_bytes || (N % 4) != 0 || (head_rows == 0 && total * 2 > CUS))
+    return vt_gemm_mx_launch(A, lda, A4, aexp, W, ldw, W4, wexp, C, ldc, bias, M, N, K, VT_EPI_F32_RESID, 1, 0, nullptr, nullptr, s);
+  if (head_rows > 0)
+    VT_TRY(vt_gemm_mx_launch(A, lda, A4, aexp, W, ldw, W4, wexp, C, ldc, bias, m0, N, K, VT_EPI_F32_RESID, 1, 0, nullptr, nullptr, s));
   const size_t slab = (size_t)mt * N;
   VT_TRY(vt_gemm_mx_launch(A + (size_t)m0 * lda, lda, A4 + (size_t)m0 * (K >> 1), aexp + (size_t)(m0 >> 6) * (K >> 5) * 64, W, ldw, W4, wexp,
-                           partials, N, nullptr, mt, N, K, VT_EPI_F32, ksplit, slab, nullptr, nullptr, s));
+                           partials, N, bias, mt, N, K, VT_EPI_F32, ksplit, slab, nullptr, nullptr, s));    // (split 0 adds the bias)
   const long tot4 = (long)mt * (N >> 2);
   hipLaunchKernelGGL(splitk_reduce_resid_kernel, dim3((int)std::min<long>((tot4 + 255) / 256, 2048)), dim3(256), 0, s, partials, slab, ksplit,
                      C + (size_t)m0 * ldc, ldc, mt, N, VtGemmNormFuse{});

@@ -99,9 +99,14 @@ int vt_rmsnorm_mx_launch(const float* x, const int* idx, const float* w, bf16_t*
 int vt_gemm_mx_launch(const bf16_t* A, int lda, const uint8_t* A4, const uint8_t* aexp, const bf16_t* W, int ldw, const uint8_t* W4,
                       const uint8_t* wexp, void* C, int ldc, const float* bias, int M, int N, int K, int epi, int ksplit, size_t slab,
                       uint8_t* out4, uint8_t* oexp, hipStream_t s);
-#define VT_EPI_SWIGLU_MX 8   // internal epilogue of vt_gemm_mx_launch: SwiGLU with the level 3 operand out (C = op16(v), out4 / oexp = image of v - f32(C))
+#define VT_EPI_SWIGLU_MX 8   // internal epilogues of vt_gemm_mx_launch: an activation with the level 3 operand out (C = op16(v), out4 / oexp = image of
+#define VT_EPI_GELU_MX 9     // v - f32(C)): SwiGLU over the interleaved gate / up columns; erf-GELU / quick-GELU of acc + bias (the towers' fc1)
+#define VT_EPI_QGELU_MX 10
 int vt_gemm_mx_resid_launch(const bf16_t* A, int lda, const uint8_t* A4, const uint8_t* aexp, const bf16_t* W, int ldw, const uint8_t* W4,
-                            const uint8_t* wexp, float* C, int ldc, int M, int N, int K, float* partials, size_t partial_bytes, hipStream_t s);
+                            const uint8_t* wexp, float* C, int ldc, const float* bias, int M, int N, int K, float* partials, size_t partial_bytes,
+                            hipStream_t s);
+int vt_layernorm_mx_launch(const float* x, const float* gamma, const float* beta, bf16_t* y, uint8_t* A4, uint8_t* aexp, int rows, int D,
+                           float eps, hipStream_t s);
 
 // ---- vt_norm.hip ----------------------------------------------------------------------------------
 int vt_layernorm_launch(float* x, const float* temb, int T, int tokens_per_frame, const float* gamma,

@@ -72,31 +72,105 @@ __global__ __launch_bounds__(256) void mx4_quant_lo_kernel(const op16_t* __restr
 }
 
 // RMSNorm (transformers-4.31 LlamaRMSNorm) with the level 3 operand out: hi = op16(v), lo = v - f32(hi) as MX-FP4.
-// One wave per row and 4 consecutive columns per lane and chunk as in vt_norm.hip (8 lanes share a 32-block). The four waves of a workgroup
-// take the FOUR rows whose block exponents share a dword of the scale array -- rows i, i + 16, i + 32, i + 48 of a 64-row group -- park
-// their exponent bytes in LDS and store them as whole dwords: a byte store per row and block, each to a line of its own, doubled this
+// One wave per row; a lane holds EIGHT consecutive columns per chunk (two 16-byte loads, one 16-byte store of the 16-bit operand, one 4-byte
+// store of codes: half as many store instructions as 4 columns per lane would issue, and a 32-block is one quad). The four waves of a
+// workgroup take the FOUR rows whose block exponents share a dword of the scale array -- rows i, i + 16, i + 32, i + 48 of a 64-row group --
+// park their exponent bytes in LDS and store them as whole dwords: a byte store per row and block, each to a line of its own, doubled this
 // kernel's time (41 us against vt_rmsnorm's 19 at 5120 x 4096), and a wave walking the four rows one after the other tripled it (63 us).
-template <int NCH>
+template <int NCH>    // chunks of 512 columns
 __global__ __launch_bounds__(256) void rmsnorm_mx_kernel(const float* __restrict__ x, const int* __restrict__ idx, const float* __restrict__ w,
                                                          op16_t* __restrict__ y, uint8_t* __restrict__ A4, uint8_t* __restrict__ aexp, int rows,
                                                          int D, float eps) {
-  __shared__ __attribute__((aligned(4))) uint8_t se[NCH * 8 * 4];     // [block][row of the four]
+  __shared__ __attribute__((aligned(4))) uint8_t se[NCH * 16 * 4];     // [block][row of the four]
   const int lane = threadIdx.x & 63, j = threadIdx.x >> 6;
   const int rg = blockIdx.x >> 4, i16 = blockIdx.x & 15;
   const int row = rg * 64 + j * 16 + i16;
   const int KB = D >> 5;
   if (row < rows) {
     const float* xr = x + (size_t)(idx ? idx[row] : row) * D;
+    f32x4 v[NCH][2];
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = (lane + i * 64) * 8;
+      if (c < D) {
+        v[i][0] = *(const f32x4*)(xr + c);
+        v[i][1] = *(const f32x4*)(xr + c + 4);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) sq += v[i][h][0] * v[i][h][0] + v[i][h][1] * v[i][h][1] + v[i][h][2] * v[i][h][2] + v[i][h][3] * v[i][h][3];
+      } else {
+        v[i][0] = v[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
+    op16_t* yr = y + (size_t)row * D;
+    uint8_t* ar = A4 + (size_t)row * (D >> 1);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = (lane + i * 64) * 8;
+      if (c < D) {                                                // (D % 512 == 0: whole quads are in or out together)
+        float val[8], lo[8];
+        u32x4 o;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const f32x4 g = *(const f32x4*)(w + c + 4 * h);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) val[4 * h + r] = v[i][h][r] * rstd * g[r];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          o[q] = pack_op2(val[2 * q], val[2 * q + 1]);
+          lo[2 * q] = val[2 * q] - oplo_to_f32(o[q]);
+          lo[2 * q + 1] = val[2 * q + 1] - ophi_to_f32(o[q]);
+        }
+        *(u32x4*)(yr + c) = o;
+        float amax = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) amax = fmaxf(amax, fabsf(lo[r]));
+        const int e = mx4_exponent(quad_max(amax));
+        *(uint32_t*)(ar + (c >> 1)) = mx4_pack8(lo[0], lo[1], lo[2], lo[3], lo[4], lo[5], lo[6], lo[7], mx4_scale(e));
+        if ((lane & 3) == 0) se[(c >> 5) * 4 + j] = (uint8_t)(e + 127);
+      }
+    }
+  } else {
+    for (int kb = lane; kb < KB; kb += 64) se[kb * 4 + j] = 0;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < KB) *(uint32_t*)(aexp + ((size_t)rg * KB + threadIdx.x) * 64 + i16 * 4) = *(const uint32_t*)(se + threadIdx.x * 4);
+}
+
+// LayerNorm (nn.LayerNorm: the towers' layer_norm2 / temporal_layer_norm2, reference modeling_video.py:72,82) with the level 3 operand out --
+// the same organisation as rmsnorm_mx_kernel (one row per wave, the four rows of an exponent dword in one workgroup).
+template <int NCH>
+__global__ __launch_bounds__(256) void layernorm_mx_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           op16_t* __restrict__ y, uint8_t* __restrict__ A4, uint8_t* __restrict__ aexp, int rows,
+                                                           int D, float eps) {
+  __shared__ __attribute__((aligned(4))) uint8_t se[NCH * 8 * 4];
+  const int lane = threadIdx.x & 63, j = threadIdx.x >> 6;
+  const int rg = blockIdx.x >> 4, i16 = blockIdx.x & 15;
+  const int row = rg * 64 + j * 16 + i16;
+  const int KB = D >> 5;
+  if (row < rows) {
+    const float* xr = x + (size_t)row * D;
     f32x4 v[NCH];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = (lane + i * 64) * 4;
+      v[i] = (c < D) ? *(const f32x4*)(xr + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    }
+    const float mean = wave_sum(sum) / (float)D;
     float sq = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int c = (lane + i * 64) * 4;
       if (c < D) {
-        v[i] = *(const f32x4*)(xr + c);
-        sq += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
-      } else {
-        v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float d = v[i][r] - mean;
+          sq += d * d;
+        }
       }
     }
     const float rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
@@ -105,12 +179,13 @@ __global__ __launch_bounds__(256) void rmsnorm_mx_kernel(const float* __restrict
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int c = (lane + i * 64) * 4;
-      if (c < D) {                                                // (D % 256 == 0: whole 8-lane groups are in or out together)
-        const f32x4 g = *(const f32x4*)(w + c);
+      if (c < D) {
+        const f32x4 g = *(const f32x4*)(gamma + c);
+        const f32x4 b = *(const f32x4*)(beta + c);
         float val[4], lo[4];
         u32x2 o;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) val[r] = v[i][r] * rstd * g[r];
+        for (int r = 0; r < 4; ++r) val[r] = (v[i][r] - mean) * rstd * g[r] + b[r];
         o.x = pack_op2(val[0], val[1]);
         o.y = pack_op2(val[2], val[3]);
         *(u32x2*)(yr + c) = o;
@@ -135,6 +210,17 @@ __global__ __launch_bounds__(256) void rmsnorm_mx_kernel(const float* __restrict
 
 }  // namespace
 
+int vt_layernorm_mx_launch(const float* x, const float* gamma, const float* beta, bf16_t* y, uint8_t* A4, uint8_t* aexp, int rows, int D,
+                           float eps, hipStream_t s) {
+  VT_REQUIRE(x && gamma && beta && y && A4 && aexp && rows > 0, "vt_layernorm_mx: null pointer");
+  VT_REQUIRE(D % 256 == 0 && D <= 4096, "vt_layernorm_mx: D = %d must be a multiple of 256, at most 4096", D);
+  const dim3 grid(cdiv(rows, 64) * 16), block(256);
+  if (D <= 1024) hipLaunchKernelGGL(layernorm_mx_kernel<4>, grid, block, 0, s, x, gamma, beta, y, A4, aexp, rows, D, eps);
+  else hipLaunchKernelGGL(layernorm_mx_kernel<16>, grid, block, 0, s, x, gamma, beta, y, A4, aexp, rows, D, eps);
+  VT_LAUNCH_CHECK();
+  return VT_OK;
+}
+
 int vt_mx4_quant_weights_launch(const bf16_t* W, int ldw, int N, int K, uint8_t* W4, uint8_t* wexp, hipStream_t s) {
   VT_REQUIRE(W && W4 && wexp && N > 0 && K > 0 && (K % 8) == 0 && (ldw % 8) == 0, "vt_mx4_quant_weights: K and ldw must be multiples of 8");
   hipLaunchKernelGGL(mx4_quant_rows_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, W, ldw, N, K, W4, wexp);
@@ -153,11 +239,11 @@ int vt_mx4_quant_lo_launch(const bf16_t* lo, int ld, int M, int K, uint8_t* A4, 
 int vt_rmsnorm_mx_launch(const float* x, const int* idx, const float* w, bf16_t* y, uint8_t* A4, uint8_t* aexp, int rows, int D, float eps,
                          hipStream_t s) {
   VT_REQUIRE(x && w && y && A4 && aexp && rows > 0, "vt_rmsnorm_mx: null pointer");
-  VT_REQUIRE(D % 256 == 0 && D <= 8192, "vt_rmsnorm_mx: D = %d must be a multiple of 256, at most 8192", D);
+  VT_REQUIRE(D % 512 == 0 && D <= 8192, "vt_rmsnorm_mx: D = %d must be a multiple of 512, at most 8192", D);
   const dim3 grid(cdiv(rows, 64) * 16), block(256);   // a workgroup per (64-row group, row % 16): its four waves take the four rows
-  if (D <= 1024) hipLaunchKernelGGL(rmsnorm_mx_kernel<4>, grid, block, 0, s, x, idx, w, y, A4, aexp, rows, D, eps);
-  else if (D <= 4096) hipLaunchKernelGGL(rmsnorm_mx_kernel<16>, grid, block, 0, s, x, idx, w, y, A4, aexp, rows, D, eps);
-  else hipLaunchKernelGGL(rmsnorm_mx_kernel<32>, grid, block, 0, s, x, idx, w, y, A4, aexp, rows, D, eps);
+  if (D <= 1024) hipLaunchKernelGGL(rmsnorm_mx_kernel<2>, grid, block, 0, s, x, idx, w, y, A4, aexp, rows, D, eps);
+  else if (D <= 4096) hipLaunchKernelGGL(rmsnorm_mx_kernel<8>, grid, block, 0, s, x, idx, w, y, A4, aexp, rows, D, eps);
+  else hipLaunchKernelGGL(rmsnorm_mx_kernel<16>, grid, block, 0, s, x, idx, w, y, A4, aexp, rows, D, eps);
   VT_LAUNCH_CHECK();
   return VT_OK;
 }

@@ -155,6 +155,7 @@ class PackedVit:
             return keep(_bf(w, dev)), keep(_f32(b, dev))
 
         self.layers = (_lib.VtVitLayer * max(self.run_layers, 1))()
+        self._mlp_w: List[tuple] = []       # (fc1, fc2) per layer: precise level 1 makes their MX-FP4 images from these
         for l in range(self.run_layers):
             p = f"encoder.layers.{l}."
             L = self.layers[l]
@@ -184,9 +185,9 @@ class PackedVit:
             L.bo = keep(_f32(sd[p + "self_attn.out_proj.bias"], dev)).data_ptr()
             L.ln2_g = keep(_f32(sd[p + "layer_norm2.weight"], dev)).data_ptr()
             L.ln2_b = keep(_f32(sd[p + "layer_norm2.bias"], dev)).data_ptr()
-            L.w1 = keep(_bf(sd[p + "mlp.fc1.weight"], dev)).data_ptr()
+            self._mlp_w.append((keep(_bf(sd[p + "mlp.fc1.weight"], dev)), keep(_bf(sd[p + "mlp.fc2.weight"], dev))))
+            L.w1, L.w2 = self._mlp_w[-1][0].data_ptr(), self._mlp_w[-1][1].data_ptr()
             L.b1 = keep(_f32(sd[p + "mlp.fc1.bias"], dev)).data_ptr()
-            L.w2 = keep(_bf(sd[p + "mlp.fc2.weight"], dev)).data_ptr()
             L.b2 = keep(_f32(sd[p + "mlp.fc2.bias"], dev)).data_ptr()
         act = cfg.get("hidden_act", "quick_gelu")
         if act not in ("gelu", "quick_gelu"):
@@ -207,10 +208,20 @@ class PackedVit:
     def set_precise(self, level: int) -> None:
         """The MODEL's precise level -> the tower's (vt_vit_model.precise; include/vitron_hip.h). Model level 2: every GEMM A operand of the
         tower (norm outputs, q / k through the scores, attention and activation outputs) and the output features as operand pairs, the
-        temporal attention in fp32 (tower level 2). Model level 3: the MLPs' operands and the output features as pairs, the attention
-        paths standard (tower level 1: the part of level 2 that carries the tower's distance from fp32, at half its cost). 0 / 1: standard."""
+        temporal attention in fp32 (tower level 2). Model level 3: the MLPs' operands with their rounding remainders (MX-FP4 images in the
+        same launch at ViT-L width, 16-bit pairs otherwise) and the output features as a pair, the attention paths standard (tower
+        level 1: the part of level 2 that carries the tower's distance from fp32). 0 / 1: standard."""
         level = int(level)
         self.model.precise = 2 if level == 2 else 1 if level >= 3 else 0
+        if self.model.precise == 1 and self.D % 256 == 0 and self.I % 128 == 0 and not getattr(self, "_mx4_done", False):
+            # tower level 1 on the MX pipe: fc1 / fc2's 4-bit images (vt_mx4_quant_weights), once; other widths keep 16-bit operand pairs
+            from . import ops
+            for l in range(self.run_layers):
+                (w14, w1e), (w24, w2e) = ops.mx4_quant_weights(self._mlp_w[l][0]), ops.mx4_quant_weights(self._mlp_w[l][1])
+                self._keep += [w14, w1e, w24, w2e]
+                L = self.layers[l]
+                L.w14, L.w1_e, L.w24, L.w2_e = w14.data_ptr(), w1e.data_ptr(), w24.data_ptr(), w2e.data_ptr()
+            self._mx4_done = True
 
     def forward(self, pixels: torch.Tensor, return_hidden: bool = False):
         """pixels [B,3,H,W] or [B,3,T,H,W] (operand dtype or fp32, on device) -> patch features [B(,T),G*G,D] in the operand
@@ -488,8 +499,8 @@ class PackedLlama:
         if level and self.hd != 128:
             raise _lib.VitronHipError(f"precise modes need head_dim 128 (got {self.hd})")
         if level == 3:
-            if self.H % 256 or self.I % 128:
-                raise _lib.VitronHipError(f"precise level 3 needs hidden % 256 == 0 and intermediate % 128 == 0 (got {self.H}, {self.I})")
+            if self.H % 512 or self.I % 128:
+                raise _lib.VitronHipError(f"precise level 3 needs hidden % 512 == 0 and intermediate % 128 == 0 (got {self.H}, {self.I})")
             self._pack_mx4()
         self.model.precise_qk = level
 

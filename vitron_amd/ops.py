@@ -413,3 +413,29 @@ def flash_attn_mx(q, k_tiles, vt_tiles, tile_table, seq_desc, max_q_len: int, he
     _lib.check(lib.vt_flash_attn_mx(_p(q), q.stride(0), _p(k_tiles), _p(vt_tiles), _p(tile_table), _p(seq_desc), seq_desc.shape[0], max_q_len,
                                     _p(o), heads * 128, _p(o4), _p(oexp), heads, scale, _stream()), "vt_flash_attn_mx", lib)
     return o, o4, oexp
+
+
+def gemm_mx_gelu(a, a4, aexp, w, w4, wexp, bias: Optional[torch.Tensor] = None, quick: bool = False):
+    """(h op16 [M][N], h4 uint8 [M][N/2], hexp): the towers' fc1 in precise level 1 -- gelu(a @ w^T + (a4..)(w4..)^T + bias) and the MX-FP4 image of
+    its rounding remainder (vt_gemm_mx_gelu)."""
+    lib, dt = _op16(a, "gemm_mx_gelu.a")
+    M, K = a.shape
+    N = w.shape[0]
+    h = torch.empty((M, N), device=a.device, dtype=dt)
+    h4 = torch.empty((M, N // 2), device=a.device, dtype=torch.uint8)
+    hexp = torch.zeros((mx4_aexp_bytes(M, N),), device=a.device, dtype=torch.uint8)
+    _lib.check(lib.vt_gemm_mx_gelu(_p(a), K, _p(a4), _p(aexp), _p(w), K, _p(w4), _p(wexp), _p(bias), _p(h), N, _p(h4), _p(hexp), M, N, K, int(quick),
+                                   _stream()), "vt_gemm_mx_gelu", lib)
+    return h, h4, hexp
+
+
+def layernorm_mx(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, dtype: torch.dtype):
+    """(y op16 [rows][D], A4, aexp): LayerNorm with the level 3 operand out (vt_layernorm_mx)."""
+    _chk(x, torch.float32, "layernorm_mx.x")
+    lib = _lib.load(operand=_lib.operand_of(dtype))
+    rows, D = x.shape
+    y = torch.empty((rows, D), device=x.device, dtype=dtype)
+    a4 = torch.empty((rows, D // 2), device=x.device, dtype=torch.uint8)
+    aexp = torch.zeros((mx4_aexp_bytes(rows, D),), device=x.device, dtype=torch.uint8)
+    _lib.check(lib.vt_layernorm_mx(_p(x), _p(gamma), _p(beta), _p(y), _p(a4), _p(aexp), rows, D, eps, _stream()), "vt_layernorm_mx", lib)
+    return y, a4, aexp
