@@ -714,6 +714,75 @@ def c4_report(model, llama, dev, world, rank, use_dist, dist, frames, image_size
             "gather": "async RCCL all-gather overlapped with the rank's own prefill" if use_dist else "none (one GPU holds every clip)"}
 
 
+def c4_uneven_report(model, llama, dev, world, rank, dist, frames, image_size, steps=2):
+    """The case that NEEDS the exchange: the same 8 clips with prompts of UNEVEN length (128 .. 896 tokens, mean
+    512: the same total as configs[3]). Clips are encoded where shard_range puts them; sequences are prefilled where
+    vitron_amd.parallel.plan_prefill_placement puts them (balanced by prefill cost), so a rank prefills sequences whose visual tokens reached it
+    over the all-gather -- the gathered tensor feeds the splice of the sequences this rank owns. N > 1 only; wrapped by the caller."""
+    import torch
+
+    from vitron_amd import ops, synth
+    from vitron_amd.engine import SequenceState, llama_forward
+    from vitron_amd.parallel import (all_gather_visual_tokens, plan_prefill_placement, sequences_of_rank, shard_range, visual_tokens_for_rank)
+
+    GLOBAL = 8
+    text_lens = [128, 896, 256, 768, 384, 640, 512, 512]
+    G = image_size // 14
+    nvis = frames * G * G
+    place = plan_prefill_placement([nvis + t for t in text_lens], world)
+    mine = sequences_of_rank(place, rank)
+    es, ee = shard_range(GLOBAL, world, rank)
+    gen = synth.make_generator(9100, dev)                                   # ONE stream on every rank: every rank knows every prompt
+    clips_all = [torch.randn((3, frames, image_size, image_size), generator=gen, device=dev).to(llama.dtype) for _ in range(GLOBAL)]
+    ids_all = [torch.cat([torch.ones((1,), dtype=torch.long, device=dev), torch.full((frames,), -200, device=dev),
+                          torch.randint(3, 32000, (t - 1,), generator=gen, device=dev)]).unsqueeze(0) for t in text_lens]
+    ids_host = [i.cpu() for i in ids_all]
+    lens = [nvis + text_lens[i] for i in mine]
+    model._ensure_kv(sum((l + 63) // 64 + 1 for l in lens) + 4)
+    orig = model.encode_videos
+    foreign = [i for i in mine if not es <= i < ee]
+
+    def step():
+        local = orig(torch.stack(clips_all[es:ee])) if ee > es else None      # this rank's clips: [n_local, T, P, H]
+        allv = all_gather_visual_tokens(local, GLOBAL)                          # blocking: the prefill below consumes it
+        feats = visual_tokens_for_rank(allv, place, rank)
+        rows = []
+        try:
+            for k, i in enumerate(mine):
+                model.encode_videos = lambda videos, f=feats[k:k + 1]: f        # the splice takes the GATHERED tokens of sequence i
+                (_, _, _, _, embeds, _) = model.prepare_inputs_labels_for_multimodal(ids_all[i], None, None, None, None, [clips_all[i]], None,
+                                                                                     input_ids_host=ids_host[i])
+                rows.append(embeds[0])
+        finally:
+            model.encode_videos = orig
+        if not rows:
+            return None
+        seqs = [SequenceState() for _ in mine]
+        tok = ops.argmax(llama_forward(llama, model.kv, seqs, torch.cat(rows, 0), lens))
+        for q in seqs:
+            model.kv.release(q.pages)
+        return tok
+
+    def fence():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    fence()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    total = sum(nvis + t for t in text_lens)
+    return {"what": "8 clips, prompts of 128 .. 896 tokens: clips encoded by shard_range, sequences prefilled by cost-balanced placement -- the gathered "
+                    "visual tokens are what the prefilling rank splices (blocking all-gather: it is on the critical path here)",
+            "placement": place, "sequences_prefilled_away_from_their_encoder_on_rank0": foreign if rank == 0 else None,
+            "steps": steps, "ms_per_step": float(dt.item()) / steps * 1e3, "tokens_per_s": total * steps / float(dt.item())}
+
+
 def gather_report(dev, world, dist, frames, image_size, iters=10):
     """The exchange step alone (blocking, nothing to hide behind): RCCL's all-gather collective vs the direct full-mesh
     point-to-point exchange (vitron_amd.parallel.all_gather_direct_p2p), on the per-rank message of BASELINE configs[3]
@@ -1206,6 +1275,15 @@ def main():
         if args.c4_steps > 0 else None
     # the N = 1 denominator of c4's strong-scaling ratio, measured in THIS run on rank 0's GPU (all 8 clips through the one device, the
     # other ranks idle at the barrier below) instead of being read from a committed file of another box
+    if c4 is not None and use_dist and (8 % world) == 0:      # (also under VT_BENCH_FORCE_DIST on one GPU: the plumbing test walks this leg)
+        try:
+            c4["uneven_prompts"] = c4_uneven_report(model, llama, dev, world, rank, dist, args.frames, args.image_size, max(2, args.c4_steps // 2))
+        except Exception as e:  # noqa: BLE001  (never run on hardware here: an error is reported, the line survives)
+            c4["uneven_prompts"] = {"error": f"{type(e).__name__}: {e}"}
+            try:
+                dist.barrier()
+            except Exception:  # noqa: BLE001
+                pass
     c4_n1 = None
     if c4 is not None and world > 1 and "tokens_per_s" in c4:
         if rank == 0:

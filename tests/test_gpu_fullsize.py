@@ -302,7 +302,8 @@ def test_bench_distributed_path_on_one_gpu(dev):
     port = str(random.randint(20000, 40000))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", port, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1",
-           "--no-cpu-baseline", "--decode-steps", "0", "--c2-reps", "0", "--no-empirical-peaks", "--c4-steps", "1"]
+           "--no-cpu-baseline", "--decode-steps", "0", "--c2-reps", "0", "--no-empirical-peaks", "--c4-steps", "1", "--no-parity", "--no-live-traffic",
+           "--reps-224", "0", "--fp16-ab-steps", "0"]
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -317,6 +318,10 @@ def test_bench_distributed_path_on_one_gpu(dev):
     c4 = d["config"]["c4"]
     assert c4["global_clips"] == 8 and c4["clips_per_gpu"] == 8 and c4["scaling"] == "strong" and c4["tokens_per_s"] > 0
     assert c4["tokens_per_s"] > 0.5 * d["value"]              # eight clips packed are no slower per token than one
+    # the leg that CONSUMES the gathered tokens (uneven prompts, cost-balanced prefill placement; world 1: every sequence on this rank)
+    un = c4["uneven_prompts"]
+    assert "error" not in un, un
+    assert un["placement"] == [0] * 8 and un["tokens_per_s"] > 0.4 * d["value"], un
     ex = d["config"]["visual_token_exchange"]
     assert isinstance(ex["rccl_all_gather_ms"], float) and isinstance(ex["direct_p2p_ms"], float), ex
     assert d["config"]["ms_per_step_hipevent_median"] > 0

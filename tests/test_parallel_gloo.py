@@ -8,8 +8,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from vitron_amd.parallel import (all_gather_direct_p2p, all_gather_visual_tokens, encode_clips_parallel, shard_range,
-                                 start_all_gather_visual_tokens)
+from vitron_amd.parallel import (all_gather_direct_p2p, all_gather_visual_tokens, encode_clips_parallel, plan_prefill_placement,
+                                 sequences_of_rank, shard_range, start_all_gather_visual_tokens, visual_tokens_for_rank)
 
 
 def _free_port():
@@ -78,3 +78,58 @@ def test_shard_range_partitions():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
             sizes = [e - s for s, e in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _worker_placement(rank, world, port, q):
+    """Uneven prompts: clips are encoded where shard_range puts them, sequences are prefilled where plan_prefill_placement puts them; the
+    rank's "prefill" (a stub: a checksum of its sequences' visual tokens and lengths) must see exactly the tokens a single process would."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n_clips = 8
+        lens = [128, 896, 256, 768, 384, 640, 512, 512]                    # prompt tokens per sequence (mean 512)
+        clips = [torch.full((3, 2, 4, 4), float(i + 1)) for i in range(n_clips)]
+        ref = _stub_encode(torch.stack(clips))                              # what one process computes for all clips
+        gathered = encode_clips_parallel(_stub_encode, clips)               # every rank encoded only its shard
+        place = plan_prefill_placement([ref.shape[1] * ref.shape[2] + n for n in lens], world)
+        mine = sequences_of_rank(place, rank)
+        enc_s, enc_e = shard_range(n_clips, world, rank)
+        foreign = [i for i in mine if not enc_s <= i < enc_e]               # sequences whose clip another rank encoded: the gather's consumer
+        toks = visual_tokens_for_rank(gathered, place, rank)
+        ok = toks.shape[0] == len(mine) and all(torch.equal(toks[k], ref[i]) for k, i in enumerate(mine))
+        # every sequence is prefilled exactly once across the ranks, and the plan is the same on every rank
+        owners = [torch.zeros(n_clips, dtype=torch.int64) for _ in range(world)]
+        mine_t = torch.zeros(n_clips, dtype=torch.int64)
+        mine_t[mine] = 1
+        dist.all_gather(owners, mine_t)
+        ok = ok and bool((torch.stack(owners).sum(0) == 1).all())
+        q.put((rank, bool(ok), len(foreign)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_prefill_placement_consumes_the_gathered_tokens_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_placement, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert [(r, ok) for r, ok, _ in res] == [(0, True), (1, True)]
+    assert sum(f for _, _, f in res) > 0          # at least one sequence was prefilled away from where its clip was encoded
+
+
+def test_prefill_placement_balances_cost():
+    from vitron_amd.parallel import prefill_cost
+    lens = [4608 + n for n in (128, 896, 256, 768, 384, 640, 512, 512)]
+    for world in (1, 2, 4, 8):
+        place = plan_prefill_placement(lens, world)
+        assert sorted(set(place)) == list(range(world)) and len(place) == 8
+        load = [sum(prefill_cost(lens[i]) for i in sequences_of_rank(place, r)) for r in range(world)]
+        assert max(load) <= 1.10 * (sum(load) / world) + (prefill_cost(max(lens)) if world == 8 else 0.0) * 0.2
+    assert plan_prefill_placement([5, 5], 2) == [0, 1]

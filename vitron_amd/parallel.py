@@ -10,7 +10,7 @@ Works with any torch.distributed backend: the tests run it under gloo on CPU ten
 """
 from __future__ import annotations
 
-from typing import Callable, Sequence, Tuple
+from typing import Callable, List, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -112,3 +112,38 @@ def encode_clips_parallel(encode: Callable[[torch.Tensor], torch.Tensor], clips:
         probe = encode(torch.stack([clips[0]]))  # shape/dtype only (more ranks than clips)
         local = probe[:0]
     return all_gather_visual_tokens(local, len(clips), group)
+
+
+# ---- prefill placement != encode placement: the case that NEEDS the gather ---------------------------------------------
+# Clips are encoded where shard_range puts them (every clip costs the same: 8 frames through the tower), but prompts differ in length, and a
+# prefill costs its sequence's tokens (linear layers) plus their square (attention): the rank that prefills a sequence is chosen by that
+# cost, not by where its clip was encoded -- so a rank prefills sequences whose visual tokens arrived over the all-gather.
+def prefill_cost(tokens: int, hidden: int = 4096, layers_linear_flop_per_token: float = 12.95e9) -> float:
+    """Algorithmic prefill FLOP of one sequence: 12.95 GFLOP per token in the linear layers + 4 H S (S + 1) / 2 per layer x 32."""
+    return layers_linear_flop_per_token * tokens + 32 * 4.0 * hidden * tokens * (tokens + 1) / 2.0
+
+
+def plan_prefill_placement(seq_tokens: Sequence[int], world: int) -> List[int]:
+    """sequence index -> rank: longest-processing-time greedy on prefill_cost (ties to the lower rank; deterministic, every rank computes the
+    same plan from the same lengths). Balanced lengths reproduce shard_range's contiguous blocks only by accident -- callers must take their
+    sequences' visual tokens from the GATHERED tensor."""
+    order = sorted(range(len(seq_tokens)), key=lambda i: (-prefill_cost(seq_tokens[i]), i))
+    load = [0.0] * world
+    place = [0] * len(seq_tokens)
+    for i in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        place[i] = r
+        load[r] += prefill_cost(seq_tokens[i])
+    return place
+
+
+def sequences_of_rank(placement: Sequence[int], rank: int) -> List[int]:
+    return [i for i, r in enumerate(placement) if r == rank]
+
+
+def visual_tokens_for_rank(gathered: torch.Tensor, placement: Sequence[int], rank: int) -> torch.Tensor:
+    """gathered [n_items, ...] (clip order = sequence order) -> the visual tokens of the sequences `rank` prefills, in sequence order."""
+    idx = sequences_of_rank(placement, rank)
+    if not idx:
+        return gathered[:0]
+    return gathered[torch.tensor(idx, dtype=torch.long, device=gathered.device)]
