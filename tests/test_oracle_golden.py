@@ -277,3 +277,39 @@ def test_f1_branches_clip_tower_and_mlp3x_projector():
     assert synth.checksum(psd) == pytest.approx(float(g["proj3_checksum"]), rel=1e-12)
     xp = cases.features((cases.PROJ3_ROWS, cases.MM_HIDDEN), cases.SEED_FEATS + 5)
     assert rel(O.projector_forward(f32(psd), xp), g["proj3_out"]) <= 1e-5
+
+
+def test_mx4_quantiser_and_level3_emulation():
+    """The oracle's restatement of precise level 3 (mx4_quant / _lin_mx / llama_forward(precise_qk = 3)): the quantiser's known answers -- exponent
+    rule, ties to the even mantissa, nothing clipped, the code map -- and that the emulated mode lands closer to fp32 than the standard
+    emulation of the same storage format (the 4-bit image carries most of what the 16-bit store drops)."""
+    x = torch.tensor([[0.25, 0.75, 1.25, 1.75, 2.5, 3.5, 5.0, -5.0, 6.0, 0.24, 0.26, -0.0] + [0.0] * 20])
+    deq, q, e = O.mx4_quant(x, 32)
+    assert int(e) == 0 and q[0, :12].tolist() == [0.0, 1.0, 1.0, 2.0, 2.0, 4.0, 4.0, -4.0, 6.0, 0.0, 0.5, -0.0]
+    assert O.mx4_codes(q)[0, :12].tolist() == [0, 2, 2, 4, 4, 6, 6, 14, 7, 0, 1, 8]
+    for amax, want in ((6.0, 0), (6.0001, 1), (3.0001, 0), (3.0, -1), (1.5, -2), (0.02, -8), (0.0, -126), (1e38, 124)):
+        assert int(O.mx4_exponent(torch.tensor(amax))) == want, (amax, want)
+    g = torch.Generator().manual_seed(3)
+    v = torch.randn((64, 256), generator=g) * torch.rand((64, 1), generator=g) * 4
+    for blk in (32, None):
+        d, qq, ee = O.mx4_quant(v, blk)
+        assert float((qq.abs().amax())) <= 6.0 and float((d - v).norm() / v.norm()) < 0.16          # e2m1 against a power-of-two scale: ~11-13 %
+        sc = torch.ldexp(torch.ones_like(ee, dtype=torch.float32), ee)
+        assert bool(((v.reshape(64, -1, 32 if blk else 256).abs().amax(-1) / sc) <= 6.0).all())     # nothing clips
+    # a Linear of level 3 against the exact product: the remainder's image removes most of the 16-bit store's error
+    w = (torch.randn((96, 256), generator=g) * 0.05).to(torch.bfloat16).float()
+    exact = v.double() @ w.double().t()
+    for emu in ("fp16", True):
+        plain = (O._r(v, emu).double() @ w.double().t())
+        mx = O._lin_mx(v, w, emu).double()
+        assert float((mx - exact).norm()) < 0.3 * float((plain - exact).norm())
+    # two decoder layers at a width the mode accepts (hidden % 512 == 0): level 3's emulation is closer to fp32 than the standard emulation
+    cfg = dict(cases.LLM, hidden_size=512, intermediate_size=1408, num_attention_heads=4, num_hidden_layers=2, vocab_size=320)
+    sd = synth.llama_state(cfg, synth.make_generator(77), w_std=0.02)
+    sd = {k: t.float() for k, t in sd.items()}
+    emb = torch.randn((1, 96, 512), generator=g) * 0.5
+    ref = O.llama_forward(sd, cfg, emb)[0]
+    std = O.llama_forward(sd, cfg, emb, emulate_bf16="fp16")[0]
+    l3 = O.llama_forward(sd, cfg, emb, emulate_bf16="fp16", precise_qk=3)[0]
+    d_std, d_l3 = float((std - ref).norm() / ref.norm()), float((l3 - ref).norm() / ref.norm())
+    assert d_l3 < 0.8 * d_std, (d_l3, d_std)
