@@ -32,7 +32,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import ops
-from .engine import PagedKVCache, SequenceState, llama_forward
+from .engine import PagedKVCache, SequenceState, llama_forward, pair_lo
 
 
 @dataclass
@@ -48,6 +48,7 @@ class _Request:
     last: Optional[torch.Tensor] = None      # device int32 [1]: the token to feed next
     done: bool = False
     flat: Optional[torch.Tensor] = None      # spliced prompt rows [rows, H] (kept while the request waits for pages)
+    flat_lo: Optional[torch.Tensor] = None   # their low halves in the precise levels 2 / 3 (the embeddings travel as an operand pair)
     need: int = 0                            # KV pages for prompt + max_new_tokens
     error: Optional[BaseException] = None    # set when the request failed on its own (it is in ServingEngine.failed then)
 
@@ -126,6 +127,8 @@ class ServingEngine:
         if embeds is None:
             return m.get_model().embed_tokens(r.input_ids)[0]
         mask = torch.tensor(m._last_splice[0][0], dtype=torch.bool, device=embeds.device)
+        lo = pair_lo(embeds)                  # precise levels 2 / 3: the spliced embeddings are an operand pair -- the low half travels explicitly
+        r.flat_lo = None if lo is None else lo[0][mask]          # (a tensor attribute would not survive the indexing below: ADVICE r5)
         return embeds[0][mask]
 
     def _admit(self, reqs: List[_Request]) -> List[_Request]:
@@ -195,7 +198,7 @@ class ServingEngine:
 
         def prefill_one(r):
             try:
-                r.last = self._pick(llama_forward(llama, m.kv, [r.seq], r.flat, [r.flat.shape[0]]))
+                r.last = self._pick(llama_forward(llama, m.kv, [r.seq], r.flat, [r.flat.shape[0]], embeds_lo=getattr(r, "flat_lo", None)))
                 ok.append(r)
             except Exception as e:  # noqa: BLE001
                 if self._is_device_error(e):
@@ -206,7 +209,11 @@ class ServingEngine:
             if self.batch_prefill and len(admitted) > 1:
                 try:
                     flats = [r.flat for r in admitted]
-                    logits = llama_forward(llama, m.kv, [r.seq for r in admitted], torch.cat(flats, 0), [f.shape[0] for f in flats])
+                    los = [getattr(r, "flat_lo", None) for r in admitted]
+                    lo_cat = None
+                    if any(l is not None for l in los):      # (requests without visual rows have an exact 16-bit embedding: low half zero)
+                        lo_cat = torch.cat([l if l is not None else torch.zeros_like(f) for l, f in zip(los, flats)], 0)
+                    logits = llama_forward(llama, m.kv, [r.seq for r in admitted], torch.cat(flats, 0), [f.shape[0] for f in flats], embeds_lo=lo_cat)
                     nxt = self._pick(logits)
                     for i, r in enumerate(admitted):
                         r.last = nxt[i:i + 1]
@@ -230,7 +237,7 @@ class ServingEngine:
                     self.waiting.appendleft(r)
             raise
         for r in ok:
-            r.flat = None                                   # the rows are in the cache now
+            r.flat = r.flat_lo = None                       # the rows are in the cache now
         self.active += ok
         return rest
 
