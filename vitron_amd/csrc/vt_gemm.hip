@@ -48,8 +48,8 @@ struct GemmP {
 };
 
 __device__ __forceinline__ float gelu_erf(float x) { return vt_gelu_erf(x); }
-__device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
-__device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float quick_gelu(float x) { return vt_quick_gelu(x); }
+__device__ __forceinline__ float silu(float x) { return vt_silu(x); }
 
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst_wave_uniform) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,

@@ -214,11 +214,11 @@ __global__ void act_pair_kernel(const float* __restrict__ in, int ldin, bf16_t* 
     const f32x4 g = *(const f32x4*)(in + r * ldin + col);
     const f32x4 u = *(const f32x4*)(in + r * ldin + col + 16);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) a[k] = g[k] / (1.0f + __expf(-g[k])) * u[k];
+    for (int k = 0; k < 4; ++k) a[k] = vt_silu(g[k]) * u[k];
   } else {
     const f32x4 v = *(const f32x4*)(in + r * ldin + c);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) a[k] = (MODE == 0) ? vt_gelu_erf(v[k]) : v[k] / (1.0f + __expf(-1.702f * v[k]));
+    for (int k = 0; k < 4; ++k) a[k] = (MODE == 0) ? vt_gelu_erf(v[k]) : vt_quick_gelu(v[k]);
   }
   store_pair4(hi + r * Nout + c, lo + r * Nout + c, a[0], a[1], a[2], a[3]);
 }
