@@ -176,8 +176,10 @@ def vit_forward(sd: SD, cfg: dict, pixels: torch.Tensor, num_layers: Optional[in
     pixels: [B,3,H,W] (image) or [B,3,T,H,W] (video). Returns the hidden state after `num_layers` encoder
     layers as [B*T, N, D] fp32 (hidden_states[num_layers] in HF numbering; select_layer=-2 <=> L-1 layers).
     precise = 2 (with an emulation mode): the storage points of the kernels' precise level 2 (vt_vit_model.precise) -- every GEMM A operand
-    an operand pair instead of one 16-bit value."""
+    an operand pair instead of one 16-bit value. precise = 1: the tower's level 1 at ViT-L width -- the spatial MLP's two products as _lin_mx
+    (16-bit operand + MX-FP4 image of its rounding remainder), the attention paths (and the image tower's temporal MLP) as in the standard mode."""
     pairs = bool(emulate_bf16) and int(precise) >= 2
+    mlp_mx = bool(emulate_bf16) and int(precise) == 1         # tower level 1 (the towers' share of the model's precise level 3)
     _st = (lambda t: _pair(t, emulate_bf16)) if pairs else (lambda t: _r(t, emulate_bf16))
     D, heads, P = cfg["hidden_size"], cfg["num_attention_heads"], cfg["patch_size"]
     L = cfg["num_hidden_layers"] if num_layers is None else num_layers
@@ -225,7 +227,13 @@ def vit_forward(sd: SD, cfg: dict, pixels: torch.Tensor, num_layers: Optional[in
         h = clip_attention(h, sd, p + "self_attn.", heads, emulate_bf16, precise=precise)
         x = res + _lin(h, sd[p + "self_attn.out_proj.weight"], sd[p + "self_attn.out_proj.bias"])
         res = x  # MLP :148-151 (CLIPMLP: fc2(act(fc1(x))))
-        h = _st(F.layer_norm(x, (D,), sd[p + "layer_norm2.weight"].float(), sd[p + "layer_norm2.bias"].float(), eps))
+        hn = F.layer_norm(x, (D,), sd[p + "layer_norm2.weight"].float(), sd[p + "layer_norm2.bias"].float(), eps)
+        if mlp_mx:      # tower level 1 on the MX pipe: both MLP products add the MX-FP4 product of their A operand's rounding remainder
+            h = _lin_mx(hn, sd[p + "mlp.fc1.weight"], emulate_bf16) + sd[p + "mlp.fc1.bias"].float()
+            h = F.gelu(h) if act == "gelu" else quick_gelu(h)
+            x = res + _lin_mx(h, sd[p + "mlp.fc2.weight"], emulate_bf16) + sd[p + "mlp.fc2.bias"].float()
+            continue
+        h = _st(hn)
         h = _lin(h, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"])
         h = F.gelu(h) if act == "gelu" else quick_gelu(h)
         h = _st(h)

@@ -228,6 +228,40 @@ def test_towers_precise_level_2_vs_reference(dev, name, op):
     assert torch.equal(h_again.float().cpu().reshape(-1, 1024), h_std)         # back to the standard kernels, bit for bit
 
 
+@pytest.mark.parametrize("op", OPERANDS)
+@pytest.mark.parametrize("name", ["video336", "image224"])
+def test_towers_precise_level_1_on_the_mx_pipe(dev, name, op):
+    """vt_vit_model.precise = 1 at ViT-L width (round 6: the towers' share of the model's precise level 3): the spatial MLP's two products run as
+    ONE launch each that adds the MX-FP4 product of the A operand's rounding remainder (LayerNorm and the GELU epilogue write the remainder's image),
+    the attention paths stay standard, the features leave as a pair. Against the oracle's emulation of exactly these storage points, against
+    fp32 and against the REFERENCE's stored rows: most of the standard mode's distance is gone (what is left is the attention paths')."""
+    from vitron_amd.engine import PackedVit, pair_lo
+    odt, emu, _ = FW.operand(op)
+    g = FW.golden_of(name)
+    cfg, sd, x = FW.vit_case(name)
+    nl = cases.FW_VIT_LAYERS
+    vit = PackedVit(sd, cfg, dev, select_layer=nl, dtype=odt)
+    _, h_std = vit.forward(x.to(dev).to(odt), return_hidden=True)
+    vit.set_precise(3)                                   # the MODEL's level: 3 -> tower level 1
+    assert vit.model.precise == 1 and vit.layers[0].w14 and vit.layers[0].w24
+    feats, hidden = vit.forward(x.to(dev).to(odt), return_hidden=True)
+    lo = pair_lo(feats)
+    assert lo is not None and lo.shape == feats.shape
+    hidden, h_std = hidden.float().cpu().reshape(-1, 1024), h_std.float().cpu().reshape(-1, 1024)
+    with torch.no_grad():
+        h32 = O.vit_forward(f32(sd), cfg, x, num_layers=nl).reshape(-1, 1024)
+        hem = O.vit_forward(f32(sd), cfg, x, num_layers=nl, emulate_bf16=emu, precise=1).reshape(-1, 1024)
+    d_f32, std_f32, d_emu, emu_f32 = FW.rel(hidden, h32), FW.rel(h_std, h32), FW.rel(hidden, hem), FW.rel(hem, h32)
+    ref_proj, ref_rows = FW.vs_pin(hidden, g, f"vit_{name}_hidden_{nl}")
+    _note(f"vit_{name}_layers{nl}_{op}-precise1", rows=hidden.shape[0], vs_fp32=d_f32, standard_mode_vs_fp32=std_f32, vs_emulation=d_emu,
+          emulation_vs_fp32=emu_f32, vs_reference_rows=ref_rows, vs_reference_proj=ref_proj)
+    assert d_f32 <= 0.6 * std_f32, (d_f32, std_f32)
+    assert d_f32 <= 1.25 * emu_f32 + 1e-4 and ref_rows <= 1.25 * emu_f32 + 1e-4, (d_f32, ref_rows, emu_f32)
+    vit.set_precise(0)
+    _, h_again = vit.forward(x.to(dev).to(odt), return_hidden=True)
+    assert torch.equal(h_again.float().cpu().reshape(-1, 1024), h_std)
+
+
 @pytest.mark.parametrize("which", ["336", "224"])
 @pytest.mark.parametrize("op", OPERANDS)
 def test_projector_and_region_at_full_width_vs_oracle_and_reference(dev, op, which):
