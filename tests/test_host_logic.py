@@ -753,6 +753,36 @@ def test_hand_placed_attention_kernel_compiles_without_scratch():
         assert all(v <= 256 for v in vgprs) and all(a <= 256 for a in agprs), (vgprs, agprs)
 
 
+def test_counted_dma_waits_have_no_scratch_access_in_their_window():
+    """Every kernel that waits for its LDS-DMA pieces by count (s_waitcnt vmcnt(N)) must have no scratch access between its first DMA
+    and its last MFMA: a spill counts in vmcnt and may retire out of order with the loads, so the counted wait could let a piece through
+    early (round 6 found one in the prologue of gemm_w4x_kernel<16-bit store> of the bf16 build). tools/check_scratch_window.py over the
+    device assembly of the four-wave GEMM file and the hand-placed attention file, both operand builds (cross-compiled, no GPU)."""
+    import importlib.util
+    import shutil
+    import subprocess
+    import tempfile
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    spec = importlib.util.spec_from_file_location("check_scratch_window", os.path.join(ROOT, "tools", "check_scratch_window.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    with tempfile.TemporaryDirectory() as tmp:
+        jobs = []
+        for name, flags in (("vt_gemm8", []), ("vt_attn_w4", ["-fno-slp-vectorize"])):
+            for tag, extra in (("bf16", []), ("f16", ["-DVT_OPERAND_F16=1"])):
+                out = os.path.join(tmp, f"{name}_{tag}.s")
+                cmd = [hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", *flags, *extra, "-S", "--cuda-device-only",
+                       os.path.join(ROOT, "vitron_amd", "csrc", name + ".hip"), "-o", out]
+                jobs.append((out, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=tmp)))
+        for out, proc in jobs:
+            _, err = proc.communicate()
+            assert proc.returncode == 0, err[-2000:]
+            n, bad = chk.check(out)
+            assert n >= 7 and not bad, (os.path.basename(out), n, [b[0] for b in bad])
+
+
 def test_hand_placed_attention_schedule_is_what_the_generator_emits():
     """vt_attn_w4_si0.inc / si1.inc are generated (tools/gen_attn_w4.py): the committed files must be the generator's output, every
     sub-iteration must carry its 32 MFMAs (16 score + 16 P.V), 8 + 8 fragment reads, and SI0 the 8 LDS-DMA pieces of the tile."""

@@ -976,10 +976,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
       for (int ni = 0; ni < 8; ++ni) t += acc[mi][ni][0] + acc[mi][ni][3];
     if (t == 1.2345e-30f) *(float*)p.C = t;
-  } else if constexpr (bf16_store && !(ABL & 64)) {
-    w4_epilogue_lds<EPI, MT>(p, acc, bm0, bn0, wr, wc, lane, smem, wave);      // (launch_w4 checked alignment and N % 8)
   } else {
-    w4_epilogue<EPI, MT>(p, acc, bm0, bn0, wr, wc, lane, split);
+    // The epilogue takes the lane id through an opaque copy: what it derives from it (row / column offsets, masks) is computed HERE and not hoisted in
+    // front of the main loop, where -- 256 + 256 registers being taken -- it was spilled: round 6 found a scratch store between the prologue's
+    // DMA pieces and their counted vmcnt wait in <16-bit store, 256-row tile> of the bf16 build (C3-224's qkv). A scratch access counts in
+    // vmcnt and may retire out of order with the loads, so the counted wait could let a piece through early. tests/test_host_logic.py now
+    // checks the generated code of every instantiation for scratch accesses between the first DMA and the last MFMA.
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    if constexpr (bf16_store && !(ABL & 64)) {
+      w4_epilogue_lds<EPI, MT>(p, acc, bm0, bn0, wr, wc, lane_e, smem, wave);    // (launch_w4 checked alignment and N % 8)
+    } else {
+      w4_epilogue<EPI, MT>(p, acc, bm0, bn0, wr, wc, lane_e, split);
+    }
   }
 }
 
