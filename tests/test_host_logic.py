@@ -757,7 +757,8 @@ def test_counted_dma_waits_have_no_scratch_access_in_their_window():
     """Every kernel that waits for its LDS-DMA pieces by count (s_waitcnt vmcnt(N)) must have no scratch access between its first DMA
     and its last MFMA: a spill counts in vmcnt and may retire out of order with the loads, so the counted wait could let a piece through
     early (round 6 found one in the prologue of gemm_w4x_kernel<16-bit store> of the bf16 build). tools/check_scratch_window.py over the
-    device assembly of the four-wave GEMM file and the hand-placed attention file, both operand builds (cross-compiled, no GPU)."""
+    device assembly of every source file that holds LDS-DMA kernels (four-wave / ping-pong / ring GEMMs, the weight-streaming GEMM, both
+    attention files), both operand builds (cross-compiled, no GPU)."""
     import importlib.util
     import shutil
     import subprocess
@@ -770,7 +771,7 @@ def test_counted_dma_waits_have_no_scratch_access_in_their_window():
     spec.loader.exec_module(chk)
     with tempfile.TemporaryDirectory() as tmp:
         jobs = []
-        for name, flags in (("vt_gemm8", []), ("vt_attn_w4", ["-fno-slp-vectorize"])):
+        for name, flags in (("vt_gemm8", []), ("vt_attn_w4", ["-fno-slp-vectorize"]), ("vt_gemm", []), ("vt_attn", [])):
             for tag, extra in (("bf16", []), ("f16", ["-DVT_OPERAND_F16=1"])):
                 out = os.path.join(tmp, f"{name}_{tag}.s")
                 cmd = [hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", *flags, *extra, "-S", "--cuda-device-only",
