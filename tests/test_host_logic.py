@@ -753,7 +753,7 @@ def test_hand_placed_attention_kernel_compiles_without_scratch():
         assert all(v <= 256 for v in vgprs) and all(a <= 256 for a in agprs), (vgprs, agprs)
 
 
-def test_counted_dma_waits_have_no_scratch_access_in_their_window():
+def test_counted_dma_waits_have_no_scratch_access_in_their_window_and_mfma_tails_are_fenced():
     """Every kernel that waits for its LDS-DMA pieces by count (s_waitcnt vmcnt(N)) must have no scratch access between its first DMA
     and its last MFMA: a spill counts in vmcnt and may retire out of order with the loads, so the counted wait could let a piece through
     early (round 6 found one in the prologue of gemm_w4x_kernel<16-bit store> of the bf16 build). tools/check_scratch_window.py over the
@@ -782,6 +782,12 @@ def test_counted_dma_waits_have_no_scratch_access_in_their_window():
             assert proc.returncode == 0, err[-2000:]
             n, bad = chk.check(out)
             assert n >= 7 and not bad, (os.path.basename(out), n, [b[0] for b in bad])
+            # ... and no read of the last MFMAs' destinations between the last (asm) MFMA and the wait states that cover its latency: the copies
+            # the compiler places on a loop's exit edge once took the very last destination four instructions behind its MFMA (round 6)
+            n2, bad2 = chk.check_mfma_tail(out)
+            assert not bad2, (os.path.basename(out), n2, bad2[:4])
+            if "vt_gemm8" in out or "vt_attn_w4" in out:
+                assert n2 >= 7, (os.path.basename(out), n2)
 
 
 def test_hand_placed_attention_schedule_is_what_the_generator_emits():

@@ -1,4 +1,6 @@
-"""No scratch access between the first LDS-DMA and the last MFMA of any kernel that waits for its DMA pieces by COUNT (s_waitcnt vmcnt(N)).
+"""Two checks of the generated device code. (1) No scratch access between the first LDS-DMA and the last MFMA of any kernel that waits for its
+DMA pieces by COUNT (s_waitcnt vmcnt(N)). (2) check_mfma_tail: no read of the last asm MFMAs' destinations in front of the wait states that
+cover their latency.
 
     python tools/check_scratch_window.py file.s [file.s ...]        (device assembly: hipcc -S --cuda-device-only, or the build's saved temps)
 
@@ -8,6 +10,70 @@ store in the prologue of gemm_w4_kernel<16-bit store, 256-row tile> of the bf16 
 tests/test_host_logic.py runs this over the saved assembly of both product builds."""
 import re
 import sys
+
+
+def _regs(tok):
+    """'a[252:255]' / 'v[94:97]' / 'a3' -> (file, set of indices)"""
+    m = re.match(r"([av])\[(\d+):(\d+)\]$", tok)
+    if m:
+        return m.group(1), set(range(int(m.group(2)), int(m.group(3)) + 1))
+    m = re.match(r"([av])(\d+)$", tok)
+    if m:
+        return m.group(1), {int(m.group(2))}
+    return None, set()
+
+
+def check_mfma_tail(path, last_n=4):
+    """Second check (round 6): the destinations of the last `last_n` MFMAs of a kernel whose MFMAs are asm statements may not be read between
+    the last MFMA and the `s_nop 15` that covers their latency (the compiler does not know it; a bare asm volatile orders nothing against a
+    register copy). Returns (kernels checked, [(name, line, text)])."""
+    s = open(path).read()
+    bad, n = [], 0
+    for m in re.finditer(r"^(_Z\w+):", s, flags=re.M):
+        i = m.start()
+        j = s.find(".Lfunc_end", i)
+        if j < 0:
+            continue
+        lines = s[i:j].split("\n")
+        mf = [a for a, l in enumerate(lines) if "v_mfma" in l and a > 0 and "ASMSTART" in lines[a - 1]]
+        if not mf:
+            continue
+        # the straight-line path behind the last MFMA: fall through conditional branches (the loop's back edge), follow `s_branch`
+        labels = {l.split(":")[0]: a for a, l in enumerate(lines) if re.match(r"\.LBB\w+:", l)}
+        path, a, steps = [], mf[-1] + 1, 0
+        while a < len(lines) and steps < 4000:
+            steps += 1
+            l = lines[a].strip()
+            if "s_nop 15" in l:
+                break
+            mb = re.match(r"s_branch\s+(\.LBB\w+)", l)
+            if mb and mb.group(1) in labels:
+                a = labels[mb.group(1)]
+                continue
+            path.append(a)
+            a += 1
+        else:
+            continue
+        if a >= len(lines):
+            continue
+        n += 1
+        hot = {"a": set(), "v": set()}
+        for k in mf[-last_n:]:
+            dst = lines[k].split()[1].rstrip(",")
+            f, r = _regs(dst)
+            if f:
+                hot[f] |= r
+        for a in path:
+            l = lines[a].strip()
+            if not l or l.startswith((";", ".", "s_")):
+                continue
+            ops = [t.strip().rstrip(",") for t in l.split(None, 1)[1].split(",")] if " " in l else []
+            for t in ops[1:]:                                  # source operands
+                f, r = _regs(t)
+                if f and (hot[f] & r):
+                    bad.append((m.group(1), a, l))
+                    break
+    return n, bad
 
 
 def check(path):
@@ -37,5 +103,10 @@ if __name__ == "__main__":
         print(f"{f}: {n} kernels with LDS-DMA + MFMA checked, {len(bad)} with scratch accesses inside the window")
         for name, hit in bad:
             print("   ", name, hit[:8])
+            rc = 1
+        n2, bad2 = check_mfma_tail(f)
+        print(f"{f}: {n2} kernels with asm MFMAs + a tail fence checked, {len(bad2)} reads of the last MFMAs' destinations in front of the fence")
+        for name, line, text in bad2[:16]:
+            print("   ", name, line, text)
             rc = 1
     sys.exit(rc)

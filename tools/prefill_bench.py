@@ -20,7 +20,10 @@ def main():
     reps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
     op = sys.argv[4] if len(sys.argv) > 4 else "bf16"
     precise = {"precise": 1, "precise_qk": 1, "precise2": 2, "precise3": 3}.get(sys.argv[5], 0) if len(sys.argv) > 5 else 0
-    _lib.load(operand=op)
+    if os.environ.get("VT_PREFILL_BENCH_ABL") == "1":      # the -DVT_ABLATIONS test library (bf16 only): step-level A/B of its exploration switches
+        _lib.load(ablations=True)
+    else:
+        _lib.load(operand=op)
     odt = _lib.torch_dtype(op)
     dev = torch.device("cuda:0")
     clip = kind == "clip"

@@ -818,6 +818,14 @@ __device__ __forceinline__ void w4_epilogue(const GemmP8& p, f32x4 (&acc)[MT][NI
 // ABL (timing ablations, wrong results; test library only): 1 = no LDS-DMA in the loop, 2 = no barriers, 4 = no fragment reads, 8 = no
 // counted waits, 16 = unswizzled DMA sources. AUX_A / AUX_B = cache-policy bits of the DMA instructions (1 sc0, 2 nt, 16 sc1): measured,
 // sc0 / sc1 make no difference and nt costs 20 %, so they stay 0.
+// The wait states between the LAST MFMAs of a main loop (asm statements: the compiler does not know their latency) and the first read of
+// their results. They sit INSIDE the loop, on its last trip only: a statement behind the loop orders nothing against the register copies
+// the compiler places on the loop's exit edge (the accumulators have a second definition on the zero-trip path, and reconciling the two
+// assignments reads them right behind the loop branch). Round 6: with another register assignment those copies took a[252:255] -- the
+// destination of the very last MFMA -- four instructions after its issue, and the SwiGLU epilogue of the 256-row tile stored stale values
+// (tests/test_gpu_fp16.py::test_fp16_gemm_tile_kernels[300-384-256-13]); the bare asm volatile("s_nop ..") behind the loop had only
+// ever worked because the copies happened to start with older accumulators. tools/check_scratch_window.py checks the generated code.
+#define VT_MFMA_TAIL_WAIT(LAST_TRIP) do { if (LAST_TRIP) asm volatile("s_nop 15\n\ts_nop 7"); } while (0)
 __host__ __device__ __forceinline__ constexpr int w4_vmcnt_imm(int n) { return (n & 15) | ((n >> 4) << 14) | (7 << 4) | (15 << 8); }   // s_waitcnt vmcnt(n) only
 
 template <int EPI, int MT = 8, int ABL = 0, int AUX_A = 0, int AUX_B = 0>
@@ -840,7 +848,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int sid = xcd_remap((int)blockIdx.x - split * nwg, nwg);
   const int ku = p.K >> 7;   // K in units of 128 (two K steps), balanced over the splits
   const int u_begin = (int)((long)ku * split / ksplit), u_end = (int)((long)ku * (split + 1) / ksplit);
-  constexpr int GROUP_M = 8;
+  // tile groups of 4 rows x all columns once there are 8 or more row blocks (round 6, bit-identical outputs: gate/up 5120 x 22016 x 4096
+  // 657 -> 640 us over three interleaved runs, the C3 step -0.45 ms; groups of 2 / 3 the same, 1 and 16 / 20 slower; with 3-5 row blocks --
+  // the single-image shapes -- a group of 4 leaves a ragged last group and measured +0.4 %): an XCD's 32 concurrent tiles are then
+  // 4 row blocks x 8 column tiles instead of 8 x 4
+  const int GROUP_M = tiles_m >= 8 ? 4 : 8;
   const int per_group = GROUP_M * tiles_n;
   const int first_m = (sid / per_group) * GROUP_M;
   const int gsz = min(tiles_m - first_m, GROUP_M);
@@ -953,6 +965,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   for (int t = 0; t < nt; t += 2) {
     W4S_KSTEP(0, t);
     W4S_KSTEP(1, t + 1);
+    VT_MFMA_TAIL_WAIT(t + 2 >= nt);
   }
   VT_VMCNT(0);                                     // the tail's redundant pieces
   asm volatile("s_nop 15\n\ts_nop 7");            // last MFMA result -> the epilogue's v_accvgpr_read (the compiler cannot see the hazard)
@@ -1128,6 +1141,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     W4R_KSTEP(1, t + 1);
     W4R_KSTEP(2, t + 2);
     W4R_KSTEP(3, t + 3);
+    VT_MFMA_TAIL_WAIT(t + 4 >= nt);
   }
   VT_VMCNT(0);                                     // the tail's redundant pieces
   asm volatile("s_nop 15\n\ts_nop 7");            // last MFMA result -> the epilogue's v_accvgpr_read
