@@ -818,6 +818,21 @@ __device__ __forceinline__ void w4_epilogue(const GemmP8& p, f32x4 (&acc)[MT][NI
 // ABL (timing ablations, wrong results; test library only): 1 = no LDS-DMA in the loop, 2 = no barriers, 4 = no fragment reads, 8 = no
 // counted waits, 16 = unswizzled DMA sources. AUX_A / AUX_B = cache-policy bits of the DMA instructions (1 sc0, 2 nt, 16 sc1): measured,
 // sc0 / sc1 make no difference and nt costs 20 %, so they stay 0.
+#ifdef VT_ABLATIONS   // exploration knobs of the tile -> workgroup mapping (test library; VT_W4_GROUP_M / VT_W4R_GROUP_M / VT_W4_NOREMAP, read at the first launch)
+__device__ int g_w4_knobs[4];
+static void w4_knobs_once() {
+  static bool done = false;
+  if (done) return;
+  done = true;
+  int h[4] = {getenv("VT_W4_GROUP_M") ? atoi(getenv("VT_W4_GROUP_M")) : 0, getenv("VT_W4R_GROUP_M") ? atoi(getenv("VT_W4R_GROUP_M")) : 0,
+              getenv("VT_W4_NOREMAP") ? atoi(getenv("VT_W4_NOREMAP")) : 0, 0};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_w4_knobs), h, sizeof(h));
+}
+#define W4_KNOB(i, dflt) (g_w4_knobs[i] > 0 ? g_w4_knobs[i] : (dflt))
+#else
+#define W4_KNOB(i, dflt) (dflt)
+static inline void w4_knobs_once() {}
+#endif
 // The wait states between the LAST MFMAs of a main loop (asm statements: the compiler does not know their latency) and the first read of
 // their results. They sit INSIDE the loop, on its last trip only: a statement behind the loop orders nothing against the register copies
 // the compiler places on the loop's exit edge (the accumulators have a second definition on the zero-trip path, and reconciling the two
@@ -845,14 +860,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // two-pass split-K (EPI == F32 only, as in the ping-pong kernel): split s of every tile writes its partial product to slab s
   const int ksplit = (EPI == VT_EPI_F32) ? p.ksplit : 1;
   const int split = (ksplit > 1) ? (int)blockIdx.x / nwg : 0;
-  const int sid = xcd_remap((int)blockIdx.x - split * nwg, nwg);
+  const int sid = W4_KNOB(2, 0) == 1 ? (int)blockIdx.x - split * nwg : xcd_remap((int)blockIdx.x - split * nwg, nwg);
   const int ku = p.K >> 7;   // K in units of 128 (two K steps), balanced over the splits
   const int u_begin = (int)((long)ku * split / ksplit), u_end = (int)((long)ku * (split + 1) / ksplit);
   // tile groups of 4 rows x all columns once there are 8 or more row blocks (round 6, bit-identical outputs: gate/up 5120 x 22016 x 4096
   // 657 -> 640 us over three interleaved runs, the C3 step -0.45 ms; groups of 2 / 3 the same, 1 and 16 / 20 slower; with 3-5 row blocks --
   // the single-image shapes -- a group of 4 leaves a ragged last group and measured +0.4 %): an XCD's 32 concurrent tiles are then
   // 4 row blocks x 8 column tiles instead of 8 x 4
-  const int GROUP_M = tiles_m >= 8 ? 4 : 8;
+  const int GROUP_M = W4_KNOB(0, tiles_m >= 8 ? 4 : 8);
   const int per_group = GROUP_M * tiles_n;
   const int first_m = (sid / per_group) * GROUP_M;
   const int gsz = min(tiles_m - first_m, GROUP_M);
@@ -1017,6 +1032,7 @@ int launch_w4(const GemmP8& p, hipStream_t s) {
     if ((nout & 7) != 0 || (p.ldc & 7) != 0 || (((size_t)p.C) & 15) != 0) return launch_w4<EPI, MT, ABL | 64, AUX_A, AUX_B>(p, s);
   }
   auto kern = gemm_w4_kernel<EPI, MT, ABL, AUX_A, AUX_B>;
+  w4_knobs_once();
   VT_LDS_ATTR_ONCE(kern, smem);
   hipLaunchKernelGGL(kern, dim3(cdiv(p.M, BM) * cdiv(p.N, 256) * (EPI == VT_EPI_F32 ? std::max(p.ksplit, 1) : 1)), dim3(256), smem, s, p);
   VT_LAUNCH_CHECK();
@@ -1054,7 +1070,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
   const int nwg = tiles_m * tiles_n;
   const int sid = xcd_remap((int)blockIdx.x, nwg);
-  constexpr int GROUP_M = 8;
+  const int GROUP_M = W4_KNOB(1, 8);
   const int per_group = GROUP_M * tiles_n;
   const int first_m = (sid / per_group) * GROUP_M;
   const int gsz = min(tiles_m - first_m, GROUP_M);
@@ -1160,6 +1176,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 template <int EPI>
 int launch_w4r(const GemmP8& p, hipStream_t s) {
   constexpr int smem = 4 * (160 + 128) * 128;      // 144 KiB
+  w4_knobs_once();
   auto kern = gemm_w4r_kernel<EPI>;
   VT_LDS_ATTR_ONCE(kern, smem);
   hipLaunchKernelGGL(kern, dim3(cdiv(p.M, 160) * cdiv(p.N, 128)), dim3(256), smem, s, p);
