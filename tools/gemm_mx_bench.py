@@ -6,7 +6,9 @@ import json
 import sys
 import torch
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
-from vitron_amd import ops  # noqa: E402
+from vitron_amd import _lib, ops  # noqa: E402
+if __import__("os").environ.get("VT_GEMM_MX_BENCH_ABL") == "1":     # the test library (bf16), for its exploration knobs
+    _lib.load(ablations=True)
 
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 5120
 dt = {"fp16": torch.float16, "bf16": torch.bfloat16}[sys.argv[2] if len(sys.argv) > 2 else "fp16"]

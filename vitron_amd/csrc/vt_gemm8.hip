@@ -818,14 +818,14 @@ __device__ __forceinline__ void w4_epilogue(const GemmP8& p, f32x4 (&acc)[MT][NI
 // ABL (timing ablations, wrong results; test library only): 1 = no LDS-DMA in the loop, 2 = no barriers, 4 = no fragment reads, 8 = no
 // counted waits, 16 = unswizzled DMA sources. AUX_A / AUX_B = cache-policy bits of the DMA instructions (1 sc0, 2 nt, 16 sc1): measured,
 // sc0 / sc1 make no difference and nt costs 20 %, so they stay 0.
-#ifdef VT_ABLATIONS   // exploration knobs of the tile -> workgroup mapping (test library; VT_W4_GROUP_M / VT_W4R_GROUP_M / VT_W4_NOREMAP, read at the first launch)
+#ifdef VT_ABLATIONS   // exploration knobs of the tile -> workgroup mapping (test library; VT_W4_GROUP_M / VT_W4R_GROUP_M / VT_W4X_GROUP_M / VT_W4_NOREMAP, read at the first launch)
 __device__ int g_w4_knobs[4];
 static void w4_knobs_once() {
   static bool done = false;
   if (done) return;
   done = true;
   int h[4] = {getenv("VT_W4_GROUP_M") ? atoi(getenv("VT_W4_GROUP_M")) : 0, getenv("VT_W4R_GROUP_M") ? atoi(getenv("VT_W4R_GROUP_M")) : 0,
-              getenv("VT_W4_NOREMAP") ? atoi(getenv("VT_W4_NOREMAP")) : 0, 0};
+              getenv("VT_W4_NOREMAP") ? atoi(getenv("VT_W4_NOREMAP")) : 0, getenv("VT_W4X_GROUP_M") ? atoi(getenv("VT_W4X_GROUP_M")) : 0};
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_w4_knobs), h, sizeof(h));
 }
 #define W4_KNOB(i, dflt) (g_w4_knobs[i] > 0 ? g_w4_knobs[i] : (dflt))
