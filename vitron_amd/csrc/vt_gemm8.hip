@@ -860,7 +860,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // two-pass split-K (EPI == F32 only, as in the ping-pong kernel): split s of every tile writes its partial product to slab s
   const int ksplit = (EPI == VT_EPI_F32) ? p.ksplit : 1;
   const int split = (ksplit > 1) ? (int)blockIdx.x / nwg : 0;
-  const int sid = W4_KNOB(2, 0) == 1 ? (int)blockIdx.x - split * nwg : xcd_remap((int)blockIdx.x - split * nwg, nwg);
+  // Workgroup id -> place in the logical tile order. Blocks are dispatched round-robin over the 8 XCDs; xcd_remap gives every XCD ONE contiguous
+  // eighth of the order (worth 2.5 % of the C3 step against no remap). A grid of WHOLE rounds (a multiple of 256 tiles, more than one round) is
+  // walked round by round instead -- XCD x takes places [256 r + 32 x, + 32) of round r, so that the eight XCDs work on adjacent 4 x 8 tile blocks
+  // at any time (round 6, bit-identical; tools/remap_ab.py: qkv 40960 x 12288 x 4096 2901 -> 2757 us, 10240 rows 715 -> 697, 5120 rows 0.5-2.7 % by
+  // box, o_proj at 40960 rows 1112 -> 1092; six paired C3 steps -0.21 ms). With a partial last round (gate/up: 1720 tiles) it measured 0.5 % slower.
+  const int b_ = (int)blockIdx.x - split * nwg;
+  const bool whole_rounds = (nwg & 255) == 0 && nwg > 256 && W4_KNOB(2, 0) != 3;
+  const int sid = W4_KNOB(2, 0) == 1 ? b_ : whole_rounds ? ((b_ >> 8) << 8) + (b_ & 7) * 32 + ((b_ >> 3) & 31) : xcd_remap(b_, nwg);
   const int ku = p.K >> 7;   // K in units of 128 (two K steps), balanced over the splits
   const int u_begin = (int)((long)ku * split / ksplit), u_end = (int)((long)ku * (split + 1) / ksplit);
   // tile groups of 4 rows x all columns once there are 8 or more row blocks (round 6, bit-identical outputs: gate/up 5120 x 22016 x 4096
