@@ -636,6 +636,21 @@ def empirical_peaks(dev):
                 torch.cuda.synchronize()
                 n += 10
             res[f"mfma_only_bf16_tflops_{name}"] = flop * n / (time.perf_counter() - t0) / 1e12
+        # what a kernel that does NOTHING BUT read sustains from HBM (vt_probe_read: 1 GiB, larger than the Infinity Cache; plain loads and the
+        # read-once policy of the weight-streaming GEMM): the yardstick of the decode step, whose bytes are weights and KV pages read once
+        buf = torch.ones(1 << 28, dtype=torch.float32, device=dev)
+        flag = torch.zeros(4, dtype=torch.int32, device=dev)
+        st = torch.cuda.current_stream().cuda_stream
+        for nt, key in ((0, "hbm_read_kernel_GBps"), (1, "hbm_read_kernel_nt_GBps")):
+            for _ in range(3):
+                _lib.check(lib.vt_probe_read(buf.data_ptr(), buf.numel() * 4, nt, flag.data_ptr(), st), "vt_probe_read", lib)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                lib.vt_probe_read(buf.data_ptr(), buf.numel() * 4, nt, flag.data_ptr(), st)
+            torch.cuda.synchronize()
+            res[key] = (1 << 30) * 20 / (time.perf_counter() - t0) / 1e9
+        del buf
     except Exception as e:  # noqa: BLE001 -- a measurement aid must not take the benchmark down
         res["error"] = f"{type(e).__name__}: {e}"
     return res
@@ -1374,6 +1389,9 @@ def main():
                 out["roofline"]["frac_of_empirical_gemm_peak"] = achieved / emp["hipblaslt_bf16_gemm_8192_tflops"]
             if emp.get("d2d_copy_GBps") and "decode" in out:
                 out["decode"]["roofline"]["frac_of_empirical_copy_rate"] = out["decode"]["roofline"]["achieved"] / emp["d2d_copy_GBps"]
+            rd = max(emp.get("hbm_read_kernel_GBps") or 0.0, emp.get("hbm_read_kernel_nt_GBps") or 0.0)
+            if rd > 0 and "decode" in out:      # the decode step only READS (weights + KV pages): held against a read-only kernel's rate on this box
+                out["decode"]["roofline"]["frac_of_empirical_read_rate"] = out["decode"]["roofline"]["achieved"] / rd
         if world == 1 and args.dtype == "bf16" and args.fp16_ab_steps > 0:
             out["config"]["fp16_ab"] = fp16_ab_report(args, dev, model, step, ids, ids_host, clip, vit_image)
             # the mode north_star's 1e-3 is met in, as a first-class number beside the headline: the fp16-operand build (the

@@ -75,7 +75,7 @@ enum { VT_ACT_GELU = 0, VT_ACT_QUICK_GELU = 1 };
 
 #define VT_PAGE_TOKENS 64 /* tokens per KV-cache page == keys per attention tile */
 
-#define VT_ABI_VERSION 112
+#define VT_ABI_VERSION 113
 int vt_version(void); /* == VT_ABI_VERSION of the header the library was built from */
 /* operand format of THIS library (see Conventions): every uint16_t tensor argument carries these bits */
 enum { VT_OPERAND_BF16 = 0, VT_OPERAND_FP16 = 1 };
@@ -488,6 +488,10 @@ int vt_profile_end(int* launches, double* total_ms, double* total_work);
  * (8 operand values: the caller chooses their distribution -- the sustained clock of this part depends on the operand VALUES, zeros
  * run ~19 % faster than N(0,1)); out: multiprocessors x 256 floats. FLOP per launch = 2 * 128*128*64 * iters * 4 * multiprocessors. */
 int vt_probe_mfma(const uint16_t* a, const uint16_t* b, float* out, int iters, void* stream);
+/* What a kernel that only READS sustains from HBM on THIS device (measurement aid for the roofline of the decode step, whose bytes are
+ * weights and KV pages read once; ABI 113): `bytes` (>= 16, p 16-byte aligned) are read once, 16 bytes per lane and load; nt != 0 uses the
+ * read-once cache policy of the weight-streaming GEMM. out: one word (never written in practice: it keeps the loads alive). */
+int vt_probe_read(const void* p, size_t bytes, int nt, unsigned* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -18,7 +18,7 @@ PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = PKG_DIR / "libvitron_hip.so"
 LIB_PATHS = {"bf16": LIB_PATH, "fp16": PKG_DIR / "libvitron_hip_f16.so"}
 OPERAND_BF16, OPERAND_FP16 = 0, 1
-ABI_VERSION = 112   # == VT_ABI_VERSION of include/vitron_hip.h; load() refuses a library that reports anything else
+ABI_VERSION = 113   # == VT_ABI_VERSION of include/vitron_hip.h; load() refuses a library that reports anything else
 
 # ---- enums (mirror include/vitron_hip.h) ---------------------------------------------------------------------
 EPI_BF16, EPI_BF16_GELU, EPI_BF16_QGELU, EPI_BF16_RELU, EPI_F32_RESID, EPI_F32, EPI_SWIGLU_BF16 = range(7)
@@ -112,6 +112,7 @@ SIGNATURES = {
     "vt_profile_begin": (_i, []),
     "vt_profile_end": (_i, [C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "vt_probe_mfma": (_i, [vp, vp, vp, _i, vp]),
+    "vt_probe_read": (_i, [vp, _sz, _i, vp, vp]),
     "vt_flash_attn_block_order": (_i, [_i, _i, _i, _i, C.POINTER(C.c_int), _i]),
     "vt_mx4_aexp_bytes": (_sz, [_i, _i]),
     "vt_mx4_quant_weights": (_i, [vp, _i, _i, _i, vp, vp, vp]),
