@@ -689,6 +689,31 @@ def test_mfma_probe_counts_what_it_claims(dev, op):
         assert torch.equal(out, torch.full_like(out, 64 * 2 * 64 * iters)), (iters, out[:4].tolist())
 
 
+@pytest.mark.parametrize("nt", [0, 1])
+def test_read_probe_reads_every_byte_it_is_timed_on(dev, nt):
+    """vt_probe_read (the read-only yardstick behind roofline.empirical_peaks / decode.roofline.frac_of_empirical_read_rate, ABI 113): every
+    lane folds what it loads into one word and stores a flag when the fold equals a magic value -- so ONE magic word anywhere in an otherwise
+    zero buffer must raise the flag (the loads are real: first chunk, middle, the last whole chunk, the grid-stride tail), and none must not."""
+    from vitron_amd import _lib
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    nbytes = (64 << 20) + 4096 + 48                           # not a multiple of the grid's stride: the tail loop runs
+    words = nbytes // 4
+    buf = torch.zeros(words, dtype=torch.int32, device=dev)
+    flag = torch.zeros(4, dtype=torch.int32, device=dev)
+    magic = 0x9e3779b9 - (1 << 32)
+    for pos in (None, 0, 5, words // 2 + 3, (nbytes // 16) * 4 - 1, (nbytes // 16) * 4 - 4 * 700):
+        buf.zero_()
+        flag.zero_()
+        if pos is not None:
+            buf[pos] = magic
+        _lib.check(lib.vt_probe_read(buf.data_ptr(), nbytes, nt, flag.data_ptr(), st), "vt_probe_read", lib)
+        torch.cuda.synchronize()
+        assert int(flag[0]) == (0 if pos is None else 1), (pos, flag.tolist())
+    with pytest.raises(_lib.VitronHipError):
+        _lib.check(lib.vt_probe_read(buf.data_ptr() + 4, 1024, nt, flag.data_ptr(), st), "vt_probe_read", lib)      # misaligned
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("epi_name", ["SWIGLU_BF16", "BF16", "F32_RESID", "F32"])
 def test_gemm_column_split_plan_is_bit_identical(epi_name):
