@@ -790,6 +790,44 @@ def test_counted_dma_waits_have_no_scratch_access_in_their_window_and_mfma_tails
                 assert n2 >= 7, (os.path.basename(out), n2)
 
 
+def test_mfma_tail_checker_on_hand_written_assembly(tmp_path):
+    """tools/check_scratch_window.py: check_mfma_tail must flag a read of the last asm MFMA's destination that comes before the wait states --
+    also when the path to it follows an s_branch around an unrelated block -- and accept the same code with the wait states first (the form
+    the loop's last trip now produces); check() must flag a scratch access between the first LDS-DMA and the last MFMA."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_scratch_window", os.path.join(ROOT, "tools", "check_scratch_window.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    head = """_Z4kernv:
+\tbuffer_load_dwordx4 v[0:3], v4, s[0:3], 0 offen lds
+.LBB0_1:
+\t;;#ASMSTART
+\tv_mfma_f32_16x16x32_bf16 a[0:3], v[6:9], v[10:13], a[0:3]
+\t;;#ASMEND
+\t;;#ASMSTART
+\tv_mfma_f32_16x16x32_bf16 a[252:255], v[6:9], v[10:13], a[252:255]
+\t;;#ASMEND
+\ts_cmp_lt_i32 s1, s2
+\ts_cbranch_scc1 .LBB0_1
+"""
+    tail = "\tv_accvgpr_read_b32 v20, a0\n\ts_endpgm\n.Lfunc_end0:\n"
+    bad = head + "\ts_branch .LBB0_3\n.LBB0_2:\n\tv_accvgpr_write_b32 a252, 0\n.LBB0_3:\n\tv_accvgpr_read_b32 v8, a252\n\t;;#ASMSTART\n\ts_nop 15\n\ts_nop 7\n\t;;#ASMEND\n" + tail
+    good = head + "\t;;#ASMSTART\n\ts_nop 15\n\ts_nop 7\n\t;;#ASMEND\n\ts_branch .LBB0_3\n.LBB0_2:\n\tv_accvgpr_write_b32 a252, 0\n.LBB0_3:\n\tv_accvgpr_read_b32 v8, a252\n" + tail
+    spill = head.replace(".LBB0_1:\n", ".LBB0_1:\n\tscratch_store_dword off, v1, off offset:8\n") + "\t;;#ASMSTART\n\ts_nop 15\n\t;;#ASMEND\n" + tail
+    for name, text, n_tail, n_scratch in (("bad", bad, 1, 0), ("good", good, 0, 0), ("spill", spill, 0, 1)):
+        f = tmp_path / f"{name}.s"
+        f.write_text(text)
+        n2, bad2 = chk.check_mfma_tail(str(f))
+        n1, bad1 = chk.check(str(f))
+        assert n1 == 1 and n2 == 1, (name, n1, n2)
+        assert len(bad2) == n_tail and len(bad1) == n_scratch, (name, bad1, bad2)
+    assert "a252" in bad_line(chk, tmp_path / "bad.s")
+
+
+def bad_line(chk, path):
+    return chk.check_mfma_tail(str(path))[1][0][2]
+
+
 def test_hand_placed_attention_schedule_is_what_the_generator_emits():
     """vt_attn_w4_si0.inc / si1.inc are generated (tools/gen_attn_w4.py): the committed files must be the generator's output, every
     sub-iteration must carry its 32 MFMAs (16 score + 16 P.V), 8 + 8 fragment reads, and SI0 the 8 LDS-DMA pieces of the tile."""
