@@ -788,6 +788,10 @@ def test_counted_dma_waits_have_no_scratch_access_in_their_window_and_mfma_tails
             assert not bad2, (os.path.basename(out), n2, bad2[:4])
             if "vt_gemm8" in out or "vt_attn_w4" in out:
                 assert n2 >= 7, (os.path.basename(out), n2)
+            # ... and the zeroing of an accumulator stays away from the first asm MFMA that reads it as C (the compiler sinks the writes behind
+            # the source's s_nop: what keeps them apart is their order, which this pins)
+            n3, bad3 = chk.check_mfma_head(out)
+            assert not bad3, (os.path.basename(out), n3, bad3[:4])
 
 
 def test_mfma_tail_checker_on_hand_written_assembly(tmp_path):

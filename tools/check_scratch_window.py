@@ -1,6 +1,6 @@
 """Two checks of the generated device code. (1) No scratch access between the first LDS-DMA and the last MFMA of any kernel that waits for its
 DMA pieces by COUNT (s_waitcnt vmcnt(N)). (2) check_mfma_tail: no read of the last asm MFMAs' destinations in front of the wait states that
-cover their latency.
+cover their latency. (3) check_mfma_head: the zeroing of an accumulator is at least 4 instructions away from the first asm MFMA that reads it.
 
     python tools/check_scratch_window.py file.s [file.s ...]        (device assembly: hipcc -S --cuda-device-only, or the build's saved temps)
 
@@ -96,6 +96,44 @@ def check(path):
     return n, bad
 
 
+def check_mfma_head(path, first_n=8, min_gap=4):
+    """Third check (round 6): the accumulators are zeroed with v_accvgpr_write (or v_accvgpr_mov) and the compiler is free to sink those
+    writes to the loop's doorstep, behind the `s_nop` the source places there; an asm MFMA that reads one of them as its C operand must still
+    be at least `min_gap` instructions away from the write (checked for the first `first_n` MFMAs: later ones are further away by
+    construction, an MFMA per 16 cycles). Returns (kernels checked, [(name, mfma line, gap)])."""
+    s = open(path).read()
+    bad, n = [], 0
+    for m in re.finditer(r"^(_Z\w+):", s, flags=re.M):
+        i = m.start()
+        j = s.find(".Lfunc_end", i)
+        if j < 0:
+            continue
+        lines = s[i:j].split("\n")
+        mf = [a for a, l in enumerate(lines) if "v_mfma" in l and a > 0 and "ASMSTART" in lines[a - 1]]
+        if not mf:
+            continue
+        n += 1
+        for a in mf[:first_n]:
+            ops = [t.strip().rstrip(",") for t in lines[a].split(None, 1)[1].split(",")]
+            f, regs = _regs(ops[-1]) if ops else (None, set())
+            if f != "a":
+                continue
+            gap = 0
+            for b in range(a - 1, -1, -1):
+                l = lines[b].strip()
+                if not l or l.startswith((";", ".")):
+                    continue
+                mw = re.match(r"v_accvgpr_(?:write_b32|mov_b32)\s+a(\d+),", l)
+                if mw and int(mw.group(1)) in regs:
+                    if gap < min_gap:
+                        bad.append((m.group(1), a, gap))
+                    break
+                gap += 1
+                if gap > 64:
+                    break
+    return n, bad
+
+
 if __name__ == "__main__":
     rc = 0
     for f in sys.argv[1:]:
@@ -108,5 +146,10 @@ if __name__ == "__main__":
         print(f"{f}: {n2} kernels with asm MFMAs + a tail fence checked, {len(bad2)} reads of the last MFMAs' destinations in front of the fence")
         for name, line, text in bad2[:16]:
             print("   ", name, line, text)
+            rc = 1
+        n3, bad3 = check_mfma_head(f)
+        print(f"{f}: {n3} kernels with asm MFMAs checked, {len(bad3)} first MFMAs closer than 4 instructions to the zeroing of their C operand")
+        for name, line, gap in bad3[:16]:
+            print("   ", name, line, gap)
             rc = 1
     sys.exit(rc)
